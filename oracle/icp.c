@@ -1,0 +1,563 @@
+/*
+ * icp.c -- the build-defined scan-to-map registration.
+ * TEST INFRASTRUCTURE ONLY (see velo_oracle.h).
+ *
+ * PARITY UNPINNED w.r.t. the reference: victl/VeloSLAM contains no ICP, no kNN,
+ * no voxel grid, no normal estimation and no linear solve (the only
+ * trace is an unused #include <pcl/kdtree/kdtree_flann.h>, HDLParser.h:66).
+ * This file IS the specification; DESIGN.md section "ICP semantics" states it in
+ * prose.  The HIP kernels are held to it:
+ *   - map sort order, cell table, normals, correspondences: BIT-EXACT
+ *     (integer/index work, and float arithmetic written with explicit
+ *     fmaf()/fma() under -ffp-contract=off on both sides);
+ *   - JtJ / Jtr sums and the pose: <= 1e-4 m, 1e-5 rad (summation order differs).
+ *
+ * Semantics
+ *  grid     origin o = component-wise min of the map points (float); inv_h =
+ *           1.0f/h; cell(p) = floorf((p - o) * inv_h) per axis; dims = cell(max)+1;
+ *           key = (cz*ny + cy)*nx + cx; points STABLY sorted by key.
+ *  normals  for sorted point s: the k smallest (d2, index) among all points of
+ *           the 27 neighbouring cells with d2 <= h*h (self included);
+ *           fewer than 5 -> normal = 0 (invalid).  Covariance about the mean in
+ *           fp64, summed in (d2,index) order; eigenvector of the smallest
+ *           eigenvalue by 8 fixed cyclic Jacobi sweeps (only + - * / sqrt);
+ *           sign: last non-zero of (nz, ny, nx) made positive; stored as float.
+ *  kNN      q = (float)(T*p) with T*p in fp64 by nested fma; exhaustive scan of
+ *           the 27 cells in ascending sorted index; d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx))
+ *           with d = candidate - q; best = first minimum (ties -> lowest sorted
+ *           index); valid iff d2 <= d_max*d_max (float) and d_max <= h.
+ *  residual r = n.(p' - q_map), J = [p' x n, n] (rotation first, left
+ *           perturbation), p' in fp64; pairs whose map normal is invalid are
+ *           dropped; 21 + 6 + 1 + 1 = 29 doubles.
+ *  solve    LDLt without pivoting; a non-positive pivot -> retry once with
+ *           H + 1e-9 I; fewer than 6 pairs -> no update.  T <- exp(xi^) T.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "velo_oracle.h"
+
+struct vo_map {
+    size_t n, ncell;
+    float o[3], inv_h, h;
+    int dims[3];
+    float *x, *y, *z, *nx, *ny, *nz;
+    int32_t* perm;
+    int32_t* cell_start;
+};
+
+static inline int cell_coord(float p, float o, float inv_h, int dim)
+{
+    float f = floorf((p - o) * inv_h);
+    /* clamp before the float->int conversion; anything outside [-2, dim+1]
+     * has no neighbour inside the grid anyway */
+    if (!(f >= -2.0f)) f = -2.0f;
+    if (f > (float)(dim + 1)) f = (float)(dim + 1);
+    return (int)f;
+}
+
+/* ---- symmetric 3x3 eigen decomposition: fixed cyclic Jacobi, fp64 ---------- */
+static void jacobi_rot(double A[3][3], double V[3][3], int p, int q)
+{
+    if (A[p][q] == 0.0) return;
+    double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+    double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+    if (theta < 0.0) t = -t;
+    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+    int r = 3 - p - q;
+    double app = A[p][p], aqq = A[q][q], apq = A[p][q];
+    double arp = A[r][p], arq = A[r][q];
+    A[p][p] = app - t * apq;
+    A[q][q] = aqq + t * apq;
+    A[p][q] = A[q][p] = 0.0;
+    A[r][p] = A[p][r] = c * arp - s * arq;
+    A[r][q] = A[q][r] = s * arp + c * arq;
+    for (int k = 0; k < 3; ++k) {
+        double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - s * vkq;
+        V[k][q] = s * vkp + c * vkq;
+    }
+}
+
+static void smallest_eigvec(const double C[6] /* xx xy xz yy yz zz */, double n[3])
+{
+    double A[3][3] = {{C[0], C[1], C[2]}, {C[1], C[3], C[4]}, {C[2], C[4], C[5]}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        jacobi_rot(A, V, 0, 1);
+        jacobi_rot(A, V, 0, 2);
+        jacobi_rot(A, V, 1, 2);
+    }
+    int m = 0;
+    if (A[1][1] < A[m][m]) m = 1;
+    if (A[2][2] < A[m][m]) m = 2;
+    double vx = V[0][m], vy = V[1][m], vz = V[2][m];
+    double inv = 1.0 / sqrt(vx * vx + vy * vy + vz * vz);
+    vx *= inv;
+    vy *= inv;
+    vz *= inv;
+    int flip = (vz < 0.0) || (vz == 0.0 && (vy < 0.0 || (vy == 0.0 && vx < 0.0)));
+    if (flip) {
+        vx = -vx;
+        vy = -vy;
+        vz = -vz;
+    }
+    n[0] = vx;
+    n[1] = vy;
+    n[2] = vz;
+}
+
+#define VO_KMAX 32
+#define VO_MIN_NB 5
+
+static void point_normal(const vo_map* m, size_t s, int k, float out[3])
+{
+    const float qx = m->x[s], qy = m->y[s], qz = m->z[s];
+    const float r2 = m->h * m->h;
+    const int cx = cell_coord(qx, m->o[0], m->inv_h, m->dims[0]);
+    const int cy = cell_coord(qy, m->o[1], m->inv_h, m->dims[1]);
+    const int cz = cell_coord(qz, m->o[2], m->inv_h, m->dims[2]);
+    float bd[VO_KMAX];
+    int32_t bi[VO_KMAX];
+    int cnt = 0;
+    for (int dz = -1; dz <= 1; ++dz) {
+        int z = cz + dz;
+        if (z < 0 || z >= m->dims[2]) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            int y = cy + dy;
+            if (y < 0 || y >= m->dims[1]) continue;
+            int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= m->dims[0] ? m->dims[0] - 1 : cx + 1;
+            if (x0 > x1) continue;
+            size_t row = ((size_t)z * m->dims[1] + y) * m->dims[0];
+            int32_t j0 = m->cell_start[row + x0], j1 = m->cell_start[row + x1 + 1];
+            for (int32_t j = j0; j < j1; ++j) {
+                float dx = m->x[j] - qx, dyy = m->y[j] - qy, dzz = m->z[j] - qz;
+                float d2 = fmaf(dzz, dzz, fmaf(dyy, dyy, dx * dx));
+                if (!(d2 <= r2)) continue;
+                /* insert into ascending (d2, j) list of at most k; j ascends, so
+                 * an equal d2 goes AFTER existing equal entries */
+                if (cnt == k && !(d2 < bd[k - 1])) continue;
+                int pos = cnt < k ? cnt : k - 1;
+                while (pos > 0 && d2 < bd[pos - 1]) {
+                    bd[pos] = bd[pos - 1];
+                    bi[pos] = bi[pos - 1];
+                    --pos;
+                }
+                bd[pos] = d2;
+                bi[pos] = j;
+                if (cnt < k) ++cnt;
+            }
+        }
+    }
+    if (cnt < VO_MIN_NB) {
+        out[0] = out[1] = out[2] = 0.0f;
+        return;
+    }
+    double mx = 0, my = 0, mz = 0;
+    for (int i = 0; i < cnt; ++i) {
+        mx += (double)m->x[bi[i]];
+        my += (double)m->y[bi[i]];
+        mz += (double)m->z[bi[i]];
+    }
+    const double invn = 1.0 / (double)cnt;
+    mx *= invn;
+    my *= invn;
+    mz *= invn;
+    double C[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < cnt; ++i) {
+        double dx = (double)m->x[bi[i]] - mx, dy = (double)m->y[bi[i]] - my,
+               dz = (double)m->z[bi[i]] - mz;
+        C[0] = fma(dx, dx, C[0]);
+        C[1] = fma(dx, dy, C[1]);
+        C[2] = fma(dx, dz, C[2]);
+        C[3] = fma(dy, dy, C[3]);
+        C[4] = fma(dy, dz, C[4]);
+        C[5] = fma(dz, dz, C[5]);
+    }
+    double nrm[3];
+    smallest_eigvec(C, nrm);
+    out[0] = (float)nrm[0];
+    out[1] = (float)nrm[1];
+    out[2] = (float)nrm[2];
+}
+
+vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, float voxel,
+                     int k_normals)
+{
+    if (n == 0 || !(voxel > 0) || k_normals > VO_KMAX) return NULL;
+    vo_map* m = (vo_map*)calloc(1, sizeof *m);
+    m->n = n;
+    m->h = voxel;
+    m->inv_h = 1.0f / voxel;
+    float mn[3] = {x[0], y[0], z[0]}, mxv[3] = {x[0], y[0], z[0]};
+    for (size_t i = 1; i < n; ++i) {
+        if (x[i] < mn[0]) mn[0] = x[i];
+        if (y[i] < mn[1]) mn[1] = y[i];
+        if (z[i] < mn[2]) mn[2] = z[i];
+        if (x[i] > mxv[0]) mxv[0] = x[i];
+        if (y[i] > mxv[1]) mxv[1] = y[i];
+        if (z[i] > mxv[2]) mxv[2] = z[i];
+    }
+    for (int a = 0; a < 3; ++a) {
+        m->o[a] = mn[a];
+        m->dims[a] = (int)floorf((mxv[a] - mn[a]) * m->inv_h) + 1;
+    }
+    m->ncell = (size_t)m->dims[0] * m->dims[1] * m->dims[2];
+    if (m->ncell >= ((size_t)1 << 31)) {
+        free(m);
+        return NULL;
+    }
+    int32_t* key = (int32_t*)malloc(n * sizeof(int32_t));
+    m->cell_start = (int32_t*)calloc(m->ncell + 1, sizeof(int32_t));
+    for (size_t i = 0; i < n; ++i) {
+        int cx = (int)floorf((x[i] - m->o[0]) * m->inv_h);
+        int cy = (int)floorf((y[i] - m->o[1]) * m->inv_h);
+        int cz = (int)floorf((z[i] - m->o[2]) * m->inv_h);
+        key[i] = (int32_t)(((size_t)cz * m->dims[1] + cy) * m->dims[0] + cx);
+        m->cell_start[key[i] + 1]++;
+    }
+    for (size_t c = 0; c < m->ncell; ++c) m->cell_start[c + 1] += m->cell_start[c];
+    int32_t* cursor = (int32_t*)malloc(m->ncell * sizeof(int32_t));
+    memcpy(cursor, m->cell_start, m->ncell * sizeof(int32_t));
+    m->perm = (int32_t*)malloc(n * sizeof(int32_t));
+    m->x = (float*)malloc(n * sizeof(float));
+    m->y = (float*)malloc(n * sizeof(float));
+    m->z = (float*)malloc(n * sizeof(float));
+    m->nx = (float*)malloc(n * sizeof(float));
+    m->ny = (float*)malloc(n * sizeof(float));
+    m->nz = (float*)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; ++i) { /* stable counting sort */
+        int32_t s = cursor[key[i]]++;
+        m->perm[s] = (int32_t)i;
+        m->x[s] = x[i];
+        m->y[s] = y[i];
+        m->z[s] = z[i];
+    }
+    free(cursor);
+    free(key);
+    if (k_normals > 0) {
+#pragma omp parallel for schedule(dynamic, 1024)
+        for (long s = 0; s < (long)n; ++s) {
+            float nn[3];
+            point_normal(m, (size_t)s, k_normals, nn);
+            m->nx[s] = nn[0];
+            m->ny[s] = nn[1];
+            m->nz[s] = nn[2];
+        }
+    } else {
+        memset(m->nx, 0, n * sizeof(float));
+        memset(m->ny, 0, n * sizeof(float));
+        memset(m->nz, 0, n * sizeof(float));
+    }
+    return m;
+}
+
+void vo_map_free(vo_map* m)
+{
+    if (!m) return;
+    free(m->x);
+    free(m->y);
+    free(m->z);
+    free(m->nx);
+    free(m->ny);
+    free(m->nz);
+    free(m->perm);
+    free(m->cell_start);
+    free(m);
+}
+size_t vo_map_size(const vo_map* m) { return m->n; }
+void vo_map_grid(const vo_map* m, float origin[3], int dims[3], float* inv_h)
+{
+    memcpy(origin, m->o, sizeof m->o);
+    memcpy(dims, m->dims, sizeof m->dims);
+    *inv_h = m->inv_h;
+}
+const float* vo_map_x(const vo_map* m) { return m->x; }
+const float* vo_map_y(const vo_map* m) { return m->y; }
+const float* vo_map_z(const vo_map* m) { return m->z; }
+const float* vo_map_nx(const vo_map* m) { return m->nx; }
+const float* vo_map_ny(const vo_map* m) { return m->ny; }
+const float* vo_map_nz(const vo_map* m) { return m->nz; }
+const int32_t* vo_map_perm(const vo_map* m) { return m->perm; }
+const int32_t* vo_map_cell_start(const vo_map* m) { return m->cell_start; }
+size_t vo_map_num_cells(const vo_map* m) { return m->ncell; }
+
+/* p' = T*p in fp64 with a fixed fma nesting (shared with the HIP kernels) */
+static inline void xform(const double T[12], float x, float y, float z, double o[3])
+{
+    const double dx = x, dy = y, dz = z;
+    o[0] = fma(T[0], dx, fma(T[1], dy, fma(T[2], dz, T[3])));
+    o[1] = fma(T[4], dx, fma(T[5], dy, fma(T[6], dz, T[7])));
+    o[2] = fma(T[8], dx, fma(T[9], dy, fma(T[10], dz, T[11])));
+}
+
+static inline int32_t nearest(const vo_map* m, float qx, float qy, float qz, float* best_d2,
+                              uint64_t* scanned)
+{
+    const int cx = cell_coord(qx, m->o[0], m->inv_h, m->dims[0]);
+    const int cy = cell_coord(qy, m->o[1], m->inv_h, m->dims[1]);
+    const int cz = cell_coord(qz, m->o[2], m->inv_h, m->dims[2]);
+    float bd = INFINITY;
+    int32_t bj = -1;
+    for (int dz = -1; dz <= 1; ++dz) {
+        int z = cz + dz;
+        if (z < 0 || z >= m->dims[2]) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            int y = cy + dy;
+            if (y < 0 || y >= m->dims[1]) continue;
+            int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= m->dims[0] ? m->dims[0] - 1 : cx + 1;
+            if (x0 > x1) continue;
+            size_t row = ((size_t)z * m->dims[1] + y) * m->dims[0];
+            int32_t j0 = m->cell_start[row + x0], j1 = m->cell_start[row + x1 + 1];
+            *scanned += (uint64_t)(j1 - j0);
+            for (int32_t j = j0; j < j1; ++j) {
+                float dx = m->x[j] - qx, dyy = m->y[j] - qy, dzz = m->z[j] - qz;
+                float d2 = fmaf(dzz, dzz, fmaf(dyy, dyy, dx * dx));
+                if (d2 < bd) {
+                    bd = d2;
+                    bj = j;
+                }
+            }
+        }
+    }
+    *best_d2 = bd;
+    return bj;
+}
+
+uint64_t vo_correspond(const vo_map* m, const float* x, const float* y, const float* z, size_t n,
+                       const double T[12], float d_max, int32_t* corr, float* d2out)
+{
+    const float dmax2 = d_max * d_max;
+    uint64_t total = 0;
+#pragma omp parallel for schedule(static) reduction(+ : total)
+    for (long i = 0; i < (long)n; ++i) {
+        double p[3];
+        xform(T, x[i], y[i], z[i], p);
+        float bd;
+        uint64_t sc = 0;
+        int32_t j = nearest(m, (float)p[0], (float)p[1], (float)p[2], &bd, &sc);
+        total += sc;
+        if (!(j >= 0 && bd <= dmax2)) {
+            j = -1;
+        }
+        corr[i] = j;
+        if (d2out) d2out[i] = (j >= 0) ? bd : INFINITY;
+    }
+    return total;
+}
+
+static inline void accum_pair(const vo_map* m, const double p[3], int32_t j, double acc[29])
+{
+    const double nx = m->nx[j], ny = m->ny[j], nz = m->nz[j];
+    if (nx == 0.0 && ny == 0.0 && nz == 0.0) return; /* invalid normal */
+    const double dx = p[0] - (double)m->x[j], dy = p[1] - (double)m->y[j],
+                 dz = p[2] - (double)m->z[j];
+    const double r = fma(nx, dx, fma(ny, dy, nz * dz));
+    double J[6];
+    J[0] = fma(p[1], nz, -(p[2] * ny));
+    J[1] = fma(p[2], nx, -(p[0] * nz));
+    J[2] = fma(p[0], ny, -(p[1] * nx));
+    J[3] = nx;
+    J[4] = ny;
+    J[5] = nz;
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b, ++k) acc[k] = fma(J[a], J[b], acc[k]);
+    for (int a = 0; a < 6; ++a) acc[21 + a] = fma(J[a], r, acc[21 + a]);
+    acc[27] = fma(r, r, acc[27]);
+    acc[28] += 1.0;
+}
+
+void vo_accumulate(const vo_map* m, const float* x, const float* y, const float* z, size_t n,
+                   const double T[12], const int32_t* corr, double acc[29])
+{
+    memset(acc, 0, 29 * sizeof(double));
+    for (size_t i = 0; i < n; ++i) {
+        if (corr[i] < 0) continue;
+        double p[3];
+        xform(T, x[i], y[i], z[i], p);
+        accum_pair(m, p, corr[i], acc);
+    }
+}
+
+/* ---- a12 ------------------------------------------------------------------ */
+static int ldlt6(const double Hin[36], const double b[6], double xs[6])
+{
+    double L[36], D[6];
+    memset(L, 0, sizeof L);
+    for (int j = 0; j < 6; ++j) {
+        double d = Hin[6 * j + j];
+        for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k] * D[k];
+        if (!(d > 0.0)) return 1;
+        D[j] = d;
+        L[6 * j + j] = 1.0;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = Hin[6 * i + j];
+            for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k] * D[k];
+            L[6 * i + j] = v / d;
+        }
+    }
+    double yv[6];
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+        for (int k = 0; k < i; ++k) v -= L[6 * i + k] * yv[k];
+        yv[i] = v;
+    }
+    for (int i = 0; i < 6; ++i) yv[i] /= D[i];
+    for (int i = 5; i >= 0; --i) {
+        double v = yv[i];
+        for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * xs[k];
+        xs[i] = v;
+    }
+    return 0;
+}
+
+static void se3_exp_apply(const double xi[6], double T[12])
+{
+    const double wx = xi[0], wy = xi[1], wz = xi[2];
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    double A, B, C;
+    if (th2 < 1e-16) {
+        A = 1.0 - th2 / 6.0;
+        B = 0.5 - th2 / 24.0;
+        C = 1.0 / 6.0 - th2 / 120.0;
+    } else {
+        const double th = sqrt(th2);
+        A = sin(th) / th;
+        B = (1.0 - cos(th)) / th2;
+        C = (1.0 - A) / th2;
+    }
+    const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double K2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    double Rd[9], Vm[9];
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        Rd[i] = I + A * K[i] + B * K2[i];
+        Vm[i] = I + B * K[i] + C * K2[i];
+    }
+    double td[3];
+    for (int i = 0; i < 3; ++i) td[i] = Vm[3 * i] * xi[3] + Vm[3 * i + 1] * xi[4] + Vm[3 * i + 2] * xi[5];
+    double N[12];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 4; ++j)
+            N[4 * i + j] = Rd[3 * i] * T[j] + Rd[3 * i + 1] * T[4 + j] + Rd[3 * i + 2] * T[8 + j];
+        N[4 * i + 3] += td[i];
+    }
+    memcpy(T, N, sizeof N);
+}
+
+int vo_solve_update(const double acc[29], double T[12], double xi[6])
+{
+    memset(xi, 0, 6 * sizeof(double));
+    if (acc[28] < 6.0) return 2;
+    double H[36], b[6];
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int c = a; c < 6; ++c, ++k) H[6 * a + c] = H[6 * c + a] = acc[k];
+    for (int a = 0; a < 6; ++a) b[a] = -acc[21 + a];
+    int rc = 0;
+    if (ldlt6(H, b, xi)) {
+        rc = 1;
+        for (int a = 0; a < 6; ++a) H[7 * a] += 1e-9;
+        if (ldlt6(H, b, xi)) {
+            memset(xi, 0, 6 * sizeof(double));
+            return 2;
+        }
+    }
+    se3_exp_apply(xi, T);
+    return rc;
+}
+
+int vo_icp(const vo_map* m, const float* x, const float* y, const float* z, size_t n,
+           const double T0[12], int iters, float d_max, double T_out[12], vo_icp_stat* stats,
+           double* trace, int threads)
+{
+    if (!(d_max <= m->h)) return -1;
+    double T[12];
+    memcpy(T, T0, sizeof T);
+    const float dmax2 = d_max * d_max;
+    int nth = 1;
+#ifdef _OPENMP
+    nth = threads > 1 ? threads : 1;
+#else
+    (void)threads;
+#endif
+    double* part = (double*)malloc((size_t)nth * 32 * sizeof(double));
+    uint64_t* cand = (uint64_t*)malloc((size_t)nth * sizeof(uint64_t));
+    for (int it = 0; it < iters; ++it) {
+        memset(part, 0, (size_t)nth * 32 * sizeof(double));
+        memset(cand, 0, (size_t)nth * sizeof(uint64_t));
+#pragma omp parallel num_threads(nth)
+        {
+            int tid = 0, nt = 1;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+            nt = omp_get_num_threads();
+#endif
+            size_t lo = n * (size_t)tid / (size_t)nt, hi = n * (size_t)(tid + 1) / (size_t)nt;
+            double* acc = part + 32 * tid;
+            uint64_t sc = 0;
+            for (size_t i = lo; i < hi; ++i) {
+                double p[3];
+                xform(T, x[i], y[i], z[i], p);
+                float bd;
+                int32_t j = nearest(m, (float)p[0], (float)p[1], (float)p[2], &bd, &sc);
+                if (j >= 0 && bd <= dmax2) accum_pair(m, p, j, acc);
+            }
+            cand[tid] = sc;
+        }
+        double acc[29];
+        memset(acc, 0, sizeof acc);
+        uint64_t sc = 0;
+        for (int t = 0; t < nth; ++t) { /* fixed thread order */
+            for (int k = 0; k < 29; ++k) acc[k] += part[32 * t + k];
+            sc += cand[t];
+        }
+        if (stats) {
+            stats[it].n_pairs = (uint32_t)acc[28];
+            stats[it].rmse = acc[28] > 0 ? sqrt(acc[27] / acc[28]) : 0.0;
+            stats[it].candidates = sc;
+        }
+        double xi[6];
+        vo_solve_update(acc, T, xi);
+        if (trace) memcpy(trace + 12 * it, T, sizeof T);
+    }
+    free(part);
+    free(cand);
+    memcpy(T_out, T, sizeof T);
+    return 0;
+}
+
+size_t vo_increment(const vo_map* m, const float* x, const float* y, const float* z, size_t n,
+                    const double T[12], int min_count, float* ox, float* oy, float* oz)
+{
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+        double p[3];
+        xform(T, x[i], y[i], z[i], p);
+        const float qx = (float)p[0], qy = (float)p[1], qz = (float)p[2];
+        const int cx = cell_coord(qx, m->o[0], m->inv_h, m->dims[0]);
+        const int cy = cell_coord(qy, m->o[1], m->inv_h, m->dims[1]);
+        const int cz = cell_coord(qz, m->o[2], m->inv_h, m->dims[2]);
+        int occ = 0;
+        if (cx >= 0 && cx < m->dims[0] && cy >= 0 && cy < m->dims[1] && cz >= 0 && cz < m->dims[2]) {
+            size_t key = ((size_t)cz * m->dims[1] + cy) * m->dims[0] + cx;
+            occ = m->cell_start[key + 1] - m->cell_start[key];
+        }
+        if (occ < min_count) {
+            if (ox) {
+                ox[cnt] = qx;
+                oy[cnt] = qy;
+                oz[cnt] = qz;
+            }
+            ++cnt;
+        }
+    }
+    return cnt;
+}
