@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the scan-to-map registration path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], named in config.workload): HDL-64E frames of
+115 200 points each, registered against a 1 M-point voxel-sorted map with 20
+point-to-plane ICP iterations.  A "step" is one pass of the hot path over one batch
+of F frames that are ALREADY RESIDENT in HBM: K1 motion compensation of the batch
+(one launch) followed by 20 x (fused kNN + residual/JtJ kernel, reduce+solve kernel).
+Frames are independent units: with N ranks every rank registers its own F frames
+against its own replica of the map (weak scaling, no data-path collective inside
+the registration); the one exchange step of the path -- the RCCL all-gather of the
+accepted map increments -- runs after every step when N > 1, and the replicas
+re-index the map once enough increment points are pending.
+
+`value` = valid correspondence pairs processed by all ranks / wall time of the K
+timed steps (max over ranks).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from veloslam_amd import capi, synth  # noqa: E402
+from veloslam_amd.dist import exchange_increments  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=16, help="frames per step per GPU (batch)")
+    ap.add_argument("--map-points", type=int, default=1_000_000)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--d-max", type=float, default=1.0)
+    ap.add_argument("--voxel", type=float, default=1.0)
+    ap.add_argument("--k-normals", type=int, default=16)
+    ap.add_argument("--sort-frames", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--rebuild-threshold", type=int, default=20000,
+                    help="pending increment points that trigger a map re-index (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    return ap.parse_args()
+
+
+def build_inputs(args, rank, dev):
+    """Seeded synthetic inputs; everything the step reads ends up in device tensors."""
+    sc = synth.Scene()
+    mx, my, mz = sc.sample_map(args.map_points)
+    mo = synth.Motion()
+    cal = synth.hdl64_calibration()
+    F = args.frames
+    xs, ys, zs, pk, tabs, T0, Tt, fs = [], [], [], [], [], [], [], [0]
+    host_frames = []
+    pkt_base = 0
+    for k in range(F):
+        fi = 3 + (rank * F + k) % 40  # distinct frames per rank; wraps inside the scene
+        packets, ts, _ = synth.make_frame_packets(sc, mo, fi, cal, seed=42)
+        fr = synth.decode_sensor_frame(packets, cal)
+        poses, n = capi.make_poses(mo.ins_track(ts[0], ts[-1]))
+        tab, valid, car = capi.packet_transforms(poses, n, ts)  # product host code (a4..a6)
+        Ttrue = np.array([1, 0, 0, car.T[0], 0, 1, 0, car.T[1], 0, 0, 1, car.T[2]], np.float64)
+        xs.append(fr["x"]); ys.append(fr["y"]); zs.append(fr["z"])
+        pk.append((fr["pkt"].astype(np.int64) + pkt_base).astype(np.uint16))
+        pkt_base += tab.shape[0]
+        tabs.append(tab)
+        T0.append(synth.perturbed_guess(Ttrue)); Tt.append(Ttrue)
+        fs.append(fs[-1] + fr["x"].size)
+        host_frames.append((fr, tab, Ttrue))
+    assert pkt_base < 65536, "uint16 packet index overflow: lower --frames"
+
+    def dv(a, dt):
+        return torch.from_numpy(np.ascontiguousarray(np.concatenate(a)).astype(dt, copy=False)).to(dev)
+
+    d = dict(
+        sx=dv(xs, np.float32), sy=dv(ys, np.float32), sz=dv(zs, np.float32),
+        pkt=torch.from_numpy(np.concatenate(pk).view(np.int16)).to(dev),
+        tab=torch.from_numpy(np.concatenate(tabs).astype(np.float64)).to(dev),
+        map=(mx, my, mz), T0=np.stack(T0), Ttrue=np.stack(Tt),
+        frame_start=np.array(fs, dtype=np.int64), n_pkt=pkt_base, host_frames=host_frames)
+    n = int(fs[-1])
+    d["cx"] = torch.empty(n, dtype=torch.float32, device=dev)
+    d["cy"] = torch.empty(n, dtype=torch.float32, device=dev)
+    d["cz"] = torch.empty(n, dtype=torch.float32, device=dev)
+    d["inc"] = torch.empty((3, int(np.diff(fs).max())), dtype=torch.float32, device=dev)
+    return d
+
+
+def cpu_baseline(args, d):
+    """The oracle (a port: the reference has no ICP) timed on this box's host cores on a
+    bounded sample: `cpu_frames` of the same frames, same map, same 20 iterations."""
+    from oracle import oracle as orc
+    threads = os.cpu_count() or 1
+    om = orc.Map(*d["map"], args.voxel, args.k_normals)
+    pairs, cand, queries, t = 0, 0, 0, 0.0
+    nf = min(args.cpu_frames, len(d["host_frames"]))
+    for k in range(nf):
+        fr, tab, _ = d["host_frames"][k]
+        cx, cy, cz = orc.compensate(fr["x"], fr["y"], fr["z"], fr["pkt"], tab)
+        t0 = time.perf_counter()
+        _, st, _ = om.icp(cx, cy, cz, d["T0"][k], args.iters, args.d_max, threads=threads)
+        t += time.perf_counter() - t0
+        pairs += sum(s["n_pairs"] for s in st)
+        cand += sum(s["candidates"] for s in st)
+        queries += cx.size * args.iters
+    return dict(value=pairs / t, unit="pairs/s", cores=threads, kind="port",
+                sample="%d frame(s) x %d ICP iterations of the same workload, %.1f s of CPU "
+                       "(oracle/icp.c, OpenMP)" % (nf, args.iters, t)), cand / max(queries, 1)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    d = build_inputs(args, rank, dev)
+    F = args.frames
+    ctx = capi.Context(local, max_batch=max(F, 1), sort_frames=args.sort_frames,
+                       linearize_variant=args.variant)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.map_reset(*d["map"], args.voxel, args.k_normals)
+    ctx.frames_adopt_dev(d["cx"].data_ptr(), d["cy"].data_ptr(), d["cz"].data_ptr(), d["frame_start"])
+    n_q = int(d["frame_start"][-1])
+    ctx.set_timing(1)
+    pending = []
+    pending_n = 0
+
+    def step(timed):
+        nonlocal pending, pending_n
+        ctx.compensate_dev(d["sx"].data_ptr(), d["sy"].data_ptr(), d["sz"].data_ptr(),
+                           d["pkt"].data_ptr(), n_q, d["tab"].data_ptr(), d["n_pkt"],
+                           d["cx"].data_ptr(), d["cy"].data_ptr(), d["cz"].data_ptr())
+        ctx.icp_batch_async(d["T0"], args.iters, args.d_max)
+        if world > 1:
+            # exchange step of the path: accepted increment of this rank's first frame of
+            # the round, all-gathered; every replica appends all blocks in rank order
+            res = ctx.icp_batch_fetch()
+            cnt = ctx.increment_dev(0, np.array(list(res[0].T)), 3, d["inc"][0].data_ptr(),
+                                    d["inc"][1].data_ptr(), d["inc"][2].data_ptr())
+            blocks, counts = exchange_increments(d["inc"], cnt)
+            pending.extend(b.contiguous() for b in blocks if b.shape[1])
+            pending_n += sum(counts)
+            if pending_n >= args.rebuild_threshold:
+                allb = torch.cat(pending, dim=1).contiguous()
+                ctx.map_append_dev(allb[0].data_ptr(), allb[1].data_ptr(), allb[2].data_ptr(),
+                                   allb.shape[1])
+                pending, pending_n = [], 0
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lin_ms, lin_n, sol_ms, call_ms = 0.0, 0, 0.0, 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+        if world == 1:
+            pass
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    # kernel time of the LAST step (HIP events on the ctx stream) -- same launches every step
+    res = ctx.icp_batch_fetch()
+    tm = ctx.last_timing()
+    pairs_step = sum(int(r.total_pairs) for r in res)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    pr = torch.tensor([float(pairs_step)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pr, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_pairs = float(pr.item()) * args.steps
+
+    # sanity: the timed work really registered the frames
+    worst = max(float(np.linalg.norm(np.array(list(r.T)).reshape(3, 4)[:, 3] - d["Ttrue"][i].reshape(3, 4)[:, 3]))
+                for i, r in enumerate(res))
+    if worst > 0.05:
+        raise SystemExit("bench: registration diverged (%.3f m from truth)" % worst)
+
+    if rank == 0:
+        out = {
+            "metric": "ICP correspondence-pairs/s", "value": total_pairs / elapsed,
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 points, f64 pose/accumulators",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 115200-pt HDL-64E frame vs %d-pt map, "
+                                   "%d ICP iters, d_max %.2f m, voxel %.2f m; %d frames per step "
+                                   "per GPU, resident in HBM" % (args.map_points, args.iters,
+                                                                 args.d_max, args.voxel, F),
+                       "frames_per_step_per_gpu": F, "points_per_frame": n_q // F,
+                       "map_points": args.map_points, "iters": args.iters,
+                       "parallelism": "frame-parallel x%d" % world},
+            "frames_per_s": world * F * args.steps / elapsed,
+            "worst_pose_error_m": worst,
+            "kernel_pairs_per_s": (pairs_step / (1e-3 * (tm["linearize_ms"] + tm["solve_ms"])))
+            if tm["linearize_ms"] > 0 else None,
+        }
+        cbar = None
+        if not args.no_cpu_baseline:
+            cb, cbar = cpu_baseline(args, d)
+            out["cpu_baseline"] = cb
+        if tm["linearize_launches"] > 0:
+            avg_s = 1e-3 * tm["linearize_ms"] / tm["linearize_launches"]
+            if cbar is None:
+                cbar = float(os.environ.get("VELO_CBAR", "247.0"))
+            bytes_per_query = 232.0 + 12.0 * cbar + 24.0  # SURVEY 8(d), fused K2+K3, k=1
+            ach = bytes_per_query * n_q / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                               "kernel": "k_linearize", "avg_launch_us": 1e6 * avg_s,
+                               "queries_per_launch": n_q, "cbar": cbar,
+                               "bytes_per_query": bytes_per_query,
+                               "compulsory_bytes_per_launch": 16.0 * n_q + 32.0 * args.map_points}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+/*
+ * velo.h -- C ABI of libveloslam_amd.so: the MI355X-native scan-to-map
+ * registration path for VeloSLAM-style LiDAR frames.
+ *
+ * The reference (victl/VeloSLAM) has no plugin / FFI layer; the seam this
+ * library drops into is the in-process consumer side of HDLManager
+ * (HDLManager.h:137-148: waitForFrame/getRecentFrame -> intrusive_ptr<HDLFrame>)
+ * plus TransformManager::interpolateTransform (TransformManager.h:108).  Each
+ * entry point below names the reference interface it replaces (file:line under
+ * the reference tree) or says that the reference has none.  INTEGRATION.md
+ * shows the few lines a maintainer adds on the reference side.
+ *
+ * Conventions: plain pointers and sizes only; every function
+ * returns 0 on success or a negative VELO_E_* code, with a message available
+ * from velo_last_error(); nothing throws.  A velo_ctx is bound to one GPU and
+ * one HIP stream and is single-threaded: use one ctx per GPU / thread.
+ * Point clouds are struct-of-arrays float32 (x[], y[], z[]); poses are
+ * row-major 3x4 double matrices [R|t] or the reference's PoseTransform fields
+ * (metres, roll/pitch/yaw DEGREES, rotation = Ry(roll) Rx(pitch) Rz(yaw),
+ * type_defs.h:134-146).
+ *
+ * Entry points whose name ends in _dev take DEVICE pointers (already resident in
+ * HBM, e.g. torch tensors); the others take host pointers and stage them.
+ * There is no CPU fallback anywhere: without a GPU velo_create fails.
+ */
+#ifndef VELO_H
+#define VELO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VELO_ABI_VERSION 1
+#define VELO_MAX_ITERS 64
+#define VELO_MAX_KNORMALS 32
+
+enum {
+    VELO_OK = 0,
+    VELO_E_INVALID = -1,  /* bad argument */
+    VELO_E_NOMAP = -2,    /* registration asked before velo_map_reset */
+    VELO_E_DEVICE = -3,   /* HIP runtime error (see velo_last_error) */
+    VELO_E_NOMEM = -4,
+    VELO_E_RANGE = -5,    /* grid too large / d_max > voxel / too many frames */
+    VELO_E_NODATA = -6    /* empty pose store etc. */
+};
+
+typedef struct velo_ctx velo_ctx;
+
+typedef struct velo_cfg {
+    uint32_t struct_size;   /* = sizeof(velo_cfg) */
+    int32_t max_batch;      /* frames registered per launch (default 64) */
+    int32_t linearize_variant; /* 0 = default kernel; others are tuning variants */
+    int32_t sort_frames;    /* 1: order each frame's queries by map cell once per registration */
+    int32_t use_graph;      /* 1: replay the per-registration launch sequence as a hipGraph */
+    int32_t reserved[11];
+} velo_cfg;
+
+/* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */
+#define VELO_TIME_INVALID INT64_MIN
+typedef struct velo_pose {
+    double T[3];
+    double R[3]; /* roll, pitch, yaw in degrees */
+    double V[3];
+    int64_t t_us;
+    uint16_t week_number;
+    uint32_t milliseconds;
+    uint32_t week_number_pos;
+    double seconds_pos; /* -1 marks "not a valid transform" (type_defs.cxx:56) */
+} velo_pose;
+
+typedef struct velo_icp_iter {
+    uint32_t n_pairs; /* valid correspondences at the pose BEFORE this iteration's update */
+    uint32_t solve_flag; /* 0 ok, 1 diagonal guard used, 2 update skipped */
+    double rmse;      /* sqrt(sum r^2 / n_pairs) at that pose */
+} velo_icp_iter;
+
+typedef struct velo_icp_result {
+    double T[12];     /* final frame->map transform, row-major 3x4 */
+    double TRdeg[6];  /* same as T[3] + roll/pitch/yaw degrees (a5 convention) */
+    int32_t iters;
+    int32_t reserved;
+    uint64_t total_pairs; /* sum of n_pairs over the iterations */
+    velo_icp_iter iter[VELO_MAX_ITERS];
+} velo_icp_result;
+
+typedef struct velo_map_info {
+    uint64_t n_points;
+    uint64_t n_cells;
+    float origin[3];
+    float voxel;
+    float inv_voxel;
+    int32_t dims[3];
+    int32_t k_normals;
+    uint64_t n_invalid_normals;
+} velo_map_info;
+
+/* ---- lifetime -------------------------------------------------------------- */
+/* No reference counterpart (the reference is CPU-only).  cfg may be NULL. */
+velo_ctx* velo_create(int device_id, const velo_cfg* cfg);
+void velo_destroy(velo_ctx*);
+const char* velo_last_error(const velo_ctx*); /* ctx may be NULL: creation errors */
+int velo_abi_version(void);
+/* Run all work of this ctx on `hip_stream` (a hipStream_t, e.g. torch's current
+ * stream).  NULL = the ctx's own stream. */
+int velo_set_stream(velo_ctx*, void* hip_stream);
+int velo_synchronize(velo_ctx*);
+
+/* ---- map (the "accumulated MapPatch cloud" of the north star) ------------------
+ * The reference's MapPatch holds vector features, not points (MapPatch.h:7-17),
+ * and MapManager is unreachable (MapManager.h:15-48, all private): there is no
+ * reference call to replace.  These build the voxel-sorted point map that
+ * MapManager::registerFrame (include/veloslam/MapManager.hpp) registers against. */
+int velo_map_reset(velo_ctx*, const float* x, const float* y, const float* z, size_t n,
+                   float voxel, int k_normals);
+int velo_map_reset_dev(velo_ctx*, const float* dx, const float* dy, const float* dz, size_t n,
+                       float voxel, int k_normals);
+/* accepted increment: appended in call order, then the grid is rebuilt */
+int velo_map_append(velo_ctx*, const float* x, const float* y, const float* z, size_t n);
+int velo_map_append_dev(velo_ctx*, const float* dx, const float* dy, const float* dz, size_t n);
+int velo_map_info_get(velo_ctx*, velo_map_info* out);
+/* Test / inspection: copy the voxel-sorted map back.  Any pointer may be NULL.
+ * perm[s] = index of sorted point s in append order; cell_start has n_cells+1 entries. */
+int velo_map_download(velo_ctx*, float* x, float* y, float* z, float* nx, float* ny, float* nz,
+                      int32_t* perm, int32_t* cell_start);
+
+/* ---- K1: per-point SE(3) motion compensation --------------------------------------
+ * Replaces transformPoint<double>() (type_defs.h:160-166) as applied by
+ * HDLParser::vsInternal::pushFiringData (HDLParser.cxx:731-737): point i is
+ * multiplied by the affine of its packet, T3x4[pkt[i]], in double, and rounded
+ * once to float.  T3x4 comes from velo_packet_transforms (below). */
+int velo_compensate(velo_ctx*, const float* x, const float* y, const float* z,
+                    const uint16_t* pkt, size_t n, const double* T3x4, size_t n_pkt, float* ox,
+                    float* oy, float* oz);
+int velo_compensate_dev(velo_ctx*, const float* dx, const float* dy, const float* dz,
+                        const uint16_t* dpkt, size_t n, const double* dT3x4, size_t n_pkt,
+                        float* dox, float* doy, float* doz);
+
+/* ---- K2+K3+solve: scan-to-map ICP (no reference counterpart) -----------
+ * Point-to-plane Gauss-Newton, exactly `iters` iterations, nearest neighbour
+ * within d_max over the 27 map cells around the transformed point.  k must be 1
+ * in this ABI version (k-NN output is a later row).  Semantics: DESIGN.md
+ * "ICP semantics" == oracle/icp.c. */
+int velo_icp(velo_ctx*, const float* x, const float* y, const float* z, size_t n,
+             const double T0[12], int iters, float d_max, int k, velo_icp_result* out);
+
+/* Batched / resident form used for throughput: upload (or adopt) `n_frames`
+ * frames concatenated SoA, frame f = [frame_start[f], frame_start[f+1]). */
+int velo_frames_upload(velo_ctx*, int n_frames, const float* x, const float* y, const float* z,
+                       const int64_t* frame_start);
+int velo_frames_adopt_dev(velo_ctx*, int n_frames, const float* dx, const float* dy,
+                          const float* dz, const int64_t* frame_start /* host */);
+/* Register every resident frame against the current map snapshot.
+ * T0: n_frames x 12 ; out: n_frames results. */
+int velo_icp_batch(velo_ctx*, const double* T0, int iters, float d_max, velo_icp_result* out);
+/* Same, but leaves poses/statistics on the device and does not synchronise
+ * (bench inner loop); fetch with velo_icp_batch_fetch. */
+int velo_icp_batch_async(velo_ctx*, const double* T0, int iters, float d_max);
+int velo_icp_batch_fetch(velo_ctx*, velo_icp_result* out);
+
+/* Diagnostics for parity tests on resident frame `frame`: one linearisation at
+ * pose T.  corr (sorted map index or -1) and d2 may be NULL; acc = the 29
+ * doubles (21 upper-triangular JtJ, 6 Jtr, sum r^2, count). */
+int velo_linearize(velo_ctx*, int frame, const double T[12], float d_max, int32_t* corr,
+                   float* d2, double acc[29]);
+
+/* Accepted map increment of resident frame `frame` under pose T: points that land
+ * in a map cell holding fewer than min_count points, order preserving.  Outputs
+ * have room for the whole frame.  _dev writes device buffers (for the RCCL
+ * all-gather) and returns the count in *n_out. */
+int velo_increment(velo_ctx*, int frame, const double T[12], int min_count, float* ox, float* oy,
+                   float* oz, size_t* n_out);
+int velo_increment_dev(velo_ctx*, int frame, const double T[12], int min_count, float* dox,
+                       float* doy, float* doz, size_t* n_out);
+
+/* per-kernel device time of the last velo_icp_batch* call, HIP events on the ctx
+ * stream: [0] linearise kernel total ms, [1] its launch count, [2] solve total ms,
+ * [3] solve launches, [4] whole call ms */
+int velo_last_timing(velo_ctx*, double out[8]);
+/* enable (1) / disable (0) per-launch event timing (adds event records) */
+int velo_set_timing(velo_ctx*, int on);
+
+/* ---- host-side pose plumbing -------------------------------------------------------- */
+/* PoseTransform::getMatrix (type_defs.h:134-146) and its inverse. TRdeg = T[3] + R[3]. */
+int velo_matrix_from_pose(const double TRdeg[6], double T[12]);
+int velo_pose_from_matrix(const double T[12], double TRdeg[6]);
+/* TransformManager::interpolateTransform (TransformManager.cxx:149-177) over a
+ * caller-held array sorted by t_us.  Returns 0 and fills *out on "true", VELO_E_NODATA on
+ * "false" (empty store). out->seconds_pos keeps the reference's validity signal. */
+int velo_interp_pose(const velo_pose* sorted, size_t n, int64_t t_us, velo_pose* out);
+/* What HDLParser::processHDLPacket does per packet before the firing loop
+ * (HDLParser.cxx:988-1007): interpolate at each packet time, take packet 0's pose as
+ * carpose, subtract carpose.T (reprojectToFrameBeginning, :1057-1062), getMatrix.
+ * T3x4: n_pkt x 12.  valid[i]=0 where the reference would have left geotransform null
+ * (identity is written there).  carpose may be NULL. */
+int velo_packet_transforms(const velo_pose* sorted, size_t n, const int64_t* pkt_t_us,
+                           size_t n_pkt, double* T3x4, uint8_t* valid, velo_pose* carpose);
+
+/* ---- CoordiTran (CoordiTran.h:7-15): reference names and signatures verbatim -------- */
+void eulr2dcm(double eul_vect[3], double DCMbn[3][3]);
+void llh2xyz(double llh[3], double xyz[3]);
+void xyz2llh(double xyz[3], double llh[3]);
+void xyz2enu(double xyz[3], double orgxyz[3], double enu[3]);
+void enu2xyz(double enu[3], double orgxyz[3], double xyz[3]);
+void enu2llh(double enu[3], double orgxyz[3], double llh[3]);
+void llh2enu(double llh[3], double orgxyz[3], double enu[3]);
+double MappingAngle(double angle);
+/* HDL2enu (CoordiTran.h:12) is intentionally absent: the reference body reads an
+ * uninitialised array (CoordiTran.cpp:232,251) and nothing calls it. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VELO_H */

@@ -1,0 +1,58 @@
+// HDLFrame.hpp -- one LiDAR revolution (HDLFrame.h:13-83), stored struct-of-arrays
+// and beam-major so it uploads to HBM as-is: x[], y[], z[], intensity[] hold the
+// beams back to back in vertical order (after the HDL-64 beam LUT,
+// HDLParser.cxx:880-893) and beamStart[b]..beamStart[b+1] delimits beam b.
+// getPointsAsOneCloud(start,end) (HDLFrame.cxx:127-144) is therefore a zero-copy
+// view.  The advisory intrusive refcount (HDLFrame.cxx:211-219) is kept, atomic.
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+#include "PoseTransform.hpp"
+
+namespace veloslam {
+
+struct PointMeta {  // type_defs.h:168-176
+    unsigned short azimuth;
+    float distance;
+    unsigned char intensityFlag, distanceFlag, flags;
+};
+
+struct CloudView {  // what pcl::PointCloud<PointXYZI>::Ptr was to the reference's callers
+    const float* x;
+    const float* y;
+    const float* z;
+    const float* intensity;
+    size_t size;
+};
+
+struct HDLFrame {
+    HDLFrame();
+    int64_t timestamp;  // microseconds
+    std::vector<float> x, y, z, intensity;
+    std::vector<uint16_t> packetIndex;  // per point: which packet of `packets` produced it
+    std::vector<PointMeta> pointsMeta;
+    std::vector<int32_t> beamStart;     // 65 entries for 64 beams
+    std::vector<std::pair<int64_t, std::string>> packets;
+    std::shared_ptr<PoseTransform> carpose;
+    bool isInMemory, isOnHardDrive;
+    std::atomic<unsigned char> count;
+    uint8_t skips;
+
+    int numBeams() const { return beamStart.empty() ? 0 : (int)beamStart.size() - 1; }
+    size_t numPoints() const { return x.size(); }
+    // beams [startBeam, endBeam); like the reference, endBeam <= startBeam+1 yields
+    // the single beam startBeam (HDLFrame.cxx:133-136)
+    CloudView getPointsAsOneCloud(int startBeam = 0, int endBeam = 64) const;
+    void setPoints(const float* px, const float* py, const float* pz, const float* pi,
+                   const uint16_t* pkt, const int32_t* beam_start, int n_beams);
+    void clear();  // HDLFrame.cxx:146-158
+};
+
+void intrusive_ptr_add_ref(HDLFrame* p);
+void intrusive_ptr_release(HDLFrame* p);
+
+}  // namespace veloslam

@@ -72,7 +72,8 @@ void vo_pose_scale(const vo_pose* a, double ratio, vo_pose* o)
 /* Eigen AngleAxis::toRotationMatrix, restated (see header comment). */
 static void angle_axis_matrix(double angle, const double ax[3], double R[9])
 {
-    const double s = sin(angle), c = cos(angle);
+    double s, c;
+    sincos(angle, &s, &c); /* one libm entry point on both sides of the parity check */
     const double sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
     const double c1[3] = {(1.0 - c) * ax[0], (1.0 - c) * ax[1], (1.0 - c) * ax[2]};
     double tmp;

@@ -1,0 +1,294 @@
+"""GPU parity tests proper: every call goes through the C ABI of
+libveloslam_amd.so (HIP kernels on the MI355X) and is checked against the CPU
+oracle on the same seeded inputs.  Bit-exact for index / byte / fp32-rounded
+outputs; <= 1e-4 m and 1e-5 rad for the pose (north star)."""
+import numpy as np
+import pytest
+
+from veloslam_amd import capi
+from tests.util_scene import make_workload, pose_delta
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL = 1e-4  # metres   (BASELINE.json north_star)
+ROT_TOL = 1e-5  # radians
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0, max_batch=16)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def wl():
+    return make_workload(map_points=200_000, n_frames=3)
+
+
+@pytest.fixture(scope="module")
+def omap(oracle, wl):
+    return oracle.Map(*wl["map"], 1.0, 16)
+
+
+@pytest.fixture(scope="module")
+def comp(oracle, wl):
+    out = []
+    for f in wl["frames"]:
+        s = f["sensor"]
+        out.append(oracle.compensate(s["x"], s["y"], s["z"], s["pkt"], f["table"]))
+    return out
+
+
+# ------------------------------------------------------------------ K1 (a7)
+def test_compensate_bit_exact(ctx, oracle, wl, comp):
+    f = wl["frames"][0]
+    s = f["sensor"]
+    gx, gy, gz = ctx.compensate(s["x"], s["y"], s["z"], s["pkt"], f["table"])
+    assert np.array_equal(gx.view(np.uint32), comp[0][0].view(np.uint32))
+    assert np.array_equal(gy.view(np.uint32), comp[0][1].view(np.uint32))
+    assert np.array_equal(gz.view(np.uint32), comp[0][2].view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 63, 64, 65, 1023, 4099])
+def test_compensate_ragged_sizes(ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    x, y, z = (rng.uniform(-120, 120, n).astype(np.float32) for _ in range(3))
+    pkt = rng.integers(0, 7, n).astype(np.uint16)
+    tab = np.stack([capi.matrix_from_pose(rng.uniform(-5, 5, 3), rng.uniform(-180, 180, 3))
+                    for _ in range(7)])
+    g = ctx.compensate(x, y, z, pkt, tab)
+    o = oracle.compensate(x, y, z, pkt, tab)
+    for a, b in zip(g, o):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_compensate_empty_and_identity(ctx):
+    e = np.zeros(0, np.float32)
+    tab = np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]], dtype=np.float64)
+    ox, oy, oz = ctx.compensate(e, e, e, np.zeros(0, np.uint16), tab)
+    assert ox.size == 0
+    x = np.linspace(-50, 50, 1000).astype(np.float32)
+    ox, oy, oz = ctx.compensate(x, x[::-1].copy(), x * 0.1, np.zeros(1000, np.uint16), tab)
+    assert np.array_equal(ox, x)
+
+
+# ------------------------------------------------------------ map build (a10)
+def test_map_build_bit_exact(ctx, omap, wl):
+    ctx.map_reset(*wl["map"], 1.0, 16)
+    g = ctx.map_download()
+    mi = ctx.map_info()
+    o, d, ih = omap.grid()
+    assert list(mi.dims) == list(d) and np.array_equal(np.array(list(mi.origin), np.float32), o)
+    assert mi.n_cells == omap.ncell
+    assert np.array_equal(g["cell_start"], omap.cell_start())
+    assert np.array_equal(g["perm"], omap.perm())
+    sx, sy, sz = omap.sorted_xyz()
+    assert np.array_equal(g["x"], sx) and np.array_equal(g["y"], sy) and np.array_equal(g["z"], sz)
+    nx, ny, nz = omap.normals()
+    for a, b in ((g["nx"], nx), (g["ny"], ny), (g["nz"], nz)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert mi.n_invalid_normals == int(((nx == 0) & (ny == 0) & (nz == 0)).sum())
+
+
+@pytest.mark.parametrize("voxel,k", [(0.5, 8), (2.0, 32), (1.0, 5)])
+def test_map_build_other_grids(ctx, oracle, voxel, k):
+    rng = np.random.default_rng(int(voxel * 10) + k)
+    n = 30000
+    x = rng.uniform(-20, 20, n).astype(np.float32)
+    y = rng.uniform(-15, 15, n).astype(np.float32)
+    z = (0.05 * np.sin(x) + rng.normal(0, 0.01, n)).astype(np.float32)
+    om = oracle.Map(x, y, z, voxel, k)
+    ctx.map_reset(x, y, z, voxel, k)
+    g = ctx.map_download()
+    assert np.array_equal(g["cell_start"], om.cell_start())
+    assert np.array_equal(g["perm"], om.perm())
+    for a, b in zip((g["nx"], g["ny"], g["nz"]), om.normals()):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_map_append_equals_rebuild(ctx, oracle):
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-10, 10, (3, 5000)).astype(np.float32)
+    more = rng.uniform(-14, 14, (3, 700)).astype(np.float32)
+    ctx.map_reset(*pts, 1.0, 8)
+    ctx.map_append(*more)
+    g = ctx.map_download()
+    om = oracle.Map(*np.concatenate([pts, more], axis=1), 1.0, 8)
+    assert np.array_equal(g["perm"], om.perm())
+    assert np.array_equal(g["cell_start"], om.cell_start())
+    for a, b in zip((g["nx"], g["ny"], g["nz"]), om.normals()):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+# ------------------------------------------------- correspondences + sums (a10, a11)
+def test_linearize_corr_bit_exact_and_sums(ctx, omap, wl, comp):
+    ctx.map_reset(*wl["map"], 1.0, 16)
+    ctx.frames_upload(comp)
+    for fi, f in enumerate(wl["frames"]):
+        for T in (f["T0"], f["T_true"]):
+            n = comp[fi][0].size
+            corr, d2, acc = ctx.linearize(fi, T, 1.0, n)
+            oc, od2, cand = omap.correspond(*comp[fi], T, 1.0)
+            assert np.array_equal(corr, oc)
+            assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+            oacc = omap.accumulate(*comp[fi], T, oc)
+            assert acc[28] == oacc[28]
+            np.testing.assert_allclose(acc, oacc, rtol=1e-11, atol=1e-9)
+
+
+def test_queries_outside_grid_and_dmax(ctx, oracle):
+    rng = np.random.default_rng(11)
+    m = rng.uniform(0, 8, (3, 4000)).astype(np.float32)
+    om = oracle.Map(*m, 1.0, 8)
+    ctx.map_reset(*m, 1.0, 8)
+    q = rng.uniform(-6, 14, (3, 5000)).astype(np.float32)  # many far outside the AABB
+    ctx.frames_upload([tuple(q)])
+    I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)
+    for dmax in (1.0, 0.3):
+        corr, d2, acc = ctx.linearize(0, I, dmax, 5000)
+        oc, od2, _ = om.correspond(*q, I, dmax)
+        assert np.array_equal(corr, oc) and (oc < 0).any() and (oc >= 0).any()
+        assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+    with pytest.raises(capi.VeloError):
+        ctx.linearize(0, I, 1.5, 5000)  # d_max > voxel is refused
+
+
+def test_exact_ties_pick_lowest_sorted_index(ctx, oracle):
+    """Duplicate map points and a query equidistant to several of them."""
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0.5, 0.5, 0.5]], np.float32)
+    m = np.concatenate([base, base, base + np.float32(2.0)], axis=0)
+    rng = np.random.default_rng(2)
+    m = np.concatenate([m, rng.uniform(-1, 4, (200, 3)).astype(np.float32)], axis=0)
+    om = oracle.Map(m[:, 0], m[:, 1], m[:, 2], 1.0, 5)
+    ctx.map_reset(m[:, 0], m[:, 1], m[:, 2], 1.0, 5)
+    q = np.array([[0.5, 0.5, 0], [0, 0, 0], [1, 1, 0], [2.5, 2.5, 2.0]], np.float32)
+    ctx.frames_upload([(q[:, 0].copy(), q[:, 1].copy(), q[:, 2].copy())])
+    I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)
+    corr, d2, _ = ctx.linearize(0, I, 1.0, 4)
+    oc, od2, _ = om.correspond(q[:, 0], q[:, 1], q[:, 2], I, 1.0)
+    assert np.array_equal(corr, oc)
+
+
+# ------------------------------------------------------------------ ICP (a9..a12)
+def test_icp_pose_matches_oracle(ctx, omap, wl, comp):
+    ctx.map_reset(*wl["map"], 1.0, 16)
+    f = wl["frames"][0]
+    res = ctx.icp(*comp[0], f["T0"], 20, 1.0)
+    T_o, st, trace = omap.icp(*comp[0], f["T0"], 20, 1.0)
+    dpos, drot = pose_delta(res.T, T_o)
+    assert dpos <= POS_TOL and drot <= ROT_TOL, (dpos, drot)
+    for i in range(20):
+        assert res.iter[i].n_pairs == st[i]["n_pairs"]
+        assert abs(res.iter[i].rmse - st[i]["rmse"]) < 1e-9
+    # and the registration is right, not merely consistent: centimetres from truth
+    dpos_t, drot_t = pose_delta(res.T, f["T_true"])
+    assert dpos_t < 0.02 and drot_t < 5e-4
+    tr = capi.pose_from_matrix(np.array(list(res.T)))
+    assert np.allclose(tr, list(res.TRdeg))
+
+
+def test_icp_batch_equals_single_and_is_deterministic(ctx, omap, wl, comp):
+    ctx.map_reset(*wl["map"], 1.0, 16)
+    T0 = np.stack([f["T0"] for f in wl["frames"]])
+    ctx.frames_upload(comp)
+    r1 = ctx.icp_batch(T0, 10, 1.0)
+    r2 = ctx.icp_batch(T0, 10, 1.0)
+    for a, b in zip(r1, r2):  # run-to-run bit reproducible (fixed reduction order)
+        assert list(a.T) == list(b.T)
+    for fi in range(len(comp)):
+        single = ctx.icp(*comp[fi], T0[fi], 10, 1.0)
+        assert list(single.T) == list(r1[fi].T)
+        T_o, _, _ = omap.icp(*comp[fi], T0[fi], 10, 1.0)
+        dpos, drot = pose_delta(r1[fi].T, T_o)
+        assert dpos <= POS_TOL and drot <= ROT_TOL
+
+
+def test_icp_ragged_batch_with_empty_frame(ctx, omap, wl, comp):
+    ctx.map_reset(*wl["map"], 1.0, 16)
+    e = np.zeros(0, np.float32)
+    part = tuple(a[:777].copy() for a in comp[1])
+    frames = [comp[0], (e, e, e), part]
+    T0 = np.stack([wl["frames"][0]["T0"], wl["frames"][0]["T0"], wl["frames"][1]["T0"]])
+    ctx.frames_upload(frames)
+    r = ctx.icp_batch(T0, 5, 1.0)
+    assert r[1].iter[0].n_pairs == 0 and r[1].iter[0].solve_flag == 2
+    assert list(r[1].T) == list(T0[1])  # untouched pose
+    T_o, st, _ = omap.icp(*part, T0[2], 5, 1.0)
+    dpos, drot = pose_delta(r[2].T, T_o)
+    assert dpos <= POS_TOL and drot <= ROT_TOL
+    assert r[2].iter[4].n_pairs == st[4]["n_pairs"]
+
+
+def test_sorted_query_order_gives_same_pose(omap, wl, comp):
+    c2 = capi.Context(0, max_batch=4, sort_frames=1)
+    try:
+        c2.map_reset(*wl["map"], 1.0, 16)
+        f = wl["frames"][0]
+        res = c2.icp(*comp[0], f["T0"], 10, 1.0)
+        T_o, st, _ = omap.icp(*comp[0], f["T0"], 10, 1.0)
+        dpos, drot = pose_delta(res.T, T_o)
+        assert dpos <= POS_TOL and drot <= ROT_TOL
+        assert res.iter[9].n_pairs == st[9]["n_pairs"]
+    finally:
+        c2.close()
+
+
+# ------------------------------------------------------------- increment (8e)
+def test_increment_bit_exact(ctx, omap, wl, comp):
+    ctx.map_reset(*wl["map"], 1.0, 16)
+    ctx.frames_upload(comp)
+    T = wl["frames"][1]["T_true"]
+    for mc in (1, 3, 40):
+        gx, gy, gz = ctx.increment(1, T, mc, comp[1][0].size)
+        ox, oy, oz = omap.increment(*comp[1], T, mc)
+        assert gx.size == ox.size
+        assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gz, oz)
+
+
+# ------------------------------------------------------------------ error paths
+def test_errors_are_loud(wl):
+    c = capi.Context(0, max_batch=2)
+    try:
+        with pytest.raises(capi.VeloError):
+            c.icp(np.zeros(4, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32),
+                  np.eye(3, 4).ravel(), 5, 1.0)  # no map yet
+        c.map_reset(*[a[:1000] for a in wl["map"]], 1.0, 8)
+        with pytest.raises(capi.VeloError):
+            c.frames_upload([(np.zeros(1, np.float32),) * 3] * 3)  # > max_batch
+        with pytest.raises(capi.VeloError):
+            c.map_reset(np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32))
+    finally:
+        c.close()
+
+
+# ------------------------------------------- full BASELINE size, property checks
+def test_config2_full_size_properties(oracle):
+    """BASELINE config 2: 115 200-point frame vs 1 M-point map, 20 iterations.
+    Checked through size-independent properties (ground truth, idempotence of a
+    converged pose, sortedness of the cell table) plus the oracle pose."""
+    wl = make_workload(map_points=1_000_000, n_frames=1)
+    c = capi.Context(0, max_batch=2)
+    try:
+        f = wl["frames"][0]
+        s = f["sensor"]
+        cx, cy, cz = c.compensate(s["x"], s["y"], s["z"], s["pkt"], f["table"])
+        c.map_reset(*wl["map"], 1.0, 16)
+        g = c.map_download()
+        assert np.all(np.diff(g["cell_start"]) >= 0) and g["cell_start"][-1] == 1_000_000
+        assert np.array_equal(np.sort(g["perm"]), np.arange(1_000_000, dtype=np.int32))
+        nn = g["nx"].astype(np.float64) ** 2 + g["ny"].astype(np.float64) ** 2 + g["nz"].astype(np.float64) ** 2
+        assert np.all((np.abs(nn - 1) < 1e-6) | (nn == 0))
+        res = c.icp(cx, cy, cz, f["T0"], 20, 1.0)
+        dpos_t, drot_t = pose_delta(res.T, f["T_true"])
+        assert dpos_t < 0.01 and drot_t < 2e-4
+        again = c.icp(cx, cy, cz, np.array(list(res.T)), 5, 1.0)  # fixed point
+        dpos, drot = pose_delta(again.T, res.T)
+        assert dpos < 1e-6 and drot < 1e-8
+        om = oracle.Map(*wl["map"], 1.0, 16)
+        T_o, st, _ = om.icp(cx, cy, cz, f["T0"], 20, 1.0, threads=8)
+        dpos, drot = pose_delta(res.T, T_o)
+        assert dpos <= POS_TOL and drot <= ROT_TOL
+        assert res.total_pairs == sum(s_["n_pairs"] for s_ in st)
+    finally:
+        c.close()

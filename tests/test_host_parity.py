@@ -1,0 +1,153 @@
+"""CPU-side parity of the product's host code (libveloslam_amd.so, no GPU calls)
+against the oracle and the reference-cut golden vectors: SURVEY 8 rows a1..a6,
+plus the C-ABI export check."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from veloslam_amd import capi
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "coorditran.json")
+
+
+def unhex(v):
+    return np.array([float.fromhex(s) for s in v], dtype=np.float64)
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "velo.h")).read()
+    for name in capi.EXPORTS:
+        assert name + "(" in hdr, "velo.h does not declare " + name
+        assert getattr(L, name) is not None
+    assert L.velo_abi_version() == 1
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = capi.lib()
+    with pytest.raises(capi.VeloError) as ei:
+        capi.Context(0)
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_geodesy_bit_exact_vs_reference_vectors():
+    gold = json.load(open(GOLD))
+    for c in gold["llh_cases"]:
+        llh, org = unhex(c["llh"]), unhex(c["org"])
+        xyz = capi.llh2xyz(llh)
+        assert same_bits(xyz, unhex(c["llh2xyz"]))
+        assert same_bits(capi.xyz2llh(xyz), unhex(c["xyz2llh"]))
+        enu = capi.llh2enu(llh, org)
+        assert same_bits(enu, unhex(c["llh2enu"]))
+        assert same_bits(capi.xyz2enu(xyz, org), unhex(c["xyz2enu"]))
+        assert same_bits(capi.enu2xyz(enu, org), unhex(c["enu2xyz"]))
+        assert same_bits(capi.enu2llh(enu, org), unhex(c["enu2llh"]))
+    for c in gold["eulr2dcm"]:
+        assert same_bits(capi.eulr2dcm(unhex(c["eul"])).ravel(), unhex(c["dcm"]))
+    for c in gold["mapping_angle"]:
+        assert same_bits([capi.mapping_angle(float.fromhex(c["angle"]))],
+                         [float.fromhex(c["out"])])
+
+
+def test_matrix_from_pose_matches_oracle_bitwise(oracle):
+    rng = np.random.default_rng(5)
+    for k in range(500):
+        T = rng.uniform(-500, 500, 3)
+        R = rng.uniform(-180, 180, 3) if k else np.zeros(3)
+        a = capi.matrix_from_pose(T, R)
+        b = oracle.pose_matrix(T, R)
+        assert same_bits(a, b)
+        back = capi.pose_from_matrix(a)
+        assert same_bits(back, oracle.matrix_to_TRdeg(b))
+
+
+def _timeline_pair(oracle, times, rng):
+    tl = oracle.Timeline()
+    samples = []
+    for t in times:
+        T, R, V = rng.uniform(-100, 100, 3), rng.uniform(-180, 180, 3), rng.uniform(-20, 20, 3)
+        tl.add(T, R, V, int(t))
+        samples.append((T, R, V, int(t)))
+    poses, n = capi.make_poses(samples)
+    return tl, poses, n
+
+
+def _same_pose(a, b):
+    return (same_bits(list(a.T), list(b.T)) and same_bits(list(a.R), list(b.R))
+            and same_bits(list(a.V), list(b.V)) and a.t_us == b.t_us
+            and a.seconds_pos == b.seconds_pos)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 11, 40, 400])
+def test_interp_pose_matches_oracle_timeline(oracle, n):
+    """In-order appends (the reference's producer pattern, INSSource.cxx:217-242): 10 ms
+    +- 1 ms spacing like Test/InterpolateTransformMeasure.cxx:50-58; queries before the
+    start, after the end, between samples and exactly on knots."""
+    rng = np.random.default_rng(100 + n)
+    t0 = 1_467_590_400_000_000
+    times = t0 + np.cumsum(np.maximum(1, (10000 + rng.normal(0, 1000, n)).astype(np.int64)))
+    tl, poses, cnt = _timeline_pair(oracle, times, rng)
+    qs = []
+    if n:
+        qs += [int(times[0]) - 5000, int(times[0]), int(times[-1]), int(times[-1]) + 7777]
+        qs += [int(t) for t in times]  # every knot
+        qs += [int(q) for q in rng.integers(times[0] - 2000, times[-1] + 2000, 200)]
+    else:
+        qs = [t0]
+    for q in qs:
+        ok_o, po = tl.interpolate(q)
+        ok_p, pp = capi.interp_pose(poses, cnt, q)
+        assert ok_o == ok_p
+        if ok_o:
+            assert _same_pose(po, pp), "query %d of %d samples" % (q, n)
+
+
+def test_single_sample_extrapolates_and_stays_invalid(oracle):
+    poses, n = capi.make_poses([((1, 2, 3), (4, 5, 6), (10, 0, -1), 1_000_000)])
+    ok, p = capi.interp_pose(poses, n, 1_123_456)
+    assert ok and p.seconds_pos == -1  # TransformManager.cxx:159-167
+    sec = float(np.float32(123456) / np.float32(1e6))  # float division quirk, :161
+    assert p.T[0] == 1 + 10 * sec and p.T[2] == 3 - sec
+
+
+def test_euler_lerp_has_no_wrap_handling(oracle):
+    """a4 quirk: angles are interpolated linearly in degrees (TransformManager.cxx:173)."""
+    poses, n = capi.make_poses([((0, 0, 0), (0, 0, 179), (0, 0, 0), 0),
+                                ((0, 0, 0), (0, 0, -179), (0, 0, 0), 1000)])
+    ok, p = capi.interp_pose(poses, n, 500)
+    assert ok and p.R[2] == 0.0 and p.seconds_pos == 0
+
+
+def test_packet_transforms_match_oracle(oracle):
+    from veloslam_amd import synth
+    mo = synth.Motion()
+    t_pk = [mo.t0_us + 3 * synth.FRAME_US + i * synth.PKT_US for i in range(300)]
+    track = mo.ins_track(t_pk[0], t_pk[-1])
+    tl = oracle.Timeline()
+    for (T, R, V, t) in track:
+        tl.add(T, R, V, t)
+    poses, n = capi.make_poses(track)
+    tab, valid, car = capi.packet_transforms(poses, n, t_pk)
+    assert valid.all()
+    _, car_o = tl.interpolate(t_pk[0])
+    assert same_bits(list(car.T), list(car_o.T))
+    for i, t in enumerate(t_pk):
+        _, p = tl.interpolate(t)
+        M = oracle.pose_matrix(np.array(p.T) - np.array(car_o.T), np.array(p.R))
+        assert same_bits(tab[i], M)
+    # empty store: the reference leaves geotransform null -> identity, valid = 0
+    e, _ = capi.make_poses([])
+    tab, valid, _ = capi.packet_transforms(e, 0, t_pk[:3])
+    assert not valid.any() and np.array_equal(tab[0], [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0])

@@ -1,0 +1,378 @@
+"""ctypes doorway to libveloslam_amd.so (include/velo.h).
+
+This is plumbing only: it marshals numpy arrays / device pointers into the C ABI.
+There is no Python or CPU implementation behind it -- if the shared library has
+not been built, or no MI355X is visible, the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libveloslam_amd.so")
+
+VELO_MAX_ITERS = 64
+VELO_TIME_INVALID = -(2 ** 63)
+
+
+class VeloError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("velo error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Cfg(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("max_batch", C.c_int32),
+                ("linearize_variant", C.c_int32), ("sort_frames", C.c_int32),
+                ("use_graph", C.c_int32), ("reserved", C.c_int32 * 11)]
+
+
+class Pose(C.Structure):
+    _fields_ = [("T", C.c_double * 3), ("R", C.c_double * 3), ("V", C.c_double * 3),
+                ("t_us", C.c_int64), ("week_number", C.c_uint16), ("milliseconds", C.c_uint32),
+                ("week_number_pos", C.c_uint32), ("seconds_pos", C.c_double)]
+
+
+class IcpIter(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint32), ("solve_flag", C.c_uint32), ("rmse", C.c_double)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("T", C.c_double * 12), ("TRdeg", C.c_double * 6), ("iters", C.c_int32),
+                ("reserved", C.c_int32), ("total_pairs", C.c_uint64),
+                ("iter", IcpIter * VELO_MAX_ITERS)]
+
+
+class MapInfo(C.Structure):
+    _fields_ = [("n_points", C.c_uint64), ("n_cells", C.c_uint64), ("origin", C.c_float * 3),
+                ("voxel", C.c_float), ("inv_voxel", C.c_float), ("dims", C.c_int32 * 3),
+                ("k_normals", C.c_int32), ("n_invalid_normals", C.c_uint64)]
+
+
+# every symbol include/velo.h declares (tests check the library exports them all)
+EXPORTS = [
+    "velo_create", "velo_destroy", "velo_last_error", "velo_abi_version", "velo_set_stream",
+    "velo_synchronize", "velo_map_reset", "velo_map_reset_dev", "velo_map_append",
+    "velo_map_append_dev", "velo_map_info_get", "velo_map_download", "velo_compensate",
+    "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
+    "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
+    "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing",
+    "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
+    "velo_packet_transforms", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
+    "llh2enu", "MappingAngle",
+]
+
+
+def build(verbose=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libveloslam_amd.so is not built (%s). Run `make -C veloslam_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback."
+            % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    fp, dp, ip = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    L.velo_create.restype = vp
+    L.velo_create.argtypes = [C.c_int, C.POINTER(Cfg)]
+    L.velo_destroy.argtypes = [vp]
+    L.velo_last_error.restype = C.c_char_p
+    L.velo_last_error.argtypes = [vp]
+    L.velo_set_stream.argtypes = [vp, vp]
+    L.velo_synchronize.argtypes = [vp]
+    L.velo_map_reset.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_int]
+    L.velo_map_reset_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_int]
+    L.velo_map_append.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.velo_map_append_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.velo_map_info_get.argtypes = [vp, C.POINTER(MapInfo)]
+    L.velo_map_download.argtypes = [vp] + [vp] * 8
+    L.velo_compensate.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp]
+    L.velo_compensate_dev.argtypes = L.velo_compensate.argtypes
+    L.velo_icp.argtypes = [vp, vp, vp, vp, C.c_size_t, dp, C.c_int, C.c_float, C.c_int,
+                           C.POINTER(IcpResult)]
+    L.velo_frames_upload.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.velo_frames_adopt_dev.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.velo_icp_batch.argtypes = [vp, dp, C.c_int, C.c_float, C.POINTER(IcpResult)]
+    L.velo_icp_batch_async.argtypes = [vp, dp, C.c_int, C.c_float]
+    L.velo_icp_batch_fetch.argtypes = [vp, C.POINTER(IcpResult)]
+    L.velo_linearize.argtypes = [vp, C.c_int, dp, C.c_float, vp, vp, dp]
+    L.velo_increment.argtypes = [vp, C.c_int, dp, C.c_int, vp, vp, vp, C.POINTER(C.c_size_t)]
+    L.velo_increment_dev.argtypes = L.velo_increment.argtypes
+    L.velo_last_timing.argtypes = [vp, dp]
+    L.velo_set_timing.argtypes = [vp, C.c_int]
+    L.velo_matrix_from_pose.argtypes = [dp, dp]
+    L.velo_pose_from_matrix.argtypes = [dp, dp]
+    L.velo_interp_pose.argtypes = [C.POINTER(Pose), C.c_size_t, C.c_int64, C.POINTER(Pose)]
+    L.velo_packet_transforms.argtypes = [C.POINTER(Pose), C.c_size_t, C.POINTER(C.c_int64),
+                                         C.c_size_t, dp, C.POINTER(C.c_uint8), C.POINTER(Pose)]
+    for nm in ("llh2xyz", "xyz2llh"):
+        getattr(L, nm).argtypes = [dp, dp]
+    for nm in ("xyz2enu", "enu2xyz", "enu2llh", "llh2enu"):
+        getattr(L, nm).argtypes = [dp, dp, dp]
+    L.eulr2dcm.argtypes = [dp, dp]
+    L.MappingAngle.argtypes = [C.c_double]
+    L.MappingAngle.restype = C.c_double
+    _lib = L
+    return L
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# --------------------------------------------------------------- host helpers
+def matrix_from_pose(T, Rdeg):
+    tr = np.array(list(T) + list(Rdeg), dtype=np.float64)
+    M = np.zeros(12)
+    lib().velo_matrix_from_pose(_d(tr), _d(M))
+    return M
+
+
+def pose_from_matrix(M):
+    M = np.ascontiguousarray(M, dtype=np.float64).reshape(12)
+    tr = np.zeros(6)
+    lib().velo_pose_from_matrix(_d(M), _d(tr))
+    return tr
+
+
+def make_poses(samples):
+    """samples: iterable of (T, Rdeg, V, t_us[, seconds_pos]) -> ctypes array of Pose."""
+    samples = list(samples)
+    arr = (Pose * max(len(samples), 1))()
+    for i, s in enumerate(samples):
+        T, R, V, t = s[:4]
+        for k in range(3):
+            arr[i].T[k], arr[i].R[k], arr[i].V[k] = float(T[k]), float(R[k]), float(V[k])
+        arr[i].t_us = int(t)
+        arr[i].seconds_pos = float(s[4]) if len(s) > 4 else 0.0
+    return arr, len(samples)
+
+
+def interp_pose(poses, n, t_us):
+    out = Pose()
+    rc = lib().velo_interp_pose(poses, n, int(t_us), C.byref(out))
+    return rc == 0, out
+
+
+def packet_transforms(poses, n, pkt_times):
+    t = np.ascontiguousarray(pkt_times, dtype=np.int64)
+    tab = np.zeros((t.size, 12))
+    valid = np.zeros(t.size, dtype=np.uint8)
+    car = Pose()
+    rc = lib().velo_packet_transforms(poses, n, t.ctypes.data_as(C.POINTER(C.c_int64)), t.size,
+                                      _d(tab), valid.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                      C.byref(car))
+    if rc:
+        raise VeloError(rc, "velo_packet_transforms")
+    return tab, valid, car
+
+
+def _geo2(name, a):
+    a = np.ascontiguousarray(a, dtype=np.float64).copy()
+    o = np.zeros(3)
+    getattr(lib(), name)(_d(a), _d(o))
+    return o
+
+
+def _geo3(name, a, org):
+    a = np.ascontiguousarray(a, dtype=np.float64).copy()
+    org = np.ascontiguousarray(org, dtype=np.float64).copy()
+    o = np.zeros(3)
+    getattr(lib(), name)(_d(a), _d(org), _d(o))
+    return o
+
+
+def llh2xyz(a): return _geo2("llh2xyz", a)
+def xyz2llh(a): return _geo2("xyz2llh", a)
+def xyz2enu(a, org): return _geo3("xyz2enu", a, org)
+def enu2xyz(a, org): return _geo3("enu2xyz", a, org)
+def enu2llh(a, org): return _geo3("enu2llh", a, org)
+def llh2enu(a, org): return _geo3("llh2enu", a, org)
+
+
+def eulr2dcm(e):
+    e = np.ascontiguousarray(e, dtype=np.float64).copy()
+    o = np.zeros(9)
+    lib().eulr2dcm(_d(e), _d(o))
+    return o.reshape(3, 3)
+
+
+def mapping_angle(a):
+    return lib().MappingAngle(float(a))
+
+
+# ----------------------------------------------------------------- GPU context
+class Context:
+    """One velo_ctx: one GPU, one stream, single-threaded."""
+
+    def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=0):
+        L = lib()
+        cfg = Cfg()
+        cfg.struct_size = C.sizeof(Cfg)
+        cfg.max_batch = max_batch
+        cfg.sort_frames = sort_frames
+        cfg.linearize_variant = linearize_variant
+        self.h = L.velo_create(device, C.byref(cfg))
+        if not self.h:
+            raise VeloError(-3, L.velo_last_error(None).decode())
+        self.max_batch = max_batch
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().velo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise VeloError(rc, lib().velo_last_error(self.h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._chk(lib().velo_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        self._chk(lib().velo_synchronize(self.h))
+
+    def set_timing(self, on):
+        self._chk(lib().velo_set_timing(self.h, int(on)))
+
+    def last_timing(self):
+        t = np.zeros(8)
+        self._chk(lib().velo_last_timing(self.h, _d(t)))
+        return dict(linearize_ms=t[0], linearize_launches=int(t[1]), solve_ms=t[2],
+                    solve_launches=int(t[3]), call_ms=t[4])
+
+    # ---- map
+    def map_reset(self, x, y, z, voxel=1.0, k_normals=16):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        self._chk(lib().velo_map_reset(self.h, _p(x), _p(y), _p(z), x.size, voxel, k_normals))
+
+    def map_reset_dev(self, px, py, pz, n, voxel=1.0, k_normals=16):
+        self._chk(lib().velo_map_reset_dev(self.h, px, py, pz, n, voxel, k_normals))
+
+    def map_append(self, x, y, z):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        self._chk(lib().velo_map_append(self.h, _p(x), _p(y), _p(z), x.size))
+
+    def map_append_dev(self, px, py, pz, n):
+        self._chk(lib().velo_map_append_dev(self.h, px, py, pz, n))
+
+    def map_info(self):
+        mi = MapInfo()
+        self._chk(lib().velo_map_info_get(self.h, C.byref(mi)))
+        return mi
+
+    def map_download(self):
+        mi = self.map_info()
+        n, nc = mi.n_points, mi.n_cells
+        out = {k: np.empty(n, np.float32) for k in ("x", "y", "z", "nx", "ny", "nz")}
+        out["perm"] = np.empty(n, np.int32)
+        out["cell_start"] = np.empty(nc + 1, np.int32)
+        self._chk(lib().velo_map_download(self.h, *[_p(out[k]) for k in
+                                                    ("x", "y", "z", "nx", "ny", "nz", "perm",
+                                                     "cell_start")]))
+        return out
+
+    # ---- K1
+    def compensate(self, x, y, z, pkt, table):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        pkt = np.ascontiguousarray(pkt, dtype=np.uint16)
+        table = np.ascontiguousarray(table, dtype=np.float64).reshape(-1, 12)
+        ox, oy, oz = (np.empty(x.size, np.float32) for _ in range(3))
+        self._chk(lib().velo_compensate(self.h, _p(x), _p(y), _p(z), _p(pkt), x.size, _p(table),
+                                        table.shape[0], _p(ox), _p(oy), _p(oz)))
+        return ox, oy, oz
+
+    def compensate_dev(self, px, py, pz, ppkt, n, ptab, n_pkt, pox, poy, poz):
+        self._chk(lib().velo_compensate_dev(self.h, px, py, pz, ppkt, n, ptab, n_pkt, pox, poy, poz))
+
+    # ---- ICP
+    def icp(self, x, y, z, T0, iters=20, d_max=1.0):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        T0 = np.ascontiguousarray(T0, dtype=np.float64).reshape(12)
+        res = IcpResult()
+        self._chk(lib().velo_icp(self.h, _p(x), _p(y), _p(z), x.size, _d(T0), iters, d_max, 1,
+                                 C.byref(res)))
+        return res
+
+    def frames_upload(self, frames):
+        """frames: list of (x, y, z) float arrays."""
+        xs = _f32(np.concatenate([f[0] for f in frames]))
+        ys = _f32(np.concatenate([f[1] for f in frames]))
+        zs = _f32(np.concatenate([f[2] for f in frames]))
+        fs = np.zeros(len(frames) + 1, dtype=np.int64)
+        fs[1:] = np.cumsum([len(f[0]) for f in frames])
+        self._chk(lib().velo_frames_upload(self.h, len(frames), _p(xs), _p(ys), _p(zs), _p(fs)))
+        self.n_frames = len(frames)
+
+    def frames_adopt_dev(self, px, py, pz, frame_start):
+        fs = np.ascontiguousarray(frame_start, dtype=np.int64)
+        self._chk(lib().velo_frames_adopt_dev(self.h, fs.size - 1, px, py, pz, _p(fs)))
+        self.n_frames = fs.size - 1
+
+    def icp_batch(self, T0, iters=20, d_max=1.0):
+        T0 = np.ascontiguousarray(T0, dtype=np.float64).reshape(self.n_frames, 12)
+        res = (IcpResult * self.n_frames)()
+        self._chk(lib().velo_icp_batch(self.h, _d(T0), iters, d_max, res))
+        return res
+
+    def icp_batch_async(self, T0, iters=20, d_max=1.0):
+        T0 = np.ascontiguousarray(T0, dtype=np.float64).reshape(self.n_frames, 12)
+        self._chk(lib().velo_icp_batch_async(self.h, _d(T0), iters, d_max))
+
+    def icp_batch_fetch(self):
+        res = (IcpResult * self.n_frames)()
+        self._chk(lib().velo_icp_batch_fetch(self.h, res))
+        return res
+
+    def linearize(self, frame, T, d_max, n):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)
+        corr = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        acc = np.zeros(29)
+        self._chk(lib().velo_linearize(self.h, frame, _d(T), d_max, _p(corr), _p(d2), _d(acc)))
+        return corr, d2, acc
+
+    def increment(self, frame, T, min_count, n):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)
+        ox, oy, oz = (np.empty(n, np.float32) for _ in range(3))
+        cnt = C.c_size_t()
+        self._chk(lib().velo_increment(self.h, frame, _d(T), min_count, _p(ox), _p(oy), _p(oz),
+                                       C.byref(cnt)))
+        k = cnt.value
+        return ox[:k].copy(), oy[:k].copy(), oz[:k].copy()
+
+    def increment_dev(self, frame, T, min_count, pox, poy, poz):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)
+        cnt = C.c_size_t()
+        self._chk(lib().velo_increment_dev(self.h, frame, _d(T), min_count, pox, poy, poz,
+                                           C.byref(cnt)))
+        return cnt.value

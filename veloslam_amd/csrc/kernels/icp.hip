@@ -1,0 +1,465 @@
+// icp.hip -- the per-iteration hot path on gfx950:
+//   k_linearize     K2+K3 fused: SE(3) transform of the query, nearest neighbour
+//                   over the 27 map cells, point-to-plane residual + Jacobian,
+//                   block reduction of the 29 normal-equation sums
+//   k_reduce_solve  fixed-order sum of the block partials, 6x6 LDLt, pose update
+// plus the small kernels around them (compensation K1, frame cell keys, map
+// increment).  Semantics: DESIGN.md "ICP semantics" == oracle/icp.c; the
+// reference has no counterpart.  Bandwidth/latency-bound integer
+// and fp32 work: no MFMA anywhere.
+#include "device_math.hpp"
+
+namespace velo {
+
+// =============================================================== K1 compensate
+// type_defs.h:160-166 semantics: ((m0*x + m1*y) + m2*z) + m3, each product
+// rounded (the TU is built with -ffp-contract=off), one rounding to float.
+__device__ __forceinline__ void apply_affine(const double* __restrict__ M, float x, float y,
+                                             float z, float& ox, float& oy, float& oz)
+{
+    const double dx = (double)x, dy = (double)y, dz = (double)z;
+    ox = (float)(M[0] * dx + M[1] * dy + M[2] * dz + M[3]);
+    oy = (float)(M[4] * dx + M[5] * dy + M[6] * dz + M[7]);
+    oz = (float)(M[8] * dx + M[9] * dy + M[10] * dz + M[11]);
+}
+
+// 4 points per lane: 16-byte coalesced SoA loads/stores (26 B/point of traffic)
+__global__ __launch_bounds__(256) void k_compensate_v4(
+    const float4* __restrict__ x4, const float4* __restrict__ y4, const float4* __restrict__ z4,
+    const ushort4* __restrict__ p4, size_t n4, const double* __restrict__ tab, unsigned n_pkt,
+    float4* __restrict__ ox4, float4* __restrict__ oy4, float4* __restrict__ oz4)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float4 x = x4[i], y = y4[i], z = z4[i];
+        const ushort4 p = p4[i];
+        const unsigned k[4] = {min((unsigned)p.x, n_pkt - 1), min((unsigned)p.y, n_pkt - 1),
+                               min((unsigned)p.z, n_pkt - 1), min((unsigned)p.w, n_pkt - 1)};
+        const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w},
+                    zs[4] = {z.x, z.y, z.z, z.w};
+        float rx[4], ry[4], rz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) apply_affine(tab + 12 * (size_t)k[j], xs[j], ys[j], zs[j], rx[j], ry[j], rz[j]);
+        ox4[i] = make_float4(rx[0], rx[1], rx[2], rx[3]);
+        oy4[i] = make_float4(ry[0], ry[1], ry[2], ry[3]);
+        oz4[i] = make_float4(rz[0], rz[1], rz[2], rz[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compensate_v1(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+    const uint16_t* __restrict__ pkt, size_t i0, size_t n, const double* __restrict__ tab,
+    unsigned n_pkt, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz)
+{
+    for (size_t i = i0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned k = min((unsigned)pkt[i], n_pkt - 1);
+        apply_affine(tab + 12 * (size_t)k, x[i], y[i], z[i], ox[i], oy[i], oz[i]);
+    }
+}
+
+hipError_t launch_compensate(const float* x, const float* y, const float* z, const uint16_t* pkt,
+                             size_t n, const double* T3x4, size_t n_pkt, float* ox, float* oy,
+                             float* oz, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    size_t done = 0;
+    if (al16(x) && al16(y) && al16(z) && al16(ox) && al16(oy) && al16(oz) &&
+        (reinterpret_cast<uintptr_t>(pkt) & 7u) == 0 && n >= 4) {
+        const size_t n4 = n / 4;
+        size_t g = (n4 + 255) / 256;
+        const int grid = (int)(g > 2048 ? 2048 : g);
+        hipLaunchKernelGGL(k_compensate_v4, dim3(grid), dim3(256), 0, s, (const float4*)x,
+                           (const float4*)y, (const float4*)z, (const ushort4*)pkt, n4, T3x4,
+                           (unsigned)n_pkt, (float4*)ox, (float4*)oy, (float4*)oz);
+        done = n4 * 4;
+    }
+    if (done < n) {
+        size_t g = (n - done + 255) / 256;
+        const int grid = (int)(g > 2048 ? 2048 : g);
+        hipLaunchKernelGGL(k_compensate_v1, dim3(grid), dim3(256), 0, s, x, y, z, pkt, done, n,
+                           T3x4, (unsigned)n_pkt, ox, oy, oz);
+    }
+    return hipGetLastError();
+}
+
+// ============================================================ K2+K3 linearise
+// Column k of the 29 sums is v[IA[k]] * v[IB[k]] with v = {J0..J5, r, valid}.
+__constant__ unsigned char c_ia[32] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3,
+                                       3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 7, 7, 7};
+__constant__ unsigned char c_ib[32] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3,
+                                       4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7};
+
+// exhaustive 27-cell scan in ascending sorted index; strict '<' keeps the lowest
+// index among equal distances
+__device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float qy, float qz,
+                                             float& bd, int& bj)
+{
+    const int cx = cell_coord(qx, mv.ox, mv.inv_h, mv.nx);
+    const int cy = cell_coord(qy, mv.oy, mv.inv_h, mv.ny);
+    const int cz = cell_coord(qz, mv.oz, mv.inv_h, mv.nz);
+    bd = INFINITY;
+    bj = -1;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, mv.nx - 1);
+    if (x0 > x1) return;
+#pragma unroll 1
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int zz = cz + dz;
+        if (zz < 0 || zz >= mv.nz) continue;
+#pragma unroll 1
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = cy + dy;
+            if (yy < 0 || yy >= mv.ny) continue;
+            const size_t row = ((size_t)zz * mv.ny + yy) * mv.nx;
+            const int j0 = mv.cell_start[row + x0], j1 = mv.cell_start[row + x1 + 1];
+#pragma unroll 4
+            for (int j = j0; j < j1; ++j) {
+                const float d2 = dist2(mv.pts[j], qx, qy, qz);
+                if (d2 < bd) {
+                    bd = d2;
+                    bj = j;
+                }
+            }
+        }
+    }
+}
+
+// One block = one BlockItem = a run of queries of one frame.  Per round of 256
+// queries every thread writes its 8 values {J, r, valid} to LDS; then lane k<29 of
+// each 32-lane half sums column k over that half's 32 entries (ascending), the two
+// halves are combined by a wavefront shuffle, the four waves through LDS, always in
+// the same order: run-to-run deterministic.
+template <bool WRITE_CORR>
+__global__ __launch_bounds__(kLinThreads) void k_linearize(
+    const BlockItem* __restrict__ items, FrameView fv, MapView mv,
+    const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
+    int32_t* __restrict__ corr, float* __restrict__ d2out)
+{
+    __shared__ double s_v[8][kLinThreads + 4];  // SoA, +4 pad: the 8 rows land on distinct banks
+    __shared__ double s_w[4][32];
+    const BlockItem it = items[blockIdx.x];
+    const double* __restrict__ T = poses + 12 * (size_t)it.frame;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int ia = c_ia[col], ib = c_ib[col];
+    double colsum = 0.0;
+
+    for (int base = it.q0; base < it.q1; base += kLinThreads) {
+        const int q = base + tid;
+        double J0 = 0, J1 = 0, J2 = 0, J3 = 0, J4 = 0, J5 = 0, r = 0, valid = 0;
+        if (q < it.q1) {
+            const int qi = fv.order ? fv.order[q] : q;
+            double px, py, pz;
+            xform(T, fv.x[qi], fv.y[qi], fv.z[qi], px, py, pz);
+            float bd;
+            int bj;
+            nearest_scan(mv, (float)px, (float)py, (float)pz, bd, bj);
+            const bool ok = (bj >= 0) && (bd <= dmax2);
+            if (WRITE_CORR) {
+                if (corr) corr[qi] = ok ? bj : -1;
+                if (d2out) d2out[qi] = ok ? bd : INFINITY;
+            }
+            if (ok) {
+                const float4 nf = mv.nrm[bj];
+                if (!(nf.x == 0.0f && nf.y == 0.0f && nf.z == 0.0f)) {
+                    const float4 mf = mv.pts[bj];
+                    const double nx = nf.x, ny = nf.y, nz = nf.z;
+                    const double dx = px - (double)mf.x, dy = py - (double)mf.y,
+                                 dz = pz - (double)mf.z;
+                    r = fma(nx, dx, fma(ny, dy, nz * dz));
+                    J0 = fma(py, nz, -(pz * ny));
+                    J1 = fma(pz, nx, -(px * nz));
+                    J2 = fma(px, ny, -(py * nx));
+                    J3 = nx;
+                    J4 = ny;
+                    J5 = nz;
+                    valid = 1.0;
+                }
+            }
+        }
+        s_v[0][tid] = J0;
+        s_v[1][tid] = J1;
+        s_v[2][tid] = J2;
+        s_v[3][tid] = J3;
+        s_v[4][tid] = J4;
+        s_v[5][tid] = J5;
+        s_v[6][tid] = r;
+        s_v[7][tid] = valid;
+        __syncthreads();
+        if (col < kAccN) {
+            const int e0 = wave * 64 + half * 32;
+#pragma unroll 8
+            for (int e = 0; e < 32; ++e) colsum = fma(s_v[ia][e0 + e], s_v[ib][e0 + e], colsum);
+        }
+        __syncthreads();
+    }
+    // halves -> wave (shuffle), waves -> block (LDS), fixed order
+    const double other = __shfl_down(colsum, 32, 64);
+    if (half == 0) s_w[wave][col] = colsum + other;
+    __syncthreads();
+    if (tid < kAccN) {
+        const double t = ((s_w[0][tid] + s_w[1][tid]) + s_w[2][tid]) + s_w[3][tid];
+        partials[(size_t)blockIdx.x * kAccStride + tid] = t;
+    }
+}
+
+hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
+                            const MapView& mv, const double* poses, float dmax2, double* partials,
+                            int32_t* corr, float* d2, hipStream_t s)
+{
+    (void)variant;
+    if (n_items == 0) return hipSuccess;
+    if (corr || d2)
+        hipLaunchKernelGGL(k_linearize<true>, dim3(n_items), dim3(kLinThreads), 0, s, items, fv,
+                           mv, poses, dmax2, partials, corr, d2);
+    else
+        hipLaunchKernelGGL(k_linearize<false>, dim3(n_items), dim3(kLinThreads), 0, s, items, fv,
+                           mv, poses, dmax2, partials, corr, d2);
+    return hipGetLastError();
+}
+
+// ============================================================= reduce + solve
+__device__ int ldlt6(const double* H, const double* b, double* xs)
+{
+    double L[36], D[6];
+    for (int i = 0; i < 36; ++i) L[i] = 0.0;
+    for (int j = 0; j < 6; ++j) {
+        double d = H[6 * j + j];
+        for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k] * D[k];
+        if (!(d > 0.0)) return 1;
+        D[j] = d;
+        L[6 * j + j] = 1.0;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = H[6 * i + j];
+            for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k] * D[k];
+            L[6 * i + j] = v / d;
+        }
+    }
+    double yv[6];
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+        for (int k = 0; k < i; ++k) v -= L[6 * i + k] * yv[k];
+        yv[i] = v;
+    }
+    for (int i = 0; i < 6; ++i) yv[i] /= D[i];
+    for (int i = 5; i >= 0; --i) {
+        double v = yv[i];
+        for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * xs[k];
+        xs[i] = v;
+    }
+    return 0;
+}
+
+__device__ void se3_exp_apply(const double* xi, double* T)
+{
+    const double wx = xi[0], wy = xi[1], wz = xi[2];
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    double A, B, C;
+    if (th2 < 1e-16) {
+        A = 1.0 - th2 / 6.0;
+        B = 0.5 - th2 / 24.0;
+        C = 1.0 / 6.0 - th2 / 120.0;
+    } else {
+        const double th = sqrt(th2);
+        A = sin(th) / th;
+        B = (1.0 - cos(th)) / th2;
+        C = (1.0 - A) / th2;
+    }
+    const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double K2[9], Rd[9], Vm[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        Rd[i] = I + A * K[i] + B * K2[i];
+        Vm[i] = I + B * K[i] + C * K2[i];
+    }
+    double N[12];
+    for (int i = 0; i < 3; ++i) {
+        const double td = Vm[3 * i] * xi[3] + Vm[3 * i + 1] * xi[4] + Vm[3 * i + 2] * xi[5];
+        for (int j = 0; j < 4; ++j)
+            N[4 * i + j] = Rd[3 * i] * T[j] + Rd[3 * i + 1] * T[4 + j] + Rd[3 * i + 2] * T[8 + j];
+        N[4 * i + 3] += td;
+    }
+    for (int i = 0; i < 12; ++i) T[i] = N[i];
+}
+
+// one 64-lane workgroup per frame
+__global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials,
+                                                     const int32_t* __restrict__ fbs,
+                                                     double* __restrict__ poses,
+                                                     velo_icp_iter* __restrict__ stats, int iter,
+                                                     double* __restrict__ acc_out, int do_update)
+{
+    __shared__ double s_acc[32];
+    const int f = blockIdx.x, k = threadIdx.x;
+    if (k < kAccN) {
+        double a = 0.0;
+        const int b0 = fbs[f], b1 = fbs[f + 1];
+        for (int b = b0; b < b1; ++b) a += partials[(size_t)b * kAccStride + k];
+        s_acc[k] = a;
+        if (acc_out) acc_out[(size_t)f * kAccStride + k] = a;
+    }
+    __syncthreads();
+    if (k != 0) return;
+    const double cnt = s_acc[28];
+    velo_icp_iter st;
+    st.n_pairs = (uint32_t)cnt;
+    st.rmse = cnt > 0.0 ? sqrt(s_acc[27] / cnt) : 0.0;
+    st.solve_flag = 0;
+    if (do_update) {
+        if (cnt < 6.0) {
+            st.solve_flag = 2;
+        } else {
+            double H[36], b[6], xi[6];
+            int c = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int e = a; e < 6; ++e, ++c) H[6 * a + e] = H[6 * e + a] = s_acc[c];
+            for (int a = 0; a < 6; ++a) b[a] = -s_acc[21 + a];
+            int bad = ldlt6(H, b, xi);
+            if (bad) {
+                st.solve_flag = 1;
+                for (int a = 0; a < 6; ++a) H[7 * a] += 1e-9;
+                bad = ldlt6(H, b, xi);
+            }
+            if (bad) {
+                st.solve_flag = 2;
+            } else {
+                double T[12];
+                for (int i = 0; i < 12; ++i) T[i] = poses[12 * (size_t)f + i];
+                se3_exp_apply(xi, T);
+                for (int i = 0; i < 12; ++i) poses[12 * (size_t)f + i] = T[i];
+            }
+        }
+    }
+    if (stats) stats[(size_t)f * VELO_MAX_ITERS + iter] = st;
+}
+
+hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
+                               int n_frames, double* poses, velo_icp_iter* stats, int iter,
+                               int iters_total, double* acc_out, int do_update, hipStream_t s)
+{
+    (void)iters_total;
+    if (n_frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_reduce_solve, dim3(n_frames), dim3(64), 0, s, partials,
+                       frame_block_start, poses, stats, iter, acc_out, do_update);
+    return hipGetLastError();
+}
+
+// ====================================================== frame query ordering
+// key = frame * (ncell + 1) + cell key of the transformed query (ncell = outside)
+__global__ __launch_bounds__(256) void k_frame_cellkeys(FrameView fv,
+                                                        const int64_t* __restrict__ frame_start,
+                                                        int n_frames, size_t n_total, MapView mv,
+                                                        const double* __restrict__ poses,
+                                                        uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ idx)
+{
+    const size_t ncell = (size_t)mv.nx * mv.ny * mv.nz;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_frames;  // frame of query i: last f with frame_start[f] <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((size_t)frame_start[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        double px, py, pz;
+        xform(poses + 12 * (size_t)lo, fv.x[i], fv.y[i], fv.z[i], px, py, pz);
+        const int cx = cell_coord((float)px, mv.ox, mv.inv_h, mv.nx);
+        const int cy = cell_coord((float)py, mv.oy, mv.inv_h, mv.ny);
+        const int cz = cell_coord((float)pz, mv.oz, mv.inv_h, mv.nz);
+        size_t key = ncell;
+        if (cx >= 0 && cx < mv.nx && cy >= 0 && cy < mv.ny && cz >= 0 && cz < mv.nz)
+            key = ((size_t)cz * mv.ny + cy) * mv.nx + cx;
+        keys[i] = (uint32_t)((size_t)lo * (ncell + 1) + key);
+        idx[i] = (uint32_t)i;
+    }
+}
+
+hipError_t launch_frame_cellkeys(const FrameView& fv, const int64_t* d_frame_start, int n_frames,
+                                 size_t n_total, const MapView& mv, const double* poses,
+                                 uint32_t* keys, uint32_t* idx, hipStream_t s)
+{
+    if (n_total == 0) return hipSuccess;
+    size_t g = (n_total + 255) / 256;
+    const int grid = (int)(g > 4096 ? 4096 : g);
+    hipLaunchKernelGGL(k_frame_cellkeys, dim3(grid), dim3(256), 0, s, fv, d_frame_start, n_frames,
+                       n_total, mv, poses, keys, idx);
+    return hipGetLastError();
+}
+
+// ============================================================= map increment
+__global__ __launch_bounds__(256) void k_increment_flags(const float* __restrict__ x,
+                                                         const float* __restrict__ y,
+                                                         const float* __restrict__ z, size_t n,
+                                                         MapView mv,
+                                                         const double* __restrict__ pose,
+                                                         int min_count,
+                                                         uint32_t* __restrict__ flags)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        double px, py, pz;
+        xform(pose, x[i], y[i], z[i], px, py, pz);
+        const int cx = cell_coord((float)px, mv.ox, mv.inv_h, mv.nx);
+        const int cy = cell_coord((float)py, mv.oy, mv.inv_h, mv.ny);
+        const int cz = cell_coord((float)pz, mv.oz, mv.inv_h, mv.nz);
+        int occ = 0;
+        if (cx >= 0 && cx < mv.nx && cy >= 0 && cy < mv.ny && cz >= 0 && cz < mv.nz) {
+            const size_t key = ((size_t)cz * mv.ny + cy) * mv.nx + cx;
+            occ = mv.cell_start[key + 1] - mv.cell_start[key];
+        }
+        flags[i] = occ < min_count ? 1u : 0u;
+    }
+}
+
+hipError_t launch_increment_flags(const float* x, const float* y, const float* z, size_t n,
+                                  const MapView& mv, const double* pose, int min_count,
+                                  uint32_t* flags, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    size_t g = (n + 255) / 256;
+    const int grid = (int)(g > 4096 ? 4096 : g);
+    hipLaunchKernelGGL(k_increment_flags, dim3(grid), dim3(256), 0, s, x, y, z, n, mv, pose,
+                       min_count, flags);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_increment_scatter(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
+    const double* __restrict__ pose, const uint32_t* __restrict__ flags,
+    const uint32_t* __restrict__ offs, float* __restrict__ ox, float* __restrict__ oy,
+    float* __restrict__ oz)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        if (!flags[i]) continue;
+        double px, py, pz;
+        xform(pose, x[i], y[i], z[i], px, py, pz);
+        const uint32_t o = offs[i];
+        ox[o] = (float)px;
+        oy[o] = (float)py;
+        oz[o] = (float)pz;
+    }
+}
+
+hipError_t launch_increment_scatter(const float* x, const float* y, const float* z, size_t n,
+                                    const double* pose, const uint32_t* flags,
+                                    const uint32_t* offs, float* ox, float* oy, float* oz,
+                                    hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    size_t g = (n + 255) / 256;
+    const int grid = (int)(g > 4096 ? 4096 : g);
+    hipLaunchKernelGGL(k_increment_scatter, dim3(grid), dim3(256), 0, s, x, y, z, n, pose, flags,
+                       offs, ox, oy, oz);
+    return hipGetLastError();
+}
+
+}  // namespace velo

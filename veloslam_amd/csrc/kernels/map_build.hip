@@ -1,0 +1,279 @@
+// map_build.hip -- voxel-sorted map construction for gfx950 (done once per map
+// update, not per ICP iteration): bounds, cell keys, gather into float4, cell
+// table, and per-point PCA normals.  Semantics: DESIGN.md "ICP semantics"
+// (grid / normals), checked bit-for-bit against oracle/icp.c in tests/.
+// The stable key sort itself lives in sortscan.hip (rocPRIM radix sort).
+#include "device_math.hpp"
+
+namespace velo {
+
+// ------------------------------------------------------------------ bounds
+__global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ x,
+                                                const float* __restrict__ y,
+                                                const float* __restrict__ z, size_t n,
+                                                unsigned* __restrict__ out6)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float v[3] = {x[i], y[i], z[i]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], v[a]);
+            mx[a] = fmaxf(mx[a], v[a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_down(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_down(mx[a], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&out6[a], enc_f32(mn[a]));
+            atomicMax(&out6[3 + a], enc_f32(mx[a]));
+        }
+    }
+}
+
+hipError_t launch_minmax(const float* x, const float* y, const float* z, size_t n,
+                         unsigned* d_scratch6, MinMax* out_host, hipStream_t s)
+{
+    const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    hipError_t e = hipMemcpyAsync(d_scratch6, init, sizeof init, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_minmax, dim3(grid), dim3(256), 0, s, x, y, z, n, d_scratch6);
+    unsigned h[6];
+    e = hipMemcpyAsync(h, d_scratch6, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    for (int a = 0; a < 3; ++a) {
+        out_host->mn[a] = dec_f32(h[a]);
+        out_host->mx[a] = dec_f32(h[3 + a]);
+    }
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------- keys
+__global__ __launch_bounds__(256) void k_keys(const float* __restrict__ x,
+                                              const float* __restrict__ y,
+                                              const float* __restrict__ z, size_t n, float ox,
+                                              float oy, float oz, float inv_h, int nx, int ny,
+                                              uint32_t* __restrict__ keys,
+                                              uint32_t* __restrict__ idx)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int cx = (int)floorf((x[i] - ox) * inv_h);
+        const int cy = (int)floorf((y[i] - oy) * inv_h);
+        const int cz = (int)floorf((z[i] - oz) * inv_h);
+        keys[i] = (uint32_t)(((size_t)cz * ny + cy) * nx + cx);
+        idx[i] = (uint32_t)i;
+    }
+}
+
+hipError_t launch_keys(const float* x, const float* y, const float* z, size_t n, float ox, float oy,
+                       float oz, float inv_h, int nx, int ny, uint32_t* keys, uint32_t* idx,
+                       hipStream_t s)
+{
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_keys, dim3(grid), dim3(256), 0, s, x, y, z, n, ox, oy, oz, inv_h, nx, ny,
+                       keys, idx);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ gather
+__global__ __launch_bounds__(256) void k_gather(const float* __restrict__ x,
+                                                const float* __restrict__ y,
+                                                const float* __restrict__ z,
+                                                const uint32_t* __restrict__ perm, size_t n,
+                                                float4* __restrict__ pts)
+{
+    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < n;
+         s += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t i = perm[s];
+        pts[s] = make_float4(x[i], y[i], z[i], 0.0f);
+    }
+}
+
+hipError_t launch_gather(const float* x, const float* y, const float* z, const uint32_t* perm,
+                         size_t n, float4* pts, hipStream_t s)
+{
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, s, x, y, z, perm, n, pts);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------- cell table
+// cell_start[c] = number of sorted keys < c  (lower bound), c in [0, ncell]
+__global__ __launch_bounds__(256) void k_cell_start(const uint32_t* __restrict__ keys, size_t n,
+                                                    size_t ncell, int32_t* __restrict__ cell_start)
+{
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c <= ncell;
+         c += (size_t)gridDim.x * blockDim.x) {
+        size_t lo = 0, hi = n;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            if ((size_t)keys[mid] < c)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        cell_start[c] = (int32_t)lo;
+    }
+}
+
+hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell,
+                             int32_t* cell_start, hipStream_t s)
+{
+    size_t g = (ncell + 1 + 255) / 256;
+    int grid = (int)(g > 8192 ? 8192 : g);
+    hipLaunchKernelGGL(k_cell_start, dim3(grid), dim3(256), 0, s, sorted_keys, n, ncell,
+                       cell_start);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------- normals
+// One thread per map point.  The running k-best list lives in LDS as
+// [slot][thread] (stride = blockDim: bank-conflict free), because a
+// dynamically indexed per-thread array would otherwise go to scratch memory.
+constexpr int kNrmThreads = 128;
+constexpr int kMinNb = 5;
+
+__device__ __forceinline__ void jacobi_rot(double A[3][3], double V[3][3], int p, int q)
+{
+    if (A[p][q] == 0.0) return;
+    const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+    double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+    if (theta < 0.0) t = -t;
+    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+    const int r = 3 - p - q;
+    const double app = A[p][p], aqq = A[q][q], apq = A[p][q];
+    const double arp = A[r][p], arq = A[r][q];
+    A[p][p] = app - t * apq;
+    A[q][q] = aqq + t * apq;
+    A[p][q] = A[q][p] = 0.0;
+    A[r][p] = A[p][r] = c * arp - s * arq;
+    A[r][q] = A[q][r] = s * arp + c * arq;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - s * vkq;
+        V[k][q] = s * vkp + c * vkq;
+    }
+}
+
+__global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
+                                                         float4* __restrict__ nrm,
+                                                         unsigned long long* __restrict__ invalid)
+{
+    __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
+    __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x * kNrmThreads + tid;
+    if (s >= mv.n) return;
+    const float4 q = mv.pts[s];
+    const float r2 = mv.h * mv.h;
+    const int cx = cell_coord(q.x, mv.ox, mv.inv_h, mv.nx);
+    const int cy = cell_coord(q.y, mv.oy, mv.inv_h, mv.ny);
+    const int cz = cell_coord(q.z, mv.oz, mv.inv_h, mv.nz);
+    int cnt = 0;
+    float worst = INFINITY;  // d2 of the last slot once the list is full
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int zz = cz + dz;
+        if (zz < 0 || zz >= mv.nz) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = cy + dy;
+            if (yy < 0 || yy >= mv.ny) continue;
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, mv.nx - 1);
+            if (x0 > x1) continue;
+            const size_t row = ((size_t)zz * mv.ny + yy) * mv.nx;
+            const int j0 = mv.cell_start[row + x0], j1 = mv.cell_start[row + x1 + 1];
+            for (int j = j0; j < j1; ++j) {
+                const float d2 = dist2(mv.pts[j], q.x, q.y, q.z);
+                if (!(d2 <= r2)) continue;
+                if (cnt == k && !(d2 < worst)) continue;
+                int pos = cnt < k ? cnt : k - 1;
+                while (pos > 0 && d2 < s_d[pos - 1][tid]) {
+                    s_d[pos][tid] = s_d[pos - 1][tid];
+                    s_i[pos][tid] = s_i[pos - 1][tid];
+                    --pos;
+                }
+                s_d[pos][tid] = d2;
+                s_i[pos][tid] = j;
+                if (cnt < k) ++cnt;
+                if (cnt == k) worst = s_d[k - 1][tid];
+            }
+        }
+    }
+    if (cnt < kMinNb) {
+        nrm[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        atomicAdd(invalid, 1ull);
+        return;
+    }
+    double mx = 0, my = 0, mz = 0;
+    for (int i = 0; i < cnt; ++i) {
+        const float4 p = mv.pts[s_i[i][tid]];
+        mx += (double)p.x;
+        my += (double)p.y;
+        mz += (double)p.z;
+    }
+    const double invn = 1.0 / (double)cnt;
+    mx *= invn;
+    my *= invn;
+    mz *= invn;
+    double C0 = 0, C1 = 0, C2 = 0, C3 = 0, C4 = 0, C5 = 0;
+    for (int i = 0; i < cnt; ++i) {
+        const float4 p = mv.pts[s_i[i][tid]];
+        const double dx = (double)p.x - mx, dy = (double)p.y - my, dz = (double)p.z - mz;
+        C0 = fma(dx, dx, C0);
+        C1 = fma(dx, dy, C1);
+        C2 = fma(dx, dz, C2);
+        C3 = fma(dy, dy, C3);
+        C4 = fma(dy, dz, C4);
+        C5 = fma(dz, dz, C5);
+    }
+    double A[3][3] = {{C0, C1, C2}, {C1, C3, C4}, {C2, C4, C5}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        jacobi_rot(A, V, 0, 1);
+        jacobi_rot(A, V, 0, 2);
+        jacobi_rot(A, V, 1, 2);
+    }
+    int m = 0;
+    if (A[1][1] < A[m][m]) m = 1;
+    if (A[2][2] < A[m][m]) m = 2;
+    double vx = V[0][m], vy = V[1][m], vz = V[2][m];
+    const double inv = 1.0 / sqrt(vx * vx + vy * vy + vz * vz);
+    vx *= inv;
+    vy *= inv;
+    vz *= inv;
+    const bool flip = (vz < 0.0) || (vz == 0.0 && (vy < 0.0 || (vy == 0.0 && vx < 0.0)));
+    if (flip) {
+        vx = -vx;
+        vy = -vy;
+        vz = -vz;
+    }
+    nrm[s] = make_float4((float)vx, (float)vy, (float)vz, 0.0f);
+}
+
+hipError_t launch_normals(const MapView& mv, int k, float4* nrm, unsigned long long* d_invalid,
+                          hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_invalid, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    const int grid = (mv.n + kNrmThreads - 1) / kNrmThreads;
+    hipLaunchKernelGGL(k_normals, dim3(grid), dim3(kNrmThreads), 0, s, mv, k, nrm, d_invalid);
+    return hipGetLastError();
+}
+
+}  // namespace velo

@@ -1,0 +1,28 @@
+// sortscan.hip -- the two library primitives of the map-side pipeline: a stable
+// LSD radix sort of (cell key, point index) pairs and an exclusive prefix sum,
+// both from rocPRIM through the hipCUB front end.  They run once per map update /
+// once per increment, never inside the ICP iteration loop.  Isolated in their own
+// translation unit because the headers are slow to compile.
+#include <hipcub/hipcub.hpp>
+#include "../velo_internal.hpp"
+
+namespace velo {
+
+// temp == nullptr: size query (temp_bytes is written).  Stable: equal keys keep
+// their input order, which is what makes the map's sorted index deterministic.
+hipError_t sort_pairs(void* temp, size_t& temp_bytes, const uint32_t* k_in, uint32_t* k_out,
+                      const uint32_t* v_in, uint32_t* v_out, size_t n, int end_bit, hipStream_t s)
+{
+    if (end_bit < 1) end_bit = 1;
+    if (end_bit > 32) end_bit = 32;
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (int)n, 0,
+                                              end_bit, s);
+}
+
+hipError_t exclusive_scan_u32(void* temp, size_t& temp_bytes, const uint32_t* in, uint32_t* out,
+                              size_t n, hipStream_t s)
+{
+    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int)n, s);
+}
+
+}  // namespace velo

@@ -1,0 +1,88 @@
+// velo_internal.hpp -- shared between the C-ABI glue (capi.cpp) and the HIP
+// kernel translation units.  Not installed; the public surface is include/velo.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "../../include/velo.h"
+
+namespace velo {
+
+// ---------------------------------------------------------------- device views
+// Voxel-sorted map as the kernels see it.  Points are float4 {x,y,z,0} so a
+// candidate is one 16-byte load; normals likewise ({0,0,0,0} = invalid normal).
+struct MapView {
+    const float4* pts;     // [n] sorted by cell key (stable)
+    const float4* nrm;     // [n]
+    const int32_t* cell_start;  // [ncell+1]
+    float ox, oy, oz, inv_h, h;
+    int nx, ny, nz;
+    int n;
+};
+
+// Frames resident on the device, concatenated SoA.
+struct FrameView {
+    const float* x;
+    const float* y;
+    const float* z;
+    const int32_t* order;  // optional query visiting order (cell-sorted) or nullptr
+};
+
+// One work item of the linearise kernel: a run of consecutive queries of one frame.
+struct BlockItem {
+    int32_t frame;
+    int32_t q0;  // first query (global index into the concatenated arrays)
+    int32_t q1;  // one past last
+    int32_t first_block_of_frame;
+};
+
+constexpr int kAccN = 29;      // 21 + 6 + 1 + 1
+constexpr int kAccStride = 32; // padded row of the partials buffer (doubles)
+constexpr int kLinThreads = 256;
+
+// ---------------------------------------------------------------- launchers (kernels/*.hip)
+struct MapBuild;  // opaque scratch owned by the ctx
+
+hipError_t launch_compensate(const float* x, const float* y, const float* z, const uint16_t* pkt,
+                             size_t n, const double* T3x4, size_t n_pkt, float* ox, float* oy,
+                             float* oz, hipStream_t s);
+
+struct MinMax {
+    float mn[3], mx[3];
+};
+hipError_t launch_minmax(const float* x, const float* y, const float* z, size_t n,
+                         unsigned* d_scratch6, MinMax* out_host, hipStream_t s);
+hipError_t launch_keys(const float* x, const float* y, const float* z, size_t n, float ox, float oy,
+                       float oz, float inv_h, int nx, int ny, uint32_t* keys, uint32_t* idx,
+                       hipStream_t s);
+hipError_t sort_pairs(void* temp, size_t& temp_bytes, const uint32_t* k_in, uint32_t* k_out,
+                      const uint32_t* v_in, uint32_t* v_out, size_t n, int end_bit, hipStream_t s);
+hipError_t launch_gather(const float* x, const float* y, const float* z, const uint32_t* perm,
+                         size_t n, float4* pts, hipStream_t s);
+hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell,
+                             int32_t* cell_start, hipStream_t s);
+hipError_t launch_normals(const MapView& mv, int k, float4* nrm, unsigned long long* d_invalid,
+                          hipStream_t s);
+
+hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
+                            const MapView& mv, const double* poses, float dmax2, double* partials,
+                            int32_t* corr, float* d2, hipStream_t s);
+hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
+                               int n_frames, double* poses, velo_icp_iter* stats, int iter,
+                               int iters_total, double* acc_out, int do_update, hipStream_t s);
+hipError_t launch_frame_cellkeys(const FrameView& fv, const int64_t* d_frame_start, int n_frames,
+                                 size_t n_total, const MapView& mv, const double* poses,
+                                 uint32_t* keys, uint32_t* idx, hipStream_t s);
+hipError_t launch_increment_flags(const float* x, const float* y, const float* z, size_t n,
+                                  const MapView& mv, const double* pose, int min_count,
+                                  uint32_t* flags, hipStream_t s);
+hipError_t exclusive_scan_u32(void* temp, size_t& temp_bytes, const uint32_t* in, uint32_t* out,
+                              size_t n, hipStream_t s);
+hipError_t launch_increment_scatter(const float* x, const float* y, const float* z, size_t n,
+                                    const double* pose, const uint32_t* flags,
+                                    const uint32_t* offs, float* ox, float* oy, float* oz,
+                                    hipStream_t s);
+
+}  // namespace velo
