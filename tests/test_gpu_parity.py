@@ -14,9 +14,11 @@ POS_TOL = 1e-4  # metres   (BASELINE.json north_star)
 ROT_TOL = 1e-5  # radians
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    c = capi.Context(0, max_batch=16)
+@pytest.fixture(scope="module", params=[0, 1], ids=["scan", "pruned"])
+def ctx(request):
+    """Both linearise kernels are held to the same oracle: variant 0 = exhaustive 27-cell
+    scan, variant 1 = pruned exact search."""
+    c = capi.Context(0, max_batch=16, linearize_variant=request.param)
     yield c
     c.close()
 
@@ -170,6 +172,29 @@ def test_exact_ties_pick_lowest_sorted_index(ctx, oracle):
     assert np.array_equal(corr, oc)
 
 
+def test_points_on_cell_faces_and_pruning_margins(ctx, oracle):
+    """Map points and queries sitting exactly on voxel faces / lattice positions, plus
+    queries a hair away from faces: the pruned search must not drop a row or cell that
+    holds the (possibly tied) winner."""
+    rng = np.random.default_rng(77)
+    g = np.arange(0, 6.01, 0.25, dtype=np.float32)
+    lat = np.stack(np.meshgrid(g, g, g[:9], indexing="ij"), -1).reshape(-1, 3)
+    m = np.concatenate([lat, rng.uniform(0, 6, (3000, 3)).astype(np.float32)], axis=0)
+    om = oracle.Map(m[:, 0], m[:, 1], m[:, 2], 1.0, 8)
+    ctx.map_reset(m[:, 0], m[:, 1], m[:, 2], 1.0, 8)
+    q = [lat + np.float32(0.125), lat[::3] + rng.normal(0, 1e-4, lat[::3].shape).astype(np.float32),
+         rng.uniform(-1.5, 7.5, (4000, 3)).astype(np.float32),
+         (rng.integers(-1, 8, (2000, 3)) + rng.choice([0.0, 1e-6, -1e-6, 0.5], (2000, 3))).astype(np.float32)]
+    q = np.concatenate(q, axis=0).astype(np.float32)
+    ctx.frames_upload([(q[:, 0].copy(), q[:, 1].copy(), q[:, 2].copy())])
+    I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)
+    for dmax in (1.0, 0.6, 0.05):
+        corr, d2, acc = ctx.linearize(0, I, dmax, q.shape[0])
+        oc, od2, _ = om.correspond(q[:, 0], q[:, 1], q[:, 2], I, dmax)
+        assert np.array_equal(corr, oc)
+        assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+
+
 # ------------------------------------------------------------------ ICP (a9..a12)
 def test_icp_pose_matches_oracle(ctx, omap, wl, comp):
     ctx.map_reset(*wl["map"], 1.0, 16)
@@ -220,8 +245,9 @@ def test_icp_ragged_batch_with_empty_frame(ctx, omap, wl, comp):
     assert r[2].iter[4].n_pairs == st[4]["n_pairs"]
 
 
-def test_sorted_query_order_gives_same_pose(omap, wl, comp):
-    c2 = capi.Context(0, max_batch=4, sort_frames=1)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_sorted_query_order_gives_same_pose(omap, wl, comp, variant):
+    c2 = capi.Context(0, max_batch=4, sort_frames=1, linearize_variant=variant)
     try:
         c2.map_reset(*wl["map"], 1.0, 16)
         f = wl["frames"][0]

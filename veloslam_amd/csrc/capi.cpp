@@ -75,9 +75,11 @@ struct velo_ctx {
     int n_frames = 0;
     std::vector<int64_t> frame_start;
     DevBuf<int64_t> d_frame_start;
-    std::vector<BlockItem> items_h;
+    std::vector<BlockItem> items_h;   // frame-major
     std::vector<int32_t> fbs_h;
     DevBuf<BlockItem> items;
+    DevBuf<BlockItem> items_xcd;      // same blocks, dealt so that XCD r works on spatial slab r
+    DevBuf<float> sx, sy, sz;         // cell-sorted copies of the frames (cfg.sort_frames)
     DevBuf<int32_t> fbs;
     DevBuf<double> poses, partials, acc;
     DevBuf<velo_icp_iter> stats;
@@ -246,7 +248,7 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
             it.frame = f;
             it.q0 = (int32_t)q;
             it.q1 = (int32_t)std::min<int64_t>(q + per_block, frame_start[f + 1]);
-            it.first_block_of_frame = c->fbs_h[f];
+            it.slot = (int32_t)c->items_h.size();
             c->items_h.push_back(it);
         }
     }
@@ -262,6 +264,27 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     if (ni)
         HIP_TRY(c, hipMemcpyAsync(c->items.p, c->items_h.data(), ni * sizeof(BlockItem),
                                   hipMemcpyHostToDevice, c->stream));
+    std::vector<BlockItem> xcd;
+    if (c->cfg.sort_frames == 1 && ni) {
+        // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an XCD, each
+        // with its own 4 MiB L2).  With cell-sorted queries, eighth r of every frame covers
+        // roughly the same slab of the map, so give all of slab r to one XCD: its L2 then
+        // holds 1/8 of the map instead of all of it.  Speed only -- never correctness.
+        std::vector<std::vector<BlockItem>> region(8);
+        for (int f = 0; f < n_frames; ++f) {
+            const int b0 = c->fbs_h[f], nb = c->fbs_h[f + 1] - b0;
+            for (int b = 0; b < nb; ++b) region[(size_t)((int64_t)b * 8 / std::max(nb, 1))].push_back(c->items_h[(size_t)b0 + b]);
+        }
+        size_t longest = 0;
+        for (auto& r : region) longest = std::max(longest, r.size());
+        xcd.reserve(ni);
+        for (size_t t = 0; t < longest; ++t)
+            for (int r = 0; r < 8; ++r)
+                if (t < region[r].size()) xcd.push_back(region[r][t]);
+        HIP_TRY(c, c->items_xcd.reserve(ni));
+        HIP_TRY(c, hipMemcpyAsync(c->items_xcd.p, xcd.data(), ni * sizeof(BlockItem),
+                                  hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(c, hipMemcpyAsync(c->fbs.p, c->fbs_h.data(), ((size_t)n_frames + 1) * sizeof(int32_t),
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_frame_start.p, c->frame_start.data(),
@@ -319,6 +342,13 @@ int maybe_sort_frames(velo_ctx* c, FrameView& fv)
     if (int rc = ensure_temp(c, tb)) return rc;
     HIP_TRY(c, sort_pairs(c->temp.p, tb, c->order_keys.p, c->order_keys2.p, c->order_idx.p,
                           c->order.p, n, bits, c->stream));
+    HIP_TRY(c, c->sx.reserve(n));
+    HIP_TRY(c, c->sy.reserve(n));
+    HIP_TRY(c, c->sz.reserve(n));
+    HIP_TRY(c, launch_permute3(fv.x, fv.y, fv.z, c->order.p, n, c->sx.p, c->sy.p, c->sz.p, c->stream));
+    fv.x = c->sx.p;
+    fv.y = c->sy.p;
+    fv.z = c->sz.p;
     fv.order = reinterpret_cast<const int32_t*>(c->order.p);
     return VELO_OK;
 }
@@ -351,7 +381,8 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     for (int it = 0; it < iters; ++it) {
         {
             Timed t(c, 0);
-            HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, c->items.p, ni, fv, c->mv,
+            HIP_TRY(c, launch_linearize(c->cfg.linearize_variant,
+                                        (fv.order && c->cfg.sort_frames == 1) ? c->items_xcd.p : c->items.p, ni, fv, c->mv,
                                         c->poses.p, dmax2, c->partials.p, nullptr, nullptr, s));
         }
         {
@@ -706,8 +737,7 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
     FrameView fv{c->ax, c->ay, c->az, nullptr};
     const int b0 = c->fbs_h[frame], b1 = c->fbs_h[frame + 1];
     HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, c->items.p + b0, b1 - b0, fv, c->mv,
-                                c->poses.p, d_max * d_max, c->partials.p + (size_t)b0 * kAccStride,
-                                c->corr.p, c->d2.p, s));
+                                c->poses.p, d_max * d_max, c->partials.p, c->corr.p, c->d2.p, s));
     HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p + frame, 1, c->poses.p, nullptr, 0, 1,
                                    c->acc.p, 0, s));
     if (corr)

@@ -113,7 +113,7 @@ __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float 
             if (yy < 0 || yy >= mv.ny) continue;
             const size_t row = ((size_t)zz * mv.ny + yy) * mv.nx;
             const int j0 = mv.cell_start[row + x0], j1 = mv.cell_start[row + x1 + 1];
-#pragma unroll 4
+#pragma unroll 8
             for (int j = j0; j < j1; ++j) {
                 const float d2 = dist2(mv.pts[j], qx, qy, qz);
                 if (d2 < bd) {
@@ -125,12 +125,123 @@ __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float 
     }
 }
 
+// ---- pruned exact search -----------------------------------------------------------
+// Same result as nearest_scan (lexicographic minimum of (d2, sorted index) over the 27
+// cells, accepted iff d2 <= dmax2), reached with far fewer distance evaluations:
+//   1. probe: min d2 over the query's OWN cell gives an upper bound ub (<= dmax2);
+//   2. a row (dy,dz) of the 3x3x3 block, or its left/right cell, is dropped when a
+//      conservative lower bound of its distance exceeds ub (bounds are computed from the
+//      query's fractional position inside its cell, shrunk by a margin that covers the
+//      float rounding of the cell-assignment expression, and scaled by 0.99999);
+//   3. the surviving index ranges are scanned in DESCENDING sorted index with '<=', so
+//      the last (lowest) index among equal distances wins -- the oracle's tie rule.
+// Ranges go through LDS (s_hi/s_lo, [slot][thread]) so each lane walks its own list in
+// one flattened loop: a wave runs for max-over-lanes of the TOTAL candidates, not the sum
+// over rows of per-row maxima.
+constexpr int kMaxRanges = 9;
+
+__device__ __forceinline__ void nearest_pruned(const MapView& mv, float qx, float qy, float qz,
+                                               float dmax2, int (*s_hi)[kLinThreads],
+                                               int (*s_lo)[kLinThreads], int tid, float& bd,
+                                               int& bj)
+{
+    bd = dmax2;
+    bj = -1;
+    const float ux = (qx - mv.ox) * mv.inv_h, uy = (qy - mv.oy) * mv.inv_h,
+                uz = (qz - mv.oz) * mv.inv_h;
+    const int cx = cell_coord(qx, mv.ox, mv.inv_h, mv.nx);
+    const int cy = cell_coord(qy, mv.oy, mv.inv_h, mv.ny);
+    const int cz = cell_coord(qz, mv.oz, mv.inv_h, mv.nz);
+    int nr = 0;
+    if (cx >= -1 && cx <= mv.nx && cy >= -1 && cy <= mv.ny && cz >= -1 && cz <= mv.nz) {
+        // distances (metres) from the query to the faces of its own cell, made conservative
+        const float mgx = 1e-6f * (float)mv.nx * mv.h + 1e-6f;
+        const float mgy = 1e-6f * (float)mv.ny * mv.h + 1e-6f;
+        const float mgz = 1e-6f * (float)mv.nz * mv.h + 1e-6f;
+        const float fxr = ux - (float)cx, fyr = uy - (float)cy, fzr = uz - (float)cz;
+        const float lox = fmaxf(fxr * mv.h - mgx, 0.0f), hix = fmaxf((1.0f - fxr) * mv.h - mgx, 0.0f);
+        const float loy = fmaxf(fyr * mv.h - mgy, 0.0f), hiy = fmaxf((1.0f - fyr) * mv.h - mgy, 0.0f);
+        const float loz = fmaxf(fzr * mv.h - mgz, 0.0f), hiz = fmaxf((1.0f - fzr) * mv.h - mgz, 0.0f);
+        const bool cin = cx >= 0 && cx < mv.nx;
+        float ub = dmax2;
+        if (cin && cy >= 0 && cy < mv.ny && cz >= 0 && cz < mv.nz) {
+            const size_t key = ((size_t)cz * mv.ny + cy) * mv.nx + cx;
+            const int j0 = mv.cell_start[key], j1 = mv.cell_start[key + 1];
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) ub = fminf(ub, dist2(mv.pts[j], qx, qy, qz));
+        }
+        const float lox2 = lox * lox, hix2 = hix * hix;
+#pragma unroll
+        for (int dz = 1; dz >= -1; --dz) {
+            const int zz = cz + dz;
+            const float bz = dz == 0 ? 0.0f : (dz > 0 ? hiz : loz);
+#pragma unroll
+            for (int dy = 1; dy >= -1; --dy) {
+                const int yy = cy + dy;
+                const float by = dy == 0 ? 0.0f : (dy > 0 ? hiy : loy);
+                const float rb2 = bz * bz + by * by;
+                const bool row_ok = zz >= 0 && zz < mv.nz && yy >= 0 && yy < mv.ny &&
+                                    !(rb2 * 0.99999f > ub);
+                int x0 = cx, x1 = cx;
+                if (!cin) {  // the centre cell does not exist: collapse onto the side that does
+                    x0 = cx + 1;
+                    x1 = cx - 1;
+                }
+                if (cx - 1 >= 0 && cx - 1 < mv.nx && !((lox2 + rb2) * 0.99999f > ub)) x0 = cx - 1;
+                if (cx + 1 >= 0 && cx + 1 < mv.nx && !((hix2 + rb2) * 0.99999f > ub)) x1 = cx + 1;
+                if (!cin) {  // only one neighbour can exist when the centre is outside
+                    if (x0 == cx - 1) x1 = cx - 1;        // left neighbour in range
+                    else if (x1 == cx + 1) x0 = cx + 1;   // right neighbour in range
+                }
+                if (row_ok && x0 <= x1) {
+                    const size_t row = ((size_t)zz * mv.ny + yy) * mv.nx;
+                    const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
+                    if (jhi > jlo) {
+                        s_hi[nr][tid] = jhi;
+                        s_lo[nr][tid] = jlo;
+                        ++nr;
+                    }
+                }
+            }
+        }
+    }
+    // flattened walk over this lane's ranges, four candidates per trip so that four loads
+    // are in flight (the loop is bound by load latency, not by arithmetic).  Indices are
+    // clamped to the range start: a candidate evaluated twice is harmless under '<='.
+    bool more = nr > 0;
+    int k = 1, j = 0, lo = 0;
+    if (more) {
+        j = s_hi[0][tid];
+        lo = s_lo[0][tid];
+    }
+    while (more) {
+        const int j0 = j - 1, j1 = max(j - 2, lo), j2 = max(j - 3, lo), j3 = max(j - 4, lo);
+        const float4 c0 = mv.pts[j0], c1 = mv.pts[j1], c2 = mv.pts[j2], c3 = mv.pts[j3];
+        const float e0 = dist2(c0, qx, qy, qz), e1 = dist2(c1, qx, qy, qz),
+                    e2 = dist2(c2, qx, qy, qz), e3 = dist2(c3, qx, qy, qz);
+        if (e0 <= bd) { bd = e0; bj = j0; }
+        if (e1 <= bd) { bd = e1; bj = j1; }
+        if (e2 <= bd) { bd = e2; bj = j2; }
+        if (e3 <= bd) { bd = e3; bj = j3; }
+        j -= 4;
+        if (j <= lo) {
+            if (k < nr) {
+                j = s_hi[k][tid];
+                lo = s_lo[k][tid];
+                ++k;
+            } else {
+                more = false;
+            }
+        }
+    }
+}
+
 // One block = one BlockItem = a run of queries of one frame.  Per round of 256
 // queries every thread writes its 8 values {J, r, valid} to LDS; then lane k<29 of
 // each 32-lane half sums column k over that half's 32 entries (ascending), the two
 // halves are combined by a wavefront shuffle, the four waves through LDS, always in
 // the same order: run-to-run deterministic.
-template <bool WRITE_CORR>
+template <bool WRITE_CORR, int VARIANT>
 __global__ __launch_bounds__(kLinThreads) void k_linearize(
     const BlockItem* __restrict__ items, FrameView fv, MapView mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
@@ -138,6 +249,8 @@ __global__ __launch_bounds__(kLinThreads) void k_linearize(
 {
     __shared__ double s_v[8][kLinThreads + 4];  // SoA, +4 pad: the 8 rows land on distinct banks
     __shared__ double s_w[4][32];
+    __shared__ int s_hi[VARIANT == 1 ? kMaxRanges : 1][kLinThreads];
+    __shared__ int s_lo[VARIANT == 1 ? kMaxRanges : 1][kLinThreads];
     const BlockItem it = items[blockIdx.x];
     const double* __restrict__ T = poses + 12 * (size_t)it.frame;
     const int tid = threadIdx.x;
@@ -150,14 +263,17 @@ __global__ __launch_bounds__(kLinThreads) void k_linearize(
         const int q = base + tid;
         double J0 = 0, J1 = 0, J2 = 0, J3 = 0, J4 = 0, J5 = 0, r = 0, valid = 0;
         if (q < it.q1) {
-            const int qi = fv.order ? fv.order[q] : q;
             double px, py, pz;
-            xform(T, fv.x[qi], fv.y[qi], fv.z[qi], px, py, pz);
+            xform(T, fv.x[q], fv.y[q], fv.z[q], px, py, pz);
             float bd;
             int bj;
-            nearest_scan(mv, (float)px, (float)py, (float)pz, bd, bj);
+            if (VARIANT == 1)
+                nearest_pruned(mv, (float)px, (float)py, (float)pz, dmax2, s_hi, s_lo, tid, bd, bj);
+            else
+                nearest_scan(mv, (float)px, (float)py, (float)pz, bd, bj);
             const bool ok = (bj >= 0) && (bd <= dmax2);
             if (WRITE_CORR) {
+                const int qi = fv.order ? fv.order[q] : q;
                 if (corr) corr[qi] = ok ? bj : -1;
                 if (d2out) d2out[qi] = ok ? bd : INFINITY;
             }
@@ -201,7 +317,7 @@ __global__ __launch_bounds__(kLinThreads) void k_linearize(
     __syncthreads();
     if (tid < kAccN) {
         const double t = ((s_w[0][tid] + s_w[1][tid]) + s_w[2][tid]) + s_w[3][tid];
-        partials[(size_t)blockIdx.x * kAccStride + tid] = t;
+        partials[(size_t)it.slot * kAccStride + tid] = t;
     }
 }
 
@@ -209,14 +325,17 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, hipStream_t s)
 {
-    (void)variant;
     if (n_items == 0) return hipSuccess;
-    if (corr || d2)
-        hipLaunchKernelGGL(k_linearize<true>, dim3(n_items), dim3(kLinThreads), 0, s, items, fv,
-                           mv, poses, dmax2, partials, corr, d2);
-    else
-        hipLaunchKernelGGL(k_linearize<false>, dim3(n_items), dim3(kLinThreads), 0, s, items, fv,
-                           mv, poses, dmax2, partials, corr, d2);
+    const bool wc = corr || d2;
+#define VELO_LAUNCH_LIN(WC, V)                                                                   \
+    hipLaunchKernelGGL((k_linearize<WC, V>), dim3(n_items), dim3(kLinThreads), 0, s, items, fv, \
+                       mv, poses, dmax2, partials, corr, d2)
+    if (variant == 1) {
+        if (wc) VELO_LAUNCH_LIN(true, 1); else VELO_LAUNCH_LIN(false, 1);
+    } else {
+        if (wc) VELO_LAUNCH_LIN(true, 0); else VELO_LAUNCH_LIN(false, 0);
+    }
+#undef VELO_LAUNCH_LIN
     return hipGetLastError();
 }
 
@@ -287,24 +406,44 @@ __device__ void se3_exp_apply(const double* xi, double* T)
     for (int i = 0; i < 12; ++i) T[i] = N[i];
 }
 
-// one 64-lane workgroup per frame
-__global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials,
-                                                     const int32_t* __restrict__ fbs,
-                                                     double* __restrict__ poses,
-                                                     velo_icp_iter* __restrict__ stats, int iter,
-                                                     double* __restrict__ acc_out, int do_update)
+// One 256-thread workgroup per frame.  Thread (g = tid/32, k = tid%32) sums column k
+// of the blocks b0+g, b0+g+8, ... (eight independent load streams per column instead of
+// one serial chain over hundreds of partials), the eight group sums are then added in
+// ascending g: a fixed order, so the result is run-to-run bit reproducible.
+constexpr int kSolveThreads = 256;
+__global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
+    const double* __restrict__ partials, const int32_t* __restrict__ fbs,
+    double* __restrict__ poses, velo_icp_iter* __restrict__ stats, int iter,
+    double* __restrict__ acc_out, int do_update)
 {
+    __shared__ double s_g[8][32];
     __shared__ double s_acc[32];
-    const int f = blockIdx.x, k = threadIdx.x;
-    if (k < kAccN) {
-        double a = 0.0;
+    const int f = blockIdx.x, k = threadIdx.x & 31, g = threadIdx.x >> 5;
+    {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         const int b0 = fbs[f], b1 = fbs[f + 1];
-        for (int b = b0; b < b1; ++b) a += partials[(size_t)b * kAccStride + k];
-        s_acc[k] = a;
-        if (acc_out) acc_out[(size_t)f * kAccStride + k] = a;
+        if (k < kAccN) {
+            int b = b0 + g;
+            for (; b + 24 < b1; b += 32) {  // four loads in flight per thread
+                a0 += partials[(size_t)b * kAccStride + k];
+                a1 += partials[(size_t)(b + 8) * kAccStride + k];
+                a2 += partials[(size_t)(b + 16) * kAccStride + k];
+                a3 += partials[(size_t)(b + 24) * kAccStride + k];
+            }
+            for (; b < b1; b += 8) a0 += partials[(size_t)b * kAccStride + k];
+        }
+        s_g[g][k] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
-    if (k != 0) return;
+    if (threadIdx.x < kAccN) {
+        double a = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) a += s_g[gg][threadIdx.x];
+        s_acc[threadIdx.x] = a;
+        if (acc_out) acc_out[(size_t)f * kAccStride + threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     const double cnt = s_acc[28];
     velo_icp_iter st;
     st.n_pairs = (uint32_t)cnt;
@@ -344,7 +483,7 @@ hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_bloc
 {
     (void)iters_total;
     if (n_frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_reduce_solve, dim3(n_frames), dim3(64), 0, s, partials,
+    hipLaunchKernelGGL(k_reduce_solve, dim3(n_frames), dim3(kSolveThreads), 0, s, partials,
                        frame_block_start, poses, stats, iter, acc_out, do_update);
     return hipGetLastError();
 }
@@ -391,6 +530,33 @@ hipError_t launch_frame_cellkeys(const FrameView& fv, const int64_t* d_frame_sta
     const int grid = (int)(g > 4096 ? 4096 : g);
     hipLaunchKernelGGL(k_frame_cellkeys, dim3(grid), dim3(256), 0, s, fv, d_frame_start, n_frames,
                        n_total, mv, poses, keys, idx);
+    return hipGetLastError();
+}
+
+// gather a frame batch into cell-sorted order (once per registration)
+__global__ __launch_bounds__(256) void k_permute3(const float* __restrict__ x,
+                                                  const float* __restrict__ y,
+                                                  const float* __restrict__ z,
+                                                  const uint32_t* __restrict__ order, size_t n,
+                                                  float* __restrict__ ox, float* __restrict__ oy,
+                                                  float* __restrict__ oz)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t s = order[i];
+        ox[i] = x[s];
+        oy[i] = y[s];
+        oz[i] = z[s];
+    }
+}
+
+hipError_t launch_permute3(const float* x, const float* y, const float* z, const uint32_t* order,
+                           size_t n, float* ox, float* oy, float* oz, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    size_t g = (n + 255) / 256;
+    const int grid = (int)(g > 4096 ? 4096 : g);
+    hipLaunchKernelGGL(k_permute3, dim3(grid), dim3(256), 0, s, x, y, z, order, n, ox, oy, oz);
     return hipGetLastError();
 }
 

@@ -27,7 +27,10 @@ struct FrameView {
     const float* x;
     const float* y;
     const float* z;
-    const int32_t* order;  // optional query visiting order (cell-sorted) or nullptr
+    // When the frames were re-ordered by map cell (cfg.sort_frames) x/y/z are the permuted
+    // copies and order[q] is the ORIGINAL index of slot q (used only to write the per-query
+    // diagnostics back in caller order); nullptr = identity.
+    const int32_t* order;
 };
 
 // One work item of the linearise kernel: a run of consecutive queries of one frame.
@@ -35,7 +38,7 @@ struct BlockItem {
     int32_t frame;
     int32_t q0;  // first query (global index into the concatenated arrays)
     int32_t q1;  // one past last
-    int32_t first_block_of_frame;
+    int32_t slot;  // row of the partials buffer this block writes (frame-major, fixed)
 };
 
 constexpr int kAccN = 29;      // 21 + 6 + 1 + 1
@@ -75,6 +78,8 @@ hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_bloc
 hipError_t launch_frame_cellkeys(const FrameView& fv, const int64_t* d_frame_start, int n_frames,
                                  size_t n_total, const MapView& mv, const double* poses,
                                  uint32_t* keys, uint32_t* idx, hipStream_t s);
+hipError_t launch_permute3(const float* x, const float* y, const float* z, const uint32_t* order,
+                           size_t n, float* ox, float* oy, float* oz, hipStream_t s);
 hipError_t launch_increment_flags(const float* x, const float* y, const float* z, size_t n,
                                   const MapView& mv, const double* pose, int min_count,
                                   uint32_t* flags, hipStream_t s);
