@@ -54,8 +54,9 @@ typedef struct velo_cfg {
     int32_t max_batch;      /* frames registered per launch (default 64) */
     int32_t linearize_variant; /* 0 = default kernel; others are tuning variants */
     int32_t sort_frames;    /* 1: order each frame's queries by map cell once per registration */
-    int32_t use_graph;      /* 1: replay the per-registration launch sequence as a hipGraph */
-    int32_t reserved[11];
+    int32_t use_graph;      /* reserved (hipGraph replay of the launch sequence) */
+    int32_t map_subdiv;     /* sub-cells per voxel edge of the map sort order (default 4) */
+    int32_t reserved[10];
 } velo_cfg;
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */
@@ -88,13 +89,15 @@ typedef struct velo_icp_result {
 
 typedef struct velo_map_info {
     uint64_t n_points;
-    uint64_t n_cells;
+    uint64_t n_cells;     /* fine cells; cell_start has n_cells + 1 entries */
     float origin[3];
     float voxel;
     float inv_voxel;
     int32_t dims[3];
     int32_t k_normals;
     uint64_t n_invalid_normals;
+    int32_t subdiv;       /* n_cells counts FINE cells: prod(dims) * subdiv^3 */
+    int32_t reserved;
 } velo_map_info;
 
 /* ---- lifetime -------------------------------------------------------------- */

@@ -14,8 +14,15 @@
  *
  * Semantics
  *  grid     origin o = component-wise min of the map points (float); inv_h =
- *           1.0f/h; cell(p) = floorf((p - o) * inv_h) per axis; dims = cell(max)+1;
- *           key = (cz*ny + cy)*nx + cx; points STABLY sorted by key.
+ *           1.0f/h; u = (p - o) * inv_h; voxel c = floorf(u) per axis; dims = c(max)+1.
+ *           Each voxel is split into S x S x S sub-cells (S = 4 by default):
+ *           s = min(S-1, floorf((u - c) * S)), fine coordinate F = c*S + s, fine
+ *           key = (Fz*NFy + Fy)*NFx + Fx with NF = S*dims.  Points are STABLY sorted
+ *           by fine key; fine_start[k] = number of keys < k.  "Sorted index" is the
+ *           position in this order.  A row of fine cells (fixed Fy,Fz) is one
+ *           contiguous index range; a voxel is S*S such row pieces.
+ *           The CANDIDATE SET of a query is still defined on voxels: all points of
+ *           the 27 voxels around the query's voxel (144 fine rows for S = 4).
  *  normals  for sorted point s: the k smallest (d2, index) among all points of
  *           the 27 neighbouring cells with d2 <= h*h (self included);
  *           fewer than 5 -> normal = 0 (invalid).  Covariance about the mean in
@@ -41,9 +48,11 @@
 #include "velo_oracle.h"
 
 struct vo_map {
-    size_t n, ncell;
+    size_t n, ncell; /* ncell = number of FINE cells */
     float o[3], inv_h, h;
-    int dims[3];
+    int dims[3];  /* voxels (coarse cells) per axis */
+    int S;        /* sub-cells per voxel edge */
+    int fd[3];    /* fine cells per axis = S * dims */
     float *x, *y, *z, *nx, *ny, *nz;
     int32_t* perm;
     int32_t* cell_start;
@@ -58,6 +67,37 @@ static inline int cell_coord(float p, float o, float inv_h, int dim)
     if (f > (float)(dim + 1)) f = (float)(dim + 1);
     return (int)f;
 }
+
+/* fine coordinate of a MAP point (always inside the grid) */
+static inline int fine_coord(float p, float o, float inv_h, int S)
+{
+    const float u = (p - o) * inv_h;
+    const float c = floorf(u);
+    int sub = (int)floorf((u - c) * (float)S);
+    if (sub > S - 1) sub = S - 1;
+    if (sub < 0) sub = 0;
+    return (int)c * S + sub;
+}
+
+/* Iterate the fine rows of the 3x3x3 voxel block around voxel (cx,cy,cz) in ascending
+ * sorted index.  Usage: ROWS_BEGIN(m,cx,cy,cz) { ... j0, j1 ... } ROWS_END */
+#define ROWS_BEGIN(m, cx, cy, cz)                                                              \
+    {                                                                                          \
+        const int vx0_ = (cx)-1 < 0 ? 0 : (cx)-1,                                              \
+                  vx1_ = (cx) + 1 >= (m)->dims[0] ? (m)->dims[0] - 1 : (cx) + 1;              \
+        const int vy0_ = (cy)-1 < 0 ? 0 : (cy)-1,                                              \
+                  vy1_ = (cy) + 1 >= (m)->dims[1] ? (m)->dims[1] - 1 : (cy) + 1;              \
+        const int vz0_ = (cz)-1 < 0 ? 0 : (cz)-1,                                              \
+                  vz1_ = (cz) + 1 >= (m)->dims[2] ? (m)->dims[2] - 1 : (cz) + 1;              \
+        if (vx0_ <= vx1_ && vy0_ <= vy1_ && vz0_ <= vz1_)                                      \
+            for (int fz_ = vz0_ * (m)->S; fz_ < (vz1_ + 1) * (m)->S; ++fz_)                   \
+                for (int fy_ = vy0_ * (m)->S; fy_ < (vy1_ + 1) * (m)->S; ++fy_) {             \
+                    const size_t row_ = ((size_t)fz_ * (m)->fd[1] + fy_) * (m)->fd[0];        \
+                    const int32_t j0 = (m)->cell_start[row_ + (size_t)vx0_ * (m)->S];         \
+                    const int32_t j1 = (m)->cell_start[row_ + (size_t)(vx1_ + 1) * (m)->S];
+#define ROWS_END \
+    }            \
+    }
 
 /* ---- symmetric 3x3 eigen decomposition: fixed cyclic Jacobi, fp64 ---------- */
 static void jacobi_rot(double A[3][3], double V[3][3], int p, int q)
@@ -123,35 +163,27 @@ static void point_normal(const vo_map* m, size_t s, int k, float out[3])
     float bd[VO_KMAX];
     int32_t bi[VO_KMAX];
     int cnt = 0;
-    for (int dz = -1; dz <= 1; ++dz) {
-        int z = cz + dz;
-        if (z < 0 || z >= m->dims[2]) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            int y = cy + dy;
-            if (y < 0 || y >= m->dims[1]) continue;
-            int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= m->dims[0] ? m->dims[0] - 1 : cx + 1;
-            if (x0 > x1) continue;
-            size_t row = ((size_t)z * m->dims[1] + y) * m->dims[0];
-            int32_t j0 = m->cell_start[row + x0], j1 = m->cell_start[row + x1 + 1];
-            for (int32_t j = j0; j < j1; ++j) {
-                float dx = m->x[j] - qx, dyy = m->y[j] - qy, dzz = m->z[j] - qz;
-                float d2 = fmaf(dzz, dzz, fmaf(dyy, dyy, dx * dx));
-                if (!(d2 <= r2)) continue;
-                /* insert into ascending (d2, j) list of at most k; j ascends, so
-                 * an equal d2 goes AFTER existing equal entries */
-                if (cnt == k && !(d2 < bd[k - 1])) continue;
-                int pos = cnt < k ? cnt : k - 1;
-                while (pos > 0 && d2 < bd[pos - 1]) {
-                    bd[pos] = bd[pos - 1];
-                    bi[pos] = bi[pos - 1];
-                    --pos;
-                }
-                bd[pos] = d2;
-                bi[pos] = j;
-                if (cnt < k) ++cnt;
+    ROWS_BEGIN(m, cx, cy, cz)
+    {
+        for (int32_t j = j0; j < j1; ++j) {
+            float dx = m->x[j] - qx, dyy = m->y[j] - qy, dzz = m->z[j] - qz;
+            float d2 = fmaf(dzz, dzz, fmaf(dyy, dyy, dx * dx));
+            if (!(d2 <= r2)) continue;
+            /* insert into ascending (d2, j) list of at most k; j ascends, so
+             * an equal d2 goes AFTER existing equal entries */
+            if (cnt == k && !(d2 < bd[k - 1])) continue;
+            int pos = cnt < k ? cnt : k - 1;
+            while (pos > 0 && d2 < bd[pos - 1]) {
+                bd[pos] = bd[pos - 1];
+                bi[pos] = bi[pos - 1];
+                --pos;
             }
+            bd[pos] = d2;
+            bi[pos] = j;
+            if (cnt < k) ++cnt;
         }
     }
+    ROWS_END
     if (cnt < VO_MIN_NB) {
         out[0] = out[1] = out[2] = 0.0f;
         return;
@@ -187,9 +219,16 @@ static void point_normal(const vo_map* m, size_t s, int k, float out[3])
 vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, float voxel,
                      int k_normals)
 {
-    if (n == 0 || !(voxel > 0) || k_normals > VO_KMAX) return NULL;
+    return vo_map_build_ex(x, y, z, n, voxel, k_normals, 4);
+}
+
+vo_map* vo_map_build_ex(const float* x, const float* y, const float* z, size_t n, float voxel,
+                        int k_normals, int subdiv)
+{
+    if (n == 0 || !(voxel > 0) || k_normals > VO_KMAX || subdiv < 1 || subdiv > 16) return NULL;
     vo_map* m = (vo_map*)calloc(1, sizeof *m);
     m->n = n;
+    m->S = subdiv;
     m->h = voxel;
     m->inv_h = 1.0f / voxel;
     float mn[3] = {x[0], y[0], z[0]}, mxv[3] = {x[0], y[0], z[0]};
@@ -204,8 +243,9 @@ vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, f
     for (int a = 0; a < 3; ++a) {
         m->o[a] = mn[a];
         m->dims[a] = (int)floorf((mxv[a] - mn[a]) * m->inv_h) + 1;
+        m->fd[a] = m->dims[a] * m->S;
     }
-    m->ncell = (size_t)m->dims[0] * m->dims[1] * m->dims[2];
+    m->ncell = (size_t)m->fd[0] * m->fd[1] * m->fd[2];
     if (m->ncell >= ((size_t)1 << 31)) {
         free(m);
         return NULL;
@@ -213,10 +253,10 @@ vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, f
     int32_t* key = (int32_t*)malloc(n * sizeof(int32_t));
     m->cell_start = (int32_t*)calloc(m->ncell + 1, sizeof(int32_t));
     for (size_t i = 0; i < n; ++i) {
-        int cx = (int)floorf((x[i] - m->o[0]) * m->inv_h);
-        int cy = (int)floorf((y[i] - m->o[1]) * m->inv_h);
-        int cz = (int)floorf((z[i] - m->o[2]) * m->inv_h);
-        key[i] = (int32_t)(((size_t)cz * m->dims[1] + cy) * m->dims[0] + cx);
+        int cx = fine_coord(x[i], m->o[0], m->inv_h, m->S);
+        int cy = fine_coord(y[i], m->o[1], m->inv_h, m->S);
+        int cz = fine_coord(z[i], m->o[2], m->inv_h, m->S);
+        key[i] = (int32_t)(((size_t)cz * m->fd[1] + cy) * m->fd[0] + cx);
         m->cell_start[key[i] + 1]++;
     }
     for (size_t c = 0; c < m->ncell; ++c) m->cell_start[c + 1] += m->cell_start[c];
@@ -269,6 +309,7 @@ void vo_map_free(vo_map* m)
     free(m);
 }
 size_t vo_map_size(const vo_map* m) { return m->n; }
+int vo_map_subdiv(const vo_map* m) { return m->S; }
 void vo_map_grid(const vo_map* m, float origin[3], int dims[3], float* inv_h)
 {
     memcpy(origin, m->o, sizeof m->o);
@@ -302,27 +343,19 @@ static inline int32_t nearest(const vo_map* m, float qx, float qy, float qz, flo
     const int cz = cell_coord(qz, m->o[2], m->inv_h, m->dims[2]);
     float bd = INFINITY;
     int32_t bj = -1;
-    for (int dz = -1; dz <= 1; ++dz) {
-        int z = cz + dz;
-        if (z < 0 || z >= m->dims[2]) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            int y = cy + dy;
-            if (y < 0 || y >= m->dims[1]) continue;
-            int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= m->dims[0] ? m->dims[0] - 1 : cx + 1;
-            if (x0 > x1) continue;
-            size_t row = ((size_t)z * m->dims[1] + y) * m->dims[0];
-            int32_t j0 = m->cell_start[row + x0], j1 = m->cell_start[row + x1 + 1];
-            *scanned += (uint64_t)(j1 - j0);
-            for (int32_t j = j0; j < j1; ++j) {
-                float dx = m->x[j] - qx, dyy = m->y[j] - qy, dzz = m->z[j] - qz;
-                float d2 = fmaf(dzz, dzz, fmaf(dyy, dyy, dx * dx));
-                if (d2 < bd) {
-                    bd = d2;
-                    bj = j;
-                }
+    ROWS_BEGIN(m, cx, cy, cz)
+    {
+        *scanned += (uint64_t)(j1 - j0);
+        for (int32_t j = j0; j < j1; ++j) {
+            float dx = m->x[j] - qx, dyy = m->y[j] - qy, dzz = m->z[j] - qz;
+            float d2 = fmaf(dzz, dzz, fmaf(dyy, dyy, dx * dx));
+            if (d2 < bd) {
+                bd = d2;
+                bj = j;
             }
         }
     }
+    ROWS_END
     *best_d2 = bd;
     return bj;
 }
@@ -547,8 +580,12 @@ size_t vo_increment(const vo_map* m, const float* x, const float* y, const float
         const int cz = cell_coord(qz, m->o[2], m->inv_h, m->dims[2]);
         int occ = 0;
         if (cx >= 0 && cx < m->dims[0] && cy >= 0 && cy < m->dims[1] && cz >= 0 && cz < m->dims[2]) {
-            size_t key = ((size_t)cz * m->dims[1] + cy) * m->dims[0] + cx;
-            occ = m->cell_start[key + 1] - m->cell_start[key];
+            for (int fz = cz * m->S; fz < (cz + 1) * m->S; ++fz)
+                for (int fy = cy * m->S; fy < (cy + 1) * m->S; ++fy) {
+                    size_t row = ((size_t)fz * m->fd[1] + fy) * m->fd[0];
+                    occ += m->cell_start[row + (size_t)(cx + 1) * m->S] -
+                           m->cell_start[row + (size_t)cx * m->S];
+                }
         }
         if (occ < min_count) {
             if (ox) {

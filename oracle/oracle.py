@@ -105,6 +105,8 @@ def lib():
     L.vo_frame_num_packets.restype = C.c_size_t
     L.vo_map_build.argtypes = [fp, fp, fp, C.c_size_t, C.c_float, C.c_int]
     L.vo_map_build.restype = C.c_void_p
+    L.vo_map_build_ex.argtypes = [fp, fp, fp, C.c_size_t, C.c_float, C.c_int, C.c_int]
+    L.vo_map_build_ex.restype = C.c_void_p
     L.vo_map_free.argtypes = [C.c_void_p]
     L.vo_map_size.argtypes = [C.c_void_p]
     L.vo_map_size.restype = C.c_size_t
@@ -304,9 +306,11 @@ class Decoder:
 
 # ----------------------------------------------------------------------- ICP
 class Map:
-    def __init__(self, x, y, z, voxel=1.0, k_normals=16):
+    def __init__(self, x, y, z, voxel=1.0, k_normals=16, subdiv=4):
         x, y, z = _f32(x), _f32(y), _f32(z)
-        self.h = lib().vo_map_build(_f(x), _f(y), _f(z), x.size, float(voxel), int(k_normals))
+        self.h = lib().vo_map_build_ex(_f(x), _f(y), _f(z), x.size, float(voxel), int(k_normals),
+                                       int(subdiv))
+        self.subdiv = int(subdiv)
         if not self.h:
             raise ValueError("vo_map_build failed")
         self.n = x.size

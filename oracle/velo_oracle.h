@@ -116,10 +116,15 @@ typedef struct vo_map vo_map;
 /* voxel: cell edge h.  k_normals: neighbours for PCA (<=32). */
 vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, float voxel,
                      int k_normals);
+/* subdiv: sub-cells per voxel edge (part of the sort order, hence of the spec); 4 above */
+vo_map* vo_map_build_ex(const float* x, const float* y, const float* z, size_t n, float voxel,
+                        int k_normals, int subdiv);
+int vo_map_subdiv(const vo_map*);
 void vo_map_free(vo_map*);
 size_t vo_map_size(const vo_map*);
 void vo_map_grid(const vo_map*, float origin[3], int dims[3], float* inv_h);
-/* sorted SoA arrays (length n), perm[s] = original index, cell_start (ncell+1) */
+/* sorted SoA arrays (length n), perm[s] = original index; cell_start = the FINE cell
+ * table (vo_map_num_cells()+1 entries, vo_map_num_cells = product of subdiv*dims) */
 const float* vo_map_x(const vo_map*);
 const float* vo_map_y(const vo_map*);
 const float* vo_map_z(const vo_map*);

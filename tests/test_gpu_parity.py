@@ -93,20 +93,38 @@ def test_map_build_bit_exact(ctx, omap, wl):
     assert mi.n_invalid_normals == int(((nx == 0) & (ny == 0) & (nz == 0)).sum())
 
 
-@pytest.mark.parametrize("voxel,k", [(0.5, 8), (2.0, 32), (1.0, 5)])
-def test_map_build_other_grids(ctx, oracle, voxel, k):
-    rng = np.random.default_rng(int(voxel * 10) + k)
+@pytest.mark.parametrize("voxel,k,subdiv", [(0.5, 8, 4), (2.0, 32, 4), (1.0, 5, 1), (1.0, 16, 2),
+                                            (1.5, 12, 3), (1.0, 16, 8)])
+def test_map_build_and_search_other_grids(oracle, voxel, k, subdiv):
+    """Other voxel sizes and sub-divisions (the sub-division is part of the sort order, hence
+    of the spec): map tables, normals and correspondences stay bit-identical to the oracle."""
+    rng = np.random.default_rng(int(voxel * 10) + k + subdiv)
     n = 30000
     x = rng.uniform(-20, 20, n).astype(np.float32)
     y = rng.uniform(-15, 15, n).astype(np.float32)
     z = (0.05 * np.sin(x) + rng.normal(0, 0.01, n)).astype(np.float32)
-    om = oracle.Map(x, y, z, voxel, k)
-    ctx.map_reset(x, y, z, voxel, k)
-    g = ctx.map_download()
-    assert np.array_equal(g["cell_start"], om.cell_start())
-    assert np.array_equal(g["perm"], om.perm())
-    for a, b in zip((g["nx"], g["ny"], g["nz"]), om.normals()):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    om = oracle.Map(x, y, z, voxel, k, subdiv)
+    q = rng.uniform(-22, 22, (3, 6000)).astype(np.float32)
+    q[2] *= 0.05
+    I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)
+    for variant in (0, 1):
+        c = capi.Context(0, max_batch=2, linearize_variant=variant, map_subdiv=subdiv)
+        try:
+            c.map_reset(x, y, z, voxel, k)
+            g = c.map_download()
+            assert c.map_info().subdiv == subdiv
+            assert np.array_equal(g["cell_start"], om.cell_start())
+            assert np.array_equal(g["perm"], om.perm())
+            for a, b in zip((g["nx"], g["ny"], g["nz"]), om.normals()):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            c.frames_upload([tuple(q)])
+            for dmax in (voxel, 0.3 * voxel):
+                corr, d2, _ = c.linearize(0, I, dmax, q.shape[1])
+                oc, od2, _ = om.correspond(*q, I, dmax)
+                assert np.array_equal(corr, oc)
+                assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+        finally:
+            c.close()
 
 
 def test_map_append_equals_rebuild(ctx, oracle):

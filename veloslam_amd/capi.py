@@ -27,7 +27,7 @@ class VeloError(RuntimeError):
 class Cfg(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_batch", C.c_int32),
                 ("linearize_variant", C.c_int32), ("sort_frames", C.c_int32),
-                ("use_graph", C.c_int32), ("reserved", C.c_int32 * 11)]
+                ("use_graph", C.c_int32), ("map_subdiv", C.c_int32), ("reserved", C.c_int32 * 10)]
 
 
 class Pose(C.Structure):
@@ -49,7 +49,8 @@ class IcpResult(C.Structure):
 class MapInfo(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("n_cells", C.c_uint64), ("origin", C.c_float * 3),
                 ("voxel", C.c_float), ("inv_voxel", C.c_float), ("dims", C.c_int32 * 3),
-                ("k_normals", C.c_int32), ("n_invalid_normals", C.c_uint64)]
+                ("k_normals", C.c_int32), ("n_invalid_normals", C.c_uint64),
+                ("subdiv", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/velo.h declares (tests check the library exports them all)
@@ -230,13 +231,14 @@ def mapping_angle(a):
 class Context:
     """One velo_ctx: one GPU, one stream, single-threaded."""
 
-    def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=0):
+    def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=1, map_subdiv=4):
         L = lib()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
         cfg.max_batch = max_batch
         cfg.sort_frames = sort_frames
         cfg.linearize_variant = linearize_variant
+        cfg.map_subdiv = map_subdiv
         self.h = L.velo_create(device, C.byref(cfg))
         if not self.h:
             raise VeloError(-3, L.velo_last_error(None).decode())

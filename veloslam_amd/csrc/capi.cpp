@@ -150,9 +150,13 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
         dims[a] = (int)ext + 1;
         ncell_d *= (double)dims[a];
     }
+    const int S = c->cfg.map_subdiv;
+    ncell_d *= (double)S * S * S;
     if (ncell_d >= 2147483648.0)
-        return c->fail(VELO_E_RANGE, "dense voxel grid of %.3g cells exceeds 2^31", ncell_d);
-    const size_t ncell = (size_t)dims[0] * dims[1] * dims[2];
+        return c->fail(VELO_E_RANGE, "dense fine-cell grid of %.3g cells (voxels x %d^3) exceeds 2^31",
+                       ncell_d, S);
+    const int fdims[3] = {dims[0] * S, dims[1] * S, dims[2] * S};
+    const size_t ncell = (size_t)fdims[0] * fdims[1] * fdims[2];
     HIP_TRY(c, c->keys.reserve(n));
     HIP_TRY(c, c->keys_sorted.reserve(n));
     HIP_TRY(c, c->idx.reserve(n));
@@ -162,7 +166,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
     HIP_TRY(c, c->cell_start.reserve(ncell + 1));
     HIP_TRY(c, c->invalid_cnt.reserve(1));
     HIP_TRY(c, launch_keys(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, mm.mn[0], mm.mn[1], mm.mn[2],
-                           inv_h, dims[0], dims[1], c->keys.p, c->idx.p, s));
+                           inv_h, S, fdims[0], fdims[1], c->keys.p, c->idx.p, s));
     int bits = 1;
     while (bits < 32 && ((size_t)1 << bits) < ncell) ++bits;
     size_t tb = 0;
@@ -183,6 +187,10 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
     mv.nx = dims[0];
     mv.ny = dims[1];
     mv.nz = dims[2];
+    mv.S = S;
+    mv.fx = fdims[0];
+    mv.fy = fdims[1];
+    mv.fz = fdims[2];
     mv.n = (int)n;
     unsigned long long invalid = n;
     if (k_normals > 0) {
@@ -205,6 +213,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
     c->info.dims[1] = dims[1];
     c->info.dims[2] = dims[2];
     c->info.k_normals = k_normals;
+    c->info.subdiv = S;
     c->info.n_invalid_normals = invalid;
     return VELO_OK;
 }
@@ -326,7 +335,7 @@ int maybe_sort_frames(velo_ctx* c, FrameView& fv)
     fv.order = nullptr;
     if (!c->cfg.sort_frames) return VELO_OK;
     const size_t n = (size_t)c->frame_start[c->n_frames];
-    const double span = (double)c->n_frames * ((double)c->info.n_cells + 1.0);
+    const double span = (double)c->n_frames * ((double)c->mv.nx * c->mv.ny * c->mv.nz + 1.0);
     if (n == 0 || span >= 4294967296.0) return VELO_OK;  // composite key would not fit 32 bits
     HIP_TRY(c, c->order_keys.reserve(n));
     HIP_TRY(c, c->order_keys2.reserve(n));
@@ -475,6 +484,8 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     if (cfg) std::memcpy(&c->cfg, cfg, std::min<size_t>(cfg->struct_size, sizeof(velo_cfg)));
     c->cfg.struct_size = sizeof(velo_cfg);
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 64;
+    if (c->cfg.map_subdiv <= 0) c->cfg.map_subdiv = 4;
+    if (c->cfg.map_subdiv > 16) c->cfg.map_subdiv = 16;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         return nullptr;

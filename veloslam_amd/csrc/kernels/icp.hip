@@ -91,29 +91,62 @@ __constant__ unsigned char c_ia[32] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2,
 __constant__ unsigned char c_ib[32] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3,
                                        4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7};
 
-// exhaustive 27-cell scan in ascending sorted index; strict '<' keeps the lowest
-// index among equal distances
+// ---- fine-grid geometry of a query --------------------------------------------------
+// The map is sorted by FINE cell (S sub-cells per voxel edge, DESIGN.md "ICP semantics");
+// one row of fine cells (fixed Fy,Fz) is one contiguous index range of the map.
+struct QueryCell {
+    int cx, cy, cz;     // voxel (clamped to [-2, dim+1])
+    int Fx, Fy, Fz;     // fine cell (meaningful when the voxel is within [-1, dim])
+    float tx, ty, tz;   // position inside the fine cell, in fine-cell units [0,1)
+    bool near;          // voxel within one voxel of the grid: candidates may exist
+};
+
+__device__ __forceinline__ void query_axis(float q, float o, float inv_h, int dim, int S, int& c,
+                                           int& F, float& t)
+{
+    const float u = (q - o) * inv_h;
+    c = cell_coord(q, o, inv_h, dim);
+    const float fr = (u - (float)c) * (float)S;  // exact for power-of-two S
+    float sf = floorf(fr);
+    sf = fminf(fmaxf(sf, 0.0f), (float)(S - 1));
+    t = fr - sf;
+    F = c * S + (int)sf;
+}
+
+__device__ __forceinline__ QueryCell locate(const MapView& mv, float qx, float qy, float qz)
+{
+    QueryCell g;
+    query_axis(qx, mv.ox, mv.inv_h, mv.nx, mv.S, g.cx, g.Fx, g.tx);
+    query_axis(qy, mv.oy, mv.inv_h, mv.ny, mv.S, g.cy, g.Fy, g.ty);
+    query_axis(qz, mv.oz, mv.inv_h, mv.nz, mv.S, g.cz, g.Fz, g.tz);
+    g.near = g.cx >= -1 && g.cx <= mv.nx && g.cy >= -1 && g.cy <= mv.ny && g.cz >= -1 &&
+             g.cz <= mv.nz;
+    return g;
+}
+
+// ---- variant 0: exhaustive scan ------------------------------------------------------
+// All points of the 27 voxels around the query, in ascending sorted index (9*S*S fine
+// rows); strict '<' keeps the lowest index among equal distances.  This is the oracle's
+// definition executed literally; it is the validation kernel, not the fast path.
 __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float qy, float qz,
                                              float& bd, int& bj)
 {
-    const int cx = cell_coord(qx, mv.ox, mv.inv_h, mv.nx);
-    const int cy = cell_coord(qy, mv.oy, mv.inv_h, mv.ny);
-    const int cz = cell_coord(qz, mv.oz, mv.inv_h, mv.nz);
+    const QueryCell g = locate(mv, qx, qy, qz);
     bd = INFINITY;
     bj = -1;
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, mv.nx - 1);
-    if (x0 > x1) return;
+    const int vx0 = max(g.cx - 1, 0), vx1 = min(g.cx + 1, mv.nx - 1);
+    const int vy0 = max(g.cy - 1, 0), vy1 = min(g.cy + 1, mv.ny - 1);
+    const int vz0 = max(g.cz - 1, 0), vz1 = min(g.cz + 1, mv.nz - 1);
+    if (vx0 > vx1 || vy0 > vy1 || vz0 > vz1) return;
+    const int S = mv.S;
 #pragma unroll 1
-    for (int dz = -1; dz <= 1; ++dz) {
-        const int zz = cz + dz;
-        if (zz < 0 || zz >= mv.nz) continue;
+    for (int fz = vz0 * S; fz < (vz1 + 1) * S; ++fz) {
 #pragma unroll 1
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = cy + dy;
-            if (yy < 0 || yy >= mv.ny) continue;
-            const size_t row = ((size_t)zz * mv.ny + yy) * mv.nx;
-            const int j0 = mv.cell_start[row + x0], j1 = mv.cell_start[row + x1 + 1];
-#pragma unroll 8
+        for (int fy = vy0 * S; fy < (vy1 + 1) * S; ++fy) {
+            const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
+            const int j0 = mv.cell_start[row + (size_t)vx0 * S];
+            const int j1 = mv.cell_start[row + (size_t)(vx1 + 1) * S];
+#pragma unroll 4
             for (int j = j0; j < j1; ++j) {
                 const float d2 = dist2(mv.pts[j], qx, qy, qz);
                 if (d2 < bd) {
@@ -125,94 +158,36 @@ __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float 
     }
 }
 
-// ---- pruned exact search -----------------------------------------------------------
-// Same result as nearest_scan (lexicographic minimum of (d2, sorted index) over the 27
-// cells, accepted iff d2 <= dmax2), reached with far fewer distance evaluations:
-//   1. probe: min d2 over the query's OWN cell gives an upper bound ub (<= dmax2);
-//   2. a row (dy,dz) of the 3x3x3 block, or its left/right cell, is dropped when a
-//      conservative lower bound of its distance exceeds ub (bounds are computed from the
-//      query's fractional position inside its cell, shrunk by a margin that covers the
-//      float rounding of the cell-assignment expression, and scaled by 0.99999);
-//   3. the surviving index ranges are scanned in DESCENDING sorted index with '<=', so
-//      the last (lowest) index among equal distances wins -- the oracle's tie rule.
-// Ranges go through LDS (s_hi/s_lo, [slot][thread]) so each lane walks its own list in
-// one flattened loop: a wave runs for max-over-lanes of the TOTAL candidates, not the sum
-// over rows of per-row maxima.
+// ---- variant 1: exact ball search on the fine grid ----------------------------------------
+// Same winner as nearest_scan (lexicographic minimum of (d2, sorted index), accepted iff
+// d2 <= dmax2) with ~an order of magnitude fewer distance evaluations:
+//   stage A  every lane scans the 3x3x3 block of FINE cells around its query: <= 9 index
+//            ranges, staged in LDS ([slot][thread]) and walked in one flattened loop, four
+//            candidate loads in flight, DESCENDING index with '<=' (the last = lowest index
+//            among equal distances wins -- the oracle's tie rule).  If the winner is closer
+//            than the distance from the query to the faces of that block (shrunk by a margin
+//            that covers the float rounding of the cell-assignment expression), nothing
+//            outside the block can beat or tie it: done.  After convergence that is ~98 %
+//            of the queries.
+//   stage B  the rest are compacted per workgroup (LDS list) and re-searched over the whole
+//            ball of radius sqrt(min(best, dmax2)): rows pruned by a conservative bound, the
+//            x-extent of each row cut to the ball, descending index, '<='.  Compaction keeps
+//            a handful of stragglers from stalling every wavefront of the workgroup.
 constexpr int kMaxRanges = 9;
 
-__device__ __forceinline__ void nearest_pruned(const MapView& mv, float qx, float qy, float qz,
-                                               float dmax2, int (*s_hi)[kLinThreads],
-                                               int (*s_lo)[kLinThreads], int tid, float& bd,
-                                               int& bj)
+struct SearchLds {
+    int hi[kMaxRanges][kLinThreads];
+    int lo[kMaxRanges][kLinThreads];
+};
+
+__device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float qy, float qz,
+                                            SearchLds& L, int tid, int nr, float& bd, int& bj)
 {
-    bd = dmax2;
-    bj = -1;
-    const float ux = (qx - mv.ox) * mv.inv_h, uy = (qy - mv.oy) * mv.inv_h,
-                uz = (qz - mv.oz) * mv.inv_h;
-    const int cx = cell_coord(qx, mv.ox, mv.inv_h, mv.nx);
-    const int cy = cell_coord(qy, mv.oy, mv.inv_h, mv.ny);
-    const int cz = cell_coord(qz, mv.oz, mv.inv_h, mv.nz);
-    int nr = 0;
-    if (cx >= -1 && cx <= mv.nx && cy >= -1 && cy <= mv.ny && cz >= -1 && cz <= mv.nz) {
-        // distances (metres) from the query to the faces of its own cell, made conservative
-        const float mgx = 1e-6f * (float)mv.nx * mv.h + 1e-6f;
-        const float mgy = 1e-6f * (float)mv.ny * mv.h + 1e-6f;
-        const float mgz = 1e-6f * (float)mv.nz * mv.h + 1e-6f;
-        const float fxr = ux - (float)cx, fyr = uy - (float)cy, fzr = uz - (float)cz;
-        const float lox = fmaxf(fxr * mv.h - mgx, 0.0f), hix = fmaxf((1.0f - fxr) * mv.h - mgx, 0.0f);
-        const float loy = fmaxf(fyr * mv.h - mgy, 0.0f), hiy = fmaxf((1.0f - fyr) * mv.h - mgy, 0.0f);
-        const float loz = fmaxf(fzr * mv.h - mgz, 0.0f), hiz = fmaxf((1.0f - fzr) * mv.h - mgz, 0.0f);
-        const bool cin = cx >= 0 && cx < mv.nx;
-        float ub = dmax2;
-        if (cin && cy >= 0 && cy < mv.ny && cz >= 0 && cz < mv.nz) {
-            const size_t key = ((size_t)cz * mv.ny + cy) * mv.nx + cx;
-            const int j0 = mv.cell_start[key], j1 = mv.cell_start[key + 1];
-#pragma unroll 8
-            for (int j = j0; j < j1; ++j) ub = fminf(ub, dist2(mv.pts[j], qx, qy, qz));
-        }
-        const float lox2 = lox * lox, hix2 = hix * hix;
-#pragma unroll
-        for (int dz = 1; dz >= -1; --dz) {
-            const int zz = cz + dz;
-            const float bz = dz == 0 ? 0.0f : (dz > 0 ? hiz : loz);
-#pragma unroll
-            for (int dy = 1; dy >= -1; --dy) {
-                const int yy = cy + dy;
-                const float by = dy == 0 ? 0.0f : (dy > 0 ? hiy : loy);
-                const float rb2 = bz * bz + by * by;
-                const bool row_ok = zz >= 0 && zz < mv.nz && yy >= 0 && yy < mv.ny &&
-                                    !(rb2 * 0.99999f > ub);
-                int x0 = cx, x1 = cx;
-                if (!cin) {  // the centre cell does not exist: collapse onto the side that does
-                    x0 = cx + 1;
-                    x1 = cx - 1;
-                }
-                if (cx - 1 >= 0 && cx - 1 < mv.nx && !((lox2 + rb2) * 0.99999f > ub)) x0 = cx - 1;
-                if (cx + 1 >= 0 && cx + 1 < mv.nx && !((hix2 + rb2) * 0.99999f > ub)) x1 = cx + 1;
-                if (!cin) {  // only one neighbour can exist when the centre is outside
-                    if (x0 == cx - 1) x1 = cx - 1;        // left neighbour in range
-                    else if (x1 == cx + 1) x0 = cx + 1;   // right neighbour in range
-                }
-                if (row_ok && x0 <= x1) {
-                    const size_t row = ((size_t)zz * mv.ny + yy) * mv.nx;
-                    const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
-                    if (jhi > jlo) {
-                        s_hi[nr][tid] = jhi;
-                        s_lo[nr][tid] = jlo;
-                        ++nr;
-                    }
-                }
-            }
-        }
-    }
-    // flattened walk over this lane's ranges, four candidates per trip so that four loads
-    // are in flight (the loop is bound by load latency, not by arithmetic).  Indices are
-    // clamped to the range start: a candidate evaluated twice is harmless under '<='.
     bool more = nr > 0;
     int k = 1, j = 0, lo = 0;
     if (more) {
-        j = s_hi[0][tid];
-        lo = s_lo[0][tid];
+        j = L.hi[0][tid];
+        lo = L.lo[0][tid];
     }
     while (more) {
         const int j0 = j - 1, j1 = max(j - 2, lo), j2 = max(j - 3, lo), j3 = max(j - 4, lo);
@@ -226,8 +201,8 @@ __device__ __forceinline__ void nearest_pruned(const MapView& mv, float qx, floa
         j -= 4;
         if (j <= lo) {
             if (k < nr) {
-                j = s_hi[k][tid];
-                lo = s_lo[k][tid];
+                j = L.hi[k][tid];
+                lo = L.lo[k][tid];
                 ++k;
             } else {
                 more = false;
@@ -236,21 +211,177 @@ __device__ __forceinline__ void nearest_pruned(const MapView& mv, float qx, floa
     }
 }
 
+// stage A; returns true when the result is final.
+// ABL (timing ablations only, results are wrong): 1 = treat stage A as final, 2 = also skip
+// the candidate walk, 3 = also skip the fine-table loads
+template <int ABL>
+__device__ __forceinline__ bool search_block(const MapView& mv, const QueryCell& g, float qx,
+                                             float qy, float qz, float dmax2, SearchLds& L,
+                                             int tid, float& bd, int& bj)
+{
+    bd = dmax2;
+    bj = -1;
+    if (!g.near) return true;  // no voxel of the 27 exists: no candidates at all
+    const int x0 = max(g.Fx - 1, 0), x1 = min(g.Fx + 1, mv.fx - 1);
+    int nr = 0;
+    if (x0 <= x1 && ABL < 3) {
+#pragma unroll
+        for (int dz = 1; dz >= -1; --dz) {
+            const int zz = g.Fz + dz;
+#pragma unroll
+            for (int dy = 1; dy >= -1; --dy) {
+                const int yy = g.Fy + dy;
+                if (zz >= 0 && zz < mv.fz && yy >= 0 && yy < mv.fy) {
+                    const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
+                    const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
+                    if (jhi > jlo) {
+                        L.hi[nr][tid] = jhi;
+                        L.lo[nr][tid] = jlo;
+                        ++nr;
+                    }
+                }
+            }
+        }
+    }
+    if (ABL >= 2) nr = min(nr, 0);
+    walk_ranges(mv, qx, qy, qz, L, tid, nr, bd, bj);
+    if (ABL >= 1) return true;
+    // guaranteed radius of the scanned block: one fine cell plus the distance to the nearer
+    // face of the query's own fine cell, per axis; shrunk for rounding
+    const float hf = mv.h / (float)mv.S;
+    const float tmin = fminf(fminf(fminf(g.tx, 1.0f - g.tx), fminf(g.ty, 1.0f - g.ty)),
+                             fminf(g.tz, 1.0f - g.tz));
+    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+    const float gr = fmaxf(hf * (1.0f + tmin) - mg, 0.0f);
+    return bd <= gr * gr * 0.99999f;
+}
+
+// stage B: whole ball, lockstep over rows (run by the compacted stragglers only)
+__device__ void search_ball(const MapView& mv, float qx, float qy, float qz, float ub, float& bd,
+                            int& bj)
+{
+    const QueryCell g = locate(mv, qx, qy, qz);
+    bd = ub;
+    bj = -1;
+    const int S = mv.S;
+    const float hf = mv.h / (float)S;
+    const float inv_hf = (float)S * mv.inv_h;
+    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+    const float xf = (float)g.Fx + g.tx;  // fine coordinate of the query along x
+#pragma unroll 1
+    for (int dz = S; dz >= -S; --dz) {
+        const int zz = g.Fz + dz;
+        if (zz < 0 || zz >= mv.fz) continue;
+        const float bz = dz == 0 ? 0.0f
+                                 : fmaxf(((float)(abs(dz) - 1) + (dz > 0 ? 1.0f - g.tz : g.tz)) * hf - mg, 0.0f);
+        if (bz * bz * 0.99999f > bd) continue;
+#pragma unroll 1
+        for (int dy = S; dy >= -S; --dy) {
+            const int yy = g.Fy + dy;
+            if (yy < 0 || yy >= mv.fy) continue;
+            const float by = dy == 0 ? 0.0f
+                                     : fmaxf(((float)(abs(dy) - 1) + (dy > 0 ? 1.0f - g.ty : g.ty)) * hf - mg, 0.0f);
+            const float rb2 = bz * bz + by * by;
+            if (rb2 * 0.99999f > bd) continue;
+            // half-width of the ball in this row, in fine cells, rounded outwards
+            const float w = (sqrtf(fmaxf(bd - rb2 * 0.99999f, 0.0f)) * 1.00001f + mg) * inv_hf;
+            const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
+            if (x0 > x1) continue;
+            const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
+            const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
+#pragma unroll 4
+            for (int j = jhi - 1; j >= jlo; --j) {
+                const float d2 = dist2(mv.pts[j], qx, qy, qz);
+                if (d2 <= bd) {
+                    bd = d2;
+                    bj = j;
+                }
+            }
+        }
+    }
+}
+
+// stage B, cooperative form: ONE straggler searched by a whole wavefront.  Lane l takes row
+// l (and l+64) of the (2S+1)^2 fine rows around the query, scans the part of it inside the
+// ball of radius sqrt(ub) in descending index with '<=', then the 64 lane results are merged
+// to the lexicographic minimum of (d2, index) by two wavefront min-reductions (shuffles).
+// Every lane returns the same winner.  Rows are independent, so all their loads are in
+// flight together: a handful of stragglers no longer costs a serial chain of ~50 dependent
+// loads while the other wavefronts of the workgroup wait at the barrier.
+__device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, float qy, float qz,
+                                                 float ub, int lane, float& bd, int& bj)
+{
+    const QueryCell g = locate(mv, qx, qy, qz);
+    bd = ub;
+    bj = -1;
+    const int S = mv.S;
+    const int side = 2 * S + 1, nrows = side * side;
+    const float hf = mv.h / (float)S;
+    const float inv_hf = (float)S * mv.inv_h;
+    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+    const float xf = (float)g.Fx + g.tx;
+    for (int r = lane; r < nrows; r += 64) {
+        const int dz = S - r / side, dy = S - r % side;
+        const int zz = g.Fz + dz, yy = g.Fy + dy;
+        if (zz < 0 || zz >= mv.fz || yy < 0 || yy >= mv.fy) continue;
+        const float bz = dz == 0 ? 0.0f
+                                 : fmaxf(((float)(abs(dz) - 1) + (dz > 0 ? 1.0f - g.tz : g.tz)) * hf - mg, 0.0f);
+        const float by = dy == 0 ? 0.0f
+                                 : fmaxf(((float)(abs(dy) - 1) + (dy > 0 ? 1.0f - g.ty : g.ty)) * hf - mg, 0.0f);
+        const float rb2 = (bz * bz + by * by) * 0.99999f;
+        if (rb2 > ub) continue;
+        const float w = (sqrtf(fmaxf(ub - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
+        const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
+        if (x0 > x1) continue;
+        const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
+        const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
+#pragma unroll 4
+        for (int j = jhi - 1; j >= jlo; --j) {
+            const float d2 = dist2(mv.pts[j], qx, qy, qz);
+            // rows are visited in descending order by each lane, so '<=' keeps the lowest
+            // index among equal distances inside the lane; lanes are merged below
+            if (d2 <= bd) {
+                bd = d2;
+                bj = j;
+            }
+        }
+    }
+    float dmin = bd;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, off, 64));
+    int jm = (bj >= 0 && bd == dmin) ? bj : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) jm = min(jm, __shfl_xor(jm, off, 64));
+    bd = dmin;
+    bj = jm == 0x7fffffff ? -1 : jm;
+}
+
 // One block = one BlockItem = a run of queries of one frame.  Per round of 256
 // queries every thread writes its 8 values {J, r, valid} to LDS; then lane k<29 of
 // each 32-lane half sums column k over that half's 32 entries (ascending), the two
 // halves are combined by a wavefront shuffle, the four waves through LDS, always in
 // the same order: run-to-run deterministic.
+struct ReduceLds {
+    double v[8][kLinThreads + 4];  // SoA, +4 pad: the 8 rows land on distinct banks
+};
+union LinLds {  // the search ranges and the reduction tile are never live together
+    SearchLds s;
+    ReduceLds r;
+};
+
 template <bool WRITE_CORR, int VARIANT>
 __global__ __launch_bounds__(kLinThreads) void k_linearize(
     const BlockItem* __restrict__ items, FrameView fv, MapView mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
     int32_t* __restrict__ corr, float* __restrict__ d2out)
 {
-    __shared__ double s_v[8][kLinThreads + 4];  // SoA, +4 pad: the 8 rows land on distinct banks
+    __shared__ LinLds s_u;
     __shared__ double s_w[4][32];
-    __shared__ int s_hi[VARIANT == 1 ? kMaxRanges : 1][kLinThreads];
-    __shared__ int s_lo[VARIANT == 1 ? kMaxRanges : 1][kLinThreads];
+    __shared__ float s_bq[4][kLinThreads];  // stage-B hand-off: query xyz + bound
+    __shared__ int s_bres[kLinThreads];
+    __shared__ float s_bresd[kLinThreads];
+    __shared__ int s_blist[kLinThreads];
+    __shared__ int s_nb;
     const BlockItem it = items[blockIdx.x];
     const double* __restrict__ T = poses + 12 * (size_t)it.frame;
     const int tid = threadIdx.x;
@@ -261,16 +392,70 @@ __global__ __launch_bounds__(kLinThreads) void k_linearize(
 
     for (int base = it.q0; base < it.q1; base += kLinThreads) {
         const int q = base + tid;
-        double J0 = 0, J1 = 0, J2 = 0, J3 = 0, J4 = 0, J5 = 0, r = 0, valid = 0;
-        if (q < it.q1) {
-            double px, py, pz;
+        const bool live = q < it.q1;
+        double px = 0, py = 0, pz = 0;
+        float bd = INFINITY;
+        int bj = -1;
+        if (VARIANT >= 1) {
+            if (tid == 0) s_nb = 0;
+            bool queued = false;
+            __syncthreads();
+            if (live) {
+                xform(T, fv.x[q], fv.y[q], fv.z[q], px, py, pz);
+                const float qx = (float)px, qy = (float)py, qz = (float)pz;
+                const QueryCell g = locate(mv, qx, qy, qz);
+                if (!search_block<(VARIANT >= 11 ? VARIANT - 10 : 0)>(mv, g, qx, qy, qz, dmax2, s_u.s,
+                                                                    tid, bd, bj)) {
+                    queued = true;
+                    const int slot = atomicAdd(&s_nb, 1);
+                    s_blist[slot] = tid;
+                    s_bq[0][tid] = qx;
+                    s_bq[1][tid] = qy;
+                    s_bq[2][tid] = qz;
+                    s_bq[3][tid] = bd;  // <= dmax2: radius^2 of the ball still to be searched
+                }
+            }
+            __syncthreads();
+            const int nb = s_nb;  // uniform across the workgroup
+            if (nb > 0) {
+                if (nb > 32) {
+                    // many stragglers (first iterations of a poorly aligned frame): one per
+                    // lane keeps every lane busy
+                    for (int i = tid; i < nb; i += kLinThreads) {
+                        const int owner = s_blist[i];
+                        float rbd;
+                        int rbj;
+                        search_ball(mv, s_bq[0][owner], s_bq[1][owner], s_bq[2][owner],
+                                    s_bq[3][owner], rbd, rbj);
+                        s_bres[owner] = rbj;
+                        s_bresd[owner] = rbd;
+                    }
+                } else {
+                    // few stragglers: one per wavefront, searched cooperatively
+                    for (int i = wave; i < nb; i += kLinThreads / 64) {
+                        const int owner = s_blist[i];
+                        float rbd;
+                        int rbj;
+                        search_ball_wave(mv, s_bq[0][owner], s_bq[1][owner], s_bq[2][owner],
+                                         s_bq[3][owner], lane, rbd, rbj);
+                        if (lane == 0) {
+                            s_bres[owner] = rbj;
+                            s_bresd[owner] = rbd;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (queued) {
+                    bj = s_bres[tid];
+                    bd = s_bresd[tid];
+                }
+            }
+        } else if (live) {
             xform(T, fv.x[q], fv.y[q], fv.z[q], px, py, pz);
-            float bd;
-            int bj;
-            if (VARIANT == 1)
-                nearest_pruned(mv, (float)px, (float)py, (float)pz, dmax2, s_hi, s_lo, tid, bd, bj);
-            else
-                nearest_scan(mv, (float)px, (float)py, (float)pz, bd, bj);
+            nearest_scan(mv, (float)px, (float)py, (float)pz, bd, bj);
+        }
+        double J0 = 0, J1 = 0, J2 = 0, J3 = 0, J4 = 0, J5 = 0, r = 0, valid = 0;
+        if (live) {
             const bool ok = (bj >= 0) && (bd <= dmax2);
             if (WRITE_CORR) {
                 const int qi = fv.order ? fv.order[q] : q;
@@ -279,8 +464,8 @@ __global__ __launch_bounds__(kLinThreads) void k_linearize(
             }
             if (ok) {
                 const float4 nf = mv.nrm[bj];
+                const float4 mf = mv.pts[bj];  // issued with the normal: one round trip, not two
                 if (!(nf.x == 0.0f && nf.y == 0.0f && nf.z == 0.0f)) {
-                    const float4 mf = mv.pts[bj];
                     const double nx = nf.x, ny = nf.y, nz = nf.z;
                     const double dx = px - (double)mf.x, dy = py - (double)mf.y,
                                  dz = pz - (double)mf.z;
@@ -295,19 +480,21 @@ __global__ __launch_bounds__(kLinThreads) void k_linearize(
                 }
             }
         }
-        s_v[0][tid] = J0;
-        s_v[1][tid] = J1;
-        s_v[2][tid] = J2;
-        s_v[3][tid] = J3;
-        s_v[4][tid] = J4;
-        s_v[5][tid] = J5;
-        s_v[6][tid] = r;
-        s_v[7][tid] = valid;
+        __syncthreads();  // the search ranges are dead: the tile may overwrite them
+        s_u.r.v[0][tid] = J0;
+        s_u.r.v[1][tid] = J1;
+        s_u.r.v[2][tid] = J2;
+        s_u.r.v[3][tid] = J3;
+        s_u.r.v[4][tid] = J4;
+        s_u.r.v[5][tid] = J5;
+        s_u.r.v[6][tid] = r;
+        s_u.r.v[7][tid] = valid;
         __syncthreads();
         if (col < kAccN) {
             const int e0 = wave * 64 + half * 32;
 #pragma unroll 8
-            for (int e = 0; e < 32; ++e) colsum = fma(s_v[ia][e0 + e], s_v[ib][e0 + e], colsum);
+            for (int e = 0; e < 32; ++e)
+                colsum = fma(s_u.r.v[ia][e0 + e], s_u.r.v[ib][e0 + e], colsum);
         }
         __syncthreads();
     }
@@ -332,6 +519,12 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
                        mv, poses, dmax2, partials, corr, d2)
     if (variant == 1) {
         if (wc) VELO_LAUNCH_LIN(true, 1); else VELO_LAUNCH_LIN(false, 1);
+    } else if (variant == 11) {  // timing ablations (wrong results by design)
+        VELO_LAUNCH_LIN(false, 11);
+    } else if (variant == 12) {
+        VELO_LAUNCH_LIN(false, 12);
+    } else if (variant == 13) {
+        VELO_LAUNCH_LIN(false, 13);
     } else {
         if (wc) VELO_LAUNCH_LIN(true, 0); else VELO_LAUNCH_LIN(false, 0);
     }
@@ -578,8 +771,12 @@ __global__ __launch_bounds__(256) void k_increment_flags(const float* __restrict
         const int cz = cell_coord((float)pz, mv.oz, mv.inv_h, mv.nz);
         int occ = 0;
         if (cx >= 0 && cx < mv.nx && cy >= 0 && cy < mv.ny && cz >= 0 && cz < mv.nz) {
-            const size_t key = ((size_t)cz * mv.ny + cy) * mv.nx + cx;
-            occ = mv.cell_start[key + 1] - mv.cell_start[key];
+            for (int fz = cz * mv.S; fz < (cz + 1) * mv.S; ++fz)
+                for (int fy = cy * mv.S; fy < (cy + 1) * mv.S; ++fy) {
+                    const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
+                    occ += mv.cell_start[row + (size_t)(cx + 1) * mv.S] -
+                           mv.cell_start[row + (size_t)cx * mv.S];
+                }
         }
         flags[i] = occ < min_count ? 1u : 0u;
     }

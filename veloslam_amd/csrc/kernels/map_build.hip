@@ -62,31 +62,41 @@ hipError_t launch_minmax(const float* x, const float* y, const float* z, size_t 
 }
 
 // -------------------------------------------------------------------- keys
+// fine coordinate of a map point: voxel c = floorf(u), sub-cell s = min(S-1, floorf((u-c)*S))
+__device__ __forceinline__ int fine_coord(float p, float o, float inv_h, int S)
+{
+    const float u = (p - o) * inv_h;
+    const float c = floorf(u);
+    int sub = (int)floorf((u - c) * (float)S);
+    sub = min(max(sub, 0), S - 1);
+    return (int)c * S + sub;
+}
+
 __global__ __launch_bounds__(256) void k_keys(const float* __restrict__ x,
                                               const float* __restrict__ y,
                                               const float* __restrict__ z, size_t n, float ox,
-                                              float oy, float oz, float inv_h, int nx, int ny,
-                                              uint32_t* __restrict__ keys,
+                                              float oy, float oz, float inv_h, int S, int fx,
+                                              int fy, uint32_t* __restrict__ keys,
                                               uint32_t* __restrict__ idx)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
-        const int cx = (int)floorf((x[i] - ox) * inv_h);
-        const int cy = (int)floorf((y[i] - oy) * inv_h);
-        const int cz = (int)floorf((z[i] - oz) * inv_h);
-        keys[i] = (uint32_t)(((size_t)cz * ny + cy) * nx + cx);
+        const int cx = fine_coord(x[i], ox, inv_h, S);
+        const int cy = fine_coord(y[i], oy, inv_h, S);
+        const int cz = fine_coord(z[i], oz, inv_h, S);
+        keys[i] = (uint32_t)(((size_t)cz * fy + cy) * fx + cx);
         idx[i] = (uint32_t)i;
     }
 }
 
 hipError_t launch_keys(const float* x, const float* y, const float* z, size_t n, float ox, float oy,
-                       float oz, float inv_h, int nx, int ny, uint32_t* keys, uint32_t* idx,
+                       float oz, float inv_h, int S, int fx, int fy, uint32_t* keys, uint32_t* idx,
                        hipStream_t s)
 {
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_keys, dim3(grid), dim3(256), 0, s, x, y, z, n, ox, oy, oz, inv_h, nx, ny,
-                       keys, idx);
+    hipLaunchKernelGGL(k_keys, dim3(grid), dim3(256), 0, s, x, y, z, n, ox, oy, oz, inv_h, S, fx,
+                       fy, keys, idx);
     return hipGetLastError();
 }
 
@@ -188,16 +198,25 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
     const int cz = cell_coord(q.z, mv.oz, mv.inv_h, mv.nz);
     int cnt = 0;
     float worst = INFINITY;  // d2 of the last slot once the list is full
-    for (int dz = -1; dz <= 1; ++dz) {
-        const int zz = cz + dz;
-        if (zz < 0 || zz >= mv.nz) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = cy + dy;
-            if (yy < 0 || yy >= mv.ny) continue;
-            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, mv.nx - 1);
-            if (x0 > x1) continue;
-            const size_t row = ((size_t)zz * mv.ny + yy) * mv.nx;
-            const int j0 = mv.cell_start[row + x0], j1 = mv.cell_start[row + x1 + 1];
+    const int vx0 = max(cx - 1, 0), vx1 = min(cx + 1, mv.nx - 1);
+    const int vy0 = max(cy - 1, 0), vy1 = min(cy + 1, mv.ny - 1);
+    const int vz0 = max(cz - 1, 0), vz1 = min(cz + 1, mv.nz - 1);
+    const int S = mv.S;
+    // fine rows of the 27 voxels in ascending sorted index; a row further than h from the
+    // point (in y,z) cannot hold a neighbour with d2 <= h*h and is skipped (the margin keeps
+    // that conservative, so the k-best list is the oracle's)
+    const float hf = mv.h / (float)S;
+    const float uy = (q.y - mv.oy) * mv.inv_h * (float)S, uz = (q.z - mv.oz) * mv.inv_h * (float)S;
+    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+    for (int fz = vz0 * S; fz < (vz1 + 1) * S; ++fz) {
+        const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
+        if (gz * gz * 0.99999f > r2) continue;
+        for (int fy = vy0 * S; fy < (vy1 + 1) * S; ++fy) {
+            const float gy = fmaxf(fmaxf((float)fy - uy, uy - (float)(fy + 1)) * hf - mg, 0.0f);
+            if ((gz * gz + gy * gy) * 0.99999f > r2) continue;
+            const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
+            const int j0 = mv.cell_start[row + (size_t)vx0 * S];
+            const int j1 = mv.cell_start[row + (size_t)(vx1 + 1) * S];
             for (int j = j0; j < j1; ++j) {
                 const float d2 = dist2(mv.pts[j], q.x, q.y, q.z);
                 if (!(d2 <= r2)) continue;

@@ -14,11 +14,13 @@ namespace velo {
 // Voxel-sorted map as the kernels see it.  Points are float4 {x,y,z,0} so a
 // candidate is one 16-byte load; normals likewise ({0,0,0,0} = invalid normal).
 struct MapView {
-    const float4* pts;     // [n] sorted by cell key (stable)
+    const float4* pts;     // [n] sorted by FINE cell key (stable)
     const float4* nrm;     // [n]
-    const int32_t* cell_start;  // [ncell+1]
+    const int32_t* cell_start;  // [fx*fy*fz + 1] fine-cell table: number of keys < k
     float ox, oy, oz, inv_h, h;
-    int nx, ny, nz;
+    int nx, ny, nz;        // voxels per axis
+    int S;                 // sub-cells per voxel edge
+    int fx, fy, fz;        // fine cells per axis = S * voxels
     int n;
 };
 
@@ -58,7 +60,7 @@ struct MinMax {
 hipError_t launch_minmax(const float* x, const float* y, const float* z, size_t n,
                          unsigned* d_scratch6, MinMax* out_host, hipStream_t s);
 hipError_t launch_keys(const float* x, const float* y, const float* z, size_t n, float ox, float oy,
-                       float oz, float inv_h, int nx, int ny, uint32_t* keys, uint32_t* idx,
+                       float oz, float inv_h, int S, int fx, int fy, uint32_t* keys, uint32_t* idx,
                        hipStream_t s);
 hipError_t sort_pairs(void* temp, size_t& temp_bytes, const uint32_t* k_in, uint32_t* k_out,
                       const uint32_t* v_in, uint32_t* v_out, size_t n, int end_bit, hipStream_t s);
