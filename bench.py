@@ -50,10 +50,16 @@ def parse():
     ap.add_argument("--voxel", type=float, default=1.0)
     ap.add_argument("--k-normals", type=int, default=16)
     ap.add_argument("--sort-frames", type=int, default=0)
+    ap.add_argument("--subdiv", type=int, default=3, help="sub-cells per voxel edge of the map order")
+    ap.add_argument("--no-hints", action="store_true")
     ap.add_argument("--variant", type=int, default=1, help="1 = fine-grid ball search (default), 0 = exhaustive validation kernel")
     ap.add_argument("--rebuild-threshold", type=int, default=20000,
                     help="pending increment points that trigger a map re-index (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="bracket the linearise launches with HIP events in every k-th timed step")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the increment exchange + map append path even with one rank")
     ap.add_argument("--no-timing", action="store_true", help="skip per-launch HIP events (A/B their overhead)")
     ap.add_argument("--cpu-frames", type=int, default=2)
     return ap.parse_args()
@@ -156,12 +162,13 @@ def main():
     d = build_inputs(args, rank, dev)
     F = args.frames
     ctx = capi.Context(local, max_batch=max(F, 1), sort_frames=args.sort_frames,
-                       linearize_variant=args.variant)
+                       linearize_variant=args.variant, map_subdiv=args.subdiv,
+                       use_hints=0 if args.no_hints else 1)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.map_reset(*d["map"], args.voxel, args.k_normals)
     ctx.frames_adopt_dev(d["cx"].data_ptr(), d["cy"].data_ptr(), d["cz"].data_ptr(), d["frame_start"])
     n_q = int(d["frame_start"][-1])
-    ctx.set_timing(0 if args.no_timing else 1)
+    ctx.set_timing(0)
     pending = []
     pending_n = 0
 
@@ -170,8 +177,9 @@ def main():
         ctx.compensate_dev(d["sx"].data_ptr(), d["sy"].data_ptr(), d["sz"].data_ptr(),
                            d["pkt"].data_ptr(), n_q, d["tab"].data_ptr(), d["n_pkt"],
                            d["cx"].data_ptr(), d["cy"].data_ptr(), d["cz"].data_ptr())
+        ctx.set_timing(1 if timed else 0)
         ctx.icp_batch_async(d["T0"], args.iters, args.d_max)
-        if world > 1:
+        if world > 1 or args.force_exchange:
             # exchange step of the path: accepted increment of this rank's first frame of
             # the round, all-gathered; every replica appends all blocks in rank order
             res = ctx.icp_batch_fetch()
@@ -191,19 +199,30 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    lin_ms, lin_n, sol_ms, call_ms = 0.0, 0, 0.0, 0.0
+    lin_ms, lin_n, lin_first, lin_min, n_samples = 0.0, 0, 0.0, 1e30, 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-        if world == 1:
-            pass
+    for k in range(args.steps):
+        sample = (not args.no_timing) and (k % max(args.time_every, 1) == 0)
+        step(sample)
+        if sample:
+            # HIP events on the ctx stream, read back after this step's work is enqueued
+            # (fetch synchronises the stream; it is part of the timed region on purpose)
+            ctx.icp_batch_fetch()
+            tm_k = ctx.last_timing()
+            lin_ms += tm_k["linearize_ms"]
+            lin_n += tm_k["linearize_launches"]
+            lin_first += tm_k["linearize_first_ms"]
+            lin_min = min(lin_min, tm_k["linearize_min_ms"])
+            n_samples += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     # kernel time of the LAST step (HIP events on the ctx stream) -- same launches every step
     res = ctx.icp_batch_fetch()
-    tm = ctx.last_timing()
+    ns = max(n_samples, 1)
+    tm = dict(linearize_ms=lin_ms, linearize_launches=lin_n, linearize_first_ms=lin_first / ns,
+              linearize_min_ms=(lin_min if lin_n else 0.0), solve_ms=0.0)
     pairs_step = sum(int(r.total_pairs) for r in res)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     pr = torch.tensor([float(pairs_step)], dtype=torch.float64, device=dev)
@@ -235,7 +254,7 @@ def main():
                        "parallelism": "frame-parallel x%d" % world},
             "frames_per_s": world * F * args.steps / elapsed,
             "worst_pose_error_m": worst,
-            "kernel_pairs_per_s": (pairs_step / (1e-3 * (tm["linearize_ms"] + tm["solve_ms"])))
+            "linearize_pairs_per_s": (pairs_step * ns / (1e-3 * tm["linearize_ms"]))
             if tm["linearize_ms"] > 0 else None,
         }
         cbar = None
@@ -258,6 +277,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                                "kernel": "k_linearize", "avg_launch_us": 1e6 * avg_s,
+                               "first_launch_us": 1e3 * tm["linearize_first_ms"],
+                               "min_launch_us": 1e3 * tm["linearize_min_ms"],
                                "queries_per_launch": n_q, "cbar": cbar,
                                "bytes_per_query": bytes_per_query,
                                "compulsory_bytes_per_launch": 16.0 * n_q + 32.0 * args.map_points}

@@ -55,8 +55,10 @@ typedef struct velo_cfg {
     int32_t linearize_variant; /* 0 = default kernel; others are tuning variants */
     int32_t sort_frames;    /* 1: order each frame's queries by map cell once per registration */
     int32_t use_graph;      /* reserved (hipGraph replay of the launch sequence) */
-    int32_t map_subdiv;     /* sub-cells per voxel edge of the map sort order (default 4) */
-    int32_t reserved[10];
+    int32_t map_subdiv;     /* sub-cells per voxel edge of the map sort order (default 3) */
+    int32_t use_hints;      /* 1: bound each query's search by its previous correspondence
+                               (exact; cfg == NULL enables it) */
+    int32_t reserved[9];
 } velo_cfg;
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */
@@ -169,6 +171,12 @@ int velo_icp_batch_fetch(velo_ctx*, velo_icp_result* out);
 int velo_linearize(velo_ctx*, int frame, const double T[12], float d_max, int32_t* corr,
                    float* d2, double acc[29]);
 
+/* mode 1: velo_linearize remembers each query's correspondence and uses it as the search-
+ * radius hint of the next call (what velo_icp_batch does between iterations); mode 0: every
+ * call searches from scratch.  Either way the results are identical -- this exists so tests
+ * can hold the hinted path to the oracle too.  Calling it forgets the stored hints. */
+int velo_linearize_hints(velo_ctx*, int mode);
+
 /* Accepted map increment of resident frame `frame` under pose T: points that land
  * in a map cell holding fewer than min_count points, order preserving.  Outputs
  * have room for the whole frame.  _dev writes device buffers (for the RCCL
@@ -180,7 +188,8 @@ int velo_increment_dev(velo_ctx*, int frame, const double T[12], int min_count, 
 
 /* per-kernel device time of the last velo_icp_batch* call, HIP events on the ctx
  * stream: [0] linearise kernel total ms, [1] its launch count, [2] solve total ms,
- * [3] solve launches, [4] whole call ms */
+ * [3] solve launches, [4] whole call ms, [5] first linearise launch ms (no hints yet),
+ * [6] fastest linearise launch ms */
 int velo_last_timing(velo_ctx*, double out[8]);
 /* enable (1) / disable (0) per-launch event timing (adds event records) */
 int velo_set_timing(velo_ctx*, int on);

@@ -15,14 +15,14 @@
  * Semantics
  *  grid     origin o = component-wise min of the map points (float); inv_h =
  *           1.0f/h; u = (p - o) * inv_h; voxel c = floorf(u) per axis; dims = c(max)+1.
- *           Each voxel is split into S x S x S sub-cells (S = 4 by default):
+ *           Each voxel is split into S x S x S sub-cells (S = 3 by default):
  *           s = min(S-1, floorf((u - c) * S)), fine coordinate F = c*S + s, fine
  *           key = (Fz*NFy + Fy)*NFx + Fx with NF = S*dims.  Points are STABLY sorted
  *           by fine key; fine_start[k] = number of keys < k.  "Sorted index" is the
  *           position in this order.  A row of fine cells (fixed Fy,Fz) is one
  *           contiguous index range; a voxel is S*S such row pieces.
  *           The CANDIDATE SET of a query is still defined on voxels: all points of
- *           the 27 voxels around the query's voxel (144 fine rows for S = 4).
+ *           the 27 voxels around the query's voxel (81 fine rows for S = 3).
  *  normals  for sorted point s: the k smallest (d2, index) among all points of
  *           the 27 neighbouring cells with d2 <= h*h (self included);
  *           fewer than 5 -> normal = 0 (invalid).  Covariance about the mean in
@@ -219,7 +219,7 @@ static void point_normal(const vo_map* m, size_t s, int k, float out[3])
 vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, float voxel,
                      int k_normals)
 {
-    return vo_map_build_ex(x, y, z, n, voxel, k_normals, 4);
+    return vo_map_build_ex(x, y, z, n, voxel, k_normals, 3);
 }
 
 vo_map* vo_map_build_ex(const float* x, const float* y, const float* z, size_t n, float voxel,

@@ -306,7 +306,7 @@ class Decoder:
 
 # ----------------------------------------------------------------------- ICP
 class Map:
-    def __init__(self, x, y, z, voxel=1.0, k_normals=16, subdiv=4):
+    def __init__(self, x, y, z, voxel=1.0, k_normals=16, subdiv=3):
         x, y, z = _f32(x), _f32(y), _f32(z)
         self.h = lib().vo_map_build_ex(_f(x), _f(y), _f(z), x.size, float(voxel), int(k_normals),
                                        int(subdiv))

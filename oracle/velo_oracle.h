@@ -116,7 +116,7 @@ typedef struct vo_map vo_map;
 /* voxel: cell edge h.  k_normals: neighbours for PCA (<=32). */
 vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, float voxel,
                      int k_normals);
-/* subdiv: sub-cells per voxel edge (part of the sort order, hence of the spec); 4 above */
+/* subdiv: sub-cells per voxel edge (part of the sort order, hence of the spec); 3 above */
 vo_map* vo_map_build_ex(const float* x, const float* y, const float* z, size_t n, float voxel,
                         int k_normals, int subdiv);
 int vo_map_subdiv(const vo_map*);

@@ -157,6 +157,30 @@ def test_linearize_corr_bit_exact_and_sums(ctx, omap, wl, comp):
             np.testing.assert_allclose(acc, oacc, rtol=1e-11, atol=1e-9)
 
 
+def test_hinted_search_is_exact(ctx, omap, wl, comp):
+    """The ICP loop bounds every query's search radius by its previous correspondence.  Walk a
+    sequence of poses (far, converged, jittered, far again) with hints carried from call to
+    call: correspondences stay bit-identical to the oracle, which knows nothing of hints."""
+    ctx.map_reset(*wl["map"], 1.0, 16)
+    ctx.frames_upload(comp)
+    f = wl["frames"][0]
+    n = comp[0][0].size
+    rng = np.random.default_rng(3)
+    jit = f["T_true"].copy()
+    jit[[3, 7, 11]] += rng.normal(0, 0.02, 3)
+    far = f["T_true"].copy()
+    far[3] += 0.8
+    ctx.linearize_hints(1)
+    try:
+        for T in (f["T0"], f["T_true"], jit, f["T_true"], far, f["T_true"]):
+            corr, d2, acc = ctx.linearize(0, T, 1.0, n)
+            oc, od2, _ = omap.correspond(*comp[0], T, 1.0)
+            assert np.array_equal(corr, oc)
+            assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+    finally:
+        ctx.linearize_hints(0)
+
+
 def test_queries_outside_grid_and_dmax(ctx, oracle):
     rng = np.random.default_rng(11)
     m = rng.uniform(0, 8, (3, 4000)).astype(np.float32)

@@ -27,7 +27,8 @@ class VeloError(RuntimeError):
 class Cfg(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_batch", C.c_int32),
                 ("linearize_variant", C.c_int32), ("sort_frames", C.c_int32),
-                ("use_graph", C.c_int32), ("map_subdiv", C.c_int32), ("reserved", C.c_int32 * 10)]
+                ("use_graph", C.c_int32), ("map_subdiv", C.c_int32), ("use_hints", C.c_int32),
+                ("reserved", C.c_int32 * 9)]
 
 
 class Pose(C.Structure):
@@ -60,7 +61,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing",
+    "velo_linearize_hints", "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
     "llh2enu", "MappingAngle",
@@ -114,6 +115,7 @@ def lib():
     L.velo_icp_batch_async.argtypes = [vp, dp, C.c_int, C.c_float]
     L.velo_icp_batch_fetch.argtypes = [vp, C.POINTER(IcpResult)]
     L.velo_linearize.argtypes = [vp, C.c_int, dp, C.c_float, vp, vp, dp]
+    L.velo_linearize_hints.argtypes = [vp, C.c_int]
     L.velo_increment.argtypes = [vp, C.c_int, dp, C.c_int, vp, vp, vp, C.POINTER(C.c_size_t)]
     L.velo_increment_dev.argtypes = L.velo_increment.argtypes
     L.velo_last_timing.argtypes = [vp, dp]
@@ -231,7 +233,8 @@ def mapping_angle(a):
 class Context:
     """One velo_ctx: one GPU, one stream, single-threaded."""
 
-    def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=1, map_subdiv=4):
+    def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=1, map_subdiv=3,
+                 use_hints=1):
         L = lib()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -239,6 +242,7 @@ class Context:
         cfg.sort_frames = sort_frames
         cfg.linearize_variant = linearize_variant
         cfg.map_subdiv = map_subdiv
+        cfg.use_hints = use_hints
         self.h = L.velo_create(device, C.byref(cfg))
         if not self.h:
             raise VeloError(-3, L.velo_last_error(None).decode())
@@ -270,7 +274,8 @@ class Context:
         t = np.zeros(8)
         self._chk(lib().velo_last_timing(self.h, _d(t)))
         return dict(linearize_ms=t[0], linearize_launches=int(t[1]), solve_ms=t[2],
-                    solve_launches=int(t[3]), call_ms=t[4])
+                    solve_launches=int(t[3]), call_ms=t[4], linearize_first_ms=t[5],
+                    linearize_min_ms=t[6])
 
     # ---- map
     def map_reset(self, x, y, z, voxel=1.0, k_normals=16):
@@ -362,6 +367,9 @@ class Context:
         acc = np.zeros(29)
         self._chk(lib().velo_linearize(self.h, frame, _d(T), d_max, _p(corr), _p(d2), _d(acc)))
         return corr, d2, acc
+
+    def linearize_hints(self, mode):
+        self._chk(lib().velo_linearize_hints(self.h, int(mode)))
 
     def increment(self, frame, T, min_count, n):
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)

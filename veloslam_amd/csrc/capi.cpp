@@ -85,10 +85,12 @@ struct velo_ctx {
     DevBuf<velo_icp_iter> stats;
     DevBuf<uint32_t> order_keys, order_keys2, order_idx, order;
     DevBuf<int32_t> corr;
+    DevBuf<int32_t> hint;  // last correspondence per query slot (search-radius hint), -1 = none
     DevBuf<float> d2;
     DevBuf<uint32_t> flags, offs;
     DevBuf<float> inc_x, inc_y, inc_z;
     int last_iters = 0;
+    bool lin_hints = false;  // velo_linearize keeps/uses hints across calls (tests)
 
     // ---- timing
     bool timing = false;
@@ -163,7 +165,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
     HIP_TRY(c, c->perm.reserve(n));
     HIP_TRY(c, c->pts.reserve(n));
     HIP_TRY(c, c->nrm.reserve(n));
-    HIP_TRY(c, c->cell_start.reserve(ncell + 1));
+    HIP_TRY(c, c->cell_start.reserve(ncell + 8));  // +1 entry, padded: rows are read 4 entries at a time
     HIP_TRY(c, c->invalid_cnt.reserve(1));
     HIP_TRY(c, launch_keys(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, mm.mn[0], mm.mn[1], mm.mn[2],
                            inv_h, S, fdims[0], fdims[1], c->keys.p, c->idx.p, s));
@@ -385,6 +387,14 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
                               hipMemcpyHostToDevice, s));
     FrameView fv{c->ax, c->ay, c->az, nullptr};
     if (int rc = maybe_sort_frames(c, fv)) return rc;
+    // hints never outlive a registration: results do not depend on earlier calls
+    const size_t n_all = (size_t)c->frame_start[c->n_frames];
+    int32_t* hint = nullptr;
+    if (c->cfg.use_hints && n_all) {
+        HIP_TRY(c, c->hint.reserve(n_all));
+        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, n_all * sizeof(int32_t), s));
+        hint = c->hint.p;
+    }
     const float dmax2 = d_max * d_max;
     const int ni = (int)c->items_h.size();
     for (int it = 0; it < iters; ++it) {
@@ -392,7 +402,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             Timed t(c, 0);
             HIP_TRY(c, launch_linearize(c->cfg.linearize_variant,
                                         (fv.order && c->cfg.sort_frames == 1) ? c->items_xcd.p : c->items.p, ni, fv, c->mv,
-                                        c->poses.p, dmax2, c->partials.p, nullptr, nullptr, s));
+                                        c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, s));
         }
         {
             Timed t(c, 1);
@@ -428,13 +438,15 @@ int fetch_icp(velo_ctx* c, velo_icp_result* out)
         }
     }
     if (c->timing) {
-        double lin = 0, sol = 0;
+        double lin = 0, sol = 0, lin_first = 0, lin_min = 1e30;
         int nl = 0, ns = 0;
         for (size_t k = 0; k < c->ev_kind.size(); ++k) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) != hipSuccess) continue;
             if (c->ev_kind[k] == 0) {
                 lin += ms;
+                if (nl == 0) lin_first = ms;
+                if (ms < lin_min) lin_min = ms;
                 ++nl;
             } else {
                 sol += ms;
@@ -448,6 +460,8 @@ int fetch_icp(velo_ctx* c, velo_icp_result* out)
         c->last_timing[2] = sol;
         c->last_timing[3] = ns;
         c->last_timing[4] = all;
+        c->last_timing[5] = lin_first;
+        c->last_timing[6] = nl ? lin_min : 0.0;
     }
     return VELO_OK;
 }
@@ -484,7 +498,8 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     if (cfg) std::memcpy(&c->cfg, cfg, std::min<size_t>(cfg->struct_size, sizeof(velo_cfg)));
     c->cfg.struct_size = sizeof(velo_cfg);
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 64;
-    if (c->cfg.map_subdiv <= 0) c->cfg.map_subdiv = 4;
+    if (!cfg) c->cfg.use_hints = 1;
+    if (c->cfg.map_subdiv <= 0) c->cfg.map_subdiv = 3;
     if (c->cfg.map_subdiv > 16) c->cfg.map_subdiv = 16;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
@@ -518,6 +533,15 @@ int velo_synchronize(velo_ctx* c)
 {
     if (!c) return VELO_E_INVALID;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VELO_OK;
+}
+
+int velo_linearize_hints(velo_ctx* c, int mode)
+{
+    if (!c) return VELO_E_INVALID;
+    c->lin_hints = mode != 0;
+    if (c->hint.p && c->hint.cap)  // (re)start from "no hint"
+        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), c->stream));
     return VELO_OK;
 }
 
@@ -742,13 +766,18 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
     const size_t q0 = (size_t)c->frame_start[frame], q1 = (size_t)c->frame_start[frame + 1];
     HIP_TRY(c, c->corr.reserve(std::max<size_t>(n_all, 1)));
     HIP_TRY(c, c->d2.reserve(std::max<size_t>(n_all, 1)));
+    if (c->lin_hints && c->hint.cap < n_all) {
+        HIP_TRY(c, c->hint.reserve(n_all));
+        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, n_all * sizeof(int32_t), s));
+    }
     // poses of the other frames are irrelevant here: only this frame's blocks are launched
     HIP_TRY(c, hipMemcpyAsync(c->poses.p + 12 * (size_t)frame, T, 12 * sizeof(double),
                               hipMemcpyHostToDevice, s));
     FrameView fv{c->ax, c->ay, c->az, nullptr};
     const int b0 = c->fbs_h[frame], b1 = c->fbs_h[frame + 1];
     HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, c->items.p + b0, b1 - b0, fv, c->mv,
-                                c->poses.p, d_max * d_max, c->partials.p, c->corr.p, c->d2.p, s));
+                                c->poses.p, d_max * d_max, c->partials.p, c->corr.p, c->d2.p,
+                                c->lin_hints ? c->hint.p : nullptr, s));
     HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p + frame, 1, c->poses.p, nullptr, 0, 1,
                                    c->acc.p, 0, s));
     if (corr)

@@ -211,34 +211,64 @@ __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float q
     }
 }
 
+// four consecutive entries of the fine-cell table with one 16-byte request (the table is
+// only 4-byte aligned at an arbitrary cell: gfx950 global loads do not need more)
+struct __attribute__((packed, aligned(4))) Int4U {
+    int v[4];
+};
+
 // stage A; returns true when the result is final.
+// ub0 (<= dmax2) is an upper bound of the winning distance known before the search: dmax2,
+// or the distance to last iteration's correspondence.  Rows and cells of the 3x3x3 block that
+// lie further than sqrt(ub0) from the query are not even looked up; with a good hint a query
+// costs one table request and a couple of candidates instead of nine and ~14.
 // ABL (timing ablations only, results are wrong): 1 = treat stage A as final, 2 = also skip
 // the candidate walk, 3 = also skip the fine-table loads
 template <int ABL>
 __device__ __forceinline__ bool search_block(const MapView& mv, const QueryCell& g, float qx,
-                                             float qy, float qz, float dmax2, SearchLds& L,
+                                             float qy, float qz, float ub0, SearchLds& L,
                                              int tid, float& bd, int& bj)
 {
-    bd = dmax2;
+    bd = ub0;
     bj = -1;
     if (!g.near) return true;  // no voxel of the 27 exists: no candidates at all
-    const int x0 = max(g.Fx - 1, 0), x1 = min(g.Fx + 1, mv.fx - 1);
+    const float hf = mv.h / (float)mv.S;
+    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+    // conservative distances from the query to the faces of its own fine cell
+    const float lox = fmaxf(g.tx * hf - mg, 0.0f), hix = fmaxf((1.0f - g.tx) * hf - mg, 0.0f);
+    const float loy = fmaxf(g.ty * hf - mg, 0.0f), hiy = fmaxf((1.0f - g.ty) * hf - mg, 0.0f);
+    const float loz = fmaxf(g.tz * hf - mg, 0.0f), hiz = fmaxf((1.0f - g.tz) * hf - mg, 0.0f);
+    const float lox2 = lox * lox, hix2 = hix * hix;
+    const int xb = max(g.Fx - 1, 0);  // first table entry fetched for a row
     int nr = 0;
-    if (x0 <= x1 && ABL < 3) {
+    if (g.Fx + 1 >= 0 && g.Fx - 1 < mv.fx && ABL < 3) {
 #pragma unroll
         for (int dz = 1; dz >= -1; --dz) {
             const int zz = g.Fz + dz;
+            const float bz = dz == 0 ? 0.0f : (dz > 0 ? hiz : loz);
 #pragma unroll
             for (int dy = 1; dy >= -1; --dy) {
                 const int yy = g.Fy + dy;
-                if (zz >= 0 && zz < mv.fz && yy >= 0 && yy < mv.fy) {
-                    const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
-                    const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
-                    if (jhi > jlo) {
-                        L.hi[nr][tid] = jhi;
-                        L.lo[nr][tid] = jlo;
-                        ++nr;
-                    }
+                const float by = dy == 0 ? 0.0f : (dy > 0 ? hiy : loy);
+                const float rb2 = bz * bz + by * by;
+                if (zz < 0 || zz >= mv.fz || yy < 0 || yy >= mv.fy || rb2 * 0.99999f > ub0)
+                    continue;
+                // cells of this row inside the ball: own cell always, neighbours by their bound
+                int x0 = g.Fx, x1 = g.Fx;
+                if (!((lox2 + rb2) * 0.99999f > ub0)) x0 = g.Fx - 1;
+                if (!((hix2 + rb2) * 0.99999f > ub0)) x1 = g.Fx + 1;
+                x0 = max(x0, 0);
+                x1 = min(x1, mv.fx - 1);
+                if (x0 > x1) continue;
+                const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
+                const Int4U e = *reinterpret_cast<const Int4U*>(mv.cell_start + row + xb);
+                const int a = x0 - xb, b = x1 + 1 - xb;  // both in [0,3]
+                const int jlo = a == 0 ? e.v[0] : (a == 1 ? e.v[1] : (a == 2 ? e.v[2] : e.v[3]));
+                const int jhi = b == 1 ? e.v[1] : (b == 2 ? e.v[2] : (b == 3 ? e.v[3] : e.v[0]));
+                if (jhi > jlo) {
+                    L.hi[nr][tid] = jhi;
+                    L.lo[nr][tid] = jlo;
+                    ++nr;
                 }
             }
         }
@@ -246,12 +276,11 @@ __device__ __forceinline__ bool search_block(const MapView& mv, const QueryCell&
     if (ABL >= 2) nr = min(nr, 0);
     walk_ranges(mv, qx, qy, qz, L, tid, nr, bd, bj);
     if (ABL >= 1) return true;
-    // guaranteed radius of the scanned block: one fine cell plus the distance to the nearer
-    // face of the query's own fine cell, per axis; shrunk for rounding
-    const float hf = mv.h / (float)mv.S;
+    // guaranteed radius of the 3x3x3 block: one fine cell plus the distance to the nearer
+    // face of the query's own fine cell, per axis; shrunk for rounding.  Whatever was pruned
+    // inside the block is further than sqrt(ub0) >= sqrt(bd).
     const float tmin = fminf(fminf(fminf(g.tx, 1.0f - g.tx), fminf(g.ty, 1.0f - g.ty)),
                              fminf(g.tz, 1.0f - g.tz));
-    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
     const float gr = fmaxf(hf * (1.0f + tmin) - mg, 0.0f);
     return bd <= gr * gr * 0.99999f;
 }
@@ -370,18 +399,13 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 };
 
 template <bool WRITE_CORR, int VARIANT>
-__global__ __launch_bounds__(kLinThreads) void k_linearize(
+__global__ __launch_bounds__(kLinThreads, 8) void k_linearize(
     const BlockItem* __restrict__ items, FrameView fv, MapView mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
-    int32_t* __restrict__ corr, float* __restrict__ d2out)
+    int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint)
 {
     __shared__ LinLds s_u;
     __shared__ double s_w[4][32];
-    __shared__ float s_bq[4][kLinThreads];  // stage-B hand-off: query xyz + bound
-    __shared__ int s_bres[kLinThreads];
-    __shared__ float s_bresd[kLinThreads];
-    __shared__ int s_blist[kLinThreads];
-    __shared__ int s_nb;
     const BlockItem it = items[blockIdx.x];
     const double* __restrict__ T = poses + 12 * (size_t)it.frame;
     const int tid = threadIdx.x;
@@ -397,57 +421,46 @@ __global__ __launch_bounds__(kLinThreads) void k_linearize(
         float bd = INFINITY;
         int bj = -1;
         if (VARIANT >= 1) {
-            if (tid == 0) s_nb = 0;
             bool queued = false;
-            __syncthreads();
+            float qx = 0.f, qy = 0.f, qz = 0.f;
             if (live) {
                 xform(T, fv.x[q], fv.y[q], fv.z[q], px, py, pz);
-                const float qx = (float)px, qy = (float)py, qz = (float)pz;
+                qx = (float)px;
+                qy = (float)py;
+                qz = (float)pz;
                 const QueryCell g = locate(mv, qx, qy, qz);
-                if (!search_block<(VARIANT >= 11 ? VARIANT - 10 : 0)>(mv, g, qx, qy, qz, dmax2, s_u.s,
-                                                                    tid, bd, bj)) {
-                    queued = true;
-                    const int slot = atomicAdd(&s_nb, 1);
-                    s_blist[slot] = tid;
-                    s_bq[0][tid] = qx;
-                    s_bq[1][tid] = qy;
-                    s_bq[2][tid] = qz;
-                    s_bq[3][tid] = bd;  // <= dmax2: radius^2 of the ball still to be searched
+                // temporal hint: last iteration's correspondence bounds the search radius
+                float ub0 = dmax2;
+                if (hint) {
+                    const int hj = hint[q];
+                    if (hj >= 0) ub0 = fminf(ub0, dist2(mv.pts[hj], qx, qy, qz));
                 }
+                queued = !search_block<(VARIANT >= 11 ? VARIANT - 10 : 0)>(mv, g, qx, qy, qz, ub0,
+                                                                         s_u.s, tid, bd, bj);
             }
-            __syncthreads();
-            const int nb = s_nb;  // uniform across the workgroup
-            if (nb > 0) {
-                if (nb > 32) {
-                    // many stragglers (first iterations of a poorly aligned frame): one per
-                    // lane keeps every lane busy
-                    for (int i = tid; i < nb; i += kLinThreads) {
-                        const int owner = s_blist[i];
-                        float rbd;
-                        int rbj;
-                        search_ball(mv, s_bq[0][owner], s_bq[1][owner], s_bq[2][owner],
-                                    s_bq[3][owner], rbd, rbj);
-                        s_bres[owner] = rbj;
-                        s_bresd[owner] = rbd;
-                    }
-                } else {
-                    // few stragglers: one per wavefront, searched cooperatively
-                    for (int i = wave; i < nb; i += kLinThreads / 64) {
-                        const int owner = s_blist[i];
-                        float rbd;
-                        int rbj;
-                        search_ball_wave(mv, s_bq[0][owner], s_bq[1][owner], s_bq[2][owner],
-                                         s_bq[3][owner], lane, rbd, rbj);
-                        if (lane == 0) {
-                            s_bres[owner] = rbj;
-                            s_bresd[owner] = rbd;
-                        }
-                    }
-                }
-                __syncthreads();
+            // stage B inside the wavefront: no workgroup barrier, no LDS hand-off.  Each
+            // straggler's query is broadcast from its lane and searched by all 64 lanes;
+            // when most lanes are stragglers (first iterations of a badly aligned frame)
+            // every lane searches its own ball instead.
+            unsigned long long need = __ballot(queued);
+            if (__popcll(need) > 16) {
                 if (queued) {
-                    bj = s_bres[tid];
-                    bd = s_bresd[tid];
+                    const float ub = bd;
+                    search_ball(mv, qx, qy, qz, ub, bd, bj);
+                }
+            } else {
+                while (need) {
+                    const int src = __ffsll((long long)need) - 1;
+                    need &= need - 1;
+                    const float sx = __shfl(qx, src, 64), sy = __shfl(qy, src, 64),
+                                sz = __shfl(qz, src, 64), sub = __shfl(bd, src, 64);
+                    float rbd;
+                    int rbj;
+                    search_ball_wave(mv, sx, sy, sz, sub, lane, rbd, rbj);
+                    if (lane == src) {
+                        bd = rbd;
+                        bj = rbj;
+                    }
                 }
             }
         } else if (live) {
@@ -457,6 +470,7 @@ __global__ __launch_bounds__(kLinThreads) void k_linearize(
         double J0 = 0, J1 = 0, J2 = 0, J3 = 0, J4 = 0, J5 = 0, r = 0, valid = 0;
         if (live) {
             const bool ok = (bj >= 0) && (bd <= dmax2);
+            if (hint) hint[q] = ok ? bj : -1;
             if (WRITE_CORR) {
                 const int qi = fv.order ? fv.order[q] : q;
                 if (corr) corr[qi] = ok ? bj : -1;
@@ -510,13 +524,13 @@ __global__ __launch_bounds__(kLinThreads) void k_linearize(
 
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
-                            int32_t* corr, float* d2, hipStream_t s)
+                            int32_t* corr, float* d2, int32_t* hint, hipStream_t s)
 {
     if (n_items == 0) return hipSuccess;
     const bool wc = corr || d2;
 #define VELO_LAUNCH_LIN(WC, V)                                                                   \
     hipLaunchKernelGGL((k_linearize<WC, V>), dim3(n_items), dim3(kLinThreads), 0, s, items, fv, \
-                       mv, poses, dmax2, partials, corr, d2)
+                       mv, poses, dmax2, partials, corr, d2, hint)
     if (variant == 1) {
         if (wc) VELO_LAUNCH_LIN(true, 1); else VELO_LAUNCH_LIN(false, 1);
     } else if (variant == 11) {  // timing ablations (wrong results by design)

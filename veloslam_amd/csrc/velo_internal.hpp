@@ -73,7 +73,7 @@ hipError_t launch_normals(const MapView& mv, int k, float4* nrm, unsigned long l
 
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
-                            int32_t* corr, float* d2, hipStream_t s);
+                            int32_t* corr, float* d2, int32_t* hint, hipStream_t s);
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, hipStream_t s);
