@@ -54,11 +54,13 @@ typedef struct velo_cfg {
     int32_t max_batch;      /* frames registered per launch (default 64) */
     int32_t linearize_variant; /* 0 = default kernel; others are tuning variants */
     int32_t sort_frames;    /* 1: order each frame's queries by map cell once per registration */
-    int32_t use_graph;      /* reserved (hipGraph replay of the launch sequence) */
+    int32_t use_graph;      /* 1: replay a registration's launch sequence as one hipGraph
+                               (cfg == NULL enables it) */
     int32_t map_subdiv;     /* sub-cells per voxel edge of the map sort order (default 3) */
     int32_t use_hints;      /* 1: bound each query's search by its previous correspondence
                                (exact; cfg == NULL enables it) */
-    int32_t reserved[9];
+    int32_t rounds_per_block; /* tuning: rounds of 256 queries per workgroup (0 = automatic) */
+    int32_t reserved[8];
 } velo_cfg;
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */

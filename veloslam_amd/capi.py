@@ -28,7 +28,7 @@ class Cfg(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_batch", C.c_int32),
                 ("linearize_variant", C.c_int32), ("sort_frames", C.c_int32),
                 ("use_graph", C.c_int32), ("map_subdiv", C.c_int32), ("use_hints", C.c_int32),
-                ("reserved", C.c_int32 * 9)]
+                ("rounds_per_block", C.c_int32), ("reserved", C.c_int32 * 8)]
 
 
 class Pose(C.Structure):
@@ -234,7 +234,7 @@ class Context:
     """One velo_ctx: one GPU, one stream, single-threaded."""
 
     def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=1, map_subdiv=3,
-                 use_hints=1):
+                 use_hints=1, use_graph=1, rounds_per_block=0):
         L = lib()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -243,6 +243,8 @@ class Context:
         cfg.linearize_variant = linearize_variant
         cfg.map_subdiv = map_subdiv
         cfg.use_hints = use_hints
+        cfg.use_graph = use_graph
+        cfg.rounds_per_block = rounds_per_block
         self.h = L.velo_create(device, C.byref(cfg))
         if not self.h:
             raise VeloError(-3, L.velo_last_error(None).decode())

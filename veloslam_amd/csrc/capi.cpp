@@ -90,6 +90,22 @@ struct velo_ctx {
     DevBuf<uint32_t> flags, offs;
     DevBuf<float> inc_x, inc_y, inc_z;
     int last_iters = 0;
+    // hipGraph replay of the per-registration launch sequence (cfg.use_graph)
+    hipGraphExec_t graph_exec = nullptr;
+    struct GraphKey {
+        int iters = 0, ni = 0, n_frames = 0, variant = 0;
+        float dmax2 = 0;
+        const void *hint = nullptr, *items = nullptr, *stream = nullptr;
+        uint64_t map_gen = 0, frames_gen = 0;
+        bool operator==(const GraphKey& o) const
+        {
+            return iters == o.iters && ni == o.ni && n_frames == o.n_frames && variant == o.variant &&
+                   dmax2 == o.dmax2 && hint == o.hint && items == o.items && stream == o.stream &&
+                   map_gen == o.map_gen && frames_gen == o.frames_gen;
+        }
+    } graph_key;
+    uint64_t map_gen = 0, frames_gen = 0;
+    double* h_T0 = nullptr;  // pinned staging of the initial poses (stable address for the graph)
     bool lin_hints = false;  // velo_linearize keeps/uses hints across calls (tests)
 
     // ---- timing
@@ -204,6 +220,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
     HIP_TRY(c, hipStreamSynchronize(s));
     c->mv = mv;
     c->has_map = true;
+    ++c->map_gen;
     c->info.n_points = n;
     c->info.n_cells = ncell;
     c->info.origin[0] = mv.ox;
@@ -248,10 +265,16 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
         if (frame_start[f + 1] < frame_start[f]) return c->fail(VELO_E_INVALID, "frame_start must ascend");
     if (frame_start[n_frames] >= INT32_MAX) return c->fail(VELO_E_RANGE, "too many query points");
     c->n_frames = n_frames;
+    ++c->frames_gen;
     c->frame_start.assign(frame_start, frame_start + n_frames + 1);
     c->items_h.clear();
     c->fbs_h.assign((size_t)n_frames + 1, 0);
-    const int per_block = kLinThreads;  // one round of queries per block
+    // rounds of 256 queries per workgroup.  Measured on config 2 (16 x 115 200 queries): 1 round
+    // = 60 us per launch, 2 = 66, 4 = 70 -- more, smaller workgroups balance better than the
+    // start-up they cost, so the default is one round; cfg.rounds_per_block overrides.
+    int rounds = 1;
+    if (c->cfg.rounds_per_block > 0) rounds = std::min(c->cfg.rounds_per_block, 64);
+    const int per_block = kLinThreads * rounds;
     for (int f = 0; f < n_frames; ++f) {
         c->fbs_h[f] = (int32_t)c->items_h.size();
         for (int64_t q = frame_start[f]; q < frame_start[f + 1]; q += per_block) {
@@ -383,20 +406,76 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         }
         HIP_TRY(c, hipEventRecord(c->ev_call0, s));
     }
-    HIP_TRY(c, hipMemcpyAsync(c->poses.p, T0, (size_t)c->n_frames * 12 * sizeof(double),
-                              hipMemcpyHostToDevice, s));
-    FrameView fv{c->ax, c->ay, c->az, nullptr};
-    if (int rc = maybe_sort_frames(c, fv)) return rc;
-    // hints never outlive a registration: results do not depend on earlier calls
     const size_t n_all = (size_t)c->frame_start[c->n_frames];
+    const float dmax2 = d_max * d_max;
+    const int ni = (int)c->items_h.size();
+    const size_t pose_bytes = (size_t)c->n_frames * 12 * sizeof(double);
     int32_t* hint = nullptr;
     if (c->cfg.use_hints && n_all) {
         HIP_TRY(c, c->hint.reserve(n_all));
-        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, n_all * sizeof(int32_t), s));
         hint = c->hint.p;
     }
-    const float dmax2 = d_max * d_max;
-    const int ni = (int)c->items_h.size();
+    const bool graph_ok = c->cfg.use_graph && !c->timing && !c->cfg.sort_frames;
+    if (graph_ok) {
+        // Replay the whole registration (pose upload, hint reset, iters x (linearise, solve)) as
+        // one hipGraph: the kernels are tens of microseconds long, so per-launch host cost and
+        // inter-kernel gaps are a visible share of an iteration.
+        if (!c->h_T0) HIP_TRY(c, hipHostMalloc((void**)&c->h_T0, (size_t)c->cfg.max_batch * 12 * sizeof(double), 0));
+        velo_ctx::GraphKey key;
+        key.iters = iters;
+        key.ni = ni;
+        key.n_frames = c->n_frames;
+        key.variant = c->cfg.linearize_variant;
+        key.dmax2 = dmax2;
+        key.hint = hint;
+        key.items = c->items.p;
+        key.stream = s;
+        key.map_gen = c->map_gen;
+        key.frames_gen = c->frames_gen;
+        if (!c->graph_exec || !(key == c->graph_key)) {
+            if (c->graph_exec) {
+                (void)hipGraphExecDestroy(c->graph_exec);
+                c->graph_exec = nullptr;
+            }
+            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            hipError_t e = hipMemcpyAsync(c->poses.p, c->h_T0, pose_bytes, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess && hint) e = hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s);
+            FrameView fv{c->ax, c->ay, c->az, nullptr};
+            for (int it = 0; it < iters && e == hipSuccess; ++it) {
+                e = launch_linearize(c->cfg.linearize_variant, c->items.p, ni, fv, c->mv, c->poses.p,
+                                     dmax2, c->partials.p, nullptr, nullptr, hint, s);
+                if (e == hipSuccess)
+                    e = launch_reduce_solve(c->partials.p, c->fbs.p, c->n_frames, c->poses.p,
+                                            c->stats.p, it, iters, nullptr, 1, s);
+            }
+            hipGraph_t g = nullptr;
+            hipError_t e2 = hipStreamEndCapture(s, &g);
+            if (e != hipSuccess || e2 != hipSuccess || !g) {
+                if (g) (void)hipGraphDestroy(g);
+                return c->fail(VELO_E_DEVICE, "graph capture failed: %s",
+                               hipGetErrorString(e != hipSuccess ? e : e2));
+            }
+            e = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) {
+                c->graph_exec = nullptr;
+                return c->fail(VELO_E_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
+            }
+            c->graph_key = key;
+        }
+        // the previous replay may still be reading h_T0
+        HIP_TRY(c, hipStreamSynchronize(s));
+        std::memcpy(c->h_T0, T0, pose_bytes);
+        HIP_TRY(c, hipGraphLaunch(c->graph_exec, s));
+        c->last_iters = iters;
+        return VELO_OK;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->poses.p, T0, pose_bytes, hipMemcpyHostToDevice, s));
+    FrameView fv{c->ax, c->ay, c->az, nullptr};
+    if (int rc = maybe_sort_frames(c, fv)) return rc;
+    // hints never outlive a registration: results do not depend on earlier calls
+    if (hint) HIP_TRY(c, hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s));
     for (int it = 0; it < iters; ++it) {
         {
             Timed t(c, 0);
@@ -498,7 +577,10 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     if (cfg) std::memcpy(&c->cfg, cfg, std::min<size_t>(cfg->struct_size, sizeof(velo_cfg)));
     c->cfg.struct_size = sizeof(velo_cfg);
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 64;
-    if (!cfg) c->cfg.use_hints = 1;
+    if (!cfg) {
+        c->cfg.use_hints = 1;
+        c->cfg.use_graph = 1;
+    }
     if (c->cfg.map_subdiv <= 0) c->cfg.map_subdiv = 3;
     if (c->cfg.map_subdiv > 16) c->cfg.map_subdiv = 16;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -514,6 +596,8 @@ void velo_destroy(velo_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->h_T0) (void)hipHostFree(c->h_T0);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_call0) (void)hipEventDestroy(c->ev_call0);
     if (c->ev_call1) (void)hipEventDestroy(c->ev_call1);

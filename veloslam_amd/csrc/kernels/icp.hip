@@ -174,12 +174,22 @@ __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float 
 //            x-extent of each row cut to the ball, descending index, '<='.  Compaction keeps
 //            a handful of stragglers from stalling every wavefront of the workgroup.
 constexpr int kMaxRanges = 9;
+#ifndef VELO_WALK_W
+#define VELO_WALK_W 4
+#endif
 
+// per WAVEFRONT: [slot][lane].  Nothing in the search or in the reduction tile below is
+// shared between wavefronts, so the query loop needs no workgroup barrier at all.
 struct SearchLds {
-    int hi[kMaxRanges][kLinThreads];
-    int lo[kMaxRanges][kLinThreads];
+    int hi[kMaxRanges][64];
+    int lo[kMaxRanges][64];
 };
 
+// Walk this lane's index ranges (descending, '<=').  W candidates per trip: W loads are in
+// flight together; indices are clamped to the range start (a candidate evaluated twice is
+// harmless under '<=').  (Carrying the winner's coordinates through the walk to save the
+// later re-fetch was measured: the extra selects and registers cost more than the fetch.)
+template <int W>
 __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float qy, float qz,
                                             SearchLds& L, int tid, int nr, float& bd, int& bj)
 {
@@ -190,15 +200,22 @@ __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float q
         lo = L.lo[0][tid];
     }
     while (more) {
-        const int j0 = j - 1, j1 = max(j - 2, lo), j2 = max(j - 3, lo), j3 = max(j - 4, lo);
-        const float4 c0 = mv.pts[j0], c1 = mv.pts[j1], c2 = mv.pts[j2], c3 = mv.pts[j3];
-        const float e0 = dist2(c0, qx, qy, qz), e1 = dist2(c1, qx, qy, qz),
-                    e2 = dist2(c2, qx, qy, qz), e3 = dist2(c3, qx, qy, qz);
-        if (e0 <= bd) { bd = e0; bj = j0; }
-        if (e1 <= bd) { bd = e1; bj = j1; }
-        if (e2 <= bd) { bd = e2; bj = j2; }
-        if (e3 <= bd) { bd = e3; bj = j3; }
-        j -= 4;
+        int jj[W];
+        float4 c[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            jj[u] = max(j - 1 - u, lo);
+            c[u] = mv.pts[jj[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const float e = dist2(c[u], qx, qy, qz);
+            if (e <= bd) {
+                bd = e;
+                bj = jj[u];
+            }
+        }
+        j -= W;
         if (j <= lo) {
             if (k < nr) {
                 j = L.hi[k][tid];
@@ -274,7 +291,7 @@ __device__ __forceinline__ bool search_block(const MapView& mv, const QueryCell&
         }
     }
     if (ABL >= 2) nr = min(nr, 0);
-    walk_ranges(mv, qx, qy, qz, L, tid, nr, bd, bj);
+    walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj);
     if (ABL >= 1) return true;
     // guaranteed radius of the 3x3x3 block: one fine cell plus the distance to the nearer
     // face of the query's own fine cell, per axis; shrunk for rounding.  Whatever was pruned
@@ -391,7 +408,7 @@ __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, fl
 // halves are combined by a wavefront shuffle, the four waves through LDS, always in
 // the same order: run-to-run deterministic.
 struct ReduceLds {
-    double v[8][kLinThreads + 4];  // SoA, +4 pad: the 8 rows land on distinct banks
+    double v[8][64 + 2];  // per wavefront, SoA; +2 pad: the 8 rows land on distinct banks
 };
 union LinLds {  // the search ranges and the reduction tile are never live together
     SearchLds s;
@@ -404,19 +421,38 @@ __global__ __launch_bounds__(kLinThreads, 8) void k_linearize(
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
     int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint)
 {
-    __shared__ LinLds s_u;
+    __shared__ LinLds s_uw[kLinThreads / 64];
     __shared__ double s_w[4][32];
     const BlockItem it = items[blockIdx.x];
     const double* __restrict__ T = poses + 12 * (size_t)it.frame;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
+    LinLds& s_u = s_uw[wave];
     const int ia = c_ia[col], ib = c_ib[col];
     double colsum = 0.0;
 
+    // software pipeline over the rounds of this block: the next round's query (and its hint)
+    // is requested before the current round is searched
+    float nx_ = 0.f, ny_ = 0.f, nz_ = 0.f;
+    int nh_ = -1;
+    if (it.q0 + tid < it.q1) {
+        nx_ = fv.x[it.q0 + tid];
+        ny_ = fv.y[it.q0 + tid];
+        nz_ = fv.z[it.q0 + tid];
+        if (hint) nh_ = hint[it.q0 + tid];
+    }
     for (int base = it.q0; base < it.q1; base += kLinThreads) {
         const int q = base + tid;
         const bool live = q < it.q1;
+        const float sxq = nx_, syq = ny_, szq = nz_;
+        const int hj = nh_;
+        if (q + kLinThreads < it.q1) {
+            nx_ = fv.x[q + kLinThreads];
+            ny_ = fv.y[q + kLinThreads];
+            nz_ = fv.z[q + kLinThreads];
+            if (hint) nh_ = hint[q + kLinThreads];
+        }
         double px = 0, py = 0, pz = 0;
         float bd = INFINITY;
         int bj = -1;
@@ -424,19 +460,16 @@ __global__ __launch_bounds__(kLinThreads, 8) void k_linearize(
             bool queued = false;
             float qx = 0.f, qy = 0.f, qz = 0.f;
             if (live) {
-                xform(T, fv.x[q], fv.y[q], fv.z[q], px, py, pz);
+                xform(T, sxq, syq, szq, px, py, pz);
                 qx = (float)px;
                 qy = (float)py;
                 qz = (float)pz;
                 const QueryCell g = locate(mv, qx, qy, qz);
                 // temporal hint: last iteration's correspondence bounds the search radius
                 float ub0 = dmax2;
-                if (hint) {
-                    const int hj = hint[q];
-                    if (hj >= 0) ub0 = fminf(ub0, dist2(mv.pts[hj], qx, qy, qz));
-                }
+                if (hj >= 0) ub0 = fminf(ub0, dist2(mv.pts[hj], qx, qy, qz));
                 queued = !search_block<(VARIANT >= 11 ? VARIANT - 10 : 0)>(mv, g, qx, qy, qz, ub0,
-                                                                         s_u.s, tid, bd, bj);
+                                                                         s_u.s, lane, bd, bj);
             }
             // stage B inside the wavefront: no workgroup barrier, no LDS hand-off.  Each
             // straggler's query is broadcast from its lane and searched by all 64 lanes;
@@ -464,7 +497,7 @@ __global__ __launch_bounds__(kLinThreads, 8) void k_linearize(
                 }
             }
         } else if (live) {
-            xform(T, fv.x[q], fv.y[q], fv.z[q], px, py, pz);
+            xform(T, sxq, syq, szq, px, py, pz);
             nearest_scan(mv, (float)px, (float)py, (float)pz, bd, bj);
         }
         double J0 = 0, J1 = 0, J2 = 0, J3 = 0, J4 = 0, J5 = 0, r = 0, valid = 0;
@@ -494,23 +527,25 @@ __global__ __launch_bounds__(kLinThreads, 8) void k_linearize(
                 }
             }
         }
-        __syncthreads();  // the search ranges are dead: the tile may overwrite them
-        s_u.r.v[0][tid] = J0;
-        s_u.r.v[1][tid] = J1;
-        s_u.r.v[2][tid] = J2;
-        s_u.r.v[3][tid] = J3;
-        s_u.r.v[4][tid] = J4;
-        s_u.r.v[5][tid] = J5;
-        s_u.r.v[6][tid] = r;
-        s_u.r.v[7][tid] = valid;
-        __syncthreads();
+        // the wavefront's own search ranges are dead: its tile may overwrite them.  DS
+        // operations of one wavefront execute in order; the fences only pin the compiler.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        s_u.r.v[0][lane] = J0;
+        s_u.r.v[1][lane] = J1;
+        s_u.r.v[2][lane] = J2;
+        s_u.r.v[3][lane] = J3;
+        s_u.r.v[4][lane] = J4;
+        s_u.r.v[5][lane] = J5;
+        s_u.r.v[6][lane] = r;
+        s_u.r.v[7][lane] = valid;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (col < kAccN) {
-            const int e0 = wave * 64 + half * 32;
+            const int e0 = half * 32;
 #pragma unroll 8
             for (int e = 0; e < 32; ++e)
                 colsum = fma(s_u.r.v[ia][e0 + e], s_u.r.v[ib][e0 + e], colsum);
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     // halves -> wave (shuffle), waves -> block (LDS), fixed order
     const double other = __shfl_down(colsum, 32, 64);
