@@ -173,6 +173,13 @@ int velo_icp_batch_fetch(velo_ctx*, velo_icp_result* out);
 int velo_linearize(velo_ctx*, int frame, const double T[12], float d_max, int32_t* corr,
                    float* d2, double acc[29]);
 
+/* a10 with k neighbours (k <= VELO_MAX_KNORMALS): for every point of resident frame `frame`,
+ * transformed by T, the k nearest map points within d_max, ascending by (d2, sorted map
+ * index).  idx and d2 are n x k row-major, padded with -1 / +inf; count (may be NULL) gets the
+ * number found per query.  No reference counterpart. */
+int velo_knn(velo_ctx*, int frame, const double T[12], float d_max, int k, int32_t* idx, float* d2,
+             int32_t* count);
+
 /* mode 1: velo_linearize remembers each query's correspondence and uses it as the search-
  * radius hint of the next call (what velo_icp_batch does between iterations); mode 0: every
  * call searches from scratch.  Either way the results are identical -- this exists so tests

@@ -382,6 +382,49 @@ uint64_t vo_correspond(const vo_map* m, const float* x, const float* y, const fl
     return total;
 }
 
+/* a10, k > 1: the k smallest (d2, sorted index) with d2 <= d_max^2 among the 27 voxels */
+void vo_knn(const vo_map* m, const float* x, const float* y, const float* z, size_t n,
+            const double T[12], float d_max, int k, int32_t* idx, float* d2o, int32_t* count)
+{
+    const float r2 = d_max * d_max;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; ++i) {
+        double p[3];
+        xform(T, x[i], y[i], z[i], p);
+        const float qx = (float)p[0], qy = (float)p[1], qz = (float)p[2];
+        const int cx = cell_coord(qx, m->o[0], m->inv_h, m->dims[0]);
+        const int cy = cell_coord(qy, m->o[1], m->inv_h, m->dims[1]);
+        const int cz = cell_coord(qz, m->o[2], m->inv_h, m->dims[2]);
+        float bd[VO_KMAX];
+        int32_t bi[VO_KMAX];
+        int cnt = 0;
+        ROWS_BEGIN(m, cx, cy, cz)
+        {
+            for (int32_t j = j0; j < j1; ++j) {
+                float dx = m->x[j] - qx, dyy = m->y[j] - qy, dzz = m->z[j] - qz;
+                float d2 = fmaf(dzz, dzz, fmaf(dyy, dyy, dx * dx));
+                if (!(d2 <= r2)) continue;
+                if (cnt == k && !(d2 < bd[k - 1])) continue;
+                int pos = cnt < k ? cnt : k - 1;
+                while (pos > 0 && d2 < bd[pos - 1]) {
+                    bd[pos] = bd[pos - 1];
+                    bi[pos] = bi[pos - 1];
+                    --pos;
+                }
+                bd[pos] = d2;
+                bi[pos] = j;
+                if (cnt < k) ++cnt;
+            }
+        }
+        ROWS_END
+        for (int t = 0; t < k; ++t) {
+            idx[(size_t)i * k + t] = t < cnt ? bi[t] : -1;
+            d2o[(size_t)i * k + t] = t < cnt ? bd[t] : INFINITY;
+        }
+        if (count) count[i] = cnt;
+    }
+}
+
 static inline void accum_pair(const vo_map* m, const double p[3], int32_t j, double acc[29])
 {
     const double nx = m->nx[j], ny = m->ny[j], nz = m->nz[j];

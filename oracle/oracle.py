@@ -123,6 +123,7 @@ def lib():
         f.restype = ip
     L.vo_correspond.argtypes = [C.c_void_p, fp, fp, fp, C.c_size_t, dp, C.c_float, ip, fp]
     L.vo_correspond.restype = C.c_uint64
+    L.vo_knn.argtypes = [C.c_void_p, fp, fp, fp, C.c_size_t, dp, C.c_float, C.c_int, ip, fp, ip]
     L.vo_accumulate.argtypes = [C.c_void_p, fp, fp, fp, C.c_size_t, dp, ip, dp]
     L.vo_solve_update.argtypes = [dp, dp, dp]
     L.vo_icp.argtypes = [C.c_void_p, fp, fp, fp, C.c_size_t, dp, C.c_int, C.c_float, dp,
@@ -356,6 +357,16 @@ class Map:
         cand = lib().vo_correspond(self.h, _f(x), _f(y), _f(z), x.size, _d(T), float(d_max),
                                    _i(corr), _f(d2))
         return corr, d2, int(cand)
+
+    def knn(self, x, y, z, T, d_max, k):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)
+        idx = np.empty((x.size, k), np.int32)
+        d2 = np.empty((x.size, k), np.float32)
+        cnt = np.empty(x.size, np.int32)
+        lib().vo_knn(self.h, _f(x), _f(y), _f(z), x.size, _d(T), float(d_max), int(k), _i(idx),
+                     _f(d2), _i(cnt))
+        return idx, d2, cnt
 
     def accumulate(self, x, y, z, T, corr):
         x, y, z = _f32(x), _f32(y), _f32(z)

@@ -141,6 +141,11 @@ size_t vo_map_num_cells(const vo_map*);
 uint64_t vo_correspond(const vo_map*, const float* x, const float* y, const float* z, size_t n,
                        const double T[12], float d_max, int32_t* corr, float* d2);
 
+/* a10 with k neighbours (k <= 32): n x k row-major, ascending (d2, sorted index), padded
+ * with -1 / +inf */
+void vo_knn(const vo_map*, const float* x, const float* y, const float* z, size_t n,
+            const double T[12], float d_max, int k, int32_t* idx, float* d2, int32_t* count);
+
 /* a11: accumulate the 29 doubles: H upper triangle (21, row-major a<=b),
  * g (6), sum r^2, count. */
 void vo_accumulate(const vo_map*, const float* x, const float* y, const float* z, size_t n,

@@ -237,6 +237,23 @@ def test_points_on_cell_faces_and_pruning_margins(ctx, oracle):
         assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
 
 
+@pytest.mark.parametrize("k", [1, 4, 32])
+def test_knn_k_neighbours_bit_exact(ctx, omap, wl, comp, k):
+    """a10 with k > 1 (BASELINE config 5 asks for 32 neighbours): indices, distances and counts."""
+    ctx.map_reset(*wl["map"], 1.0, 16)
+    sub = tuple(a[::7].copy() for a in comp[0])
+    ctx.frames_upload([sub])
+    for T, dmax in ((wl["frames"][0]["T0"], 1.0), (wl["frames"][0]["T_true"], 0.4)):
+        gi, gd, gc = ctx.knn(0, T, dmax, k, sub[0].size)
+        oi, od, oc = omap.knn(*sub, T, dmax, k)
+        assert np.array_equal(gc, oc)
+        assert np.array_equal(gi, oi)
+        assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    if k == 1:  # consistent with the ICP correspondence
+        corr, d2, _ = ctx.linearize(0, wl["frames"][0]["T_true"], 0.4, sub[0].size)
+        assert np.array_equal(corr, gi[:, 0])
+
+
 # ------------------------------------------------------------------ ICP (a9..a12)
 def test_icp_pose_matches_oracle(ctx, omap, wl, comp):
     ctx.map_reset(*wl["map"], 1.0, 16)

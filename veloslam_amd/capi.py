@@ -61,7 +61,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing",
+    "velo_linearize_hints", "velo_knn", "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
     "llh2enu", "MappingAngle",
@@ -116,6 +116,7 @@ def lib():
     L.velo_icp_batch_fetch.argtypes = [vp, C.POINTER(IcpResult)]
     L.velo_linearize.argtypes = [vp, C.c_int, dp, C.c_float, vp, vp, dp]
     L.velo_linearize_hints.argtypes = [vp, C.c_int]
+    L.velo_knn.argtypes = [vp, C.c_int, dp, C.c_float, C.c_int, vp, vp, vp]
     L.velo_increment.argtypes = [vp, C.c_int, dp, C.c_int, vp, vp, vp, C.POINTER(C.c_size_t)]
     L.velo_increment_dev.argtypes = L.velo_increment.argtypes
     L.velo_last_timing.argtypes = [vp, dp]
@@ -369,6 +370,14 @@ class Context:
         acc = np.zeros(29)
         self._chk(lib().velo_linearize(self.h, frame, _d(T), d_max, _p(corr), _p(d2), _d(acc)))
         return corr, d2, acc
+
+    def knn(self, frame, T, d_max, k, n):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)
+        idx = np.empty((n, k), np.int32)
+        d2 = np.empty((n, k), np.float32)
+        cnt = np.empty(n, np.int32)
+        self._chk(lib().velo_knn(self.h, frame, _d(T), d_max, k, _p(idx), _p(d2), _p(cnt)))
+        return idx, d2, cnt
 
     def linearize_hints(self, mode):
         self._chk(lib().velo_linearize_hints(self.h, int(mode)))

@@ -875,6 +875,37 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
     return VELO_OK;
 }
 
+// ----------------------------------------------------------------------- kNN
+int velo_knn(velo_ctx* c, int frame, const double T[12], float d_max, int k, int32_t* idx,
+             float* d2, int32_t* count)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
+    if (frame < 0 || frame >= c->n_frames) return c->fail(VELO_E_INVALID, "frame index out of range");
+    if (!T || !idx || !d2) return c->fail(VELO_E_INVALID, "null argument");
+    if (k < 1 || k > VELO_MAX_KNORMALS) return c->fail(VELO_E_INVALID, "k must be in [1,%d]", VELO_MAX_KNORMALS);
+    if (!(d_max > 0.0f) || !(d_max <= c->mv.h))
+        return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv.h);
+    hipStream_t s = c->stream;
+    const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
+    if (n == 0) return VELO_OK;
+    DevBuf<int32_t> di, dc;
+    DevBuf<float> dd;
+    DevBuf<double> dT;
+    HIP_TRY(c, di.reserve(n * (size_t)k));
+    HIP_TRY(c, dd.reserve(n * (size_t)k));
+    HIP_TRY(c, dc.reserve(n));
+    HIP_TRY(c, dT.reserve(12));
+    HIP_TRY(c, hipMemcpyAsync(dT.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, dT.p, d_max * d_max, k, di.p,
+                          dd.p, dc.p, s));
+    HIP_TRY(c, hipMemcpyAsync(idx, di.p, n * (size_t)k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(d2, dd.p, n * (size_t)k * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (count) HIP_TRY(c, hipMemcpyAsync(count, dc.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return VELO_OK;
+}
+
 // ----------------------------------------------------------------- increment
 static int increment_impl(velo_ctx* c, int frame, const double T[12], int min_count, float* ox,
                           float* oy, float* oz, size_t* n_out, bool dev)

@@ -182,31 +182,26 @@ __device__ __forceinline__ void jacobi_rot(double A[3][3], double V[3][3], int p
     }
 }
 
-__global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
-                                                         float4* __restrict__ nrm,
-                                                         unsigned long long* __restrict__ invalid)
+// The k smallest (d2, sorted index) among the points of the 27 voxels around q with
+// d2 <= r2, ascending, into the LDS lists s_d/s_i ([slot][thread]).  Returns how many.
+// Fine rows further than sqrt(r2) from q (in y,z) cannot contribute and are skipped; the
+// margin keeps that conservative, so the list is the oracle's.
+__device__ __forceinline__ int collect_knn(const MapView& mv, float qx, float qy, float qz,
+                                           float r2, int k, float (*s_d)[kNrmThreads],
+                                           int (*s_i)[kNrmThreads], int tid)
 {
-    __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
-    __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
-    const int tid = threadIdx.x;
-    const int s = blockIdx.x * kNrmThreads + tid;
-    if (s >= mv.n) return;
-    const float4 q = mv.pts[s];
-    const float r2 = mv.h * mv.h;
-    const int cx = cell_coord(q.x, mv.ox, mv.inv_h, mv.nx);
-    const int cy = cell_coord(q.y, mv.oy, mv.inv_h, mv.ny);
-    const int cz = cell_coord(q.z, mv.oz, mv.inv_h, mv.nz);
+    const int cx = cell_coord(qx, mv.ox, mv.inv_h, mv.nx);
+    const int cy = cell_coord(qy, mv.oy, mv.inv_h, mv.ny);
+    const int cz = cell_coord(qz, mv.oz, mv.inv_h, mv.nz);
     int cnt = 0;
     float worst = INFINITY;  // d2 of the last slot once the list is full
     const int vx0 = max(cx - 1, 0), vx1 = min(cx + 1, mv.nx - 1);
     const int vy0 = max(cy - 1, 0), vy1 = min(cy + 1, mv.ny - 1);
     const int vz0 = max(cz - 1, 0), vz1 = min(cz + 1, mv.nz - 1);
+    if (vx0 > vx1 || vy0 > vy1 || vz0 > vz1) return 0;
     const int S = mv.S;
-    // fine rows of the 27 voxels in ascending sorted index; a row further than h from the
-    // point (in y,z) cannot hold a neighbour with d2 <= h*h and is skipped (the margin keeps
-    // that conservative, so the k-best list is the oracle's)
     const float hf = mv.h / (float)S;
-    const float uy = (q.y - mv.oy) * mv.inv_h * (float)S, uz = (q.z - mv.oz) * mv.inv_h * (float)S;
+    const float uy = (qy - mv.oy) * mv.inv_h * (float)S, uz = (qz - mv.oz) * mv.inv_h * (float)S;
     const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
     for (int fz = vz0 * S; fz < (vz1 + 1) * S; ++fz) {
         const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
@@ -218,7 +213,7 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
             const int j0 = mv.cell_start[row + (size_t)vx0 * S];
             const int j1 = mv.cell_start[row + (size_t)(vx1 + 1) * S];
             for (int j = j0; j < j1; ++j) {
-                const float d2 = dist2(mv.pts[j], q.x, q.y, q.z);
+                const float d2 = dist2(mv.pts[j], qx, qy, qz);
                 if (!(d2 <= r2)) continue;
                 if (cnt == k && !(d2 < worst)) continue;
                 int pos = cnt < k ? cnt : k - 1;
@@ -234,6 +229,20 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
             }
         }
     }
+    return cnt;
+}
+
+__global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
+                                                         float4* __restrict__ nrm,
+                                                         unsigned long long* __restrict__ invalid)
+{
+    __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
+    __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x * kNrmThreads + tid;
+    if (s >= mv.n) return;
+    const float4 q = mv.pts[s];
+    const int cnt = collect_knn(mv, q.x, q.y, q.z, mv.h * mv.h, k, s_d, s_i, tid);
     if (cnt < kMinNb) {
         nrm[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         atomicAdd(invalid, 1ull);
@@ -283,6 +292,42 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
         vz = -vz;
     }
     nrm[s] = make_float4((float)vx, (float)vy, (float)vz, 0.0f);
+}
+
+// a10 with k > 1: the k nearest map points of every (transformed) query within d_max,
+// ascending (d2, sorted index); rows of idx/d2 are padded with -1 / +inf.
+__global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __restrict__ x,
+                                                     const float* __restrict__ y,
+                                                     const float* __restrict__ z, int n,
+                                                     const double* __restrict__ T, float dmax2,
+                                                     int k, int32_t* __restrict__ idx,
+                                                     float* __restrict__ d2o,
+                                                     int32_t* __restrict__ count)
+{
+    __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
+    __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kNrmThreads + tid;
+    if (i >= n) return;
+    double px, py, pz;
+    xform(T, x[i], y[i], z[i], px, py, pz);
+    const int cnt = collect_knn(mv, (float)px, (float)py, (float)pz, dmax2, k, s_d, s_i, tid);
+    for (int m = 0; m < k; ++m) {
+        idx[(size_t)i * k + m] = m < cnt ? s_i[m][tid] : -1;
+        d2o[(size_t)i * k + m] = m < cnt ? s_d[m][tid] : INFINITY;
+    }
+    if (count) count[i] = cnt;
+}
+
+hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
+                      const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
+                      hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const int grid = (int)((n + kNrmThreads - 1) / kNrmThreads);
+    hipLaunchKernelGGL(k_knn, dim3(grid), dim3(kNrmThreads), 0, s, mv, x, y, z, (int)n, T, dmax2, k,
+                       idx, d2, count);
+    return hipGetLastError();
 }
 
 hipError_t launch_normals(const MapView& mv, int k, float4* nrm, unsigned long long* d_invalid,

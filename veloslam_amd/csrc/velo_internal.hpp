@@ -71,6 +71,9 @@ hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell
 hipError_t launch_normals(const MapView& mv, int k, float4* nrm, unsigned long long* d_invalid,
                           hipStream_t s);
 
+hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
+                      const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
+                      hipStream_t s);
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, int32_t* hint, hipStream_t s);
