@@ -145,6 +145,37 @@ int velo_compensate_dev(velo_ctx*, const float* dx, const float* dy, const float
                         const uint16_t* dpkt, size_t n, const double* dT3x4, size_t n_pkt,
                         float* dox, float* doy, float* doz);
 
+/* ---- f1: packet decode + calibration + frame split + compensation on the GPU ----------
+ * Replaces HDLParser::vsInternal::processHDLPacket / processFiring / pushFiringData /
+ * splitFrame (HDLParser.cxx:980-1055, 900-977, 587-752, 867-897) for a packet sequence that
+ * starts with fresh parser state: raw 1206-byte packets in (HDLParser.cxx:67-87), frames out as
+ * beam-major SoA (HDLFrame::getPointsAsOneCloud order, HDLFrame.cxx:127-144; HDL-64 beams
+ * re-ordered by the LUT of HDLParser.cxx:179-187).  Quirks are reproduced: a frame's first
+ * packet counts twice, the rest of a packet after a mid-packet split keeps the previous
+ * frame's origin, and the packet after a split starts at the split's firing block. */
+typedef struct velo_laser_corr { /* HDLLaserCorrection, HDLParser.cxx:89-100, metres/degrees */
+    double azimuthCorrection, verticalCorrection, distanceCorrection;
+    double verticalOffsetCorrection, horizontalOffsetCorrection;
+    double sinVertCorrection, cosVertCorrection;
+    double sinVertOffsetCorrection, cosVertOffsetCorrection;
+} velo_laser_corr;
+/* packets: n_pkt x 1206 bytes (host).  poses: sorted pose store (n_poses may be 0: frames stay
+ * in the sensor frame, as when the reference has no valid transform).  flush != 0 also emits the
+ * unfinished last frame (HDLParser::getFrame's tail, HDLParser.cxx:541).  crop_region: NULL or
+ * {xmin,xmax,ymin,ymax,zmin,zmax} (HDLParser.cxx:629-639).  Results stay on the device. */
+int velo_decode(velo_ctx*, const uint8_t* packets, const int64_t* pkt_t_us, size_t n_pkt,
+                const velo_laser_corr corr[64], int n_lasers, const velo_pose* poses,
+                size_t n_poses, int flush, const double* crop_region, int crop_inside,
+                int32_t* n_frames, size_t* n_points);
+/* Copy the last decode back; any pointer may be NULL.  frame_start: n_frames+1; beam_start:
+ * n_frames x 65 (absolute offsets); packet_index: index of the source packet of each point. */
+int velo_decode_fetch(velo_ctx*, float* x, float* y, float* z, float* intensity, uint16_t* azimuth,
+                      float* distance, uint16_t* packet_index, int64_t* frame_start,
+                      int32_t* beam_start, velo_pose* carposes, int64_t* frame_t_us,
+                      int32_t* frame_packets);
+/* The decoded frames become the resident frames of velo_icp_batch (no host round-trip). */
+int velo_decode_to_frames(velo_ctx*);
+
 /* ---- K2+K3+solve: scan-to-map ICP (no reference counterpart) -----------
  * Point-to-plane Gauss-Newton, exactly `iters` iterations, nearest neighbour
  * within d_max over the 27 map cells around the transformed point.  k must be 1

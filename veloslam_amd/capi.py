@@ -61,7 +61,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_knn", "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing",
+    "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
     "llh2enu", "MappingAngle",
@@ -117,6 +117,10 @@ def lib():
     L.velo_linearize.argtypes = [vp, C.c_int, dp, C.c_float, vp, vp, dp]
     L.velo_linearize_hints.argtypes = [vp, C.c_int]
     L.velo_knn.argtypes = [vp, C.c_int, dp, C.c_float, C.c_int, vp, vp, vp]
+    L.velo_decode.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_int, C.POINTER(Pose), C.c_size_t, C.c_int,
+                              vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
+    L.velo_decode_fetch.argtypes = [vp] * 13
+    L.velo_decode_to_frames.argtypes = [vp]
     L.velo_increment.argtypes = [vp, C.c_int, dp, C.c_int, vp, vp, vp, C.POINTER(C.c_size_t)]
     L.velo_increment_dev.argtypes = L.velo_increment.argtypes
     L.velo_last_timing.argtypes = [vp, dp]
@@ -378,6 +382,39 @@ class Context:
         cnt = np.empty(n, np.int32)
         self._chk(lib().velo_knn(self.h, frame, _d(T), d_max, k, _p(idx), _p(d2), _p(cnt)))
         return idx, d2, cnt
+
+    def decode(self, packets, times_us, calib, n_lasers=64, poses=None, n_poses=0, flush=True,
+               crop_region=None, crop_inside=False):
+        """packets: list of 1206-byte strings; calib: (64, 9) float64.  Returns a dict with the
+        decoded frames (beam-major SoA) fetched back to the host."""
+        buf = np.frombuffer(b"".join(packets), dtype=np.uint8)
+        t = np.ascontiguousarray(times_us, dtype=np.int64)
+        cal = np.ascontiguousarray(calib, dtype=np.float64).reshape(64, 9)
+        crop = None if crop_region is None else np.ascontiguousarray(crop_region, dtype=np.float64)
+        nf = C.c_int32()
+        npts = C.c_size_t()
+        self._chk(lib().velo_decode(self.h, _p(buf), _p(t), len(packets), _p(cal), n_lasers,
+                                    poses, n_poses, int(bool(flush)), _p(crop), int(bool(crop_inside)),
+                                    C.byref(nf), C.byref(npts)))
+        F, n = nf.value, npts.value
+        self._decoded_frames = F
+        out = dict(n_frames=F, n_points=n,
+                   x=np.empty(n, np.float32), y=np.empty(n, np.float32), z=np.empty(n, np.float32),
+                   intensity=np.empty(n, np.float32), azimuth=np.empty(n, np.uint16),
+                   distance=np.empty(n, np.float32), packet_index=np.empty(n, np.uint16),
+                   frame_start=np.zeros(F + 1, np.int64), beam_start=np.zeros((F, 65), np.int32),
+                   frame_t_us=np.zeros(F, np.int64), frame_packets=np.zeros(F, np.int32))
+        car = (Pose * max(F, 1))()
+        self._chk(lib().velo_decode_fetch(
+            self.h, _p(out["x"]), _p(out["y"]), _p(out["z"]), _p(out["intensity"]), _p(out["azimuth"]),
+            _p(out["distance"]), _p(out["packet_index"]), _p(out["frame_start"]), _p(out["beam_start"]),
+            C.cast(car, C.c_void_p), _p(out["frame_t_us"]), _p(out["frame_packets"])))
+        out["carposes"] = car
+        return out
+
+    def decode_to_frames(self):
+        self._chk(lib().velo_decode_to_frames(self.h))
+        self.n_frames = self._decoded_frames
 
     def linearize_hints(self, mode):
         self._chk(lib().velo_linearize_hints(self.h, int(mode)))

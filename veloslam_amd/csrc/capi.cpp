@@ -8,6 +8,7 @@
 #include <cstring>
 #include <memory>
 #include "velo_internal.hpp"
+#include "../../include/veloslam/TransformManager.hpp"
 
 using namespace velo;
 
@@ -107,6 +108,21 @@ struct velo_ctx {
     uint64_t map_gen = 0, frames_gen = 0;
     double* h_T0 = nullptr;  // pinned staging of the initial poses (stable address for the graph)
     bool lin_hints = false;  // velo_linearize keeps/uses hints across calls (tests)
+
+    // ---- f1 decode
+    DevBuf<uint8_t> dk_pkts, dk_perm, dk_tvalid, dk_invlut;
+    DevBuf<int16_t> dk_blk;
+    DevBuf<double> dk_table, dk_corr, dk_lutc, dk_luts, dk_azc, dk_azs;
+    DevBuf<int32_t> dk_azdiff, dk_starts;
+    DevBuf<uint32_t> dk_keys, dk_keys2, dk_idx, dk_order;
+    DevBuf<float> dk_x, dk_y, dk_z, dk_i, dk_dist;
+    DevBuf<uint16_t> dk_az, dk_pidx;
+    std::vector<double> dk_corr_host;      // calibration the device tables were built for
+    int dk_frames = 0;
+    size_t dk_points = 0;
+    std::vector<int64_t> dk_frame_start, dk_frame_t;
+    std::vector<int32_t> dk_beam_start, dk_frame_packets;
+    std::vector<velo_pose> dk_carposes;
 
     // ---- timing
     bool timing = false;
@@ -873,6 +889,258 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
     HIP_TRY(c, hipStreamSynchronize(s));
     if (acc) std::memcpy(acc, a, kAccN * sizeof(double));
     return VELO_OK;
+}
+
+// -------------------------------------------------------------------- decode (f1)
+namespace {
+
+// HDLParser.cxx:179-181: vertical-order index -> raw laser id
+const int kHdl64BeamLut[64] = {38, 39, 42, 43, 32, 33, 36, 37, 40, 41, 46, 47, 50, 51, 54, 55,
+                               44, 45, 48, 49, 52, 53, 58, 59, 62, 63, 34, 35, 56, 57, 60, 61,
+                               6,  7,  10, 11, 0,  1,  4,  5,  8,  9,  14, 15, 18, 19, 22, 23,
+                               12, 13, 16, 17, 20, 21, 26, 27, 30, 31, 2,  3,  24, 25, 28, 29};
+
+// sin/cos tables exactly as the reference builds / evaluates them on the host (libm), so the
+// device results are bit-identical: 36001-entry LUT (HDLParser.cxx:754-768) and, for lasers
+// with a non-zero azimuth correction, cos/sin((az/100 - corr) deg) per azimuth (:607-611)
+int upload_calibration(velo_ctx* c, const velo_laser_corr corr[64])
+{
+    const double* cd = reinterpret_cast<const double*>(corr);
+    if (c->dk_corr_host.size() == 64 * 9 && std::memcmp(c->dk_corr_host.data(), cd, 64 * 9 * sizeof(double)) == 0)
+        return VELO_OK;
+    std::vector<double> lc(36001), ls(36001);
+    for (unsigned i = 0; i < 36001; ++i) {
+        const double rad = (i / 100.0) * M_PI / 180.0;
+        lc[i] = std::cos(rad);
+        ls[i] = std::sin(rad);
+    }
+    std::vector<double> ac((size_t)64 * 36000, 0.0), as((size_t)64 * 36000, 0.0);
+    for (int l = 0; l < 64; ++l) {
+        if (corr[l].azimuthCorrection == 0) continue;
+        for (unsigned a = 0; a < 36000; ++a) {
+            const double rad = ((static_cast<double>(a) / 100.0) - corr[l].azimuthCorrection) * M_PI / 180.0;
+            ac[(size_t)l * 36000 + a] = std::cos(rad);
+            as[(size_t)l * 36000 + a] = std::sin(rad);
+        }
+    }
+    uint8_t inv[64];
+    for (int i = 0; i < 64; ++i) inv[kHdl64BeamLut[i]] = (uint8_t)i;
+    HIP_TRY(c, c->dk_corr.reserve(64 * 9));
+    HIP_TRY(c, c->dk_lutc.reserve(36001));
+    HIP_TRY(c, c->dk_luts.reserve(36001));
+    HIP_TRY(c, c->dk_azc.reserve((size_t)64 * 36000));
+    HIP_TRY(c, c->dk_azs.reserve((size_t)64 * 36000));
+    HIP_TRY(c, c->dk_invlut.reserve(64));
+    HIP_TRY(c, hipMemcpy(c->dk_corr.p, cd, 64 * 9 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dk_lutc.p, lc.data(), 36001 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dk_luts.p, ls.data(), 36001 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dk_azc.p, ac.data(), ac.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dk_azs.p, as.data(), as.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dk_invlut.p, inv, 64, hipMemcpyHostToDevice));
+    c->dk_corr_host.assign(cd, cd + 64 * 9);
+    return VELO_OK;
+}
+
+}  // namespace
+
+int velo_decode(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, size_t n_pkt,
+                const velo_laser_corr corr[64], int n_lasers, const velo_pose* poses,
+                size_t n_poses, int flush, const double* crop_region, int crop_inside,
+                int32_t* n_frames, size_t* n_points)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!packets || !pkt_t_us || !corr || (n_poses && !poses))
+        return c->fail(VELO_E_INVALID, "velo_decode: null argument");
+    if (n_lasers != 64 && n_lasers != 32 && n_lasers != 16)
+        return c->fail(VELO_E_INVALID, "n_lasers must be 64, 32 or 16");
+    if (n_pkt == 0 || n_pkt > 60000) return c->fail(VELO_E_RANGE, "n_pkt must be in [1, 60000]");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = upload_calibration(c, corr)) return rc;
+    hipStream_t s = c->stream;
+
+    // ---- the sequential part of the parser, 12 integers per packet (HDLParser.cxx:980-1055)
+    veloslam::TransformManager tm;
+    for (size_t i = 0; i < n_poses; ++i) tm.addTransform(veloslam::PoseTransform::fromC(poses[i]));
+    std::vector<int16_t> blk((size_t)n_pkt * 12, -1);
+    std::vector<double> table((size_t)n_pkt * 12, 0.0);
+    std::vector<uint8_t> tvalid(n_pkt, 0), perm;
+    std::vector<int32_t> azdiff(n_pkt, 0);
+    c->dk_carposes.clear();
+    c->dk_frame_t.clear();
+    c->dk_frame_packets.clear();
+    int last_az = -1, firing_skip = 0, cur = 0;
+    bool inited = false, is_hdl64 = false;
+    veloslam::PoseTransform carpose;
+    auto open_frame = [&]() {
+        c->dk_carposes.push_back(veloslam::PoseTransform().toC());
+        c->dk_frame_t.push_back(VELO_TIME_INVALID);
+        c->dk_frame_packets.push_back(0);
+        perm.push_back(0);
+    };
+    open_frame();
+    for (size_t p = 0; p < n_pkt; ++p) {
+        const uint8_t* d = packets + p * 1206;
+        veloslam::PoseTransform tr;
+        tm.interpolateTransform(pkt_t_us[p], &tr);
+        if (!inited) {  // :992-1001
+            carpose = tr;
+            c->dk_carposes[cur] = tr.toC();
+            c->dk_frame_t[cur] = pkt_t_us[p];
+            c->dk_frame_packets[cur]++;
+            inited = true;
+        }
+        tr.timestamp = pkt_t_us[p];
+        if (tr.seconds_pos != -1) {  // :1004-1007 (+ :1057-1062)
+            for (int a = 0; a < 3; ++a) tr.T[a] -= carpose.T[a];
+            const veloslam::Affine3x4 M = tr.getMatrix();
+            std::memcpy(&table[p * 12], M.data(), 12 * sizeof(double));
+            tvalid[p] = 1;
+        }
+        c->dk_frame_packets[cur]++;  // :1009
+        int block = firing_skip;
+        firing_skip = 0;
+        int diffs[11];
+        for (int i = 0; i < 11; ++i) {
+            const int r1 = d[100 * (i + 1) + 2] | (d[100 * (i + 1) + 3] << 8);
+            const int r0 = d[100 * i + 2] | (d[100 * i + 3] << 8);
+            diffs[i] = (36000 + r1 - r0) % 36000;
+        }
+        std::sort(diffs, diffs + 11);
+        azdiff[p] = diffs[6];  // nth_element(..., 12/2): element 6 of 11, :1021-1026
+        for (; block < 12; ++block) {
+            const uint8_t* fd = d + 100 * block;
+            const unsigned id = fd[0] | (fd[1] << 8);
+            const int rot = fd[2] | (fd[3] << 8);
+            is_hdl64 |= (id != 0xeeff);
+            if (rot < last_az) {  // :1035-1039 -> splitFrame
+                firing_skip = block;
+                perm[cur] = is_hdl64 ? 1 : 0;
+                ++cur;
+                if (cur >= 32000) return c->fail(VELO_E_RANGE, "too many frames in one decode call");
+                open_frame();
+                inited = false;
+            }
+            blk[p * 12 + block] = (int16_t)cur;
+            last_az = rot;
+        }
+    }
+    int nfr = cur;
+    if (flush) {
+        perm[cur] = is_hdl64 ? 1 : 0;
+        nfr = cur + 1;
+    } else {
+        for (auto& b : blk)
+            if (b == cur) b = -1;  // the unfinished frame is not emitted
+        c->dk_carposes.resize((size_t)nfr);
+        c->dk_frame_t.resize((size_t)nfr);
+        c->dk_frame_packets.resize((size_t)nfr);
+    }
+
+    // ---- device side
+    const size_t n_ret = n_pkt * 384;
+    HIP_TRY(c, c->dk_pkts.reserve(n_pkt * 1206));
+    HIP_TRY(c, c->dk_blk.reserve(blk.size()));
+    HIP_TRY(c, c->dk_perm.reserve(perm.size()));
+    HIP_TRY(c, c->dk_table.reserve(table.size()));
+    HIP_TRY(c, c->dk_tvalid.reserve(n_pkt));
+    HIP_TRY(c, c->dk_azdiff.reserve(n_pkt));
+    HIP_TRY(c, c->dk_keys.reserve(n_ret));
+    HIP_TRY(c, c->dk_keys2.reserve(n_ret));
+    HIP_TRY(c, c->dk_idx.reserve(n_ret));
+    HIP_TRY(c, c->dk_order.reserve(n_ret));
+    const uint32_t n_keys = (uint32_t)std::max(nfr, 1) * 64u;
+    HIP_TRY(c, c->dk_starts.reserve((size_t)n_keys + 1));
+    HIP_TRY(c, hipMemcpyAsync(c->dk_pkts.p, packets, n_pkt * 1206, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->dk_blk.p, blk.data(), blk.size() * sizeof(int16_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->dk_perm.p, perm.data(), perm.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->dk_table.p, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->dk_tvalid.p, tvalid.data(), n_pkt, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->dk_azdiff.p, azdiff.data(), n_pkt * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    DecodeView v;
+    v.pkts = c->dk_pkts.p;
+    v.blk_frame = c->dk_blk.p;
+    v.frame_perm = c->dk_perm.p;
+    v.table = c->dk_table.p;
+    v.tvalid = c->dk_tvalid.p;
+    v.az_diff = c->dk_azdiff.p;
+    v.corr = c->dk_corr.p;
+    v.lut_cos = c->dk_lutc.p;
+    v.lut_sin = c->dk_luts.p;
+    v.az_cos = c->dk_azc.p;
+    v.az_sin = c->dk_azs.p;
+    v.inv_lut = c->dk_invlut.p;
+    v.n_pkt = (int)n_pkt;
+    v.n_lasers = n_lasers;
+    v.crop = crop_region != nullptr;
+    v.crop_inside = crop_inside;
+    for (int i = 0; i < 6; ++i) v.region[i] = crop_region ? crop_region[i] : 0.0;
+    HIP_TRY(c, launch_decode_keys(v, n_ret, c->dk_keys.p, c->dk_idx.p, s));
+    size_t tb = 0;
+    HIP_TRY(c, sort_pairs(nullptr, tb, c->dk_keys.p, c->dk_keys2.p, c->dk_idx.p, c->dk_order.p, n_ret, 32, s));
+    if (int rc = ensure_temp(c, tb)) return rc;
+    HIP_TRY(c, sort_pairs(c->temp.p, tb, c->dk_keys.p, c->dk_keys2.p, c->dk_idx.p, c->dk_order.p, n_ret, 32, s));
+    HIP_TRY(c, launch_key_starts(c->dk_keys2.p, n_ret, n_keys, c->dk_starts.p, s));
+    std::vector<int32_t> starts((size_t)n_keys + 1);
+    HIP_TRY(c, hipMemcpyAsync(starts.data(), c->dk_starts.p, starts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const size_t n_valid = nfr > 0 ? (size_t)starts[(size_t)nfr * 64] : 0;
+    HIP_TRY(c, c->dk_x.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_y.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_z.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_i.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_dist.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_az.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_pidx.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, launch_decode_emit(v, c->dk_order.p, n_valid, c->dk_x.p, c->dk_y.p, c->dk_z.p, c->dk_i.p,
+                                  c->dk_az.p, c->dk_dist.p, c->dk_pidx.p, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->dk_frames = nfr;
+    c->dk_points = n_valid;
+    c->dk_frame_start.assign((size_t)nfr + 1, 0);
+    c->dk_beam_start.assign((size_t)nfr * 65, 0);
+    for (int f = 0; f < nfr; ++f) {
+        c->dk_frame_start[f] = starts[(size_t)f * 64];
+        for (int b = 0; b <= 64; ++b) c->dk_beam_start[(size_t)f * 65 + b] = starts[(size_t)f * 64 + b];
+    }
+    c->dk_frame_start[nfr] = (int64_t)n_valid;
+    if (n_frames) *n_frames = nfr;
+    if (n_points) *n_points = n_valid;
+    return VELO_OK;
+}
+
+int velo_decode_fetch(velo_ctx* c, float* x, float* y, float* z, float* intensity, uint16_t* azimuth,
+                      float* distance, uint16_t* packet_index, int64_t* frame_start,
+                      int32_t* beam_start, velo_pose* carposes, int64_t* frame_t_us,
+                      int32_t* frame_packets)
+{
+    if (!c) return VELO_E_INVALID;
+    const size_t n = c->dk_points;
+    hipStream_t s = c->stream;
+    if (n) {
+        if (x) HIP_TRY(c, hipMemcpyAsync(x, c->dk_x.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (y) HIP_TRY(c, hipMemcpyAsync(y, c->dk_y.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (z) HIP_TRY(c, hipMemcpyAsync(z, c->dk_z.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (intensity) HIP_TRY(c, hipMemcpyAsync(intensity, c->dk_i.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (azimuth) HIP_TRY(c, hipMemcpyAsync(azimuth, c->dk_az.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+        if (distance) HIP_TRY(c, hipMemcpyAsync(distance, c->dk_dist.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (packet_index) HIP_TRY(c, hipMemcpyAsync(packet_index, c->dk_pidx.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    const size_t F = (size_t)c->dk_frames;
+    if (frame_start) std::memcpy(frame_start, c->dk_frame_start.data(), (F + 1) * sizeof(int64_t));
+    if (beam_start && F) std::memcpy(beam_start, c->dk_beam_start.data(), F * 65 * sizeof(int32_t));
+    if (carposes && F) std::memcpy(carposes, c->dk_carposes.data(), F * sizeof(velo_pose));
+    if (frame_t_us && F) std::memcpy(frame_t_us, c->dk_frame_t.data(), F * sizeof(int64_t));
+    if (frame_packets && F) std::memcpy(frame_packets, c->dk_frame_packets.data(), F * sizeof(int32_t));
+    return VELO_OK;
+}
+
+int velo_decode_to_frames(velo_ctx* c)
+{
+    if (!c) return VELO_E_INVALID;
+    if (c->dk_frames < 1) return c->fail(VELO_E_INVALID, "nothing decoded");
+    return velo_frames_adopt_dev(c, c->dk_frames, c->dk_x.p, c->dk_y.p, c->dk_z.p,
+                                 c->dk_frame_start.data());
 }
 
 // ----------------------------------------------------------------------- kNN

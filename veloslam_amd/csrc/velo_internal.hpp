@@ -95,4 +95,30 @@ hipError_t launch_increment_scatter(const float* x, const float* y, const float*
                                     const uint32_t* offs, float* ox, float* oy, float* oz,
                                     hipStream_t s);
 
+// ---- f1: packet decode (kernels/decode.hip)
+struct DecodeView {
+    const uint8_t* pkts;        // n_pkt * 1206
+    const int16_t* blk_frame;   // n_pkt * 12: frame of the firing block, -1 = not processed
+    const uint8_t* frame_perm;  // per frame: 1 = apply the HDL-64 beam LUT
+    const double* table;        // n_pkt * 12 affine
+    const uint8_t* tvalid;      // n_pkt: 1 = transform present
+    const int32_t* az_diff;     // n_pkt
+    const double* corr;         // 64 * 9
+    const double* lut_cos;      // 36001
+    const double* lut_sin;
+    const double* az_cos;       // 64 * 36000 (rows of lasers with azimuthCorrection != 0)
+    const double* az_sin;
+    const uint8_t* inv_lut;     // 64
+    int n_pkt, n_lasers;
+    int crop, crop_inside;
+    double region[6];
+};
+hipError_t launch_decode_keys(const DecodeView& v, size_t n_ret, uint32_t* keys, uint32_t* idx,
+                              hipStream_t s);
+hipError_t launch_decode_emit(const DecodeView& v, const uint32_t* order, size_t n_valid, float* ox,
+                              float* oy, float* oz, float* oi, uint16_t* oaz, float* odist,
+                              uint16_t* opkt, hipStream_t s);
+hipError_t launch_key_starts(const uint32_t* keys, size_t n, uint32_t n_keys, int32_t* starts,
+                             hipStream_t s);
+
 }  // namespace velo
