@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libveloslam_amd.so")
+LIB_PATH = os.environ.get("VELO_LIB") or os.path.join(CSRC, "libveloslam_amd.so")  # VELO_LIB: A/B builds
 
 VELO_MAX_ITERS = 64
 VELO_TIME_INVALID = -(2 ** 63)

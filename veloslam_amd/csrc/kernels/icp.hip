@@ -416,7 +416,10 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 };
 
 template <bool WRITE_CORR, int VARIANT>
-__global__ __launch_bounds__(kLinThreads, 8) void k_linearize(
+#ifndef VELO_LIN_WAVES
+#define VELO_LIN_WAVES 7  // measured: 8 spills (64 VGPRs), 7 = 72 VGPRs no spill, fastest
+#endif
+__global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
     const BlockItem* __restrict__ items, FrameView fv, MapView mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
     int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint)
@@ -432,26 +435,16 @@ __global__ __launch_bounds__(kLinThreads, 8) void k_linearize(
     const int ia = c_ia[col], ib = c_ib[col];
     double colsum = 0.0;
 
-    // software pipeline over the rounds of this block: the next round's query (and its hint)
-    // is requested before the current round is searched
-    float nx_ = 0.f, ny_ = 0.f, nz_ = 0.f;
-    int nh_ = -1;
-    if (it.q0 + tid < it.q1) {
-        nx_ = fv.x[it.q0 + tid];
-        ny_ = fv.y[it.q0 + tid];
-        nz_ = fv.z[it.q0 + tid];
-        if (hint) nh_ = hint[it.q0 + tid];
-    }
     for (int base = it.q0; base < it.q1; base += kLinThreads) {
         const int q = base + tid;
         const bool live = q < it.q1;
-        const float sxq = nx_, syq = ny_, szq = nz_;
-        const int hj = nh_;
-        if (q + kLinThreads < it.q1) {
-            nx_ = fv.x[q + kLinThreads];
-            ny_ = fv.y[q + kLinThreads];
-            nz_ = fv.z[q + kLinThreads];
-            if (hint) nh_ = hint[q + kLinThreads];
+        float sxq = 0.f, syq = 0.f, szq = 0.f;
+        int hj = -1;
+        if (live) {
+            sxq = fv.x[q];
+            syq = fv.y[q];
+            szq = fv.z[q];
+            if (hint) hj = hint[q];
         }
         double px = 0, py = 0, pz = 0;
         float bd = INFINITY;
@@ -648,17 +641,18 @@ __device__ void se3_exp_apply(const double* xi, double* T)
     for (int i = 0; i < 12; ++i) T[i] = N[i];
 }
 
-// One 256-thread workgroup per frame.  Thread (g = tid/32, k = tid%32) sums column k
-// of the blocks b0+g, b0+g+8, ... (eight independent load streams per column instead of
-// one serial chain over hundreds of partials), the eight group sums are then added in
-// ascending g: a fixed order, so the result is run-to-run bit reproducible.
-constexpr int kSolveThreads = 256;
+// One 1024-thread workgroup per frame.  Thread (g = tid/32, k = tid%32) sums column k of the
+// blocks b0+g, b0+g+32, ... (32 independent load streams per column instead of one serial
+// chain over hundreds of partials); the group sums are then added in ascending g: a fixed
+// order, so the result is run-to-run bit reproducible.
+constexpr int kSolveThreads = 1024;
+constexpr int kSolveGroups = kSolveThreads / 32;
 __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     const double* __restrict__ partials, const int32_t* __restrict__ fbs,
     double* __restrict__ poses, velo_icp_iter* __restrict__ stats, int iter,
     double* __restrict__ acc_out, int do_update)
 {
-    __shared__ double s_g[8][32];
+    __shared__ double s_g[kSolveGroups][32];
     __shared__ double s_acc[32];
     const int f = blockIdx.x, k = threadIdx.x & 31, g = threadIdx.x >> 5;
     {
@@ -666,13 +660,13 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
         const int b0 = fbs[f], b1 = fbs[f + 1];
         if (k < kAccN) {
             int b = b0 + g;
-            for (; b + 24 < b1; b += 32) {  // four loads in flight per thread
+            for (; b + 3 * kSolveGroups < b1; b += 4 * kSolveGroups) {  // four loads in flight
                 a0 += partials[(size_t)b * kAccStride + k];
-                a1 += partials[(size_t)(b + 8) * kAccStride + k];
-                a2 += partials[(size_t)(b + 16) * kAccStride + k];
-                a3 += partials[(size_t)(b + 24) * kAccStride + k];
+                a1 += partials[(size_t)(b + kSolveGroups) * kAccStride + k];
+                a2 += partials[(size_t)(b + 2 * kSolveGroups) * kAccStride + k];
+                a3 += partials[(size_t)(b + 3 * kSolveGroups) * kAccStride + k];
             }
-            for (; b < b1; b += 8) a0 += partials[(size_t)b * kAccStride + k];
+            for (; b < b1; b += kSolveGroups) a0 += partials[(size_t)b * kAccStride + k];
         }
         s_g[g][k] = (a0 + a1) + (a2 + a3);
     }
@@ -680,7 +674,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     if (threadIdx.x < kAccN) {
         double a = 0.0;
 #pragma unroll
-        for (int gg = 0; gg < 8; ++gg) a += s_g[gg][threadIdx.x];
+        for (int gg = 0; gg < kSolveGroups; ++gg) a += s_g[gg][threadIdx.x];
         s_acc[threadIdx.x] = a;
         if (acc_out) acc_out[(size_t)f * kAccStride + threadIdx.x] = a;
     }
