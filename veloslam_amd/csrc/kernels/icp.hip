@@ -177,6 +177,9 @@ constexpr int kMaxRanges = 9;
 #ifndef VELO_WALK_W
 #define VELO_WALK_W 4
 #endif
+#ifndef VELO_WALK_UNPACKED
+#define VELO_WALK_PACKED 1  // measured: 54 vs 57.5 us per launch against one-range-per-trip
+#endif
 
 // per WAVEFRONT: [slot][lane].  Nothing in the search or in the reduction tile below is
 // shared between wavefronts, so the query loop needs no workgroup barrier at all.
@@ -193,6 +196,36 @@ template <int W>
 __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float qy, float qz,
                                             SearchLds& L, int tid, int nr, float& bd, int& bj)
 {
+#ifdef VELO_WALK_PACKED
+    // W candidates per trip drawn ACROSS ranges: a lane with three short ranges needs one or
+    // two trips instead of three.  Slots past the end repeat the last valid index.
+    int k = 0, j = 0, lo = 0, last = 0;
+    bool more = nr > 0;
+    while (more) {
+        int jj[W];
+        float4 c[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            if (j <= lo && k < nr) {
+                j = L.hi[k][tid];
+                lo = L.lo[k][tid];
+                ++k;
+            }
+            if (j > lo) last = --j;
+            jj[u] = last;
+            c[u] = mv.pts[last];
+        }
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const float e = dist2(c[u], qx, qy, qz);
+            if (e <= bd) {
+                bd = e;
+                bj = jj[u];
+            }
+        }
+        more = (j > lo) || (k < nr);
+    }
+#else
     bool more = nr > 0;
     int k = 1, j = 0, lo = 0;
     if (more) {
@@ -226,6 +259,7 @@ __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float q
             }
         }
     }
+#endif
 }
 
 // four consecutive entries of the fine-cell table with one 16-byte request (the table is
@@ -302,9 +336,13 @@ __device__ __forceinline__ bool search_block(const MapView& mv, const QueryCell&
     return bd <= gr * gr * 0.99999f;
 }
 
-// stage B: whole ball, lockstep over rows (run by the compacted stragglers only)
-__device__ void search_ball(const MapView& mv, float qx, float qy, float qz, float ub, float& bd,
-                            int& bj)
+// stage B, per-lane form (used when most lanes of a wavefront are stragglers, i.e. the first
+// iterations of a badly aligned frame): the whole ball of radius sqrt(ub), rows visited in
+// descending order in chunks of kMaxRanges.  Per chunk the table entries of all its rows are
+// requested together, the surviving ranges staged in LDS and walked like stage A -- two
+// memory round trips per nine rows instead of two per row.
+__device__ void search_ball(const MapView& mv, float qx, float qy, float qz, float ub,
+                            SearchLds& L, int tid, float& bd, int& bj)
 {
     const QueryCell g = locate(mv, qx, qy, qz);
     bd = ub;
@@ -314,36 +352,41 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
     const float inv_hf = (float)S * mv.inv_h;
     const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
     const float xf = (float)g.Fx + g.tx;  // fine coordinate of the query along x
+    int dz = S, dy = S;
+    const int nrows = (2 * S + 1) * (2 * S + 1);
 #pragma unroll 1
-    for (int dz = S; dz >= -S; --dz) {
-        const int zz = g.Fz + dz;
-        if (zz < 0 || zz >= mv.fz) continue;
-        const float bz = dz == 0 ? 0.0f
-                                 : fmaxf(((float)(abs(dz) - 1) + (dz > 0 ? 1.0f - g.tz : g.tz)) * hf - mg, 0.0f);
-        if (bz * bz * 0.99999f > bd) continue;
-#pragma unroll 1
-        for (int dy = S; dy >= -S; --dy) {
-            const int yy = g.Fy + dy;
-            if (yy < 0 || yy >= mv.fy) continue;
-            const float by = dy == 0 ? 0.0f
-                                     : fmaxf(((float)(abs(dy) - 1) + (dy > 0 ? 1.0f - g.ty : g.ty)) * hf - mg, 0.0f);
-            const float rb2 = bz * bz + by * by;
-            if (rb2 * 0.99999f > bd) continue;
-            // half-width of the ball in this row, in fine cells, rounded outwards
-            const float w = (sqrtf(fmaxf(bd - rb2 * 0.99999f, 0.0f)) * 1.00001f + mg) * inv_hf;
-            const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
-            if (x0 > x1) continue;
-            const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
-            const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
-#pragma unroll 4
-            for (int j = jhi - 1; j >= jlo; --j) {
-                const float d2 = dist2(mv.pts[j], qx, qy, qz);
-                if (d2 <= bd) {
-                    bd = d2;
-                    bj = j;
+    for (int r0 = 0; r0 < nrows; r0 += kMaxRanges) {
+        int nr = 0;
+#pragma unroll
+        for (int t = 0; t < kMaxRanges; ++t) {
+            if (r0 + t < nrows) {
+                const int zz = g.Fz + dz, yy = g.Fy + dy;
+                const float bz = dz == 0 ? 0.0f
+                                         : fmaxf(((float)(abs(dz) - 1) + (dz > 0 ? 1.0f - g.tz : g.tz)) * hf - mg, 0.0f);
+                const float by = dy == 0 ? 0.0f
+                                         : fmaxf(((float)(abs(dy) - 1) + (dy > 0 ? 1.0f - g.ty : g.ty)) * hf - mg, 0.0f);
+                const float rb2 = (bz * bz + by * by) * 0.99999f;
+                if (zz >= 0 && zz < mv.fz && yy >= 0 && yy < mv.fy && !(rb2 > bd)) {
+                    // half-width of the ball in this row, in fine cells, rounded outwards
+                    const float w = (sqrtf(fmaxf(bd - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
+                    const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
+                    if (x0 <= x1) {
+                        const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
+                        const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
+                        if (jhi > jlo) {
+                            L.hi[nr][tid] = jhi;
+                            L.lo[nr][tid] = jlo;
+                            ++nr;
+                        }
+                    }
+                }
+                if (--dy < -S) {
+                    dy = S;
+                    --dz;
                 }
             }
         }
+        walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj);
     }
 }
 
@@ -472,7 +515,7 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
             if (__popcll(need) > 16) {
                 if (queued) {
                     const float ub = bd;
-                    search_ball(mv, qx, qy, qz, ub, bd, bj);
+                    search_ball(mv, qx, qy, qz, ub, s_u.s, lane, bd, bj);
                 }
             } else {
                 while (need) {
