@@ -1,0 +1,95 @@
+// api_smoke.cpp -- exercises the reference-shaped C++ surface (include/veloslam/*.hpp) the way a
+// VeloSLAM maintainer would: TransformManager -> HDLFrame -> MapManager::registerFrame.
+// Inputs are raw little-endian arrays written by tests/test_cpp_api.py; the result is printed
+// for the test to compare with the C-ABI path.  Build: hipcc -std=c++17 (host code only).
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <vector>
+#include <veloslam/HDLFrame.hpp>
+#include <veloslam/MapManager.hpp>
+#include <veloslam/TransformManager.hpp>
+
+template <typename T>
+static std::vector<T> slurp(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) {
+        std::cerr << "cannot open " << path << std::endl;
+        std::exit(2);
+    }
+    const std::streamsize n = f.tellg();
+    f.seekg(0);
+    std::vector<T> v((size_t)n / sizeof(T));
+    f.read(reinterpret_cast<char*>(v.data()), n);
+    return v;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) return 2;
+    const std::string dir = argv[1];
+    using namespace veloslam;
+    // pose store: rows of 10 doubles (T, Rdeg, V, t_us)
+    TransformManager tm;
+    const auto poses = slurp<double>(dir + "/poses.f64");
+    for (size_t i = 0; i + 9 < poses.size(); i += 10) {
+        PoseTransform p;
+        for (int k = 0; k < 3; ++k) {
+            p.T[k] = poses[i + k];
+            p.R[k] = poses[i + 3 + k];
+            p.V[k] = poses[i + 6 + k];
+        }
+        p.timestamp = (int64_t)poses[i + 9];
+        p.seconds_pos = 0;
+        tm.addTransform(p);
+    }
+    const auto t = slurp<int64_t>(dir + "/query_t.i64");
+    PoseTransform q;
+    if (!tm.interpolateTransform(t[0], &q) || !q.valid()) {
+        std::cerr << "interpolateTransform failed" << std::endl;
+        return 3;
+    }
+    std::printf("interp %.17g %.17g %.17g %.17g\n", q.T[0], q.T[1], q.T[2], q.R[2]);
+
+    // frame (already motion compensated) and map
+    HDLFrame frame;
+    const auto fx = slurp<float>(dir + "/fx.f32"), fy = slurp<float>(dir + "/fy.f32"),
+               fz = slurp<float>(dir + "/fz.f32");
+    const auto bs = slurp<int32_t>(dir + "/beam_start.i32");
+    frame.setPoints(fx.data(), fy.data(), fz.data(), nullptr, nullptr, bs.data(), (int)bs.size() - 1);
+    frame.timestamp = t[0];
+    const CloudView one = frame.getPointsAsOneCloud(3, 4);
+    std::printf("beam3 %zu\n", one.size);
+
+    MapManager mgr(400.0f, 0);
+    if (!mgr.context()) {
+        std::cerr << "no context: " << mgr.lastError() << std::endl;
+        return 4;
+    }
+    const auto mx = slurp<float>(dir + "/mx.f32"), my = slurp<float>(dir + "/my.f32"),
+               mz = slurp<float>(dir + "/mz.f32");
+    mgr.addPoints(mx.data(), my.data(), mz.data(), mx.size());
+    std::printf("patches %zu\n", mgr.numPatches());
+
+    const auto init = slurp<double>(dir + "/init.f64");  // T[3], Rdeg[3]
+    PoseTransform prior;
+    for (int k = 0; k < 3; ++k) {
+        prior.T[k] = init[k];
+        prior.R[k] = init[3 + k];
+    }
+    RegisterOptions opt;
+    opt.iters = 10;
+    PoseTransform out;
+    velo_icp_result res;
+    if (!mgr.registerFrame(frame, prior, opt, &out, &res)) {
+        std::cerr << "registerFrame failed: " << mgr.lastError() << std::endl;
+        return 5;
+    }
+    std::printf("pose");
+    for (int k = 0; k < 12; ++k) std::printf(" %.17g", res.T[k]);
+    std::printf("\npairs %u\n", res.iter[9].n_pairs);
+    std::printf("trdeg %.12g %.12g %.12g %.12g %.12g %.12g\n", out.T[0], out.T[1], out.T[2], out.R[0], out.R[1], out.R[2]);
+    return 0;
+}

@@ -512,7 +512,10 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
             // when most lanes are stragglers (first iterations of a badly aligned frame)
             // every lane searches its own ball instead.
             unsigned long long need = __ballot(queued);
-            if (__popcll(need) > 16) {
+#ifndef VELO_COOP_MAX
+#define VELO_COOP_MAX 16
+#endif
+            if (__popcll(need) > VELO_COOP_MAX) {
                 if (queued) {
                     const float ub = bd;
                     search_ball(mv, qx, qy, qz, ub, s_u.s, lane, bd, bj);
