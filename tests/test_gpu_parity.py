@@ -414,6 +414,52 @@ def test_gpu_decode_crop_and_registration(ctx, oracle, wl):
     assert dpos < 0.02 and drot < 5e-4
 
 
+def test_stream_decode_register_integrate(oracle):
+    """Config-3 style slice of the whole path on the GPU, frame after frame: raw packets ->
+    decode + compensate -> register against the current map -> accepted increment -> append
+    -> re-index.  The oracle runs the same sequence (fed the GPU's pose for the increment so
+    both maps stay comparable): poses agree within the north star's tolerance at every frame,
+    increments and the re-indexed map tables bit for bit."""
+    from veloslam_amd import synth
+    sc, mo = synth.Scene(), synth.Motion()
+    cal = synth.hdl64_calibration()
+    mx, my, mz = sc.sample_map(120_000, seed=5)
+    c = capi.Context(0, max_batch=2)
+    try:
+        c.map_reset(mx, my, mz, 1.0, 16)
+        om = oracle.Map(mx, my, mz, 1.0, 16)
+        for k in range(4):
+            pk, ts, _ = synth.make_frame_packets(sc, mo, 3 + k, cal, seed=42)
+            track = mo.ins_track(ts[0], ts[-1])
+            poses, n = capi.make_poses(track)
+            g = c.decode(pk, ts, cal, 64, poses, n, flush=True)
+            assert g["n_frames"] == 1
+            c.decode_to_frames()
+            car = g["carposes"][0]
+            T_true = np.array([1, 0, 0, car.T[0], 0, 1, 0, car.T[1], 0, 0, 1, car.T[2]], np.float64)
+            T0 = synth.perturbed_guess(T_true, dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))
+            res = c.icp_batch(T0.reshape(1, 12), 12, 1.0)[0]
+            fx, fy, fz = g["x"], g["y"], g["z"]
+            T_o, st, _ = om.icp(fx, fy, fz, T0, 12, 1.0)
+            dpos, drot = pose_delta(res.T, T_o)
+            assert dpos <= POS_TOL and drot <= ROT_TOL, (k, dpos, drot)
+            assert res.iter[11].n_pairs == st[11]["n_pairs"]
+            Tg = np.array(list(res.T))
+            ix, iy, iz = c.increment(0, Tg, 3, fx.size)
+            ox, oy, oz = om.increment(fx, fy, fz, Tg, 3)
+            assert np.array_equal(ix, ox) and np.array_equal(iy, oy) and np.array_equal(iz, oz)
+            assert 0 < ix.size < fx.size
+            c.map_append(ix, iy, iz)
+            mx, my, mz = (np.concatenate([a, b]) for a, b in ((mx, ix), (my, iy), (mz, iz)))
+            om = oracle.Map(mx, my, mz, 1.0, 16)
+            gm = c.map_download()
+            assert np.array_equal(gm["cell_start"], om.cell_start())
+            assert np.array_equal(gm["perm"], om.perm())
+            assert np.array_equal(gm["nx"].view(np.uint32), om.normals()[0].view(np.uint32))
+    finally:
+        c.close()
+
+
 # ------------------------------------------------------------------ error paths
 def test_errors_are_loud(wl):
     c = capi.Context(0, max_batch=2)
