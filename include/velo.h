@@ -250,6 +250,34 @@ int velo_interp_pose(const velo_pose* sorted, size_t n, int64_t t_us, velo_pose*
 int velo_packet_transforms(const velo_pose* sorted, size_t n, const int64_t* pkt_t_us,
                            size_t n_pkt, double* T3x4, uint8_t* valid, velo_pose* carpose);
 
+/* ---- f2 / f4: the formats on either side of the path (host only) ---------------------- */
+/* pcap of 1206-byte lidar packets, no libpcap: what vtkPacketFileWriter::writePacket
+ * (vtkPacketFileWriter.cxx:118-161) produces and vtkPacketFileReader::nextPacket
+ * (vtkPacketFileReader.h:166-197) consumes -- 24 B global header, per packet 16 B record header
+ * + 42 B Ethernet/IPv4/UDP prefix + payload (PCAP_PACKET_LEN 1264, vtkPacketFileReader.h:66).
+ * Time stamps are epoch microseconds (the reference's +8 h shift, type_defs.cxx:69-72, is not
+ * applied).  velo_pcap_read: packets/t_us may be NULL to count; returns VELO_E_RANGE (with
+ * *n_out = cap) when the file holds more than cap packets. */
+int velo_pcap_write(const char* path, const uint8_t* packets, const int64_t* t_us, size_t n_pkt);
+int velo_pcap_read(const char* path, uint8_t* packets, int64_t* t_us, size_t cap, size_t* n_out);
+/* InsPVA wire struct (type_defs.h:39-58, natural alignment: 104 bytes) */
+typedef struct velo_inspva {
+    uint16_t message_id;
+    uint16_t week_number;
+    uint32_t milliseconds;
+    uint32_t week_number_pos;
+    double seconds_pos;
+    double LLH[3];  /* degrees, degrees, metres */
+    double V[3];
+    double Eulr[3]; /* degrees */
+    int32_t ins_status;
+} velo_inspva;
+/* INSSource::calcTransform (INSSource.cxx:305-326) with the origin as a parameter */
+int velo_ins_to_pose(const velo_inspva* ins, const double orig_xyz[3], int64_t t_us, velo_pose* out);
+/* pose-store persistence: the record layout of type_defs.cxx:4-33 (ptime -> int64 us) */
+int velo_insmeta_write(const char* path, const velo_pose* poses, size_t n);
+int velo_insmeta_read(const char* path, velo_pose* poses, size_t cap, size_t* n_out);
+
 /* ---- CoordiTran (CoordiTran.h:7-15): reference names and signatures verbatim -------- */
 void eulr2dcm(double eul_vect[3], double DCMbn[3][3]);
 void llh2xyz(double llh[3], double xyz[3]);

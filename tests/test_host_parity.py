@@ -151,3 +151,57 @@ def test_packet_transforms_match_oracle(oracle):
     e, _ = capi.make_poses([])
     tab, valid, _ = capi.packet_transforms(e, 0, t_pk[:3])
     assert not valid.any() and np.array_equal(tab[0], [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0])
+
+
+def test_pcap_roundtrip_and_layout(tmp_path):
+    """f2: the pcap container the reference writes/reads (vtkPacketFileWriter.cxx:41-54,118-161;
+    vtkPacketFileReader.h:57-66): sizes, the 42-byte prefix and the round trip."""
+    from veloslam_amd import synth
+    sc, mo = synth.Scene(), synth.Motion()
+    pk, ts, _ = synth.make_frame_packets(sc, mo, 3, synth.hdl64_calibration())
+    path = str(tmp_path / "f.pcap")
+    capi.pcap_write(path, pk[:40], ts[:40])
+    raw = open(path, "rb").read()
+    assert len(raw) == 24 + 40 * 1264  # PCAP_GLOBAL_HEADER_LEN + n * PCAP_PACKET_LEN
+    assert raw[:4] == bytes.fromhex("d4c3b2a1") and raw[20:24] == (1).to_bytes(4, "little")
+    # the reference's LidarPacketHeader words (vtkPacketFileWriter.cxx:41-47), little endian
+    words = [0xffff, 0xffff, 0xffff, 0x7660, 0x0088, 0x0000, 0x0008, 0x0045, 0xd204, 0x0000, 0x0040,
+             0x11ff, 0xaab4, 0xa8c0, 0xc801, 0xffff, 0xffff, 0x4009, 0x4009, 0xbe04, 0x0000]
+    assert raw[40:82] == b"".join(w.to_bytes(2, "little") for w in words)
+    assert int.from_bytes(raw[32:36], "little") == 1248 and raw[82:82 + 1206] == pk[0]
+    back, t = capi.pcap_read(path)
+    assert back == pk[:40] and list(t) == ts[:40]
+    # a foreign record (wrong size) is skipped, as HDLParser would drop it (HDLParser.cxx:982-985)
+    with open(path, "ab") as f:
+        f.write((1).to_bytes(4, "little") + (0).to_bytes(4, "little") + (60).to_bytes(4, "little") * 2 + bytes(60))
+    back, t = capi.pcap_read(path)
+    assert len(back) == 40
+
+
+def test_ins_to_pose_and_insmeta(tmp_path, oracle):
+    """f4: InsPVA -> pose (INSSource.cxx:305-326) and the .insmeta record (type_defs.cxx:4-33)."""
+    assert C.sizeof(capi.InsPVA) == 104
+    org = np.array([-2781621.9891904, 4672106.75052387, 18.8910392])  # INSSource.cxx:334
+    rng = np.random.default_rng(8)
+    poses = (capi.Pose * 5)()
+    for k in range(5):
+        ins = capi.InsPVA()
+        ins.message_id, ins.week_number, ins.milliseconds = 508, 1904, 1000 * k
+        ins.LLH[0], ins.LLH[1], ins.LLH[2] = 39.85 + 1e-4 * k, 116.17 - 1e-4 * k, 50.0 + k
+        for i in range(3):
+            ins.V[i], ins.Eulr[i] = rng.normal(), rng.uniform(-180, 180)
+        assert capi.lib().velo_ins_to_pose(C.byref(ins), org.ctypes.data_as(C.POINTER(C.c_double)),
+                                           10_000 * k, C.byref(poses[k])) == 0
+        # TO_RADIUS(deg) = deg * M_PI / 180, in that order (type_defs.h:25)
+        enu = oracle.llh2enu([ins.LLH[0] * np.pi / 180, ins.LLH[1] * np.pi / 180, ins.LLH[2]], org)
+        assert same_bits(list(poses[k].T), enu)
+        assert list(poses[k].R) == list(ins.Eulr) and list(poses[k].V) == list(ins.V)
+        assert poses[k].t_us == 10_000 * k and poses[k].milliseconds == 1000 * k
+    path = str(tmp_path / "p.insmeta")
+    assert capi.lib().velo_insmeta_write(path.encode(), poses, 5) == 0
+    assert os.path.getsize(path) == 5 * 98
+    back = (capi.Pose * 5)()
+    n = C.c_size_t()
+    assert capi.lib().velo_insmeta_read(path.encode(), back, 5, C.byref(n)) == 0 and n.value == 5
+    for a, b in zip(poses, back):
+        assert bytes(a)[:72] == bytes(b)[:72] and a.t_us == b.t_us and a.seconds_pos == b.seconds_pos

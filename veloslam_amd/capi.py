@@ -37,6 +37,12 @@ class Pose(C.Structure):
                 ("week_number_pos", C.c_uint32), ("seconds_pos", C.c_double)]
 
 
+class InsPVA(C.Structure):
+    _fields_ = [("message_id", C.c_uint16), ("week_number", C.c_uint16), ("milliseconds", C.c_uint32),
+                ("week_number_pos", C.c_uint32), ("seconds_pos", C.c_double), ("LLH", C.c_double * 3),
+                ("V", C.c_double * 3), ("Eulr", C.c_double * 3), ("ins_status", C.c_int32)]
+
+
 class IcpIter(C.Structure):
     _fields_ = [("n_pairs", C.c_uint32), ("solve_flag", C.c_uint32), ("rmse", C.c_double)]
 
@@ -63,7 +69,8 @@ EXPORTS = [
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
     "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
-    "velo_packet_transforms", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
+    "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
+    "velo_insmeta_write", "velo_insmeta_read", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
     "llh2enu", "MappingAngle",
 ]
 
@@ -130,6 +137,11 @@ def lib():
     L.velo_interp_pose.argtypes = [C.POINTER(Pose), C.c_size_t, C.c_int64, C.POINTER(Pose)]
     L.velo_packet_transforms.argtypes = [C.POINTER(Pose), C.c_size_t, C.POINTER(C.c_int64),
                                          C.c_size_t, dp, C.POINTER(C.c_uint8), C.POINTER(Pose)]
+    L.velo_pcap_write.argtypes = [C.c_char_p, vp, vp, C.c_size_t]
+    L.velo_pcap_read.argtypes = [C.c_char_p, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.velo_ins_to_pose.argtypes = [C.POINTER(InsPVA), dp, C.c_int64, C.POINTER(Pose)]
+    L.velo_insmeta_write.argtypes = [C.c_char_p, C.POINTER(Pose), C.c_size_t]
+    L.velo_insmeta_read.argtypes = [C.c_char_p, C.POINTER(Pose), C.c_size_t, C.POINTER(C.c_size_t)]
     for nm in ("llh2xyz", "xyz2llh"):
         getattr(L, nm).argtypes = [dp, dp]
     for nm in ("xyz2enu", "enu2xyz", "enu2llh", "llh2enu"):
@@ -198,6 +210,27 @@ def packet_transforms(poses, n, pkt_times):
     if rc:
         raise VeloError(rc, "velo_packet_transforms")
     return tab, valid, car
+
+
+def pcap_write(path, packets, times_us):
+    buf = np.frombuffer(b"".join(packets), dtype=np.uint8)
+    t = np.ascontiguousarray(times_us, dtype=np.int64)
+    rc = lib().velo_pcap_write(path.encode(), _p(buf), _p(t), len(packets))
+    if rc:
+        raise VeloError(rc, "velo_pcap_write")
+
+
+def pcap_read(path):
+    n = C.c_size_t()
+    rc = lib().velo_pcap_read(path.encode(), None, None, 0, C.byref(n))
+    if rc:
+        raise VeloError(rc, "velo_pcap_read")
+    buf = np.empty(n.value * 1206, np.uint8)
+    t = np.empty(n.value, np.int64)
+    rc = lib().velo_pcap_read(path.encode(), _p(buf), _p(t), n.value, C.byref(n))
+    if rc:
+        raise VeloError(rc, "velo_pcap_read")
+    return [bytes(buf[i * 1206:(i + 1) * 1206]) for i in range(n.value)], t
 
 
 def _geo2(name, a):
