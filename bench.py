@@ -284,7 +284,15 @@ def main():
                                "min_launch_us": 1e3 * tm["linearize_min_ms"],
                                "queries_per_launch": n_q, "cbar": cbar,
                                "bytes_per_query": bytes_per_query,
-                               "compulsory_bytes_per_launch": 16.0 * n_q + 32.0 * args.map_points}
+                               "compulsory_bytes_per_launch": 16.0 * n_q + 32.0 * args.map_points,
+                               "traffic_GBps": (traffic / avg_s / 1e9) if traffic else None,
+                               "note": "achieved = SURVEY 8(d) algorithmic bytes (232+12*Cbar+24 per "
+                                       "query, exhaustive 27-voxel definition) / mean launch time; the "
+                                       "map is cache-resident and the exact ball search never touches "
+                                       "most of those candidates, so frac > 1 is a throughput figure in "
+                                       "HBM-equivalent bytes, not HBM saturation. traffic = PMC "
+                                       "(2*FETCH_SIZE+WRITE_SIZE) per launch from profiles/"
+                                       "traffic_latest.json (taken at its own batch size)"}
         print(json.dumps(out))
     ctx.close()
     if world > 1:
