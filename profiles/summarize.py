@@ -34,9 +34,9 @@ def counters(sub):
     return out
 
 
-stats = glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[0], os.path.join(DST, "kernel_stats_%s.csv" % TAG))
+    shutil.copy(stats[-1], os.path.join(DST, "kernel_stats_%s.csv" % TAG))
 summary = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
     for k, v in counters(sub).items():
