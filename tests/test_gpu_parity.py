@@ -460,6 +460,30 @@ def test_stream_decode_register_integrate(oracle):
         c.close()
 
 
+def test_huge_extent_lowers_subdivision():
+    """A map whose dense fine-cell table would exceed 2^31 entries at the configured
+    sub-division is indexed at the largest sub-division that fits (reported in map_info);
+    registration queries still work."""
+    rng = np.random.default_rng(4)
+    a = rng.uniform(0, 30, (3, 3000)).astype(np.float32)
+    b = a.copy()
+    b[0] += 2990.0
+    b[1] += 2990.0
+    m = np.concatenate([a, b], axis=1)  # 3020 x 3020 x 30 m at 1 m voxels = 2.7e8 voxels
+    c = capi.Context(0, max_batch=2, map_subdiv=3)
+    try:
+        c.map_reset(m[0], m[1], m[2], 1.0, 8)
+        mi = c.map_info()
+        assert mi.subdiv == 1 and mi.n_cells == int(mi.dims[0]) * int(mi.dims[1]) * int(mi.dims[2])
+        q = a[:, :500] + np.float32(0.01)
+        c.frames_upload([tuple(q)])
+        I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)
+        corr, d2, _ = c.linearize(0, I, 1.0, 500)
+        assert (corr >= 0).all() and np.all(d2 <= 3 * 0.0101 ** 2)
+    finally:
+        c.close()
+
+
 # ------------------------------------------------------------------ error paths
 def test_errors_are_loud(wl):
     c = capi.Context(0, max_batch=2)

@@ -184,11 +184,14 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
         dims[a] = (int)ext + 1;
         ncell_d *= (double)dims[a];
     }
-    const int S = c->cfg.map_subdiv;
+    // sub-division: as configured, lowered (never raised) until the dense fine-cell table fits
+    // 2^31 entries; the value actually used is reported in velo_map_info.subdiv
+    int S = c->cfg.map_subdiv;
+    while (S > 1 && ncell_d * (double)S * S * S >= 2147483648.0) --S;
     ncell_d *= (double)S * S * S;
     if (ncell_d >= 2147483648.0)
-        return c->fail(VELO_E_RANGE, "dense fine-cell grid of %.3g cells (voxels x %d^3) exceeds 2^31",
-                       ncell_d, S);
+        return c->fail(VELO_E_RANGE, "dense voxel grid of %.3g cells exceeds 2^31 even without "
+                       "sub-division (sparse/hashed grids are a later row)", ncell_d);
     const int fdims[3] = {dims[0] * S, dims[1] * S, dims[2] * S};
     const size_t ncell = (size_t)fdims[0] * fdims[1] * fdims[2];
     HIP_TRY(c, c->keys.reserve(n));
