@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--sort-frames", type=int, default=0)
     ap.add_argument("--subdiv", type=int, default=3, help="sub-cells per voxel edge of the map order")
     ap.add_argument("--no-hints", action="store_true")
+    ap.add_argument("--hints", type=int, default=2, help="1 = radius hints, 2 = + uniqueness certificates")
     ap.add_argument("--rounds", type=int, default=0, help="rounds of 256 queries per workgroup (0=auto)")
     ap.add_argument("--no-graph", action="store_true", help="plain stream launches, no hipGraph replay")
     ap.add_argument("--variant", type=int, default=1, help="1 = fine-grid ball search (default), 0 = exhaustive validation kernel")
@@ -165,7 +166,7 @@ def main():
     F = args.frames
     ctx = capi.Context(local, max_batch=max(F, 1), sort_frames=args.sort_frames,
                        linearize_variant=args.variant, map_subdiv=args.subdiv,
-                       use_hints=0 if args.no_hints else 1, use_graph=0 if args.no_graph else 1,
+                       use_hints=0 if args.no_hints else args.hints, use_graph=0 if args.no_graph else 1,
                        rounds_per_block=args.rounds)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.map_reset(*d["map"], args.voxel, args.k_normals)

@@ -57,8 +57,10 @@ typedef struct velo_cfg {
     int32_t use_graph;      /* 1: replay a registration's launch sequence as one hipGraph
                                (cfg == NULL enables it) */
     int32_t map_subdiv;     /* sub-cells per voxel edge of the map sort order (default 3) */
-    int32_t use_hints;      /* 1: bound each query's search by its previous correspondence
-                               (exact; cfg == NULL enables it) */
+    int32_t use_hints;      /* temporal coherence, exact either way.  1: bound each query's search by
+                               its previous correspondence; 2: also skip the search when last
+                               iteration certified that correspondence as the unique nearest
+                               point within a radius the query has not left (cfg == NULL: 2) */
     int32_t rounds_per_block; /* tuning: rounds of 256 queries per workgroup (0 = automatic) */
     int32_t reserved[8];
 } velo_cfg;

@@ -272,7 +272,7 @@ class Context:
     """One velo_ctx: one GPU, one stream, single-threaded."""
 
     def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=1, map_subdiv=3,
-                 use_hints=1, use_graph=1, rounds_per_block=0):
+                 use_hints=2, use_graph=1, rounds_per_block=0):
         L = lib()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)

@@ -87,6 +87,8 @@ struct velo_ctx {
     DevBuf<uint32_t> order_keys, order_keys2, order_idx, order;
     DevBuf<int32_t> corr;
     DevBuf<int32_t> hint;  // last correspondence per query slot (search-radius hint), -1 = none
+    DevBuf<float> rho;     // certified uniqueness radius per query slot (valid with hint >= 0)
+    DevBuf<double> poses_prev;  // pose each frame was linearised at in the previous iteration
     DevBuf<float> d2;
     DevBuf<uint32_t> flags, offs;
     DevBuf<float> inc_x, inc_y, inc_z;
@@ -96,12 +98,12 @@ struct velo_ctx {
     struct GraphKey {
         int iters = 0, ni = 0, n_frames = 0, variant = 0;
         float dmax2 = 0;
-        const void *hint = nullptr, *items = nullptr, *stream = nullptr;
+        const void *hint = nullptr, *rho = nullptr, *items = nullptr, *stream = nullptr;
         uint64_t map_gen = 0, frames_gen = 0;
         bool operator==(const GraphKey& o) const
         {
             return iters == o.iters && ni == o.ni && n_frames == o.n_frames && variant == o.variant &&
-                   dmax2 == o.dmax2 && hint == o.hint && items == o.items && stream == o.stream &&
+                   dmax2 == o.dmax2 && hint == o.hint && rho == o.rho && items == o.items && stream == o.stream &&
                    map_gen == o.map_gen && frames_gen == o.frames_gen;
         }
     } graph_key;
@@ -430,10 +432,16 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     const int ni = (int)c->items_h.size();
     const size_t pose_bytes = (size_t)c->n_frames * 12 * sizeof(double);
     int32_t* hint = nullptr;
+    float* rho = nullptr;
     if (c->cfg.use_hints && n_all) {
         HIP_TRY(c, c->hint.reserve(n_all));
         hint = c->hint.p;
+        if (c->cfg.use_hints >= 2) {
+            HIP_TRY(c, c->rho.reserve(n_all));
+            rho = c->rho.p;
+        }
     }
+    HIP_TRY(c, c->poses_prev.reserve((size_t)c->cfg.max_batch * 12));
     const bool graph_ok = c->cfg.use_graph && !c->timing && !c->cfg.sort_frames;
     if (graph_ok) {
         // Replay the whole registration (pose upload, hint reset, iters x (linearise, solve)) as
@@ -447,6 +455,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         key.variant = c->cfg.linearize_variant;
         key.dmax2 = dmax2;
         key.hint = hint;
+        key.rho = rho;
         key.items = c->items.p;
         key.stream = s;
         key.map_gen = c->map_gen;
@@ -463,10 +472,11 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             FrameView fv{c->ax, c->ay, c->az, nullptr};
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
                 e = launch_linearize(c->cfg.linearize_variant, c->items.p, ni, fv, c->mv, c->poses.p,
-                                     dmax2, c->partials.p, nullptr, nullptr, hint, s);
+                                     dmax2, c->partials.p, nullptr, nullptr, hint, rho,
+                                     c->poses_prev.p, s);
                 if (e == hipSuccess)
                     e = launch_reduce_solve(c->partials.p, c->fbs.p, c->n_frames, c->poses.p,
-                                            c->stats.p, it, iters, nullptr, 1, s);
+                                            c->stats.p, it, iters, nullptr, 1, c->poses_prev.p, s);
             }
             hipGraph_t g = nullptr;
             hipError_t e2 = hipStreamEndCapture(s, &g);
@@ -500,12 +510,13 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             Timed t(c, 0);
             HIP_TRY(c, launch_linearize(c->cfg.linearize_variant,
                                         (fv.order && c->cfg.sort_frames == 1) ? c->items_xcd.p : c->items.p, ni, fv, c->mv,
-                                        c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, s));
+                                        c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, rho,
+                                        c->poses_prev.p, s));
         }
         {
             Timed t(c, 1);
             HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p, c->n_frames, c->poses.p,
-                                           c->stats.p, it, iters, nullptr, 1, s));
+                                           c->stats.p, it, iters, nullptr, 1, c->poses_prev.p, s));
         }
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev_call1, s));
@@ -597,7 +608,7 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     c->cfg.struct_size = sizeof(velo_cfg);
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 64;
     if (!cfg) {
-        c->cfg.use_hints = 1;
+        c->cfg.use_hints = 2;
         c->cfg.use_graph = 1;
     }
     if (c->cfg.map_subdiv <= 0) c->cfg.map_subdiv = 3;
@@ -873,6 +884,13 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
         HIP_TRY(c, c->hint.reserve(n_all));
         HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, n_all * sizeof(int32_t), s));
     }
+    HIP_TRY(c, c->poses_prev.reserve((size_t)c->cfg.max_batch * 12));
+    if (c->lin_hints) {
+        HIP_TRY(c, c->rho.reserve(n_all));
+        // the pose of the previous call is this call's "previous iteration"
+        HIP_TRY(c, hipMemcpyAsync(c->poses_prev.p + 12 * (size_t)frame, c->poses.p + 12 * (size_t)frame,
+                                  12 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
     // poses of the other frames are irrelevant here: only this frame's blocks are launched
     HIP_TRY(c, hipMemcpyAsync(c->poses.p + 12 * (size_t)frame, T, 12 * sizeof(double),
                               hipMemcpyHostToDevice, s));
@@ -880,9 +898,11 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
     const int b0 = c->fbs_h[frame], b1 = c->fbs_h[frame + 1];
     HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, c->items.p + b0, b1 - b0, fv, c->mv,
                                 c->poses.p, d_max * d_max, c->partials.p, c->corr.p, c->d2.p,
-                                c->lin_hints ? c->hint.p : nullptr, s));
+                                c->lin_hints ? c->hint.p : nullptr,
+                                (c->lin_hints && c->cfg.use_hints >= 2) ? c->rho.p : nullptr,
+                                c->poses_prev.p, s));
     HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p + frame, 1, c->poses.p, nullptr, 0, 1,
-                                   c->acc.p, 0, s));
+                                   c->acc.p, 0, nullptr, s));
     if (corr)
         HIP_TRY(c, hipMemcpyAsync(corr, c->corr.p + q0, (q1 - q0) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (d2)

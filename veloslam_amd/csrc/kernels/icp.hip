@@ -174,12 +174,11 @@ __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float 
 //            x-extent of each row cut to the ball, descending index, '<='.  Compaction keeps
 //            a handful of stragglers from stalling every wavefront of the workgroup.
 constexpr int kMaxRanges = 9;
+constexpr float kCertSlack = 0.05f;  // metres searched beyond the hinted point (tuning only)
 #ifndef VELO_WALK_W
 #define VELO_WALK_W 4
 #endif
-#ifndef VELO_WALK_UNPACKED
-#define VELO_WALK_PACKED 1  // measured: 54 vs 57.5 us per launch against one-range-per-trip
-#endif
+
 
 // per WAVEFRONT: [slot][lane].  Nothing in the search or in the reduction tile below is
 // shared between wavefronts, so the query loop needs no workgroup barrier at all.
@@ -194,16 +193,19 @@ struct SearchLds {
 // later re-fetch was measured: the extra selects and registers cost more than the fetch.)
 template <int W>
 __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float qy, float qz,
-                                            SearchLds& L, int tid, int nr, float& bd, int& bj)
+                                            SearchLds& L, int tid, int nr, float& bd, int& bj,
+                                            float& sd)
 {
-#ifdef VELO_WALK_PACKED
     // W candidates per trip drawn ACROSS ranges: a lane with three short ranges needs one or
-    // two trips instead of three.  Slots past the end repeat the last valid index.
+    // two trips instead of three (measured 54 vs 57.5 us per launch against one range per
+    // trip).  Slots past the end repeat the last index and are masked.  sd tracks the
+    // second-smallest distance seen (for the uniqueness certificate, see k_linearize).
     int k = 0, j = 0, lo = 0, last = 0;
     bool more = nr > 0;
     while (more) {
         int jj[W];
         float4 c[W];
+        bool live[W];
 #pragma unroll
         for (int u = 0; u < W; ++u) {
             if (j <= lo && k < nr) {
@@ -211,55 +213,26 @@ __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float q
                 lo = L.lo[k][tid];
                 ++k;
             }
-            if (j > lo) last = --j;
+            live[u] = j > lo;
+            if (live[u]) last = --j;
             jj[u] = last;
             c[u] = mv.pts[last];
         }
 #pragma unroll
         for (int u = 0; u < W; ++u) {
             const float e = dist2(c[u], qx, qy, qz);
-            if (e <= bd) {
-                bd = e;
-                bj = jj[u];
+            if (live[u]) {
+                if (e <= bd) {
+                    sd = bd;
+                    bd = e;
+                    bj = jj[u];
+                } else {
+                    sd = fminf(sd, e);
+                }
             }
         }
         more = (j > lo) || (k < nr);
     }
-#else
-    bool more = nr > 0;
-    int k = 1, j = 0, lo = 0;
-    if (more) {
-        j = L.hi[0][tid];
-        lo = L.lo[0][tid];
-    }
-    while (more) {
-        int jj[W];
-        float4 c[W];
-#pragma unroll
-        for (int u = 0; u < W; ++u) {
-            jj[u] = max(j - 1 - u, lo);
-            c[u] = mv.pts[jj[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < W; ++u) {
-            const float e = dist2(c[u], qx, qy, qz);
-            if (e <= bd) {
-                bd = e;
-                bj = jj[u];
-            }
-        }
-        j -= W;
-        if (j <= lo) {
-            if (k < nr) {
-                j = L.hi[k][tid];
-                lo = L.lo[k][tid];
-                ++k;
-            } else {
-                more = false;
-            }
-        }
-    }
-#endif
 }
 
 // four consecutive entries of the fine-cell table with one 16-byte request (the table is
@@ -278,10 +251,11 @@ struct __attribute__((packed, aligned(4))) Int4U {
 template <int ABL>
 __device__ __forceinline__ bool search_block(const MapView& mv, const QueryCell& g, float qx,
                                              float qy, float qz, float ub0, SearchLds& L,
-                                             int tid, float& bd, int& bj)
+                                             int tid, float& bd, int& bj, float& cert)
 {
     bd = ub0;
     bj = -1;
+    cert = 0.0f;  // radius (m) around the query inside which the winner is the only map point
     if (!g.near) return true;  // no voxel of the 27 exists: no candidates at all
     const float hf = mv.h / (float)mv.S;
     const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
@@ -325,7 +299,8 @@ __device__ __forceinline__ bool search_block(const MapView& mv, const QueryCell&
         }
     }
     if (ABL >= 2) nr = min(nr, 0);
-    walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj);
+    float sd = ub0;  // everything not scanned inside the block is further than sqrt(ub0)
+    walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd);
     if (ABL >= 1) return true;
     // guaranteed radius of the 3x3x3 block: one fine cell plus the distance to the nearer
     // face of the query's own fine cell, per axis; shrunk for rounding.  Whatever was pruned
@@ -333,7 +308,10 @@ __device__ __forceinline__ bool search_block(const MapView& mv, const QueryCell&
     const float tmin = fminf(fminf(fminf(g.tx, 1.0f - g.tx), fminf(g.ty, 1.0f - g.ty)),
                              fminf(g.tz, 1.0f - g.tz));
     const float gr = fmaxf(hf * (1.0f + tmin) - mg, 0.0f);
-    return bd <= gr * gr * 0.99999f;
+    const bool final = bd <= gr * gr * 0.99999f;
+    // second-best scanned / pruned-cell bound / block faces, rounded down
+    if (final) cert = fmaxf(fminf(sqrtf(sd) * 0.999999f, gr) - 1e-6f, 0.0f);
+    return final;
 }
 
 // stage B, per-lane form (used when most lanes of a wavefront are stragglers, i.e. the first
@@ -386,7 +364,8 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
                 }
             }
         }
-        walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj);
+        float sd_unused = bd;
+        walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd_unused);
     }
 }
 
@@ -465,7 +444,8 @@ template <bool WRITE_CORR, int VARIANT>
 __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
     const BlockItem* __restrict__ items, FrameView fv, MapView mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
-    int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint)
+    int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint,
+    float* __restrict__ rho, const double* __restrict__ poses_prev)
 {
     __shared__ LinLds s_uw[kLinThreads / 64];
     __shared__ double s_w[4][32];
@@ -492,6 +472,7 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
         double px = 0, py = 0, pz = 0;
         float bd = INFINITY;
         int bj = -1;
+        float rho_new_out = 0.0f;  // certified radius for the next iteration (0 = none)
         if (VARIANT >= 1) {
             bool queued = false;
             float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -500,17 +481,48 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
                 qx = (float)px;
                 qy = (float)py;
                 qz = (float)pz;
-                const QueryCell g = locate(mv, qx, qy, qz);
-                // temporal hint: last iteration's correspondence bounds the search radius
+                // Temporal coherence, exact:
+                //  hint  last iteration's correspondence bounds the search radius;
+                //  rho   radius certified last iteration around the query's PREVIOUS position c
+                //        inside which the hinted point was the only map point.  The query moved
+                //        by delta = |q - c| (c is recomputed from the previous pose), so every
+                //        other map point is at least rho - delta away: if the hinted point is
+                //        strictly closer than that, it is the unique nearest neighbour and the
+                //        search is skipped altogether.  All margins round against skipping.
                 float ub0 = dmax2;
-                if (hj >= 0) ub0 = fminf(ub0, dist2(mv.pts[hj], qx, qy, qz));
-                queued = !search_block<(VARIANT >= 11 ? VARIANT - 10 : 0)>(mv, g, qx, qy, qz, ub0,
-                                                                         s_u.s, lane, bd, bj);
+                bool certified = false;
+                if (hj >= 0) {
+                    const float d1sq = dist2(mv.pts[hj], qx, qy, qz);
+                    const float d1 = sqrtf(d1sq) * 1.000001f + 1e-7f;
+                    if (rho) {
+                        double cx, cy, cz;
+                        xform(poses_prev + 12 * (size_t)it.frame, sxq, syq, szq, cx, cy, cz);
+                        const float ex = qx - (float)cx, ey = qy - (float)cy, ez = qz - (float)cz;
+                        const float delta = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * 1.000001f + 1e-7f;
+                        const float room = (rho[q] - delta) * 0.999999f - 1e-7f;
+                        if (d1 < room) {
+                            certified = true;
+                            bd = d1sq;
+                            bj = hj;
+                            rho_new_out = room;
+                        }
+                    }
+                    // search a little beyond the hinted point so that the result certifies a
+                    // radius the next iterations can live on
+                    const float rs = d1 + kCertSlack;
+                    ub0 = fminf(ub0, rs * rs * 1.00001f);
+                }
+                if (!certified) {
+                    const QueryCell g = locate(mv, qx, qy, qz);
+                    queued = !search_block<(VARIANT >= 11 ? VARIANT - 10 : 0)>(mv, g, qx, qy, qz, ub0,
+                                                                             s_u.s, lane, bd, bj, rho_new_out);
+                }
             }
             // stage B inside the wavefront: no workgroup barrier, no LDS hand-off.  Each
             // straggler's query is broadcast from its lane and searched by all 64 lanes;
             // when most lanes are stragglers (first iterations of a badly aligned frame)
             // every lane searches its own ball instead.
+            if (queued) rho_new_out = 0.0f;
             unsigned long long need = __ballot(queued);
 #ifndef VELO_COOP_MAX
 #define VELO_COOP_MAX 16
@@ -543,6 +555,7 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
         if (live) {
             const bool ok = (bj >= 0) && (bd <= dmax2);
             if (hint) hint[q] = ok ? bj : -1;
+            if (VARIANT >= 1 && rho) rho[q] = rho_new_out;
             if (WRITE_CORR) {
                 const int qi = fv.order ? fv.order[q] : q;
                 if (corr) corr[qi] = ok ? bj : -1;
@@ -598,13 +611,14 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
 
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
-                            int32_t* corr, float* d2, int32_t* hint, hipStream_t s)
+                            int32_t* corr, float* d2, int32_t* hint, float* rho,
+                            const double* poses_prev, hipStream_t s)
 {
     if (n_items == 0) return hipSuccess;
     const bool wc = corr || d2;
 #define VELO_LAUNCH_LIN(WC, V)                                                                   \
     hipLaunchKernelGGL((k_linearize<WC, V>), dim3(n_items), dim3(kLinThreads), 0, s, items, fv, \
-                       mv, poses, dmax2, partials, corr, d2, hint)
+                       mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev)
     if (variant == 1) {
         if (wc) VELO_LAUNCH_LIN(true, 1); else VELO_LAUNCH_LIN(false, 1);
     } else if (variant == 11) {  // timing ablations (wrong results by design)
@@ -696,7 +710,7 @@ constexpr int kSolveGroups = kSolveThreads / 32;
 __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     const double* __restrict__ partials, const int32_t* __restrict__ fbs,
     double* __restrict__ poses, velo_icp_iter* __restrict__ stats, int iter,
-    double* __restrict__ acc_out, int do_update)
+    double* __restrict__ acc_out, int do_update, double* __restrict__ poses_prev)
 {
     __shared__ double s_g[kSolveGroups][32];
     __shared__ double s_acc[32];
@@ -726,6 +740,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
+    // the pose this iteration was linearised at: the next k_linearize recomputes every
+    // query's previous position from it (uniqueness certificate)
+    if (do_update && poses_prev)
+        for (int i = 0; i < 12; ++i) poses_prev[12 * (size_t)f + i] = poses[12 * (size_t)f + i];
     const double cnt = s_acc[28];
     velo_icp_iter st;
     st.n_pairs = (uint32_t)cnt;
@@ -761,12 +779,13 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
 
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
-                               int iters_total, double* acc_out, int do_update, hipStream_t s)
+                               int iters_total, double* acc_out, int do_update, double* poses_prev,
+                               hipStream_t s)
 {
     (void)iters_total;
     if (n_frames == 0) return hipSuccess;
     hipLaunchKernelGGL(k_reduce_solve, dim3(n_frames), dim3(kSolveThreads), 0, s, partials,
-                       frame_block_start, poses, stats, iter, acc_out, do_update);
+                       frame_block_start, poses, stats, iter, acc_out, do_update, poses_prev);
     return hipGetLastError();
 }
 

@@ -76,10 +76,12 @@ hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const f
                       hipStream_t s);
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
-                            int32_t* corr, float* d2, int32_t* hint, hipStream_t s);
+                            int32_t* corr, float* d2, int32_t* hint, float* rho,
+                            const double* poses_prev, hipStream_t s);
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
-                               int iters_total, double* acc_out, int do_update, hipStream_t s);
+                               int iters_total, double* acc_out, int do_update, double* poses_prev,
+                               hipStream_t s);
 hipError_t launch_frame_cellkeys(const FrameView& fv, const int64_t* d_frame_start, int n_frames,
                                  size_t n_total, const MapView& mv, const double* poses,
                                  uint32_t* keys, uint32_t* idx, hipStream_t s);
