@@ -460,6 +460,39 @@ def test_stream_decode_register_integrate(oracle):
         c.close()
 
 
+def test_config3_size_10m_map_properties():
+    """BASELINE config 3 size: a 10 M-point map (too large for the CPU oracle to finish in
+    seconds), checked through size-independent properties: the exact ball search and the
+    literal exhaustive kernel return the same correspondences bit for bit, the registration
+    lands on the ground truth, the cell table is a valid cumulative count."""
+    wl = make_workload(map_points=10_000_000, n_frames=1)
+    f = wl["frames"][0]
+    s = f["sensor"]
+    res = {}
+    for variant in (1, 0):
+        c = capi.Context(0, max_batch=2, linearize_variant=variant, map_subdiv=6)
+        try:
+            cx, cy, cz = c.compensate(s["x"], s["y"], s["z"], s["pkt"], f["table"])
+            c.map_reset(*wl["map"], 1.0, 16)
+            mi = c.map_info()
+            assert mi.n_points == 10_000_000 and mi.subdiv == 6
+            sub = tuple(a[::5].copy() for a in (cx, cy, cz))
+            c.frames_upload([sub])
+            res[variant] = [c.linearize(0, T, 1.0, sub[0].size)[:2] for T in (f["T0"], f["T_true"])]
+            if variant == 1:
+                g = c.map_download()
+                assert g["cell_start"][0] == 0 and g["cell_start"][-1] == 10_000_000
+                assert np.all(np.diff(g["cell_start"]) >= 0)
+                r = c.icp(cx, cy, cz, f["T0"], 20, 1.0)
+                dpos, drot = pose_delta(r.T, f["T_true"])
+                assert dpos < 0.01 and drot < 2e-4
+        finally:
+            c.close()
+    for (c1, d1), (c0, d0) in zip(res[1], res[0]):
+        assert np.array_equal(c1, c0)
+        assert np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
+
+
 def test_huge_extent_lowers_subdivision():
     """A map whose dense fine-cell table would exceed 2^31 entries at the configured
     sub-division is indexed at the largest sub-division that fits (reported in map_info);
