@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=48, help="frames per step per GPU (batch)")
+    ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU (batch)")
     ap.add_argument("--map-points", type=int, default=1_000_000)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--d-max", type=float, default=1.0)
