@@ -43,6 +43,16 @@ public:
     // on error; lastError() says why.  result (optional) gets per-iteration stats.
     bool registerFrame(const HDLFrame& frame, const PoseTransform& init, const RegisterOptions& opts,
                        PoseTransform* out, velo_icp_result* result = nullptr);
+    // f3: drop every tile whose centre is further than `radius` (+ half a tile diagonal) from
+    // (x, y) -- the rolling-map policy behind ROI_RANGE; returns the number of points dropped
+    size_t evictOutside(double x, double y, double radius);
+    // f3: persistence.  Manager header and per-patch header follow the reference's stream
+    // operators (MapManager.cxx:81-110, MapPatch.cxx:3-69: centerX, centerY, range[, patchRange],
+    // u16 count; per patch centerX, centerY, range and four u16 feature counts, written as 0);
+    // each patch is then followed by its point payload: u64 n, x[n], y[n], z[n] (f32).
+    bool save(const std::string& filename) const;
+    bool load(const std::string& filename);
+    size_t numPoints() const;
     const char* lastError() const;
     size_t numPatches() const { return patches_.size(); }
     velo_ctx* context() { return ctx_; }

@@ -26,9 +26,36 @@ static std::vector<T> slurp(const std::string& path)
     return v;
 }
 
+// f3 on the CPU: tiles, eviction, save/load round trip (no GPU needed: the tile index is host code)
+static int tiles_mode(const std::string& dir)
+{
+    using namespace veloslam;
+    MapManager mgr(50.0f, 0);  // without a GPU the context is null; tile operations still work
+    std::vector<float> x, y, z;
+    for (int i = 0; i < 4000; ++i) {
+        x.push_back((float)((i * 37) % 400) - 200.0f);
+        y.push_back((float)((i * 91) % 300) - 150.0f);
+        z.push_back((float)(i % 7) * 0.1f);
+    }
+    mgr.addPoints(x.data(), y.data(), z.data(), x.size());
+    std::printf("patches %zu points %zu\n", mgr.numPatches(), mgr.numPoints());
+    const std::string path = dir + "/map.bin";
+    if (!mgr.save(path)) return 6;
+    MapManager back(1.0f, 0);
+    if (!back.load(path)) return 7;
+    std::printf("loaded %zu %zu\n", back.numPatches(), back.numPoints());
+    auto p = back.findPatch(x[5], y[5]);
+    std::printf("tile %d\n", p ? (int)p->size() : -1);
+    const size_t roi = back.getROI(0, 0).size();
+    const size_t dropped = back.evictOutside(0.0, 0.0, 100.0);
+    std::printf("roi %zu dropped %zu left %zu %zu\n", roi, dropped, back.numPatches(), back.numPoints());
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
+    if (std::string(argv[1]) == "--tiles") return argc < 3 ? 2 : tiles_mode(argv[2]);
     const std::string dir = argv[1];
     using namespace veloslam;
     // pose store: rows of 10 doubles (T, Rdeg, V, t_us)

@@ -28,6 +28,24 @@ def test_cpp_api_compiles_and_links():
     assert os.path.exists(EXE)
 
 
+def test_map_tiles_evict_and_persist(tmp_path):
+    """f3: MapManager tiles, ROI lookup, eviction and the save/load round trip (host only)."""
+    exe = build_exe()
+    out = subprocess.run([exe, "--tiles", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    npatch, npts = (int(v) for v in lines["patches"].replace("points", "").split())
+    assert npts == 4000 and npatch > 20
+    assert lines["loaded"] == "%d %d" % (npatch, npts)
+    assert int(lines["tile"]) > 0
+    roi, dropped, left_p, left_n = (int(v) for v in lines["roi"].replace("dropped", "").replace("left", "").split())
+    assert 1 <= roi <= 4 and dropped > 0 and left_n == npts - dropped and 0 < left_p < npatch
+    # header layout follows MapManager.cxx:81-110: 2 doubles, 2 floats, u16 count
+    raw = open(os.path.join(str(tmp_path), "map.bin"), "rb").read()
+    assert int.from_bytes(raw[24:26], "little") == npatch
+    assert np.frombuffer(raw[20:24], np.float32)[0] == 50.0
+
+
 @pytest.mark.gpu
 def test_cpp_register_frame_matches_c_abi(tmp_path, oracle):
     exe = build_exe()

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <fstream>
 #include "../../../include/veloslam/MapManager.hpp"
 
 namespace veloslam {
@@ -120,6 +121,110 @@ void MapManager::addPoints(const float* x, const float* y, const float* z, size_
 {
     for (size_t i = 0; i < n; ++i) getPatch(x[i], y[i])->append(x + i, y + i, z + i, 1);
     dirty_ = true;
+}
+
+size_t MapManager::numPoints() const
+{
+    size_t n = 0;
+    for (const auto& kv : patches_) n += kv.second->size();
+    return n;
+}
+
+size_t MapManager::evictOutside(double x, double y, double radius)
+{
+    const double reach = radius + 0.70710678118654752 * patchRange_;
+    size_t dropped = 0;
+    for (auto it = patches_.begin(); it != patches_.end();) {
+        const double dx = it->second->centerX - x, dy = it->second->centerY - y;
+        if (dx * dx + dy * dy > reach * reach) {
+            dropped += it->second->size();
+            resident_.erase(it->second);
+            it = patches_.erase(it);
+            dirty_ = true;
+        } else {
+            ++it;
+        }
+    }
+    return dropped;
+}
+
+bool MapManager::save(const std::string& filename) const
+{
+    std::ofstream os(filename, std::ios::binary);
+    if (!os) return false;
+    const double cx = 0, cy = 0;
+    const float range = 0;
+    os.write(reinterpret_cast<const char*>(&cx), sizeof(double));
+    os.write(reinterpret_cast<const char*>(&cy), sizeof(double));
+    os.write(reinterpret_cast<const char*>(&range), sizeof(float));
+    os.write(reinterpret_cast<const char*>(&patchRange_), sizeof(float));
+    const unsigned short sz = (unsigned short)patches_.size();
+    os.write(reinterpret_cast<const char*>(&sz), sizeof(unsigned short));
+    for (const auto& kv : patches_) {
+        const MapPatch& p = *kv.second;
+        os.write(reinterpret_cast<const char*>(&p.centerX), sizeof(double));
+        os.write(reinterpret_cast<const char*>(&p.centerY), sizeof(double));
+        os.write(reinterpret_cast<const char*>(&p.range), sizeof(float));
+        const unsigned short zero = 0;  // posts, planes, marks, cplxes: not carried
+        for (int k = 0; k < 4; ++k) os.write(reinterpret_cast<const char*>(&zero), sizeof(unsigned short));
+        const uint64_t n = p.size();
+        os.write(reinterpret_cast<const char*>(&n), sizeof n);
+        os.write(reinterpret_cast<const char*>(p.x.data()), (std::streamsize)(n * sizeof(float)));
+        os.write(reinterpret_cast<const char*>(p.y.data()), (std::streamsize)(n * sizeof(float)));
+        os.write(reinterpret_cast<const char*>(p.z.data()), (std::streamsize)(n * sizeof(float)));
+    }
+    return (bool)os;
+}
+
+bool MapManager::load(const std::string& filename)
+{
+    std::ifstream is(filename, std::ios::binary);
+    if (!is) {
+        err_ = "cannot open " + filename;
+        return false;
+    }
+    double cx, cy;
+    float range, pr;
+    unsigned short sz = 0;
+    is.read(reinterpret_cast<char*>(&cx), sizeof(double));
+    is.read(reinterpret_cast<char*>(&cy), sizeof(double));
+    is.read(reinterpret_cast<char*>(&range), sizeof(float));
+    is.read(reinterpret_cast<char*>(&pr), sizeof(float));
+    is.read(reinterpret_cast<char*>(&sz), sizeof(unsigned short));
+    if (!is || !(pr > 0)) {
+        err_ = "bad map file header";
+        return false;
+    }
+    patches_.clear();
+    resident_.clear();
+    patchRange_ = pr;
+    for (unsigned short i = 0; i < sz; ++i) {
+        auto p = std::make_shared<MapPatch>();
+        unsigned short counts[4];
+        uint64_t n = 0;
+        is.read(reinterpret_cast<char*>(&p->centerX), sizeof(double));
+        is.read(reinterpret_cast<char*>(&p->centerY), sizeof(double));
+        is.read(reinterpret_cast<char*>(&p->range), sizeof(float));
+        is.read(reinterpret_cast<char*>(counts), sizeof counts);
+        is.read(reinterpret_cast<char*>(&n), sizeof n);
+        if (!is || counts[0] || counts[1] || counts[2] || counts[3] || n > (1ull << 33)) {
+            err_ = "bad map patch record";
+            return false;
+        }
+        p->x.resize(n);
+        p->y.resize(n);
+        p->z.resize(n);
+        is.read(reinterpret_cast<char*>(p->x.data()), (std::streamsize)(n * sizeof(float)));
+        is.read(reinterpret_cast<char*>(p->y.data()), (std::streamsize)(n * sizeof(float)));
+        is.read(reinterpret_cast<char*>(p->z.data()), (std::streamsize)(n * sizeof(float)));
+        if (!is) {
+            err_ = "truncated map file";
+            return false;
+        }
+        patches_[getPatchIdx(p->centerX, p->centerY)] = p;
+    }
+    dirty_ = true;
+    return true;
 }
 
 bool MapManager::syncDeviceMap(double x, double y, const RegisterOptions& o)
