@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_build_variant.sh <name> <extra hipcc flags...>   (A/B builds of the linearise TU)
+# usage: tools/build_variant.sh <name> <extra hipcc flags...>   (A/B builds of the linearise TU)
 set -e
 cd /root/repo/veloslam_amd/csrc
 name=$1; shift

@@ -242,6 +242,9 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
     c->mv = mv;
     c->has_map = true;
     ++c->map_gen;
+    // hints / certificates are indices and radii in the OLD map: forget them
+    if (c->hint.p && c->hint.cap)
+        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), s));
     c->info.n_points = n;
     c->info.n_cells = ncell;
     c->info.origin[0] = mv.ox;

@@ -473,6 +473,7 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
         float bd = INFINITY;
         int bj = -1;
         float rho_new_out = 0.0f;  // certified radius for the next iteration (0 = none)
+        bool state_same = false;   // hint and rho unchanged: nothing to write back
         if (VARIANT >= 1) {
             bool queued = false;
             float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -498,13 +499,18 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
                         double cx, cy, cz;
                         xform(poses_prev + 12 * (size_t)it.frame, sxq, syq, szq, cx, cy, cz);
                         const float ex = qx - (float)cx, ey = qy - (float)cy, ez = qz - (float)cz;
+                        const float rho_in = rho[q];
+                        // a query that has not moved at all (converged pose: bit-identical q)
+                        // sees exactly last iteration's distances: the certificate holds verbatim
+                        const bool still = (ex == 0.0f) && (ey == 0.0f) && (ez == 0.0f);
                         const float delta = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * 1.000001f + 1e-7f;
-                        const float room = (rho[q] - delta) * 0.999999f - 1e-7f;
+                        const float room = still ? rho_in : (rho_in - delta) * 0.999999f - 1e-7f;
                         if (d1 < room) {
                             certified = true;
                             bd = d1sq;
                             bj = hj;
                             rho_new_out = room;
+                            state_same = still;  // hint == hj and rho unchanged
                         }
                     }
                     // search a little beyond the hinted point so that the result certifies a
@@ -554,8 +560,11 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
         double J0 = 0, J1 = 0, J2 = 0, J3 = 0, J4 = 0, J5 = 0, r = 0, valid = 0;
         if (live) {
             const bool ok = (bj >= 0) && (bd <= dmax2);
-            if (hint) hint[q] = ok ? bj : -1;
-            if (VARIANT >= 1 && rho) rho[q] = rho_new_out;
+            // (a certified, unmoved query with a still-valid match keeps its state: no stores)
+            if (!(state_same && ok)) {
+                if (hint) hint[q] = ok ? bj : -1;
+                if (VARIANT >= 1 && rho) rho[q] = rho_new_out;
+            }
             if (WRITE_CORR) {
                 const int qi = fv.order ? fv.order[q] : q;
                 if (corr) corr[qi] = ok ? bj : -1;
