@@ -177,6 +177,16 @@ def test_hinted_search_is_exact(ctx, omap, wl, comp):
             oc, od2, _ = omap.correspond(*comp[0], T, 1.0)
             assert np.array_equal(corr, oc)
             assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+        # the map changes under the carried hints (every other point dropped): indices and
+        # uniqueness radii of the old map must not leak into the search on the new one
+        half = [a[::2].copy() for a in wl["map"]]
+        ctx.map_reset(*half, 1.0, 16)
+        om2 = omap.__class__(*half, 1.0, 16)
+        for T in (f["T_true"], f["T_true"], jit):
+            corr, d2, acc = ctx.linearize(0, T, 1.0, n)
+            oc, od2, _ = om2.correspond(*comp[0], T, 1.0)
+            assert np.array_equal(corr, oc)
+            assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
     finally:
         ctx.linearize_hints(0)
 
