@@ -62,7 +62,12 @@ typedef struct velo_cfg {
                                iteration certified that correspondence as the unique nearest
                                point within a radius the query has not left (cfg == NULL: 2) */
     int32_t rounds_per_block; /* tuning: rounds of 256 queries per workgroup (0 = automatic) */
-    int32_t reserved[8];
+    int32_t map_margin;     /* rolling map: the grid is anchored this many voxels below the lowest
+                               point and padded as many above, so appends/evictions inside the
+                               slack update the sorted map incrementally (default 0 = tight) */
+    int32_t map_full_rebuild; /* 1: every append/evict re-sorts and re-estimates the whole map
+                               (same result; A/B switch for the incremental update) */
+    int32_t reserved[6];
 } velo_cfg;
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */
@@ -103,7 +108,9 @@ typedef struct velo_map_info {
     int32_t k_normals;
     uint64_t n_invalid_normals;
     int32_t subdiv;       /* n_cells counts FINE cells: prod(dims) * subdiv^3 */
-    int32_t reserved;
+    int32_t last_update;  /* how the last reset/append/evict was applied: 0 = full build on a
+                             freshly anchored grid, 1 = incremental on the kept grid */
+    uint64_t n_normals_recomputed; /* normals estimated by that update */
 } velo_map_info;
 
 /* ---- lifetime -------------------------------------------------------------- */
@@ -126,9 +133,18 @@ int velo_map_reset(velo_ctx*, const float* x, const float* y, const float* z, si
                    float voxel, int k_normals);
 int velo_map_reset_dev(velo_ctx*, const float* dx, const float* dy, const float* dz, size_t n,
                        float voxel, int k_normals);
-/* accepted increment: appended in call order, then the grid is rebuilt */
+/* accepted increment: appended in call order.  The map afterwards equals a fresh
+ * build of the whole point list on the map's grid.  The grid (origin, dims) is sticky: it is
+ * re-anchored (origin = min - margin*voxel, full rebuild) only when a new point lies below the
+ * origin; otherwise the new points are merged into the sorted order, the cell table is shifted
+ * and only normals within one voxel of a new point are re-estimated. */
 int velo_map_append(velo_ctx*, const float* x, const float* y, const float* z, size_t n);
 int velo_map_append_dev(velo_ctx*, const float* dx, const float* dy, const float* dz, size_t n);
+/* Rolling map (BASELINE configs[2]; the reference's patch eviction policy is unimplemented,
+ * MapManager.h:43): drop every map point outside the closed box [lo, hi]; append order of the
+ * survivors is kept.  Refused (VELO_E_INVALID, map unchanged) if nothing would remain.  The
+ * grid is re-anchored when the lowest survivor is >= 2*margin+2 voxels above the origin. */
+int velo_map_evict_outside(velo_ctx*, const float lo[3], const float hi[3]);
 int velo_map_info_get(velo_ctx*, velo_map_info* out);
 /* Test / inspection: copy the voxel-sorted map back.  Any pointer may be NULL.
  * perm[s] = index of sorted point s in append order; cell_start has n_cells+1 entries. */

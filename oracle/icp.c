@@ -225,6 +225,15 @@ vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, f
 vo_map* vo_map_build_ex(const float* x, const float* y, const float* z, size_t n, float voxel,
                         int k_normals, int subdiv)
 {
+    return vo_map_build_grid(x, y, z, n, voxel, k_normals, subdiv, NULL, NULL);
+}
+
+/* Fresh build on an explicit grid: origin (must not exceed the min of the points on any
+ * axis; NULL = the min itself) and a lower bound on the voxel dims (NULL = tight).  The
+ * rolling map below is DEFINED as "fresh build of the current raw list on the current grid". */
+vo_map* vo_map_build_grid(const float* x, const float* y, const float* z, size_t n, float voxel,
+                          int k_normals, int subdiv, const float* origin, const int* dims_min)
+{
     if (n == 0 || !(voxel > 0) || k_normals > VO_KMAX || subdiv < 1 || subdiv > 16) return NULL;
     vo_map* m = (vo_map*)calloc(1, sizeof *m);
     m->n = n;
@@ -241,8 +250,13 @@ vo_map* vo_map_build_ex(const float* x, const float* y, const float* z, size_t n
         if (z[i] > mxv[2]) mxv[2] = z[i];
     }
     for (int a = 0; a < 3; ++a) {
-        m->o[a] = mn[a];
-        m->dims[a] = (int)floorf((mxv[a] - mn[a]) * m->inv_h) + 1;
+        if (origin && origin[a] > mn[a]) {
+            free(m);
+            return NULL;
+        }
+        m->o[a] = origin ? origin[a] : mn[a];
+        m->dims[a] = (int)floorf((mxv[a] - m->o[a]) * m->inv_h) + 1;
+        if (dims_min && dims_min[a] > m->dims[a]) m->dims[a] = dims_min[a];
         m->fd[a] = m->dims[a] * m->S;
     }
     m->ncell = (size_t)m->fd[0] * m->fd[1] * m->fd[2];
@@ -325,6 +339,165 @@ const float* vo_map_nz(const vo_map* m) { return m->nz; }
 const int32_t* vo_map_perm(const vo_map* m) { return m->perm; }
 const int32_t* vo_map_cell_start(const vo_map* m) { return m->cell_start; }
 size_t vo_map_num_cells(const vo_map* m) { return m->ncell; }
+
+
+/* ---- rolling map (BASELINE configs[2]) ---------------------------------------
+ * State: the raw point list in insertion order, a sticky grid (origin o, voxel dims) and a
+ * margin of M voxels.  After every operation the map equals
+ * vo_map_build_grid(raw list, o, dims): the GPU's incremental update is held to that.
+ *   anchor   o = min - M*h (float), dims = floorf((max - o)*inv_h) + 1 + M
+ *   append   if a new point lies below o on some axis -> anchor on the whole list; else o
+ *            stays and an axis whose needed dims floorf((max - o)*inv_h)+1 exceed dims grows
+ *            to needed + M
+ *   evict    keep the points with lo <= p <= hi on every axis (order preserving); nothing
+ *            kept -> refused, map unchanged; if floorf((min - o)*inv_h) >= 2M+2 on some axis
+ *            -> anchor; else the grid stays as it is */
+struct vo_roll {
+    float *x, *y, *z;
+    size_t n, cap;
+    float h;
+    int k, S, M;
+    float o[3];
+    int dims[3];
+    vo_map* map;
+};
+
+static void roll_minmax(const vo_roll* r, float mn[3], float mx[3])
+{
+    mn[0] = mx[0] = r->x[0];
+    mn[1] = mx[1] = r->y[0];
+    mn[2] = mx[2] = r->z[0];
+    for (size_t i = 1; i < r->n; ++i) {
+        if (r->x[i] < mn[0]) mn[0] = r->x[i];
+        if (r->y[i] < mn[1]) mn[1] = r->y[i];
+        if (r->z[i] < mn[2]) mn[2] = r->z[i];
+        if (r->x[i] > mx[0]) mx[0] = r->x[i];
+        if (r->y[i] > mx[1]) mx[1] = r->y[i];
+        if (r->z[i] > mx[2]) mx[2] = r->z[i];
+    }
+}
+
+static void roll_anchor(vo_roll* r, const float mn[3], const float mx[3])
+{
+    const float inv_h = 1.0f / r->h;
+    for (int a = 0; a < 3; ++a) {
+        r->o[a] = mn[a] - (float)r->M * r->h;
+        r->dims[a] = (int)floorf((mx[a] - r->o[a]) * inv_h) + 1 + r->M;
+    }
+}
+
+static int roll_rebuild(vo_roll* r)
+{
+    vo_map* m = vo_map_build_grid(r->x, r->y, r->z, r->n, r->h, r->k, r->S, r->o, r->dims);
+    if (!m) return -1;
+    vo_map_free(r->map);
+    r->map = m;
+    return 0;
+}
+
+static void roll_reserve(vo_roll* r, size_t n)
+{
+    if (n <= r->cap) return;
+    size_t c = r->cap ? r->cap : 1024;
+    while (c < n) c *= 2;
+    r->x = (float*)realloc(r->x, c * sizeof(float));
+    r->y = (float*)realloc(r->y, c * sizeof(float));
+    r->z = (float*)realloc(r->z, c * sizeof(float));
+    r->cap = c;
+}
+
+vo_roll* vo_roll_new(const float* x, const float* y, const float* z, size_t n, float voxel,
+                     int k_normals, int subdiv, int margin)
+{
+    if (n == 0 || margin < 0) return NULL;
+    vo_roll* r = (vo_roll*)calloc(1, sizeof *r);
+    r->h = voxel;
+    r->k = k_normals;
+    r->S = subdiv;
+    r->M = margin;
+    roll_reserve(r, n);
+    memcpy(r->x, x, n * sizeof(float));
+    memcpy(r->y, y, n * sizeof(float));
+    memcpy(r->z, z, n * sizeof(float));
+    r->n = n;
+    float mn[3], mx[3];
+    roll_minmax(r, mn, mx);
+    roll_anchor(r, mn, mx);
+    if (roll_rebuild(r)) {
+        vo_roll_free(r);
+        return NULL;
+    }
+    return r;
+}
+
+void vo_roll_free(vo_roll* r)
+{
+    if (!r) return;
+    vo_map_free(r->map);
+    free(r->x);
+    free(r->y);
+    free(r->z);
+    free(r);
+}
+
+const vo_map* vo_roll_map(const vo_roll* r) { return r->map; }
+size_t vo_roll_size(const vo_roll* r) { return r->n; }
+
+int vo_roll_append(vo_roll* r, const float* x, const float* y, const float* z, size_t m)
+{
+    if (m == 0) return 0;
+    roll_reserve(r, r->n + m);
+    memcpy(r->x + r->n, x, m * sizeof(float));
+    memcpy(r->y + r->n, y, m * sizeof(float));
+    memcpy(r->z + r->n, z, m * sizeof(float));
+    int below = 0;
+    for (size_t i = 0; i < m; ++i)
+        if (x[i] < r->o[0] || y[i] < r->o[1] || z[i] < r->o[2]) below = 1;
+    r->n += m;
+    float mn[3], mx[3];
+    roll_minmax(r, mn, mx);
+    if (below) {
+        roll_anchor(r, mn, mx);
+    } else {
+        const float inv_h = 1.0f / r->h;
+        for (int a = 0; a < 3; ++a) {
+            const int need = (int)floorf((mx[a] - r->o[a]) * inv_h) + 1;
+            if (need > r->dims[a]) r->dims[a] = need + r->M;
+        }
+    }
+    if (roll_rebuild(r)) return -1;
+    return below;
+}
+
+int vo_roll_evict_outside(vo_roll* r, const float lo[3], const float hi[3])
+{
+    size_t kept = 0;
+    for (size_t i = 0; i < r->n; ++i)
+        if (r->x[i] >= lo[0] && r->x[i] <= hi[0] && r->y[i] >= lo[1] && r->y[i] <= hi[1] &&
+            r->z[i] >= lo[2] && r->z[i] <= hi[2])
+            ++kept;
+    if (kept == 0) return -1;
+    if (kept == r->n) return 0;
+    size_t w = 0;
+    for (size_t i = 0; i < r->n; ++i)
+        if (r->x[i] >= lo[0] && r->x[i] <= hi[0] && r->y[i] >= lo[1] && r->y[i] <= hi[1] &&
+            r->z[i] >= lo[2] && r->z[i] <= hi[2]) {
+            r->x[w] = r->x[i];
+            r->y[w] = r->y[i];
+            r->z[w] = r->z[i];
+            ++w;
+        }
+    r->n = w;
+    float mn[3], mx[3];
+    roll_minmax(r, mn, mx);
+    const float inv_h = 1.0f / r->h;
+    int anchor = 0;
+    for (int a = 0; a < 3; ++a)
+        if (floorf((mn[a] - r->o[a]) * inv_h) >= (float)(2 * r->M + 2)) anchor = 1;
+    if (anchor) roll_anchor(r, mn, mx);
+    if (roll_rebuild(r)) return -1;
+    return anchor ? 1 : 2;
+}
 
 /* p' = T*p in fp64 with a fixed fma nesting (shared with the HIP kernels) */
 static inline void xform(const double T[12], float x, float y, float z, double o[3])

@@ -107,8 +107,20 @@ def lib():
     L.vo_map_build.restype = C.c_void_p
     L.vo_map_build_ex.argtypes = [fp, fp, fp, C.c_size_t, C.c_float, C.c_int, C.c_int]
     L.vo_map_build_ex.restype = C.c_void_p
+    L.vo_map_build_grid.argtypes = [fp, fp, fp, C.c_size_t, C.c_float, C.c_int, C.c_int, fp, ip]
+    L.vo_map_build_grid.restype = C.c_void_p
+    L.vo_roll_new.argtypes = [fp, fp, fp, C.c_size_t, C.c_float, C.c_int, C.c_int, C.c_int]
+    L.vo_roll_new.restype = C.c_void_p
+    L.vo_roll_free.argtypes = [C.c_void_p]
+    L.vo_roll_map.argtypes = [C.c_void_p]
+    L.vo_roll_map.restype = C.c_void_p
+    L.vo_roll_size.argtypes = [C.c_void_p]
+    L.vo_roll_size.restype = C.c_size_t
+    L.vo_roll_append.argtypes = [C.c_void_p, fp, fp, fp, C.c_size_t]
+    L.vo_roll_evict_outside.argtypes = [C.c_void_p, fp, fp]
     L.vo_map_free.argtypes = [C.c_void_p]
     L.vo_map_size.argtypes = [C.c_void_p]
+    L.vo_map_subdiv.argtypes = [C.c_void_p]
     L.vo_map_size.restype = C.c_size_t
     L.vo_map_num_cells.argtypes = [C.c_void_p]
     L.vo_map_num_cells.restype = C.c_size_t
@@ -307,20 +319,40 @@ class Decoder:
 
 # ----------------------------------------------------------------------- ICP
 class Map:
-    def __init__(self, x, y, z, voxel=1.0, k_normals=16, subdiv=3):
+    def __init__(self, x, y, z, voxel=1.0, k_normals=16, subdiv=3, origin=None, dims_min=None):
         x, y, z = _f32(x), _f32(y), _f32(z)
-        self.h = lib().vo_map_build_ex(_f(x), _f(y), _f(z), x.size, float(voxel), int(k_normals),
-                                       int(subdiv))
+        self._owned = True
+        if origin is None and dims_min is None:
+            self.h = lib().vo_map_build_ex(_f(x), _f(y), _f(z), x.size, float(voxel),
+                                           int(k_normals), int(subdiv))
+        else:
+            o = None if origin is None else _f(np.ascontiguousarray(origin, np.float32))
+            dm = None if dims_min is None else _i(np.ascontiguousarray(dims_min, np.int32))
+            self.h = lib().vo_map_build_grid(_f(x), _f(y), _f(z), x.size, float(voxel),
+                                             int(k_normals), int(subdiv), o, dm)
         self.subdiv = int(subdiv)
         if not self.h:
             raise ValueError("vo_map_build failed")
         self.n = x.size
         self.voxel = float(voxel)
 
+    @classmethod
+    def _view(cls, handle, owner):
+        """Non-owning view of a vo_map that lives inside `owner` (a RollingMap)."""
+        m = cls.__new__(cls)
+        m.h = handle
+        m._owned = False
+        m._owner = owner
+        m.n = lib().vo_map_size(handle)
+        m.subdiv = lib().vo_map_subdiv(handle)
+        o, d, ih = m.grid()
+        m.voxel = 1.0 / ih
+        return m
+
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(self, "_owned", False):
             lib().vo_map_free(self.h)
-            self.h = None
+        self.h = None
 
     def _arr(self, nm, n, dt):
         p = getattr(lib(), "vo_map_" + nm)(self.h)
@@ -396,6 +428,39 @@ class Map:
         n = lib().vo_increment(self.h, _f(x), _f(y), _f(z), x.size, _d(T), int(min_count),
                                _f(ox), _f(oy), _f(oz))
         return ox[:n].copy(), oy[:n].copy(), oz[:n].copy()
+
+
+class RollingMap:
+    """oracle/icp.c vo_roll: raw list + sticky grid + margin; `.map` is the fresh build."""
+
+    def __init__(self, x, y, z, voxel=1.0, k_normals=16, subdiv=3, margin=0):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        self.r = lib().vo_roll_new(_f(x), _f(y), _f(z), x.size, float(voxel), int(k_normals),
+                                   int(subdiv), int(margin))
+        if not self.r:
+            raise ValueError("vo_roll_new failed")
+
+    def __del__(self):
+        if getattr(self, "r", None):
+            lib().vo_roll_free(self.r)
+            self.r = None
+
+    @property
+    def map(self):
+        return Map._view(lib().vo_roll_map(self.r), self)
+
+    @property
+    def n(self):
+        return lib().vo_roll_size(self.r)
+
+    def append(self, x, y, z):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        return lib().vo_roll_append(self.r, _f(x), _f(y), _f(z), x.size)
+
+    def evict_outside(self, lo, hi):
+        lo = np.ascontiguousarray(lo, np.float32)
+        hi = np.ascontiguousarray(hi, np.float32)
+        return lib().vo_roll_evict_outside(self.r, _f(lo), _f(hi))
 
 
 def solve_update(acc, T):

@@ -119,8 +119,26 @@ vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, f
 /* subdiv: sub-cells per voxel edge (part of the sort order, hence of the spec); 3 above */
 vo_map* vo_map_build_ex(const float* x, const float* y, const float* z, size_t n, float voxel,
                         int k_normals, int subdiv);
+/* fresh build on an explicit grid: origin (<= min of the points, NULL = min) and a lower
+ * bound on the voxel dims (NULL = tight) */
+vo_map* vo_map_build_grid(const float* x, const float* y, const float* z, size_t n, float voxel,
+                          int k_normals, int subdiv, const float* origin, const int* dims_min);
 int vo_map_subdiv(const vo_map*);
 void vo_map_free(vo_map*);
+
+/* f3 / configs[2]: rolling map = raw list + sticky grid + margin; after every operation the
+ * map equals vo_map_build_grid(raw list, grid).  Rules in icp.c.
+ * append: 0 = grid kept, 1 = re-anchored, -1 = failed.
+ * evict_outside: 0 = nothing removed, 1 = re-anchored, 2 = removed with the grid kept,
+ * -1 = refused (nothing would remain). */
+typedef struct vo_roll vo_roll;
+vo_roll* vo_roll_new(const float* x, const float* y, const float* z, size_t n, float voxel,
+                     int k_normals, int subdiv, int margin);
+void vo_roll_free(vo_roll*);
+const vo_map* vo_roll_map(const vo_roll*);
+size_t vo_roll_size(const vo_roll*);
+int vo_roll_append(vo_roll*, const float* x, const float* y, const float* z, size_t m);
+int vo_roll_evict_outside(vo_roll*, const float lo[3], const float hi[3]);
 size_t vo_map_size(const vo_map*);
 void vo_map_grid(const vo_map*, float origin[3], int dims[3], float* inv_h);
 /* sorted SoA arrays (length n), perm[s] = original index; cell_start = the FINE cell

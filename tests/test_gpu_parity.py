@@ -141,6 +141,117 @@ def test_map_append_equals_rebuild(ctx, oracle):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def _assert_map_equal(ctx, om):
+    g = ctx.map_download()
+    mi = ctx.map_info()
+    o, d, ih = om.grid()
+    assert mi.n_points == om.n
+    assert list(mi.dims) == list(d)
+    assert np.array_equal(np.array(list(mi.origin), np.float32), o)
+    assert mi.n_cells == om.ncell
+    assert np.array_equal(g["cell_start"], om.cell_start())
+    assert np.array_equal(g["perm"], om.perm())
+    for a, b in zip((g["x"], g["y"], g["z"]), om.sorted_xyz()):
+        assert np.array_equal(a, b)
+    nn = om.normals()
+    for a, b in zip((g["nx"], g["ny"], g["nz"]), nn):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert mi.n_invalid_normals == int(((nn[0] == 0) & (nn[1] == 0) & (nn[2] == 0)).sum())
+
+
+@pytest.mark.parametrize("margin,full,k", [(0, 0, 8), (2, 0, 8), (2, 1, 8), (5, 0, 16), (3, 0, 0)])
+def test_rolling_map_incremental_equals_fresh_build(oracle, margin, full, k):
+    """f3 / BASELINE configs[2]: appends and evictions update the sorted map in place (merge,
+    shifted cell table, normals re-estimated only near changed points).  After every
+    operation the device map is bit-identical to the oracle's fresh build of the current
+    point list on the current grid, whichever way (incremental / full) it was applied."""
+    rng = np.random.default_rng(21)
+    base = rng.uniform(0, 12, (3, 9000)).astype(np.float32)
+    base[2] *= 0.25
+    q = rng.uniform(-1, 14, (3, 3000)).astype(np.float32)
+    q[2] *= 0.25
+    I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+    c = capi.Context(0, max_batch=2, map_margin=margin, map_full_rebuild=full)
+    try:
+        c.map_reset(*base, 1.0, k)
+        roll = oracle.RollingMap(*base, 1.0, k, 3, margin=margin)
+        _assert_map_equal(c, roll.map)
+        assert c.map_info().last_update == 0
+
+        def check(expect_incremental):
+            om = roll.map
+            _assert_map_equal(c, om)
+            mi = c.map_info()
+            if not full and expect_incremental is not None:
+                assert mi.last_update == (1 if expect_incremental else 0)
+                if expect_incremental and k > 0:
+                    assert mi.n_normals_recomputed < mi.n_points
+            c.frames_upload([tuple(q)])
+            corr, d2, _ = c.linearize(0, I, 1.0, q.shape[1])
+            oc, od2, _ = om.correspond(*q, I, 1.0)
+            assert np.array_equal(corr, oc)
+            assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+
+        # 1. inside the grid: pure merge
+        a1 = rng.uniform(2, 5, (3, 400)).astype(np.float32); a1[2] *= 0.25
+        c.map_append(*a1); assert roll.append(*a1) == 0; check(True)
+        # 2. duplicates of existing points and of each other (ties keep append order)
+        a2 = np.concatenate([base[:, :50], base[:, :50], a1[:, :20]], axis=1)
+        c.map_append(*a2); assert roll.append(*a2) == 0; check(True)
+        # 3. above the grid: dims grow (keys re-encoded, table rebuilt), still no re-sort
+        a3 = rng.uniform(11, 12 + margin + 2.5, (3, 300)).astype(np.float32); a3[2] *= 0.1
+        c.map_append(*a3); assert roll.append(*a3) == 0; check(True)
+        # 4. a single point
+        a4 = np.array([[6.0], [6.0], [1.0]], np.float32)
+        c.map_append(*a4); assert roll.append(*a4) == 0; check(True)
+        # 5. below the origin: re-anchor
+        a5 = rng.uniform(-margin - 3.0, 1.0, (3, 200)).astype(np.float32); a5[2] *= 0.1
+        c.map_append(*a5); assert roll.append(*a5) == 1; check(False)
+        # 6. eviction inside the slack: grid kept
+        lo = np.array([-margin - 2.5, -100, -100], np.float32); hi = np.array([10.5, 100, 100], np.float32)
+        c.map_evict_outside(lo, hi); assert roll.evict_outside(lo, hi) == 2; check(True)
+        # 7. eviction that leaves the low side empty: re-anchor
+        lo = np.array([margin + 2.0, -100, -100], np.float32)
+        c.map_evict_outside(lo, hi); assert roll.evict_outside(lo, hi) == 1; check(False)
+        # 8. nothing to evict; then an append again on the re-anchored grid
+        n_before = c.map_info().n_points
+        c.map_evict_outside(np.float32([-1e3] * 3), np.float32([1e3] * 3))
+        assert roll.evict_outside([-1e3] * 3, [1e3] * 3) == 0 and c.map_info().n_points == n_before
+        a8 = rng.uniform(margin + 3.0, 9, (3, 500)).astype(np.float32); a8[2] *= 0.25
+        c.map_append(*a8); assert roll.append(*a8) == 0; check(True)
+        # 9. evicting everything is refused and changes nothing
+        with pytest.raises(capi.VeloError):
+            c.map_evict_outside(np.float32([500] * 3), np.float32([600] * 3))
+        assert roll.evict_outside([500] * 3, [600] * 3) == -1
+        check(None)
+    finally:
+        c.close()
+
+
+def test_rolling_map_registration_after_updates(oracle, wl, comp):
+    """ICP against a map that was appended to and evicted from incrementally gives the pose of
+    the oracle's ICP on the fresh build (hints of the previous map are forgotten)."""
+    mx, my, mz = wl["map"]
+    n0 = mx.size * 3 // 4
+    c = capi.Context(0, max_batch=2, map_margin=4)
+    try:
+        c.map_reset(mx[:n0], my[:n0], mz[:n0], 1.0, 16)
+        roll = oracle.RollingMap(mx[:n0], my[:n0], mz[:n0], 1.0, 16, 3, margin=4)
+        f = wl["frames"][0]
+        c.frames_upload([comp[0]])
+        c.icp_batch([f["T0"]], 5, 1.0)
+        c.map_append(mx[n0:], my[n0:], mz[n0:]); roll.append(mx[n0:], my[n0:], mz[n0:])
+        lo = np.float32([mx.min() + 3.0, my.min(), mz.min()]); hi = np.float32([mx.max(), my.max(), mz.max()])
+        c.map_evict_outside(lo, hi); roll.evict_outside(lo, hi)
+        res = c.icp_batch([f["T0"]], 20, 1.0)[0]
+        To, st, _ = roll.map.icp(*comp[0], f["T0"], 20, 1.0)
+        dt, dr = pose_delta(np.array(list(res.T)), To)
+        assert dt <= 1e-4 and dr <= 1e-5
+        assert int(st[0]["n_pairs"]) == int(res.iter[0].n_pairs)
+    finally:
+        c.close()
+
+
 # ------------------------------------------------- correspondences + sums (a10, a11)
 def test_linearize_corr_bit_exact_and_sums(ctx, omap, wl, comp):
     ctx.map_reset(*wl["map"], 1.0, 16)

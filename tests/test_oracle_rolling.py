@@ -1,0 +1,65 @@
+"""CPU: the rolling-map rules of the oracle (oracle/icp.c vo_roll) -- sticky grid, margin,
+re-anchoring -- and the property that makes a sticky grid legitimate: nearest neighbours do
+not depend on where the grid is anchored (only the sorted numbering does)."""
+import numpy as np
+import pytest
+
+
+def _nn_raw(m, q):
+    I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+    corr, d2, _ = m.correspond(*q, I, 1.0)
+    perm = m.perm()
+    raw = np.where(corr >= 0, perm[np.maximum(corr, 0)], -1)
+    return raw, d2
+
+
+def test_roll_rules_and_grid_independence(oracle):
+    rng = np.random.default_rng(5)
+    base = rng.uniform(0, 10, (3, 6000)).astype(np.float32)
+    q = rng.uniform(-1, 12, (3, 2000)).astype(np.float32)
+    tight = oracle.RollingMap(*base, 1.0, 8, 3, margin=0)
+    wide = oracle.RollingMap(*base, 1.0, 8, 3, margin=3)
+    o0, d0, _ = tight.map.grid()
+    o3, d3, _ = wide.map.grid()
+    assert np.array_equal(o0, base.min(axis=1))
+    assert np.array_equal(o3, base.min(axis=1) - np.float32(3.0))
+    assert list(d3) == [int(v) + 6 for v in d0]
+    # distinct points: the nearest neighbour (as an append-order index) is grid independent
+    r0, e0 = _nn_raw(tight.map, q)
+    r3, e3 = _nn_raw(wide.map, q)
+    assert np.array_equal(r0, r3) and np.array_equal(e0.view(np.uint32), e3.view(np.uint32))
+
+    inside = rng.uniform(1, 9, (3, 200)).astype(np.float32)
+    assert tight.append(*inside) == 0 and wide.append(*inside) == 0
+    assert np.array_equal(tight.map.grid()[0], o0) and list(tight.map.grid()[1]) == list(d0)
+    below = np.array([[-1.5], [5.0], [5.0]], np.float32)
+    assert tight.append(*below) == 1          # tight grid: any point below re-anchors
+    assert wide.append(*below) == 0           # inside the 3-voxel slack: grid kept
+    assert np.array_equal(wide.map.grid()[0], o3)
+    r0, e0 = _nn_raw(tight.map, q)
+    r3, e3 = _nn_raw(wide.map, q)
+    assert np.array_equal(r0, r3) and np.array_equal(e0.view(np.uint32), e3.view(np.uint32))
+
+    # explicit-grid build == what the rolling map holds
+    allp = np.concatenate([base, inside, below], axis=1)
+    o, d, _ = wide.map.grid()
+    ref = oracle.Map(*allp, 1.0, 8, 3, origin=o, dims_min=d)
+    assert np.array_equal(ref.perm(), wide.map.perm())
+    assert np.array_equal(ref.cell_start(), wide.map.cell_start())
+    for a, b in zip(ref.normals(), wide.map.normals()):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    with pytest.raises(ValueError):
+        oracle.Map(*allp, 1.0, 8, 3, origin=o + np.float32(2.0))  # origin above a point
+
+    # eviction: order preserving, refusal when nothing remains, re-anchor past 2M+2 voxels
+    n = wide.n
+    assert wide.evict_outside([-100] * 3, [100] * 3) == 0 and wide.n == n
+    assert wide.evict_outside([500] * 3, [600] * 3) == -1 and wide.n == n
+    assert wide.evict_outside([2.0, -100, -100], [100] * 3) == 2   # gap 5 < 8 voxels
+    assert np.array_equal(wide.map.grid()[0], o3)
+    assert wide.evict_outside([6.5, -100, -100], [100] * 3) == 1   # gap >= 8: anchor
+    assert wide.map.grid()[0][0] > o3[0]
+    keep = allp[:, allp[0] >= 6.5]
+    sx, sy, sz = wide.map.sorted_xyz()
+    perm = wide.map.perm()
+    assert np.array_equal(sx, keep[0][perm]) and np.array_equal(sz, keep[2][perm])

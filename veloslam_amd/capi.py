@@ -28,7 +28,8 @@ class Cfg(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_batch", C.c_int32),
                 ("linearize_variant", C.c_int32), ("sort_frames", C.c_int32),
                 ("use_graph", C.c_int32), ("map_subdiv", C.c_int32), ("use_hints", C.c_int32),
-                ("rounds_per_block", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("rounds_per_block", C.c_int32), ("map_margin", C.c_int32),
+                ("map_full_rebuild", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class Pose(C.Structure):
@@ -57,14 +58,15 @@ class MapInfo(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("n_cells", C.c_uint64), ("origin", C.c_float * 3),
                 ("voxel", C.c_float), ("inv_voxel", C.c_float), ("dims", C.c_int32 * 3),
                 ("k_normals", C.c_int32), ("n_invalid_normals", C.c_uint64),
-                ("subdiv", C.c_int32), ("reserved", C.c_int32)]
+                ("subdiv", C.c_int32), ("last_update", C.c_int32),
+                ("n_normals_recomputed", C.c_uint64)]
 
 
 # every symbol include/velo.h declares (tests check the library exports them all)
 EXPORTS = [
     "velo_create", "velo_destroy", "velo_last_error", "velo_abi_version", "velo_set_stream",
     "velo_synchronize", "velo_map_reset", "velo_map_reset_dev", "velo_map_append",
-    "velo_map_append_dev", "velo_map_info_get", "velo_map_download", "velo_compensate",
+    "velo_map_append_dev", "velo_map_evict_outside", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
     "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing",
@@ -110,6 +112,7 @@ def lib():
     L.velo_map_reset_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_int]
     L.velo_map_append.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.velo_map_append_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.velo_map_evict_outside.argtypes = [vp, vp, vp]
     L.velo_map_info_get.argtypes = [vp, C.POINTER(MapInfo)]
     L.velo_map_download.argtypes = [vp] + [vp] * 8
     L.velo_compensate.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp]
@@ -272,7 +275,7 @@ class Context:
     """One velo_ctx: one GPU, one stream, single-threaded."""
 
     def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=1, map_subdiv=3,
-                 use_hints=2, use_graph=1, rounds_per_block=0):
+                 use_hints=2, use_graph=1, rounds_per_block=0, map_margin=0, map_full_rebuild=0):
         L = lib()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -283,6 +286,8 @@ class Context:
         cfg.use_hints = use_hints
         cfg.use_graph = use_graph
         cfg.rounds_per_block = rounds_per_block
+        cfg.map_margin = map_margin
+        cfg.map_full_rebuild = map_full_rebuild
         self.h = L.velo_create(device, C.byref(cfg))
         if not self.h:
             raise VeloError(-3, L.velo_last_error(None).decode())
@@ -331,6 +336,11 @@ class Context:
 
     def map_append_dev(self, px, py, pz, n):
         self._chk(lib().velo_map_append_dev(self.h, px, py, pz, n))
+
+    def map_evict_outside(self, lo, hi):
+        lo = np.ascontiguousarray(lo, np.float32)
+        hi = np.ascontiguousarray(hi, np.float32)
+        self._chk(lib().velo_map_evict_outside(self.h, _p(lo), _p(hi)))
 
     def map_info(self):
         mi = MapInfo()

@@ -65,6 +65,15 @@ struct velo_ctx {
     DevBuf<int32_t> cell_start;
     DevBuf<unsigned> mm_scratch;
     DevBuf<unsigned long long> invalid_cnt;
+    // incremental update (f3): second set of sorted arrays (swapped in), new-point keys,
+    // dirty voxels and the normal work list
+    DevBuf<float> raw_x2, raw_y2, raw_z2;
+    DevBuf<uint32_t> keys_alt, perm_alt, nk, nk_sorted, nidx, nidx_sorted, rflags, roffs;
+    DevBuf<float4> pts_alt, nrm_alt;
+    DevBuf<uint8_t> dirty;
+    DevBuf<int32_t> work;
+    DevBuf<unsigned> work_cnt;
+    float map_mx[3] = {0, 0, 0};  // component-wise max of the map points
     DevBuf<char> temp;
     MapView mv{};
     bool has_map = false;
@@ -162,8 +171,40 @@ int ensure_temp(velo_ctx* c, size_t bytes)
     return VELO_OK;
 }
 
+// make `mv` the ctx's map: bookkeeping shared by the full build and the incremental updates
+int publish_map(velo_ctx* c, const MapView& mv, int k_normals, unsigned long long invalid,
+                int last_update, uint64_t n_recomputed)
+{
+    hipStream_t s = c->stream;
+    c->mv = mv;
+    c->has_map = true;
+    ++c->map_gen;
+    // hints / certificates are indices and radii in the OLD map: forget them
+    if (c->hint.p && c->hint.cap)
+        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), s));
+    c->info.n_points = (uint64_t)mv.n;
+    c->info.n_cells = (uint64_t)mv.fx * mv.fy * mv.fz;
+    c->info.origin[0] = mv.ox;
+    c->info.origin[1] = mv.oy;
+    c->info.origin[2] = mv.oz;
+    c->info.voxel = mv.h;
+    c->info.inv_voxel = mv.inv_h;
+    c->info.dims[0] = mv.nx;
+    c->info.dims[1] = mv.ny;
+    c->info.dims[2] = mv.nz;
+    c->info.k_normals = k_normals;
+    c->info.subdiv = mv.S;
+    c->info.n_invalid_normals = invalid;
+    c->info.last_update = last_update;
+    c->info.n_normals_recomputed = n_recomputed;
+    return VELO_OK;
+}
+
 // (re)build the voxel grid over raw_x/y/z[0..raw_n)
-int rebuild_map(velo_ctx* c, float voxel, int k_normals)
+// grid_org/grid_dims == nullptr: anchor the grid on the points (origin = min - margin*h);
+// otherwise build on that explicit grid (which must contain every point)
+int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org = nullptr,
+                const int* grid_dims = nullptr)
 {
     const size_t n = c->raw_n;
     hipStream_t s = c->stream;
@@ -177,14 +218,22 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
     HIP_TRY(c, launch_minmax(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, c->mm_scratch.p, &mm, s));
     const float inv_h = 1.0f / voxel;
     int dims[3];
+    float org[3];
     double ncell_d = 1.0;
+    const int M = c->cfg.map_margin;
     for (int a = 0; a < 3; ++a) {
         if (!std::isfinite(mm.mn[a]) || !std::isfinite(mm.mx[a]))
             return c->fail(VELO_E_INVALID, "map points must be finite");
-        const float ext = floorf((mm.mx[a] - mm.mn[a]) * inv_h);
+        // anchor (oracle/icp.c roll_anchor): M voxels of slack below the lowest point and above
+        // the highest, so that a rolling map keeps its grid across appends and evictions
+        org[a] = grid_org ? grid_org[a] : mm.mn[a] - (float)M * voxel;
+        const float ext = floorf((mm.mx[a] - org[a]) * inv_h);
         if (!(ext < 2.0e9f)) return c->fail(VELO_E_RANGE, "map extent / voxel too large");
-        dims[a] = (int)ext + 1;
+        dims[a] = grid_dims ? grid_dims[a] : (int)ext + 1 + M;
+        if (mm.mn[a] < org[a] || (int)ext + 1 > dims[a])
+            return c->fail(VELO_E_INVALID, "explicit grid does not contain the map points");
         ncell_d *= (double)dims[a];
+        c->map_mx[a] = mm.mx[a];
     }
     // sub-division: as configured, lowered (never raised) until the dense fine-cell table fits
     // 2^31 entries; the value actually used is reported in velo_map_info.subdiv
@@ -204,7 +253,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
     HIP_TRY(c, c->nrm.reserve(n));
     HIP_TRY(c, c->cell_start.reserve(ncell + 8));  // +1 entry, padded: rows are read 4 entries at a time
     HIP_TRY(c, c->invalid_cnt.reserve(1));
-    HIP_TRY(c, launch_keys(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, mm.mn[0], mm.mn[1], mm.mn[2],
+    HIP_TRY(c, launch_keys(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, org[0], org[1], org[2],
                            inv_h, S, fdims[0], fdims[1], c->keys.p, c->idx.p, s));
     int bits = 1;
     while (bits < 32 && ((size_t)1 << bits) < ncell) ++bits;
@@ -218,9 +267,9 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
     mv.pts = c->pts.p;
     mv.nrm = c->nrm.p;
     mv.cell_start = c->cell_start.p;
-    mv.ox = mm.mn[0];
-    mv.oy = mm.mn[1];
-    mv.oz = mm.mn[2];
+    mv.ox = org[0];
+    mv.oy = org[1];
+    mv.oz = org[2];
     mv.inv_h = inv_h;
     mv.h = voxel;
     mv.nx = dims[0];
@@ -239,26 +288,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals)
         HIP_TRY(c, hipMemsetAsync(c->nrm.p, 0, n * sizeof(float4), s));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
-    c->mv = mv;
-    c->has_map = true;
-    ++c->map_gen;
-    // hints / certificates are indices and radii in the OLD map: forget them
-    if (c->hint.p && c->hint.cap)
-        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), s));
-    c->info.n_points = n;
-    c->info.n_cells = ncell;
-    c->info.origin[0] = mv.ox;
-    c->info.origin[1] = mv.oy;
-    c->info.origin[2] = mv.oz;
-    c->info.voxel = voxel;
-    c->info.inv_voxel = inv_h;
-    c->info.dims[0] = dims[0];
-    c->info.dims[1] = dims[1];
-    c->info.dims[2] = dims[2];
-    c->info.k_normals = k_normals;
-    c->info.subdiv = S;
-    c->info.n_invalid_normals = invalid;
-    return VELO_OK;
+    return publish_map(c, mv, k_normals, invalid, 0, k_normals > 0 ? n : 0);
 }
 
 int stage_raw(velo_ctx* c, const float* x, const float* y, const float* z, size_t n, bool dev,
@@ -277,6 +307,135 @@ int stage_raw(velo_ctx* c, const float* x, const float* y, const float* z, size_
     c->raw_n = total;
     return VELO_OK;
 }
+
+template <typename T>
+hipError_t reserve_slack(DevBuf<T>& b, size_t n)
+{
+    if (n <= b.cap) return hipSuccess;
+    return b.reserve(n + n / 8 + 4096);  // a rolling map grows a little every frame
+}
+
+// normals of the points in dirty voxels, after the sorted arrays were updated in place
+int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, unsigned* n_work_out)
+{
+    hipStream_t s = c->stream;
+    HIP_TRY(c, reserve_slack(c->work, (size_t)mv.n));
+    HIP_TRY(c, c->work_cnt.reserve(1));
+    HIP_TRY(c, launch_select_dirty(c->keys_sorted.p, (uint32_t)mv.n, mv, c->dirty.p, c->work.p,
+                                   c->work_cnt.p, s));
+    unsigned n_work = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_work, c->work_cnt.p, sizeof n_work, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, launch_normals_subset(mv, k, c->work.p, (int)n_work, c->nrm.p, c->invalid_cnt.p, s));
+    *n_work_out = n_work;
+    return VELO_OK;
+}
+
+// Append raw points [n_old, n_old+m) (already staged) without re-sorting the map.  Returns
+// 1 if the grid cannot be kept (caller does the full, re-anchoring rebuild), 0 when done.
+int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
+{
+    *done = 0;
+    hipStream_t s = c->stream;
+    const MapView old = c->mv;
+    const int k = c->info.k_normals;
+    const int M = c->cfg.map_margin;
+    if (n_old + m >= (size_t)INT32_MAX) return c->fail(VELO_E_RANGE, "map larger than 2^31-1 points");
+    HIP_TRY(c, c->mm_scratch.reserve(8));
+    MinMax mm;
+    HIP_TRY(c, launch_minmax(c->raw_x.p + n_old, c->raw_y.p + n_old, c->raw_z.p + n_old, m,
+                             c->mm_scratch.p, &mm, s));
+    const float org[3] = {old.ox, old.oy, old.oz};
+    int dims[3] = {old.nx, old.ny, old.nz};
+    bool grew = false;
+    float mx[3];
+    for (int a = 0; a < 3; ++a) {
+        if (!std::isfinite(mm.mn[a]) || !std::isfinite(mm.mx[a]))
+            return c->fail(VELO_E_INVALID, "map points must be finite");
+        if (mm.mn[a] < org[a]) return VELO_OK;  // below the origin: re-anchor (done == 0)
+        mx[a] = std::max(c->map_mx[a], mm.mx[a]);
+        const float ext = floorf((mx[a] - org[a]) * old.inv_h);
+        if (!(ext < 2.0e9f)) return c->fail(VELO_E_RANGE, "map extent / voxel too large");
+        const int need = (int)ext + 1;
+        if (need > dims[a]) {
+            dims[a] = need + M;
+            grew = true;
+        }
+    }
+    const int S = old.S;
+    const double ncell_d = (double)dims[0] * dims[1] * dims[2] * (double)S * S * S;
+    if (ncell_d >= 2147483648.0) return VELO_OK;  // let the full path lower S or refuse
+    MapView g = old;
+    g.nx = dims[0];
+    g.ny = dims[1];
+    g.nz = dims[2];
+    g.fx = dims[0] * S;
+    g.fy = dims[1] * S;
+    g.fz = dims[2] * S;
+    const size_t ncell = (size_t)g.fx * g.fy * g.fz;
+    const size_t total = n_old + m;
+    if (c->cfg.map_full_rebuild) {  // A/B switch: same grid, everything recomputed
+        *done = 1;
+        return rebuild_map(c, old.h, k, org, dims);
+    }
+    // the dims moved: every old key is re-encoded (the ORDER does not change -- keys are
+    // lexicographic in (Fz, Fy, Fx) whatever the row lengths are)
+    if (grew) HIP_TRY(c, launch_keys4(c->pts.p, n_old, g, c->keys_sorted.p, s));
+    HIP_TRY(c, reserve_slack(c->nk, m));
+    HIP_TRY(c, reserve_slack(c->nk_sorted, m));
+    HIP_TRY(c, reserve_slack(c->nidx, m));
+    HIP_TRY(c, reserve_slack(c->nidx_sorted, m));
+    HIP_TRY(c, launch_keys(c->raw_x.p + n_old, c->raw_y.p + n_old, c->raw_z.p + n_old, m, org[0],
+                           org[1], org[2], old.inv_h, S, g.fx, g.fy, c->nk.p, c->nidx.p, s));
+    int bits = 1;
+    while (bits < 32 && ((size_t)1 << bits) < ncell) ++bits;
+    size_t tb = 0;
+    HIP_TRY(c, sort_pairs(nullptr, tb, c->nk.p, c->nk_sorted.p, c->nidx.p, c->nidx_sorted.p, m, bits, s));
+    if (int rc = ensure_temp(c, tb)) return rc;
+    HIP_TRY(c, sort_pairs(c->temp.p, tb, c->nk.p, c->nk_sorted.p, c->nidx.p, c->nidx_sorted.p, m, bits, s));
+    HIP_TRY(c, reserve_slack(c->pts_alt, total));
+    HIP_TRY(c, reserve_slack(c->nrm_alt, total));
+    HIP_TRY(c, reserve_slack(c->perm_alt, total));
+    HIP_TRY(c, reserve_slack(c->keys_alt, total));
+    HIP_TRY(c, launch_merge(c->pts.p, c->nrm.p, c->perm.p, c->keys_sorted.p, (uint32_t)n_old,
+                            c->raw_x.p, c->raw_y.p, c->raw_z.p, (uint32_t)n_old, c->nk_sorted.p,
+                            c->nidx_sorted.p, (uint32_t)m, c->pts_alt.p, c->nrm_alt.p,
+                            c->perm_alt.p, c->keys_alt.p, s));
+    if (grew) {
+        HIP_TRY(c, hipStreamSynchronize(s));  // the old table may still be read by queued work
+        HIP_TRY(c, c->cell_start.reserve(ncell + 8));
+        HIP_TRY(c, launch_cell_start(c->keys_alt.p, total, ncell, c->cell_start.p, s));
+    } else {
+        HIP_TRY(c, launch_table_shift(c->cell_start.p, ncell + 1, c->nk_sorted.p, (uint32_t)m, s));
+    }
+    std::swap(c->pts.p, c->pts_alt.p);
+    std::swap(c->pts.cap, c->pts_alt.cap);
+    std::swap(c->nrm.p, c->nrm_alt.p);
+    std::swap(c->nrm.cap, c->nrm_alt.cap);
+    std::swap(c->perm.p, c->perm_alt.p);
+    std::swap(c->perm.cap, c->perm_alt.cap);
+    std::swap(c->keys_sorted.p, c->keys_alt.p);
+    std::swap(c->keys_sorted.cap, c->keys_alt.cap);
+    g.pts = c->pts.p;
+    g.nrm = c->nrm.p;
+    g.cell_start = c->cell_start.p;
+    g.n = (int)total;
+    unsigned long long invalid = total;
+    unsigned n_work = 0;
+    if (k > 0) {
+        const size_t nvox = (size_t)dims[0] * dims[1] * dims[2];
+        HIP_TRY(c, reserve_slack(c->dirty, nvox));
+        HIP_TRY(c, hipMemsetAsync(c->dirty.p, 0, nvox, s));
+        HIP_TRY(c, launch_mark_dirty(c->nk_sorted.p, (uint32_t)m, nullptr, g, c->dirty.p, s));
+        if (int rc = refresh_dirty_normals(c, g, k, &n_work)) return rc;
+        HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (int a = 0; a < 3; ++a) c->map_mx[a] = mx[a];
+    *done = 1;
+    return publish_map(c, g, k, invalid, 1, n_work);
+}
+
 
 // work decomposition of the linearise kernel over the resident frames
 int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
@@ -704,8 +863,15 @@ static int map_append_impl(velo_ctx* c, const float* x, const float* y, const fl
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "velo_map_append before velo_map_reset");
     if (n == 0) return VELO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n_old = c->raw_n;
     if (int rc = stage_raw(c, x, y, z, n, dev, true)) return rc;
-    return rebuild_map(c, c->info.voxel, c->info.k_normals);
+    int done = 0;
+    if (int rc = append_incremental(c, n_old, n, &done)) {
+        c->raw_n = n_old;  // refused: the map is unchanged
+        return rc;
+    }
+    if (done) return VELO_OK;
+    return rebuild_map(c, c->info.voxel, c->info.k_normals);  // re-anchor
 }
 int velo_map_append(velo_ctx* c, const float* x, const float* y, const float* z, size_t n)
 {
@@ -714,6 +880,110 @@ int velo_map_append(velo_ctx* c, const float* x, const float* y, const float* z,
 int velo_map_append_dev(velo_ctx* c, const float* x, const float* y, const float* z, size_t n)
 {
     return map_append_impl(c, x, y, z, n, true);
+}
+
+int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
+{
+    if (!c) return VELO_E_INVALID;
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "velo_map_evict_outside before velo_map_reset");
+    if (!lo || !hi) return c->fail(VELO_E_INVALID, "null box");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const MapView old = c->mv;
+    const uint32_t n = (uint32_t)c->raw_n;
+    const int k = c->info.k_normals;
+    const int M = c->cfg.map_margin;
+    // keep flags + exclusive scans, in sorted order and in append order
+    HIP_TRY(c, reserve_slack(c->flags, n));
+    HIP_TRY(c, reserve_slack(c->offs, n));
+    HIP_TRY(c, reserve_slack(c->rflags, n));
+    HIP_TRY(c, reserve_slack(c->roffs, n));
+    HIP_TRY(c, launch_keep_flags(c->pts.p, nullptr, nullptr, nullptr, n, lo, hi, c->flags.p, s));
+    HIP_TRY(c, launch_keep_flags(nullptr, c->raw_x.p, c->raw_y.p, c->raw_z.p, n, lo, hi, c->rflags.p, s));
+    size_t tb = 0;
+    HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->flags.p, c->offs.p, n, s));
+    if (int rc = ensure_temp(c, tb)) return rc;
+    HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->flags.p, c->offs.p, n, s));
+    HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->rflags.p, c->roffs.p, n, s));
+    uint32_t last[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(&last[0], c->offs.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&last[1], c->flags.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint32_t kept = last[0] + last[1];
+    if (kept == 0) return c->fail(VELO_E_INVALID, "eviction box would remove every map point");
+    if (kept == n) return VELO_OK;
+    // append-order arrays first: they decide whether the grid keeps
+    HIP_TRY(c, reserve_slack(c->raw_x2, kept));
+    HIP_TRY(c, reserve_slack(c->raw_y2, kept));
+    HIP_TRY(c, reserve_slack(c->raw_z2, kept));
+    HIP_TRY(c, launch_compact_raw(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, c->rflags.p, c->roffs.p,
+                                  c->raw_x2.p, c->raw_y2.p, c->raw_z2.p, s));
+    MinMax mm;
+    HIP_TRY(c, c->mm_scratch.reserve(8));
+    HIP_TRY(c, launch_minmax(c->raw_x2.p, c->raw_y2.p, c->raw_z2.p, kept, c->mm_scratch.p, &mm, s));
+    const float org[3] = {old.ox, old.oy, old.oz};
+    bool anchor = false;
+    for (int a = 0; a < 3; ++a)
+        if (floorf((mm.mn[a] - org[a]) * old.inv_h) >= (float)(2 * M + 2)) anchor = true;
+    auto swap_raw = [&]() {
+        std::swap(c->raw_x.p, c->raw_x2.p);
+        std::swap(c->raw_x.cap, c->raw_x2.cap);
+        std::swap(c->raw_y.p, c->raw_y2.p);
+        std::swap(c->raw_y.cap, c->raw_y2.cap);
+        std::swap(c->raw_z.p, c->raw_z2.p);
+        std::swap(c->raw_z.cap, c->raw_z2.cap);
+    };
+    if (anchor || c->cfg.map_full_rebuild) {
+        swap_raw();
+        c->raw_n = kept;
+        const int dims[3] = {old.nx, old.ny, old.nz};
+        int rc = anchor ? rebuild_map(c, old.h, k) : rebuild_map(c, old.h, k, org, dims);
+        if (rc) {  // restore the old list; the old sorted map is still in place
+            swap_raw();
+            c->raw_n = n;
+        }
+        return rc;
+    }
+    HIP_TRY(c, reserve_slack(c->pts_alt, kept));
+    HIP_TRY(c, reserve_slack(c->nrm_alt, kept));
+    HIP_TRY(c, reserve_slack(c->perm_alt, kept));
+    HIP_TRY(c, reserve_slack(c->keys_alt, kept));
+    const size_t nvox = (size_t)old.nx * old.ny * old.nz;
+    if (k > 0) {  // voxels that lose a point, marked from the OLD arrays
+        HIP_TRY(c, reserve_slack(c->dirty, nvox));
+        HIP_TRY(c, hipMemsetAsync(c->dirty.p, 0, nvox, s));
+        HIP_TRY(c, launch_mark_dirty(c->keys_sorted.p, n, c->flags.p, old, c->dirty.p, s));
+    }
+    HIP_TRY(c, launch_compact_sorted(c->pts.p, c->nrm.p, c->perm.p, c->keys_sorted.p, n, c->flags.p,
+                                     c->offs.p, c->roffs.p, c->pts_alt.p, c->nrm_alt.p,
+                                     c->perm_alt.p, c->keys_alt.p, s));
+    const size_t ncell = (size_t)old.fx * old.fy * old.fz;
+    HIP_TRY(c, launch_table_remap(c->cell_start.p, ncell + 1, c->offs.p, n, kept, s));
+    swap_raw();
+    c->raw_n = kept;
+    std::swap(c->pts.p, c->pts_alt.p);
+    std::swap(c->pts.cap, c->pts_alt.cap);
+    std::swap(c->nrm.p, c->nrm_alt.p);
+    std::swap(c->nrm.cap, c->nrm_alt.cap);
+    std::swap(c->perm.p, c->perm_alt.p);
+    std::swap(c->perm.cap, c->perm_alt.cap);
+    std::swap(c->keys_sorted.p, c->keys_alt.p);
+    std::swap(c->keys_sorted.cap, c->keys_alt.cap);
+    MapView g = old;
+    g.pts = c->pts.p;
+    g.nrm = c->nrm.p;
+    g.cell_start = c->cell_start.p;
+    g.n = (int)kept;
+    unsigned long long invalid = kept;
+    unsigned n_work = 0;
+    if (k > 0) {
+        if (int rc = refresh_dirty_normals(c, g, k, &n_work)) return rc;
+        HIP_TRY(c, launch_count_invalid(c->nrm.p, kept, c->invalid_cnt.p, s));
+        HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (int a = 0; a < 3; ++a) c->map_mx[a] = mm.mx[a];
+    return publish_map(c, g, k, invalid, 1, n_work);
 }
 
 int velo_map_info_get(velo_ctx* c, velo_map_info* out)

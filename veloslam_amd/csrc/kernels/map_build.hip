@@ -244,22 +244,14 @@ __device__ __forceinline__ int collect_knn(const MapView& mv, float qx, float qy
     return cnt;
 }
 
-__global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
-                                                         float4* __restrict__ nrm,
-                                                         unsigned long long* __restrict__ invalid)
+// PCA normal of sorted point s: {0,0,0,0} = invalid (fewer than kMinNb neighbours within h)
+__device__ __forceinline__ float4 point_normal(const MapView& mv, int s, int k,
+                                               float (*s_d)[kNrmThreads], int (*s_i)[kNrmThreads],
+                                               int tid)
 {
-    __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
-    __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
-    const int tid = threadIdx.x;
-    const int s = blockIdx.x * kNrmThreads + tid;
-    if (s >= mv.n) return;
     const float4 q = mv.pts[s];
     const int cnt = collect_knn(mv, q.x, q.y, q.z, mv.h * mv.h, k, s_d, s_i, tid);
-    if (cnt < kMinNb) {
-        nrm[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-        atomicAdd(invalid, 1ull);
-        return;
-    }
+    if (cnt < kMinNb) return make_float4(0.f, 0.f, 0.f, 0.f);
     double mx = 0, my = 0, mz = 0;
     for (int i = 0; i < cnt; ++i) {
         const float4 p = mv.pts[s_i[i][tid]];
@@ -303,7 +295,44 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
         vy = -vy;
         vz = -vz;
     }
-    nrm[s] = make_float4((float)vx, (float)vy, (float)vz, 0.0f);
+    return make_float4((float)vx, (float)vy, (float)vz, 0.0f);
+}
+
+__device__ __forceinline__ bool is_zero3(const float4& v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f; }
+
+__global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
+                                                         float4* __restrict__ nrm,
+                                                         unsigned long long* __restrict__ invalid)
+{
+    __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
+    __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x * kNrmThreads + tid;
+    if (s >= mv.n) return;
+    const float4 nv = point_normal(mv, s, k, s_d, s_i, tid);
+    nrm[s] = nv;
+    if (is_zero3(nv)) atomicAdd(invalid, 1ull);
+}
+
+// Incremental update: recompute the normals of the listed sorted points only.  nrm[] holds
+// the previous normal of every surviving point and {0,0,0,1} for points that are new, so
+// the invalid-normal count is maintained by difference (two's complement add).
+__global__ __launch_bounds__(kNrmThreads) void k_normals_subset(
+    MapView mv, int k, const int32_t* __restrict__ work, int n_work, float4* __restrict__ nrm,
+    unsigned long long* __restrict__ invalid)
+{
+    __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
+    __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
+    const int tid = threadIdx.x;
+    const int w = blockIdx.x * kNrmThreads + tid;
+    if (w >= n_work) return;
+    const int s = work[w];
+    const float4 old = nrm[s];
+    const float4 nv = point_normal(mv, s, k, s_d, s_i, tid);
+    nrm[s] = nv;
+    const int was = (old.w == 0.0f && is_zero3(old)) ? 1 : 0;
+    const int now = is_zero3(nv) ? 1 : 0;
+    if (now != was) atomicAdd(invalid, (unsigned long long)(long long)(now - was));
 }
 
 // a10 with k > 1: the k nearest map points of every (transformed) query within d_max,
@@ -349,6 +378,363 @@ hipError_t launch_normals(const MapView& mv, int k, float4* nrm, unsigned long l
     if (e != hipSuccess) return e;
     const int grid = (mv.n + kNrmThreads - 1) / kNrmThreads;
     hipLaunchKernelGGL(k_normals, dim3(grid), dim3(kNrmThreads), 0, s, mv, k, nrm, d_invalid);
+    return hipGetLastError();
+}
+
+
+// ============================================================ incremental map update (f3)
+// The sorted arrays of a map are updated in place of a rebuild when the grid (origin, dims)
+// keeps: a stable merge of the new points' sorted keys into the old order, a shifted cell
+// table, and normals recomputed only where a changed point is within one voxel.  The result
+// is bit-identical to a fresh build on the same grid (oracle: vo_roll / vo_map_build_grid).
+
+__global__ __launch_bounds__(256) void k_keys4(const float4* __restrict__ pts, size_t n, float ox,
+                                               float oy, float oz, float inv_h, int S, int fx,
+                                               int fy, uint32_t* __restrict__ keys)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float4 p = pts[i];
+        const int cx = fine_coord(p.x, ox, inv_h, S);
+        const int cy = fine_coord(p.y, oy, inv_h, S);
+        const int cz = fine_coord(p.z, oz, inv_h, S);
+        keys[i] = (uint32_t)(((size_t)cz * fy + cy) * fx + cx);
+    }
+}
+
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t n,
+                                                    uint32_t v)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t* __restrict__ a, uint32_t n,
+                                                    uint32_t v)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] <= v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// old sorted element i moves right by the number of new keys strictly below its key
+// (old points precede new ones inside a cell: the stable order of the concatenated list)
+__global__ __launch_bounds__(256) void k_merge_old(
+    const float4* __restrict__ pts, const float4* __restrict__ nrm,
+    const uint32_t* __restrict__ perm, const uint32_t* __restrict__ keys, uint32_t n,
+    const uint32_t* __restrict__ nk, uint32_t m, float4* __restrict__ pts2,
+    float4* __restrict__ nrm2, uint32_t* __restrict__ perm2, uint32_t* __restrict__ keys2)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t key = keys[i];
+    const uint32_t d = i + lower_bound_u32(nk, m, key);
+    pts2[d] = pts[i];
+    nrm2[d] = nrm[i];
+    perm2[d] = perm[i];
+    keys2[d] = key;
+}
+
+__global__ __launch_bounds__(256) void k_merge_new(
+    const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+    uint32_t raw_base, const uint32_t* __restrict__ nk, const uint32_t* __restrict__ nidx,
+    uint32_t m, const uint32_t* __restrict__ keys_old, uint32_t n, float4* __restrict__ pts2,
+    float4* __restrict__ nrm2, uint32_t* __restrict__ perm2, uint32_t* __restrict__ keys2)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t key = nk[j];
+    const uint32_t d = upper_bound_u32(keys_old, n, key) + j;
+    const uint32_t r = raw_base + nidx[j];
+    pts2[d] = make_float4(rx[r], ry[r], rz[r], 0.0f);
+    nrm2[d] = make_float4(0.f, 0.f, 0.f, 1.0f);  // w = 1: "no previous normal"
+    perm2[d] = r;
+    keys2[d] = key;
+}
+
+// cell_start[c] += number of new keys < c; four consecutive entries per thread
+__global__ __launch_bounds__(256) void k_table_shift(int32_t* __restrict__ cell_start,
+                                                     size_t n_entries,
+                                                     const uint32_t* __restrict__ nk, uint32_t m)
+{
+    for (size_t c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; c0 < n_entries;
+         c0 += (size_t)gridDim.x * blockDim.x * 4) {
+        uint32_t j = lower_bound_u32(nk, m, (uint32_t)c0);
+        if (j == 0 && (m == 0 || (size_t)nk[0] >= c0 + 3)) continue;  // nothing below this quad
+        if (c0 + 3 < n_entries) {
+            int4 v = *reinterpret_cast<int4*>(cell_start + c0);  // rows are 16-byte aligned
+            v.x += (int)j;
+            while (j < m && (size_t)nk[j] < c0 + 1) ++j;
+            v.y += (int)j;
+            while (j < m && (size_t)nk[j] < c0 + 2) ++j;
+            v.z += (int)j;
+            while (j < m && (size_t)nk[j] < c0 + 3) ++j;
+            v.w += (int)j;
+            *reinterpret_cast<int4*>(cell_start + c0) = v;
+        } else {
+            for (size_t c = c0; c < n_entries; ++c) {
+                while (j < m && (size_t)nk[j] < c) ++j;
+                cell_start[c] += (int)j;
+            }
+        }
+    }
+}
+
+// mark the 27 voxels around the voxel of every listed fine key (sel == nullptr: all of
+// keys[0..m); else only those with sel[i] == 0, i.e. the removed points of an eviction)
+__global__ __launch_bounds__(256) void k_mark_dirty(const uint32_t* __restrict__ keys, uint32_t m,
+                                                    const uint32_t* __restrict__ sel, int S,
+                                                    int fx, int fy, int nx, int ny, int nz,
+                                                    uint8_t* __restrict__ dirty)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    if (sel && sel[i]) return;
+    const uint32_t key = keys[i];
+    const int Fx = (int)(key % (uint32_t)fx);
+    const uint32_t t = key / (uint32_t)fx;
+    const int Fy = (int)(t % (uint32_t)fy), Fz = (int)(t / (uint32_t)fy);
+    const int vx = Fx / S, vy = Fy / S, vz = Fz / S;
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int z = vz + dz;
+        if (z < 0 || z >= nz) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = vy + dy;
+            if (y < 0 || y >= ny) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = vx + dx;
+                if (x < 0 || x >= nx) continue;
+                dirty[((size_t)z * ny + y) * nx + x] = 1;
+            }
+        }
+    }
+}
+
+// work list of the sorted points that live in a dirty voxel (order irrelevant)
+__global__ __launch_bounds__(256) void k_select_dirty(const uint32_t* __restrict__ keys,
+                                                      uint32_t n, int S, int fx, int fy, int nx,
+                                                      int ny, const uint8_t* __restrict__ dirty,
+                                                      int32_t* __restrict__ work,
+                                                      unsigned* __restrict__ count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    if (i < n) {
+        const uint32_t key = keys[i];
+        const int Fx = (int)(key % (uint32_t)fx);
+        const uint32_t t = key / (uint32_t)fx;
+        const int Fy = (int)(t % (uint32_t)fy), Fz = (int)(t / (uint32_t)fy);
+        hit = dirty[((size_t)(Fz / S) * ny + (Fy / S)) * nx + (Fx / S)] != 0;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(count, (unsigned)__popcll(mask));
+    base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+    if (hit) work[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)i;
+}
+
+// ---- eviction: keep the points inside the closed box [lo, hi]
+__global__ __launch_bounds__(256) void k_keep4(const float4* __restrict__ pts, uint32_t n, float lx,
+                                               float ly, float lz, float hx, float hy, float hz,
+                                               uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    flags[i] = (p.x >= lx && p.x <= hx && p.y >= ly && p.y <= hy && p.z >= lz && p.z <= hz) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_keep3(const float* __restrict__ x,
+                                               const float* __restrict__ y,
+                                               const float* __restrict__ z, uint32_t n, float lx,
+                                               float ly, float lz, float hx, float hy, float hz,
+                                               uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float px = x[i], py = y[i], pz = z[i];
+    flags[i] = (px >= lx && px <= hx && py >= ly && py <= hy && pz >= lz && pz <= hz) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_compact_sorted(
+    const float4* __restrict__ pts, const float4* __restrict__ nrm,
+    const uint32_t* __restrict__ perm, const uint32_t* __restrict__ keys, uint32_t n,
+    const uint32_t* __restrict__ flags, const uint32_t* __restrict__ offs,
+    const uint32_t* __restrict__ raw_offs, float4* __restrict__ pts2, float4* __restrict__ nrm2,
+    uint32_t* __restrict__ perm2, uint32_t* __restrict__ keys2)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const uint32_t d = offs[i];
+    pts2[d] = pts[i];
+    nrm2[d] = nrm[i];
+    perm2[d] = raw_offs[perm[i]];
+    keys2[d] = keys[i];
+}
+__global__ __launch_bounds__(256) void k_compact_raw(const float* __restrict__ x,
+                                                     const float* __restrict__ y,
+                                                     const float* __restrict__ z, uint32_t n,
+                                                     const uint32_t* __restrict__ flags,
+                                                     const uint32_t* __restrict__ offs,
+                                                     float* __restrict__ x2, float* __restrict__ y2,
+                                                     float* __restrict__ z2)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const uint32_t d = offs[i];
+    x2[d] = x[i];
+    y2[d] = y[i];
+    z2[d] = z[i];
+}
+// cell_start[c] (a position in the old order) -> number of kept points before it
+__global__ __launch_bounds__(256) void k_table_remap(int32_t* __restrict__ cell_start,
+                                                     size_t n_entries,
+                                                     const uint32_t* __restrict__ offs, uint32_t n,
+                                                     uint32_t kept)
+{
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_entries;
+         c += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t v = (uint32_t)cell_start[c];
+        cell_start[c] = (int32_t)(v < n ? offs[v] : kept);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count_invalid(const float4* __restrict__ nrm, uint32_t n,
+                                                       unsigned long long* __restrict__ invalid)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool z = i < n && is_zero3(nrm[i]);
+    const unsigned long long mask = __ballot(z);
+    if (mask && (threadIdx.x & 63) == 0) atomicAdd(invalid, (unsigned long long)__popcll(mask));
+}
+
+static inline int grid_for(size_t n, int threads, int cap)
+{
+    size_t g = (n + threads - 1) / threads;
+    if (g < 1) g = 1;
+    return (int)(g > (size_t)cap ? (size_t)cap : g);
+}
+
+hipError_t launch_keys4(const float4* pts, size_t n, const MapView& g, uint32_t* keys, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_keys4, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, pts, n, g.ox, g.oy,
+                       g.oz, g.inv_h, g.S, g.fx, g.fy, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge(const float4* pts, const float4* nrm, const uint32_t* perm,
+                        const uint32_t* keys, uint32_t n, const float* rx, const float* ry,
+                        const float* rz, uint32_t raw_base, const uint32_t* nk,
+                        const uint32_t* nidx, uint32_t m, float4* pts2, float4* nrm2,
+                        uint32_t* perm2, uint32_t* keys2, hipStream_t s)
+{
+    if (n)
+        hipLaunchKernelGGL(k_merge_old, dim3((n + 255) / 256), dim3(256), 0, s, pts, nrm, perm, keys,
+                           n, nk, m, pts2, nrm2, perm2, keys2);
+    if (m)
+        hipLaunchKernelGGL(k_merge_new, dim3((m + 255) / 256), dim3(256), 0, s, rx, ry, rz, raw_base,
+                           nk, nidx, m, keys, n, pts2, nrm2, perm2, keys2);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_shift(int32_t* cell_start, size_t n_entries, const uint32_t* nk, uint32_t m,
+                              hipStream_t s)
+{
+    hipLaunchKernelGGL(k_table_shift, dim3(grid_for((n_entries + 3) / 4, 256, 16384)), dim3(256), 0,
+                       s, cell_start, n_entries, nk, m);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_dirty(const uint32_t* keys, uint32_t m, const uint32_t* sel, const MapView& g,
+                             uint8_t* dirty, hipStream_t s)
+{
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mark_dirty, dim3((m + 255) / 256), dim3(256), 0, s, keys, m, sel, g.S, g.fx,
+                       g.fy, g.nx, g.ny, g.nz, dirty);
+    return hipGetLastError();
+}
+
+hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& g,
+                               const uint8_t* dirty, int32_t* work, unsigned* count, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_select_dirty, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, g.S, g.fx,
+                       g.fy, g.nx, g.ny, dirty, work, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_normals_subset(const MapView& mv, int k, const int32_t* work, int n_work,
+                                 float4* nrm, unsigned long long* d_invalid, hipStream_t s)
+{
+    if (n_work <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_normals_subset, dim3((n_work + kNrmThreads - 1) / kNrmThreads),
+                       dim3(kNrmThreads), 0, s, mv, k, work, n_work, nrm, d_invalid);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_invalid(const float4* nrm, uint32_t n, unsigned long long* d_invalid,
+                                hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_invalid, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_count_invalid, dim3((n + 255) / 256), dim3(256), 0, s, nrm, n, d_invalid);
+    return hipGetLastError();
+}
+
+hipError_t launch_keep_flags(const float4* pts, const float* x, const float* y, const float* z,
+                             uint32_t n, const float lo[3], const float hi[3], uint32_t* flags,
+                             hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    if (pts)
+        hipLaunchKernelGGL(k_keep4, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, lo[0], lo[1],
+                           lo[2], hi[0], hi[1], hi[2], flags);
+    else
+        hipLaunchKernelGGL(k_keep3, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, lo[0], lo[1],
+                           lo[2], hi[0], hi[1], hi[2], flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_sorted(const float4* pts, const float4* nrm, const uint32_t* perm,
+                                 const uint32_t* keys, uint32_t n, const uint32_t* flags,
+                                 const uint32_t* offs, const uint32_t* raw_offs, float4* pts2,
+                                 float4* nrm2, uint32_t* perm2, uint32_t* keys2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compact_sorted, dim3((n + 255) / 256), dim3(256), 0, s, pts, nrm, perm,
+                       keys, n, flags, offs, raw_offs, pts2, nrm2, perm2, keys2);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_raw(const float* x, const float* y, const float* z, uint32_t n,
+                              const uint32_t* flags, const uint32_t* offs, float* x2, float* y2,
+                              float* z2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compact_raw, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, flags,
+                       offs, x2, y2, z2);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_remap(int32_t* cell_start, size_t n_entries, const uint32_t* offs, uint32_t n,
+                              uint32_t kept, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_table_remap, dim3(grid_for(n_entries, 256, 16384)), dim3(256), 0, s,
+                       cell_start, n_entries, offs, n, kept);
     return hipGetLastError();
 }
 

@@ -71,6 +71,37 @@ hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell
 hipError_t launch_normals(const MapView& mv, int k, float4* nrm, unsigned long long* d_invalid,
                           hipStream_t s);
 
+// incremental map update (f3): see kernels/map_build.hip
+hipError_t launch_keys4(const float4* pts, size_t n, const MapView& grid, uint32_t* keys,
+                        hipStream_t s);
+hipError_t launch_merge(const float4* pts, const float4* nrm, const uint32_t* perm,
+                        const uint32_t* keys, uint32_t n, const float* rx, const float* ry,
+                        const float* rz, uint32_t raw_base, const uint32_t* nk,
+                        const uint32_t* nidx, uint32_t m, float4* pts2, float4* nrm2,
+                        uint32_t* perm2, uint32_t* keys2, hipStream_t s);
+hipError_t launch_table_shift(int32_t* cell_start, size_t n_entries, const uint32_t* nk, uint32_t m,
+                              hipStream_t s);
+hipError_t launch_mark_dirty(const uint32_t* keys, uint32_t m, const uint32_t* sel,
+                             const MapView& grid, uint8_t* dirty, hipStream_t s);
+hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& grid,
+                               const uint8_t* dirty, int32_t* work, unsigned* count, hipStream_t s);
+hipError_t launch_normals_subset(const MapView& mv, int k, const int32_t* work, int n_work,
+                                 float4* nrm, unsigned long long* d_invalid, hipStream_t s);
+hipError_t launch_count_invalid(const float4* nrm, uint32_t n, unsigned long long* d_invalid,
+                                hipStream_t s);
+hipError_t launch_keep_flags(const float4* pts, const float* x, const float* y, const float* z,
+                             uint32_t n, const float lo[3], const float hi[3], uint32_t* flags,
+                             hipStream_t s);
+hipError_t launch_compact_sorted(const float4* pts, const float4* nrm, const uint32_t* perm,
+                                 const uint32_t* keys, uint32_t n, const uint32_t* flags,
+                                 const uint32_t* offs, const uint32_t* raw_offs, float4* pts2,
+                                 float4* nrm2, uint32_t* perm2, uint32_t* keys2, hipStream_t s);
+hipError_t launch_compact_raw(const float* x, const float* y, const float* z, uint32_t n,
+                              const uint32_t* flags, const uint32_t* offs, float* x2, float* y2,
+                              float* z2, hipStream_t s);
+hipError_t launch_table_remap(int32_t* cell_start, size_t n_entries, const uint32_t* offs, uint32_t n,
+                              uint32_t kept, hipStream_t s);
+
 hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
                       const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
                       hipStream_t s);
