@@ -65,7 +65,116 @@ def parse():
                     help="run the increment exchange + map append path even with one rank")
     ap.add_argument("--no-timing", action="store_true", help="skip per-launch HIP events (A/B their overhead)")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--workload", choices=["batch", "stream"], default="batch",
+                    help="batch = BASELINE configs[1] (the headline line); stream = configs[2]: "
+                         "packets -> decode -> register -> increment -> rolling-map update, "
+                         "frame after frame")
+    ap.add_argument("--stream-frames", type=int, default=24, help="distinct synthetic frames (cycled)")
+    ap.add_argument("--half-box", type=float, default=45.0, help="rolling map: kept half-extent in x around the sensor (m)")
+    ap.add_argument("--evict-every", type=int, default=5)
+    ap.add_argument("--map-margin", type=int, default=16)
+    ap.add_argument("--full-rebuild", action="store_true", help="stream: re-sort the whole map on every update (A/B)")
     return ap.parse_args()
+
+
+def run_stream(args, dev, local):
+    """BASELINE configs[2]: an HDL-64E packet stream against a rolling map, one frame at a
+    time (each frame sees the map the previous one updated).  Per frame: 300 packets H2D ->
+    GPU decode + motion compensation -> 20 ICP iterations -> accepted increment ->
+    incremental map append; every `evict_every` frames the map is cropped to a box that
+    follows the sensor.  Reports sustained frames/s and where the time goes."""
+    sc, mo, cal = synth.Scene(), synth.Motion(), synth.hdl64_calibration()
+    mx, my, mz = sc.sample_map(args.map_points)
+    frames = []
+    for k in range(args.stream_frames):
+        pk, ts, _ = synth.make_frame_packets(sc, mo, 3 + k, cal, seed=42)
+        poses, n = capi.make_poses(mo.ins_track(ts[0], ts[-1]))
+        _, _, car = capi.packet_transforms(poses, n, ts)
+        Tt = np.array([1, 0, 0, car.T[0], 0, 1, 0, car.T[1], 0, 0, 1, car.T[2]], np.float64)
+        frames.append(dict(buf=np.frombuffer(b"".join(pk), dtype=np.uint8).copy(),
+                           ts=np.ascontiguousarray(ts, dtype=np.int64), poses=poses, n=n, Tt=Tt,
+                           T0=synth.perturbed_guess(Tt, dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))))
+    calc = np.ascontiguousarray(cal, dtype=np.float64).reshape(64, 9)
+    ctx = capi.Context(local, max_batch=2, map_margin=args.map_margin, map_subdiv=args.subdiv,
+                       map_full_rebuild=1 if args.full_rebuild else 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def box(f):
+        cx = f["Tt"][3]
+        return (np.float32([cx - args.half_box, -1e4, -1e4]), np.float32([cx + args.half_box, 1e4, 1e4]))
+
+    lo, hi = box(frames[0])
+    keep = (mx >= lo[0]) & (mx <= hi[0])
+    ctx.map_reset(mx[keep], my[keep], mz[keep], args.voxel, args.k_normals)
+    inc = torch.empty((3, 200_000), dtype=torch.float32, device=dev)
+    stage = dict(decode=0.0, icp=0.0, increment=0.0, append=0.0, evict=0.0)
+    counts = dict(pairs=0, inc=0, pts=0, recomputed=0, incremental=0, updates=0, worst=0.0, map=0)
+
+    def one(f, k, timed):
+        t = [time.perf_counter()]
+        ctx.decode_resident(f["buf"], f["ts"], calc, f["poses"], f["n"])
+        ctx.decode_to_frames()
+        ctx.synchronize(); t.append(time.perf_counter())
+        res = ctx.icp_batch(f["T0"].reshape(1, 12), args.iters, args.d_max)[0]
+        t.append(time.perf_counter())
+        T = np.array(list(res.T))
+        cnt = ctx.increment_dev(0, T, 3, inc[0].data_ptr(), inc[1].data_ptr(), inc[2].data_ptr())
+        t.append(time.perf_counter())
+        if cnt:
+            ctx.map_append_dev(inc[0].data_ptr(), inc[1].data_ptr(), inc[2].data_ptr(), cnt)
+            mi = ctx.map_info()
+            if timed:
+                counts["updates"] += 1
+                counts["incremental"] += int(mi.last_update)
+                counts["recomputed"] += int(mi.n_normals_recomputed)
+        t.append(time.perf_counter())
+        if (k + 1) % max(args.evict_every, 1) == 0:
+            ctx.map_evict_outside(*box(f))
+            mi = ctx.map_info()
+            if timed:
+                counts["updates"] += 1
+                counts["incremental"] += int(mi.last_update)
+                counts["recomputed"] += int(mi.n_normals_recomputed)
+        t.append(time.perf_counter())
+        if timed:
+            for name, a, b in zip(stage, t[:-1], t[1:]):
+                stage[name] += b - a
+            counts["pairs"] += int(res.total_pairs)
+            counts["inc"] += int(cnt)
+            counts["map"] += int(ctx.map_info().n_points)
+            err = float(np.linalg.norm(T.reshape(3, 4)[:, 3] - f["Tt"].reshape(3, 4)[:, 3]))
+            counts["worst"] = max(counts["worst"], err)
+
+    nfr = len(frames)
+    for k in range(args.warmup):
+        one(frames[k % nfr], k, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one(frames[(args.warmup + k) % nfr], args.warmup + k, True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if counts["worst"] > 0.05:
+        raise SystemExit("bench stream: registration diverged (%.3f m)" % counts["worst"])
+    out = {"metric": "rolling-map registered frames/s", "value": args.steps / elapsed,
+           "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32 points, f64 pose/accumulators", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: HDL-64E packet stream, one frame per step: decode "
+                                  "+ compensate + %d ICP iters + increment + rolling-map update "
+                                  "(append every frame, evict every %d), map cropped to +-%.0f m around "
+                                  "the sensor" % (args.iters, args.evict_every, args.half_box),
+                      "map_points_mean": counts["map"] / max(args.steps, 1),
+                      "map_update": "full rebuild" if args.full_rebuild else "incremental",
+                      "map_margin_voxels": args.map_margin},
+           "pairs_per_s": counts["pairs"] / elapsed,
+           "stage_ms_per_frame": {k: 1e3 * v / args.steps for k, v in stage.items()},
+           "increment_points_per_frame": counts["inc"] / max(args.steps, 1),
+           "map_updates": counts["updates"], "map_updates_incremental": counts["incremental"],
+           "normals_recomputed_per_update": counts["recomputed"] / max(counts["updates"], 1),
+           "worst_pose_error_m": counts["worst"]}
+    print(json.dumps(out))
+    ctx.close()
 
 
 def build_inputs(args, rank, dev):
@@ -161,6 +270,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.workload == "stream":
+        if world > 1:
+            raise SystemExit("the stream workload is one sequence on one GPU (run N replicas for N GPUs)")
+        return run_stream(args, dev, local)
 
     d = build_inputs(args, rank, dev)
     F = args.frames

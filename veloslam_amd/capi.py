@@ -455,6 +455,18 @@ class Context:
         out["carposes"] = car
         return out
 
+    def decode_resident(self, buf, times_us, calib, poses, n_poses, n_lasers=64, flush=True):
+        """velo_decode without the host fetch: buf = contiguous uint8 packets (n x 1206),
+        the decoded frames stay on the device (follow with decode_to_frames).
+        Returns (n_frames, n_points)."""
+        nf = C.c_int32()
+        npts = C.c_size_t()
+        self._chk(lib().velo_decode(self.h, _p(buf), _p(times_us), times_us.size, _p(calib),
+                                    n_lasers, poses, n_poses, int(bool(flush)), None, 0,
+                                    C.byref(nf), C.byref(npts)))
+        self._decoded_frames = nf.value
+        return nf.value, npts.value
+
     def decode_to_frames(self):
         self._chk(lib().velo_decode_to_frames(self.h))
         self.n_frames = self._decoded_frames

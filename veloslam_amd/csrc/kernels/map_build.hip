@@ -196,8 +196,11 @@ __device__ __forceinline__ void jacobi_rot(double A[3][3], double V[3][3], int p
 
 // The k smallest (d2, sorted index) among the points of the 27 voxels around q with
 // d2 <= r2, ascending, into the LDS lists s_d/s_i ([slot][thread]).  Returns how many.
-// Fine rows further than sqrt(r2) from q (in y,z) cannot contribute and are skipped; the
-// margin keeps that conservative, so the list is the oracle's.
+// Exact ball search: fine rows are visited centre-out from the query's own row, and once the
+// list is full its k-th distance is the search radius -- rows, and the cells of a row, that
+// lie outside it are never touched.  The visiting order therefore is not ascending in the
+// sorted index, so ties are ordered explicitly by (d2, index): the list is the oracle's.
+// Margins keep every pruning test conservative (cell membership is decided in float).
 __device__ __forceinline__ int collect_knn(const MapView& mv, float qx, float qy, float qz,
                                            float r2, int k, float (*s_d)[kNrmThreads],
                                            int (*s_i)[kNrmThreads], int tid)
@@ -206,40 +209,75 @@ __device__ __forceinline__ int collect_knn(const MapView& mv, float qx, float qy
     const int cy = cell_coord(qy, mv.oy, mv.inv_h, mv.ny);
     const int cz = cell_coord(qz, mv.oz, mv.inv_h, mv.nz);
     int cnt = 0;
-    float worst = INFINITY;  // d2 of the last slot once the list is full
+    float bound = r2;  // min(r2, d2 of the last slot once the list is full)
     const int vx0 = max(cx - 1, 0), vx1 = min(cx + 1, mv.nx - 1);
     const int vy0 = max(cy - 1, 0), vy1 = min(cy + 1, mv.ny - 1);
     const int vz0 = max(cz - 1, 0), vz1 = min(cz + 1, mv.nz - 1);
     if (vx0 > vx1 || vy0 > vy1 || vz0 > vz1) return 0;
     const int S = mv.S;
     const float hf = mv.h / (float)S;
-    const float uy = (qy - mv.oy) * mv.inv_h * (float)S, uz = (qz - mv.oz) * mv.inv_h * (float)S;
+    const float inv_hf = mv.inv_h * (float)S;
+    const float ux = (qx - mv.ox) * inv_hf, uy = (qy - mv.oy) * inv_hf, uz = (qz - mv.oz) * inv_hf;
     const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
-    for (int fz = vz0 * S; fz < (vz1 + 1) * S; ++fz) {
-        const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
-        if (gz * gz * 0.99999f > r2) continue;
-        for (int fy = vy0 * S; fy < (vy1 + 1) * S; ++fy) {
-            const float gy = fmaxf(fmaxf((float)fy - uy, uy - (float)(fy + 1)) * hf - mg, 0.0f);
-            if ((gz * gz + gy * gy) * 0.99999f > r2) continue;
-            const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
-            const int j0 = mv.cell_start[row + (size_t)vx0 * S];
-            const int j1 = mv.cell_start[row + (size_t)(vx1 + 1) * S];
-            for (int j = j0; j < j1; ++j) {
-                const float d2 = dist2(mv.pts[j], qx, qy, qz);
-                if (!(d2 <= r2)) continue;
-                if (cnt == k && !(d2 < worst)) continue;
-                int pos = cnt < k ? cnt : k - 1;
-                while (pos > 0 && d2 < s_d[pos - 1][tid]) {
-                    s_d[pos][tid] = s_d[pos - 1][tid];
-                    s_i[pos][tid] = s_i[pos - 1][tid];
-                    --pos;
+    const int x0 = vx0 * S, x1 = (vx1 + 1) * S - 1;  // inclusive fine ranges
+    const int y0 = vy0 * S, y1 = (vy1 + 1) * S - 1;
+    const int z0 = vz0 * S, z1 = (vz1 + 1) * S - 1;
+    const int hy = min(max((int)floorf(fminf(fmaxf(uy, -4.0f), 2.0e9f)), y0), y1);
+    const int hz = min(max((int)floorf(fminf(fmaxf(uz, -4.0f), 2.0e9f)), z0), z1);
+    for (int dz = 0; dz <= z1 - z0; ++dz) {
+        bool any_z = false;
+        for (int sz = 0; sz < 2; ++sz) {
+            if (dz == 0 && sz) continue;
+            const int fz = sz ? hz - dz : hz + dz;
+            if (fz < z0 || fz > z1) continue;
+            const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
+            if (gz * gz * 0.99999f > bound) continue;
+            any_z = true;
+            for (int dy = 0; dy <= y1 - y0; ++dy) {
+                bool any_y = false;
+                for (int sy = 0; sy < 2; ++sy) {
+                    if (dy == 0 && sy) continue;
+                    const int fy = sy ? hy - dy : hy + dy;
+                    if (fy < y0 || fy > y1) continue;
+                    const float gy =
+                        fmaxf(fmaxf((float)fy - uy, uy - (float)(fy + 1)) * hf - mg, 0.0f);
+                    const float g2 = gz * gz + gy * gy;
+                    if (g2 * 0.99999f > bound) continue;
+                    any_y = true;
+                    // cells of this row that can hold a point within sqrt(bound - g2) in x
+                    const float xr = (sqrtf(fmaxf(bound - g2 * 0.99999f, 0.0f)) * 1.00001f + 2.0f * mg) * inv_hf;
+                    const int fa = max(x0, (int)floorf(fmaxf(ux - xr, -4.0f)));
+                    const int fb = min(x1, (int)floorf(fminf(ux + xr, 2.0e9f)));
+                    if (fa > fb) continue;
+                    const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
+                    const int j0 = mv.cell_start[row + (size_t)fa];
+                    const int j1 = mv.cell_start[row + (size_t)fb + 1];
+                    for (int j = j0; j < j1; ++j) {
+                        const float d2 = dist2(mv.pts[j], qx, qy, qz);
+                        if (!(d2 <= r2)) continue;
+                        if (cnt == k) {
+                            const float wd = s_d[k - 1][tid];
+                            if (!(d2 < wd || (d2 == wd && j < s_i[k - 1][tid]))) continue;
+                        }
+                        int pos = cnt < k ? cnt : k - 1;
+                        while (pos > 0) {
+                            const float pd = s_d[pos - 1][tid];
+                            const int pi = s_i[pos - 1][tid];
+                            if (!(d2 < pd || (d2 == pd && j < pi))) break;
+                            s_d[pos][tid] = pd;
+                            s_i[pos][tid] = pi;
+                            --pos;
+                        }
+                        s_d[pos][tid] = d2;
+                        s_i[pos][tid] = j;
+                        if (cnt < k) ++cnt;
+                        if (cnt == k) bound = fminf(r2, s_d[k - 1][tid]);
+                    }
                 }
-                s_d[pos][tid] = d2;
-                s_i[pos][tid] = j;
-                if (cnt < k) ++cnt;
-                if (cnt == k) worst = s_d[k - 1][tid];
+                if (!any_y) break;  // gaps only grow with dy and the bound only shrinks
             }
         }
+        if (!any_z) break;
     }
     return cnt;
 }
