@@ -13,7 +13,8 @@
  *   - JtJ / Jtr sums and the pose: <= 1e-4 m, 1e-5 rad (summation order differs).
  *
  * Semantics
- *  grid     origin o = component-wise min of the map points (float); inv_h =
+ *  grid     origin o = component-wise min of the map points (float) unless an explicit grid
+ *           is given (vo_map_build_grid; rolling map rules further down); inv_h =
  *           1.0f/h; u = (p - o) * inv_h; voxel c = floorf(u) per axis; dims = c(max)+1.
  *           Each voxel is split into S x S x S sub-cells (S = 3 by default):
  *           s = min(S-1, floorf((u - c) * S)), fine coordinate F = c*S + s, fine
@@ -23,10 +24,11 @@
  *           contiguous index range; a voxel is S*S such row pieces.
  *           The CANDIDATE SET of a query is still defined on voxels: all points of
  *           the 27 voxels around the query's voxel (81 fine rows for S = 3).
- *  normals  for sorted point s: the k smallest (d2, index) among all points of
- *           the 27 neighbouring cells with d2 <= h*h (self included);
- *           fewer than 5 -> normal = 0 (invalid).  Covariance about the mean in
- *           fp64, summed in (d2,index) order; eigenvector of the smallest
+ *  normals  for sorted point s: the k smallest (d2, append-order index) among all points
+ *           of the 27 neighbouring cells with d2 <= h*h (self included) -- that ball lies
+ *           inside the 27 voxels wherever the grid is anchored, so a normal is a function
+ *           of the point list alone; fewer than 5 -> normal = 0 (invalid).  Covariance
+ *           about the mean in fp64, summed in that (d2, append index) order; eigenvector of the smallest
  *           eigenvalue by 8 fixed cyclic Jacobi sweeps (only + - * / sqrt);
  *           sign: last non-zero of (nz, ny, nx) made positive; stored as float.
  *  kNN      q = (float)(T*p) with T*p in fp64 by nested fma; exhaustive scan of
@@ -169,15 +171,19 @@ static void point_normal(const vo_map* m, size_t s, int k, float out[3])
             float dx = m->x[j] - qx, dyy = m->y[j] - qy, dzz = m->z[j] - qz;
             float d2 = fmaf(dzz, dzz, fmaf(dyy, dyy, dx * dx));
             if (!(d2 <= r2)) continue;
-            /* insert into ascending (d2, j) list of at most k; j ascends, so
-             * an equal d2 goes AFTER existing equal entries */
-            if (cnt == k && !(d2 < bd[k - 1])) continue;
+            /* insert into the ascending (d2, append-order index) list of at most k.  Ties are
+             * broken by the APPEND-ORDER index perm[j], not the sorted index, so that a
+             * normal depends on the point list only and not on where the grid is anchored */
+#define NB_BEFORE(d2_, j_, i_) \
+    ((d2_) < bd[i_] || ((d2_) == bd[i_] && m->perm[j_] < m->perm[bi[i_]]))
+            if (cnt == k && !NB_BEFORE(d2, j, k - 1)) continue;
             int pos = cnt < k ? cnt : k - 1;
-            while (pos > 0 && d2 < bd[pos - 1]) {
+            while (pos > 0 && NB_BEFORE(d2, j, pos - 1)) {
                 bd[pos] = bd[pos - 1];
                 bi[pos] = bi[pos - 1];
                 --pos;
             }
+#undef NB_BEFORE
             bd[pos] = d2;
             bi[pos] = j;
             if (cnt < k) ++cnt;

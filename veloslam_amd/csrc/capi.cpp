@@ -69,7 +69,7 @@ struct velo_ctx {
     // dirty voxels and the normal work list
     DevBuf<float> raw_x2, raw_y2, raw_z2;
     DevBuf<uint32_t> keys_alt, perm_alt, nk, nk_sorted, nidx, nidx_sorted, rflags, roffs;
-    DevBuf<float4> pts_alt, nrm_alt;
+    DevBuf<float4> pts_alt, nrm_alt, nrm_raw;
     DevBuf<uint8_t> dirty;
     DevBuf<int32_t> work;
     DevBuf<unsigned> work_cnt;
@@ -171,6 +171,29 @@ int ensure_temp(velo_ctx* c, size_t bytes)
     return VELO_OK;
 }
 
+template <typename T>
+hipError_t reserve_slack(DevBuf<T>& b, size_t n)
+{
+    if (n <= b.cap) return hipSuccess;
+    return b.reserve(n + n / 8 + 4096);  // a rolling map grows a little every frame
+}
+
+// normals of the points in dirty voxels, after the sorted arrays were updated in place
+int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, unsigned* n_work_out)
+{
+    hipStream_t s = c->stream;
+    HIP_TRY(c, reserve_slack(c->work, (size_t)mv.n));
+    HIP_TRY(c, c->work_cnt.reserve(1));
+    HIP_TRY(c, launch_select_dirty(c->keys_sorted.p, (uint32_t)mv.n, mv, c->dirty.p, c->work.p,
+                                   c->work_cnt.p, s));
+    unsigned n_work = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_work, c->work_cnt.p, sizeof n_work, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, launch_normals_subset(mv, c->perm.p, k, c->work.p, (int)n_work, c->nrm.p, c->invalid_cnt.p, s));
+    *n_work_out = n_work;
+    return VELO_OK;
+}
+
 // make `mv` the ctx's map: bookkeeping shared by the full build and the incremental updates
 int publish_map(velo_ctx* c, const MapView& mv, int k_normals, unsigned long long invalid,
                 int last_update, uint64_t n_recomputed)
@@ -203,8 +226,17 @@ int publish_map(velo_ctx* c, const MapView& mv, int k_normals, unsigned long lon
 // (re)build the voxel grid over raw_x/y/z[0..raw_n)
 // grid_org/grid_dims == nullptr: anchor the grid on the points (origin = min - margin*h);
 // otherwise build on that explicit grid (which must contain every point)
+//
+// carry: c->nrm_raw holds the normals of the raw list in append order (w == 1 marks points
+// without one).  A normal depends on the point list only, so they are permuted into the new
+// order and only the neighbourhoods of fresh points -- and of the removed points
+// old_pts[i] with removed_keep[i] == 0 -- are re-estimated.
+struct CarryNormals {
+    const uint32_t* removed_keep = nullptr;  // flags over the OLD sorted order (0 = removed)
+    uint32_t removed_n = 0;
+};
 int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org = nullptr,
-                const int* grid_dims = nullptr)
+                const int* grid_dims = nullptr, const CarryNormals* carry = nullptr)
 {
     const size_t n = c->raw_n;
     hipStream_t s = c->stream;
@@ -249,8 +281,14 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     HIP_TRY(c, c->keys_sorted.reserve(n));
     HIP_TRY(c, c->idx.reserve(n));
     HIP_TRY(c, c->perm.reserve(n));
-    HIP_TRY(c, c->pts.reserve(n));
-    HIP_TRY(c, c->nrm.reserve(n));
+    if (carry) {  // build into the second set of arrays: the old points are still needed
+        HIP_TRY(c, reserve_slack(c->pts_alt, n));
+        HIP_TRY(c, reserve_slack(c->nrm_alt, n));
+    } else {
+        HIP_TRY(c, c->pts.reserve(n));
+        HIP_TRY(c, c->nrm.reserve(n));
+    }
+    if (ncell + 8 > c->cell_start.cap) HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, c->cell_start.reserve(ncell + 8));  // +1 entry, padded: rows are read 4 entries at a time
     HIP_TRY(c, c->invalid_cnt.reserve(1));
     HIP_TRY(c, launch_keys(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, org[0], org[1], org[2],
@@ -261,7 +299,17 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     HIP_TRY(c, sort_pairs(nullptr, tb, c->keys.p, c->keys_sorted.p, c->idx.p, c->perm.p, n, bits, s));
     if (int rc = ensure_temp(c, tb)) return rc;
     HIP_TRY(c, sort_pairs(c->temp.p, tb, c->keys.p, c->keys_sorted.p, c->idx.p, c->perm.p, n, bits, s));
-    HIP_TRY(c, launch_gather(c->raw_x.p, c->raw_y.p, c->raw_z.p, c->perm.p, n, c->pts.p, s));
+    const float4* old_pts = c->pts.p;
+    if (carry) {
+        HIP_TRY(c, launch_gather(c->raw_x.p, c->raw_y.p, c->raw_z.p, c->perm.p, n, c->pts_alt.p, s));
+        HIP_TRY(c, launch_gather_nrm(c->nrm_raw.p, c->perm.p, (uint32_t)n, c->nrm_alt.p, s));
+        std::swap(c->pts.p, c->pts_alt.p);
+        std::swap(c->pts.cap, c->pts_alt.cap);
+        std::swap(c->nrm.p, c->nrm_alt.p);
+        std::swap(c->nrm.cap, c->nrm_alt.cap);
+    } else {
+        HIP_TRY(c, launch_gather(c->raw_x.p, c->raw_y.p, c->raw_z.p, c->perm.p, n, c->pts.p, s));
+    }
     HIP_TRY(c, launch_cell_start(c->keys_sorted.p, n, ncell, c->cell_start.p, s));
     MapView mv;
     mv.pts = c->pts.p;
@@ -281,8 +329,23 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     mv.fz = fdims[2];
     mv.n = (int)n;
     unsigned long long invalid = n;
+    if (carry && k_normals > 0) {
+        const size_t nvox = (size_t)dims[0] * dims[1] * dims[2];
+        HIP_TRY(c, reserve_slack(c->dirty, nvox));
+        HIP_TRY(c, hipMemsetAsync(c->dirty.p, 0, nvox, s));
+        HIP_TRY(c, launch_mark_dirty_pts(c->pts.p, c->nrm.p, nullptr, (uint32_t)n, mv, c->dirty.p, s));
+        if (carry->removed_keep)
+            HIP_TRY(c, launch_mark_dirty_pts(old_pts, nullptr, carry->removed_keep, carry->removed_n,
+                                             mv, c->dirty.p, s));
+        unsigned n_work = 0;
+        if (int rc = refresh_dirty_normals(c, mv, k_normals, &n_work)) return rc;
+        HIP_TRY(c, launch_count_invalid(c->nrm.p, (uint32_t)n, c->invalid_cnt.p, s));
+        HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        return publish_map(c, mv, k_normals, invalid, 0, n_work);
+    }
     if (k_normals > 0) {
-        HIP_TRY(c, launch_normals(mv, k_normals, c->nrm.p, c->invalid_cnt.p, s));
+        HIP_TRY(c, launch_normals(mv, c->perm.p, k_normals, c->nrm.p, c->invalid_cnt.p, s));
         HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
     } else {
         HIP_TRY(c, hipMemsetAsync(c->nrm.p, 0, n * sizeof(float4), s));
@@ -305,29 +368,6 @@ int stage_raw(velo_ctx* c, const float* x, const float* y, const float* z, size_
     HIP_TRY(c, hipMemcpyAsync(c->raw_y.p + base, y, n * sizeof(float), kind, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->raw_z.p + base, z, n * sizeof(float), kind, c->stream));
     c->raw_n = total;
-    return VELO_OK;
-}
-
-template <typename T>
-hipError_t reserve_slack(DevBuf<T>& b, size_t n)
-{
-    if (n <= b.cap) return hipSuccess;
-    return b.reserve(n + n / 8 + 4096);  // a rolling map grows a little every frame
-}
-
-// normals of the points in dirty voxels, after the sorted arrays were updated in place
-int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, unsigned* n_work_out)
-{
-    hipStream_t s = c->stream;
-    HIP_TRY(c, reserve_slack(c->work, (size_t)mv.n));
-    HIP_TRY(c, c->work_cnt.reserve(1));
-    HIP_TRY(c, launch_select_dirty(c->keys_sorted.p, (uint32_t)mv.n, mv, c->dirty.p, c->work.p,
-                                   c->work_cnt.p, s));
-    unsigned n_work = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n_work, c->work_cnt.p, sizeof n_work, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    HIP_TRY(c, launch_normals_subset(mv, k, c->work.p, (int)n_work, c->nrm.p, c->invalid_cnt.p, s));
-    *n_work_out = n_work;
     return VELO_OK;
 }
 
@@ -871,7 +911,22 @@ static int map_append_impl(velo_ctx* c, const float* x, const float* y, const fl
         return rc;
     }
     if (done) return VELO_OK;
-    return rebuild_map(c, c->info.voxel, c->info.k_normals);  // re-anchor
+    // re-anchor: new origin, full re-sort; the normals of the old points travel with them
+    const int k = c->info.k_normals;
+    if (k > 0 && !c->cfg.map_full_rebuild) {
+        hipStream_t s = c->stream;
+        HIP_TRY(c, reserve_slack(c->nrm_raw, n_old + n));
+        HIP_TRY(c, launch_scatter_nrm_raw(c->nrm.p, c->perm.p, (uint32_t)n_old, nullptr, nullptr,
+                                          c->nrm_raw.p, s));
+        HIP_TRY(c, launch_fill_fresh(c->nrm_raw.p + n_old, (uint32_t)n, s));
+        CarryNormals cr;
+        int rc = rebuild_map(c, c->info.voxel, k, nullptr, nullptr, &cr);
+        if (rc) c->raw_n = n_old;
+        return rc;
+    }
+    int rc = rebuild_map(c, c->info.voxel, k);
+    if (rc) c->raw_n = n_old;
+    return rc;
 }
 int velo_map_append(velo_ctx* c, const float* x, const float* y, const float* z, size_t n)
 {
@@ -934,10 +989,20 @@ int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
         std::swap(c->raw_z.cap, c->raw_z2.cap);
     };
     if (anchor || c->cfg.map_full_rebuild) {
+        CarryNormals cr;
+        const bool carry = anchor && k > 0 && !c->cfg.map_full_rebuild;
+        if (carry) {  // surviving normals into append order of the compacted list
+            HIP_TRY(c, reserve_slack(c->nrm_raw, kept));
+            HIP_TRY(c, launch_scatter_nrm_raw(c->nrm.p, c->perm.p, n, c->flags.p, c->roffs.p,
+                                              c->nrm_raw.p, s));
+            cr.removed_keep = c->flags.p;
+            cr.removed_n = n;
+        }
         swap_raw();
         c->raw_n = kept;
         const int dims[3] = {old.nx, old.ny, old.nz};
-        int rc = anchor ? rebuild_map(c, old.h, k) : rebuild_map(c, old.h, k, org, dims);
+        int rc = anchor ? rebuild_map(c, old.h, k, nullptr, nullptr, carry ? &cr : nullptr)
+                        : rebuild_map(c, old.h, k, org, dims);
         if (rc) {  // restore the old list; the old sorted map is still in place
             swap_raw();
             c->raw_n = n;

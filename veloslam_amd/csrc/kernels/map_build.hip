@@ -201,10 +201,18 @@ __device__ __forceinline__ void jacobi_rot(double A[3][3], double V[3][3], int p
 // lie outside it are never touched.  The visiting order therefore is not ascending in the
 // sorted index, so ties are ordered explicitly by (d2, index): the list is the oracle's.
 // Margins keep every pruning test conservative (cell membership is decided in float).
-__device__ __forceinline__ int collect_knn(const MapView& mv, float qx, float qy, float qz,
-                                           float r2, int k, float (*s_d)[kNrmThreads],
-                                           int (*s_i)[kNrmThreads], int tid)
+// TIE_RAW: equal distances are ordered by the append-order index perm[j] (normals: grid
+// independent) instead of the sorted index j (velo_knn's documented order).
+template <bool TIE_RAW>
+__device__ __forceinline__ int collect_knn(const MapView& mv, const uint32_t* __restrict__ perm,
+                                           float qx, float qy, float qz, float r2, int k,
+                                           float (*s_d)[kNrmThreads], int (*s_i)[kNrmThreads],
+                                           int tid)
 {
+    auto before = [&](float d2, int j, float pd, int pi) -> bool {
+        if (d2 != pd) return d2 < pd;
+        return TIE_RAW ? perm[j] < perm[pi] : j < pi;
+    };
     const int cx = cell_coord(qx, mv.ox, mv.inv_h, mv.nx);
     const int cy = cell_coord(qy, mv.oy, mv.inv_h, mv.ny);
     const int cz = cell_coord(qz, mv.oz, mv.inv_h, mv.nz);
@@ -255,15 +263,12 @@ __device__ __forceinline__ int collect_knn(const MapView& mv, float qx, float qy
                     for (int j = j0; j < j1; ++j) {
                         const float d2 = dist2(mv.pts[j], qx, qy, qz);
                         if (!(d2 <= r2)) continue;
-                        if (cnt == k) {
-                            const float wd = s_d[k - 1][tid];
-                            if (!(d2 < wd || (d2 == wd && j < s_i[k - 1][tid]))) continue;
-                        }
+                        if (cnt == k && !before(d2, j, s_d[k - 1][tid], s_i[k - 1][tid])) continue;
                         int pos = cnt < k ? cnt : k - 1;
                         while (pos > 0) {
                             const float pd = s_d[pos - 1][tid];
                             const int pi = s_i[pos - 1][tid];
-                            if (!(d2 < pd || (d2 == pd && j < pi))) break;
+                            if (!before(d2, j, pd, pi)) break;
                             s_d[pos][tid] = pd;
                             s_i[pos][tid] = pi;
                             --pos;
@@ -283,12 +288,12 @@ __device__ __forceinline__ int collect_knn(const MapView& mv, float qx, float qy
 }
 
 // PCA normal of sorted point s: {0,0,0,0} = invalid (fewer than kMinNb neighbours within h)
-__device__ __forceinline__ float4 point_normal(const MapView& mv, int s, int k,
-                                               float (*s_d)[kNrmThreads], int (*s_i)[kNrmThreads],
-                                               int tid)
+__device__ __forceinline__ float4 point_normal(const MapView& mv, const uint32_t* __restrict__ perm,
+                                               int s, int k, float (*s_d)[kNrmThreads],
+                                               int (*s_i)[kNrmThreads], int tid)
 {
     const float4 q = mv.pts[s];
-    const int cnt = collect_knn(mv, q.x, q.y, q.z, mv.h * mv.h, k, s_d, s_i, tid);
+    const int cnt = collect_knn<true>(mv, perm, q.x, q.y, q.z, mv.h * mv.h, k, s_d, s_i, tid);
     if (cnt < kMinNb) return make_float4(0.f, 0.f, 0.f, 0.f);
     double mx = 0, my = 0, mz = 0;
     for (int i = 0; i < cnt; ++i) {
@@ -338,7 +343,8 @@ __device__ __forceinline__ float4 point_normal(const MapView& mv, int s, int k,
 
 __device__ __forceinline__ bool is_zero3(const float4& v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f; }
 
-__global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
+__global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv,
+                                                         const uint32_t* __restrict__ perm, int k,
                                                          float4* __restrict__ nrm,
                                                          unsigned long long* __restrict__ invalid)
 {
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
     const int tid = threadIdx.x;
     const int s = blockIdx.x * kNrmThreads + tid;
     if (s >= mv.n) return;
-    const float4 nv = point_normal(mv, s, k, s_d, s_i, tid);
+    const float4 nv = point_normal(mv, perm, s, k, s_d, s_i, tid);
     nrm[s] = nv;
     if (is_zero3(nv)) atomicAdd(invalid, 1ull);
 }
@@ -356,8 +362,8 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv, int k,
 // the previous normal of every surviving point and {0,0,0,1} for points that are new, so
 // the invalid-normal count is maintained by difference (two's complement add).
 __global__ __launch_bounds__(kNrmThreads) void k_normals_subset(
-    MapView mv, int k, const int32_t* __restrict__ work, int n_work, float4* __restrict__ nrm,
-    unsigned long long* __restrict__ invalid)
+    MapView mv, const uint32_t* __restrict__ perm, int k, const int32_t* __restrict__ work,
+    int n_work, float4* __restrict__ nrm, unsigned long long* __restrict__ invalid)
 {
     __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
     __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals_subset(
     if (w >= n_work) return;
     const int s = work[w];
     const float4 old = nrm[s];
-    const float4 nv = point_normal(mv, s, k, s_d, s_i, tid);
+    const float4 nv = point_normal(mv, perm, s, k, s_d, s_i, tid);
     nrm[s] = nv;
     const int was = (old.w == 0.0f && is_zero3(old)) ? 1 : 0;
     const int now = is_zero3(nv) ? 1 : 0;
@@ -390,7 +396,8 @@ __global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __
     if (i >= n) return;
     double px, py, pz;
     xform(T, x[i], y[i], z[i], px, py, pz);
-    const int cnt = collect_knn(mv, (float)px, (float)py, (float)pz, dmax2, k, s_d, s_i, tid);
+    const int cnt = collect_knn<false>(mv, nullptr, (float)px, (float)py, (float)pz, dmax2, k, s_d,
+                                       s_i, tid);
     for (int m = 0; m < k; ++m) {
         idx[(size_t)i * k + m] = m < cnt ? s_i[m][tid] : -1;
         d2o[(size_t)i * k + m] = m < cnt ? s_d[m][tid] : INFINITY;
@@ -409,13 +416,13 @@ hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const f
     return hipGetLastError();
 }
 
-hipError_t launch_normals(const MapView& mv, int k, float4* nrm, unsigned long long* d_invalid,
-                          hipStream_t s)
+hipError_t launch_normals(const MapView& mv, const uint32_t* perm, int k, float4* nrm,
+                          unsigned long long* d_invalid, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(d_invalid, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     const int grid = (mv.n + kNrmThreads - 1) / kNrmThreads;
-    hipLaunchKernelGGL(k_normals, dim3(grid), dim3(kNrmThreads), 0, s, mv, k, nrm, d_invalid);
+    hipLaunchKernelGGL(k_normals, dim3(grid), dim3(kNrmThreads), 0, s, mv, perm, k, nrm, d_invalid);
     return hipGetLastError();
 }
 
@@ -716,12 +723,13 @@ hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& 
     return hipGetLastError();
 }
 
-hipError_t launch_normals_subset(const MapView& mv, int k, const int32_t* work, int n_work,
-                                 float4* nrm, unsigned long long* d_invalid, hipStream_t s)
+hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
+                                 const int32_t* work, int n_work, float4* nrm,
+                                 unsigned long long* d_invalid, hipStream_t s)
 {
     if (n_work <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_normals_subset, dim3((n_work + kNrmThreads - 1) / kNrmThreads),
-                       dim3(kNrmThreads), 0, s, mv, k, work, n_work, nrm, d_invalid);
+                       dim3(kNrmThreads), 0, s, mv, perm, k, work, n_work, nrm, d_invalid);
     return hipGetLastError();
 }
 
@@ -773,6 +781,94 @@ hipError_t launch_table_remap(int32_t* cell_start, size_t n_entries, const uint3
 {
     hipLaunchKernelGGL(k_table_remap, dim3(grid_for(n_entries, 256, 16384)), dim3(256), 0, s,
                        cell_start, n_entries, offs, n, kept);
+    return hipGetLastError();
+}
+
+// ---- re-anchoring with carried normals: a normal depends on the point list only (ties are
+// broken by append-order index), so when the grid moves the normals are permuted, not
+// re-estimated; only points near added / removed points go through the PCA again.
+__global__ __launch_bounds__(256) void k_scatter_nrm_raw(const float4* __restrict__ nrm,
+                                                         const uint32_t* __restrict__ perm,
+                                                         uint32_t n, const uint32_t* __restrict__ keep,
+                                                         const uint32_t* __restrict__ raw_offs,
+                                                         float4* __restrict__ nrm_raw)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n || (keep && !keep[s])) return;
+    const uint32_t r = perm[s];
+    nrm_raw[raw_offs ? raw_offs[r] : r] = nrm[s];
+}
+__global__ __launch_bounds__(256) void k_fill_fresh(float4* __restrict__ nrm_raw, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) nrm_raw[i] = make_float4(0.f, 0.f, 0.f, 1.0f);
+}
+__global__ __launch_bounds__(256) void k_gather_nrm(const float4* __restrict__ nrm_raw,
+                                                    const uint32_t* __restrict__ perm, uint32_t n,
+                                                    float4* __restrict__ nrm)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) nrm[s] = nrm_raw[perm[s]];
+}
+// mark the 27 voxels around points chosen by position: mode 0 = nrm[i].w == 1 (fresh points
+// of the new order), mode 1 = keep[i] == 0 (removed points of the old order; they may lie
+// outside the new grid)
+__global__ __launch_bounds__(256) void k_mark_dirty_pts(const float4* __restrict__ pts,
+                                                        const float4* __restrict__ nrm,
+                                                        const uint32_t* __restrict__ keep,
+                                                        uint32_t n, MapView g,
+                                                        uint8_t* __restrict__ dirty)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (nrm ? nrm[i].w != 1.0f : keep[i] != 0u) return;
+    const float4 p = pts[i];
+    const int vx = cell_coord(p.x, g.ox, g.inv_h, g.nx);
+    const int vy = cell_coord(p.y, g.oy, g.inv_h, g.ny);
+    const int vz = cell_coord(p.z, g.oz, g.inv_h, g.nz);
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int z = vz + dz;
+        if (z < 0 || z >= g.nz) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = vy + dy;
+            if (y < 0 || y >= g.ny) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = vx + dx;
+                if (x < 0 || x >= g.nx) continue;
+                dirty[((size_t)z * g.ny + y) * g.nx + x] = 1;
+            }
+        }
+    }
+}
+
+hipError_t launch_scatter_nrm_raw(const float4* nrm, const uint32_t* perm, uint32_t n,
+                                  const uint32_t* keep, const uint32_t* raw_offs, float4* nrm_raw,
+                                  hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_nrm_raw, dim3((n + 255) / 256), dim3(256), 0, s, nrm, perm, n, keep,
+                       raw_offs, nrm_raw);
+    return hipGetLastError();
+}
+hipError_t launch_fill_fresh(float4* nrm_raw, uint32_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_fresh, dim3((n + 255) / 256), dim3(256), 0, s, nrm_raw, n);
+    return hipGetLastError();
+}
+hipError_t launch_gather_nrm(const float4* nrm_raw, const uint32_t* perm, uint32_t n, float4* nrm,
+                             hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_nrm, dim3((n + 255) / 256), dim3(256), 0, s, nrm_raw, perm, n, nrm);
+    return hipGetLastError();
+}
+hipError_t launch_mark_dirty_pts(const float4* pts, const float4* nrm, const uint32_t* keep,
+                                 uint32_t n, const MapView& g, uint8_t* dirty, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mark_dirty_pts, dim3((n + 255) / 256), dim3(256), 0, s, pts, nrm, keep, n,
+                       g, dirty);
     return hipGetLastError();
 }
 

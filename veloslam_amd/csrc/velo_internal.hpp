@@ -68,8 +68,8 @@ hipError_t launch_gather(const float* x, const float* y, const float* z, const u
                          size_t n, float4* pts, hipStream_t s);
 hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell,
                              int32_t* cell_start, hipStream_t s);
-hipError_t launch_normals(const MapView& mv, int k, float4* nrm, unsigned long long* d_invalid,
-                          hipStream_t s);
+hipError_t launch_normals(const MapView& mv, const uint32_t* perm, int k, float4* nrm,
+                          unsigned long long* d_invalid, hipStream_t s);
 
 // incremental map update (f3): see kernels/map_build.hip
 hipError_t launch_keys4(const float4* pts, size_t n, const MapView& grid, uint32_t* keys,
@@ -85,8 +85,9 @@ hipError_t launch_mark_dirty(const uint32_t* keys, uint32_t m, const uint32_t* s
                              const MapView& grid, uint8_t* dirty, hipStream_t s);
 hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& grid,
                                const uint8_t* dirty, int32_t* work, unsigned* count, hipStream_t s);
-hipError_t launch_normals_subset(const MapView& mv, int k, const int32_t* work, int n_work,
-                                 float4* nrm, unsigned long long* d_invalid, hipStream_t s);
+hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
+                                 const int32_t* work, int n_work, float4* nrm,
+                                 unsigned long long* d_invalid, hipStream_t s);
 hipError_t launch_count_invalid(const float4* nrm, uint32_t n, unsigned long long* d_invalid,
                                 hipStream_t s);
 hipError_t launch_keep_flags(const float4* pts, const float* x, const float* y, const float* z,
@@ -101,6 +102,15 @@ hipError_t launch_compact_raw(const float* x, const float* y, const float* z, ui
                               float* z2, hipStream_t s);
 hipError_t launch_table_remap(int32_t* cell_start, size_t n_entries, const uint32_t* offs, uint32_t n,
                               uint32_t kept, hipStream_t s);
+
+hipError_t launch_scatter_nrm_raw(const float4* nrm, const uint32_t* perm, uint32_t n,
+                                  const uint32_t* keep, const uint32_t* raw_offs, float4* nrm_raw,
+                                  hipStream_t s);
+hipError_t launch_fill_fresh(float4* nrm_raw, uint32_t n, hipStream_t s);
+hipError_t launch_gather_nrm(const float4* nrm_raw, const uint32_t* perm, uint32_t n, float4* nrm,
+                             hipStream_t s);
+hipError_t launch_mark_dirty_pts(const float4* pts, const float4* nrm, const uint32_t* keep,
+                                 uint32_t n, const MapView& grid, uint8_t* dirty, hipStream_t s);
 
 hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
                       const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
