@@ -96,7 +96,9 @@ def run_stream(args, dev, local):
                            T0=synth.perturbed_guess(Tt, dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))))
     calc = np.ascontiguousarray(cal, dtype=np.float64).reshape(64, 9)
     ctx = capi.Context(local, max_batch=2, map_margin=args.map_margin, map_subdiv=args.subdiv,
-                       map_full_rebuild=1 if args.full_rebuild else 0)
+                       map_full_rebuild=1 if args.full_rebuild else 0, sort_frames=args.sort_frames,
+                       use_hints=0 if args.no_hints else args.hints,
+                       use_graph=0 if args.no_graph else 1)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def box(f):

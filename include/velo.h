@@ -250,6 +250,11 @@ int velo_increment_dev(velo_ctx*, int frame, const double T[12], int min_count, 
  * [6] fastest linearise launch ms */
 int velo_last_timing(velo_ctx*, double out[8]);
 /* enable (1) / disable (0) per-launch event timing (adds event records) */
+/* Search statistics of the linearise kernel since the last reset, for tuning; all zero unless
+ * the library was built with -DVELO_STATS (tools/build_variant.sh).  out[8]: live queries,
+ * certified without search, searched, empty-neighbourhood skips, stage-A final, stage-B per
+ * lane, stage-B cooperative, valid pairs. */
+int velo_debug_search_stats(velo_ctx*, uint64_t out[8], int reset);
 int velo_set_timing(velo_ctx*, int on);
 
 /* ---- host-side pose plumbing -------------------------------------------------------- */

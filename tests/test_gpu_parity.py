@@ -288,6 +288,20 @@ def test_hinted_search_is_exact(ctx, omap, wl, comp):
             oc, od2, _ = omap.correspond(*comp[0], T, 1.0)
             assert np.array_equal(corr, oc)
             assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+        # a small d_max leaves many queries without a match: those carry an emptiness
+        # certificate from call to call (creeping poses: certificates hold, shrink, expire)
+        creep = [f["T_true"].copy() for _ in range(7)]
+        for i, T in enumerate(creep):
+            T[3] += 0.004 * i
+            T[7] -= 0.003 * i
+        lifted = f["T_true"].copy()
+        lifted[11] += 0.6
+        for T in [lifted, lifted] + creep + [far, creep[0], creep[0]]:
+            corr, d2, acc = ctx.linearize(0, T, 0.25, n)
+            oc, od2, _ = omap.correspond(*comp[0], T, 0.25)
+            assert np.array_equal(corr, oc)
+            assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+        assert (oc < 0).sum() > 100
         # the map changes under the carried hints (every other point dropped): indices and
         # uniqueness radii of the old map must not leak into the search on the new one
         half = [a[::2].copy() for a in wl["map"]]
@@ -317,6 +331,30 @@ def test_queries_outside_grid_and_dmax(ctx, oracle):
         assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
     with pytest.raises(capi.VeloError):
         ctx.linearize(0, I, 1.5, 5000)  # d_max > voxel is refused
+
+
+def test_empty_neighbourhoods_between_clusters(ctx, oracle):
+    """Two clusters 30 voxels apart: most of the grid is empty.  Queries whose 27 voxels hold
+    no map point are answered from the dilated occupancy map without a search -- same
+    correspondences as the oracle's exhaustive definition, including the voxels that touch a
+    cluster on a face, an edge or a corner only."""
+    rng = np.random.default_rng(17)
+    a = rng.uniform(0, 4, (3, 3000)).astype(np.float32)
+    b = (rng.uniform(0, 4, (3, 3000)) + np.array([[30.0], [2.0], [1.0]])).astype(np.float32)
+    m = np.concatenate([a, b], axis=1)
+    om = oracle.Map(*m, 1.0, 8)
+    ctx.map_reset(*m, 1.0, 8)
+    q = np.concatenate([rng.uniform(-2, 36, (3, 6000)) * np.array([[1.0], [0.2], [0.15]]),
+                        rng.uniform(3.5, 6.5, (3, 3000)),          # shell around cluster a
+                        rng.uniform(-1.5, 0.5, (3, 1000))], axis=1).astype(np.float32)
+    I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+    ctx.frames_upload([tuple(q)])
+    for dmax in (1.0, 0.4):
+        corr, d2, acc = ctx.linearize(0, I, dmax, q.shape[1])
+        oc, od2, _ = om.correspond(*q, I, dmax)
+        assert np.array_equal(corr, oc)
+        assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+    assert 0 < (oc < 0).sum() < oc.size
 
 
 def test_exact_ties_pick_lowest_sorted_index(ctx, oracle):

@@ -69,7 +69,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_evict_outside", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing",
+    "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
     "velo_insmeta_write", "velo_insmeta_read", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
@@ -113,6 +113,7 @@ def lib():
     L.velo_map_append.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.velo_map_append_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.velo_map_evict_outside.argtypes = [vp, vp, vp]
+    L.velo_debug_search_stats.argtypes = [vp, vp, C.c_int]
     L.velo_map_info_get.argtypes = [vp, C.POINTER(MapInfo)]
     L.velo_map_download.argtypes = [vp] + [vp] * 8
     L.velo_compensate.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp]
@@ -308,6 +309,12 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self._chk(lib().velo_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def search_stats(self, reset=True):
+        out = (C.c_uint64 * 8)()
+        self._chk(lib().velo_debug_search_stats(self.h, out, int(reset)))
+        return dict(zip(("live", "certified", "searched", "empty_skips", "stage_a_final",
+                         "stage_b_lane", "stage_b_coop", "valid_pairs"), [int(v) for v in out]))
 
     def synchronize(self):
         self._chk(lib().velo_synchronize(self.h))

@@ -70,7 +70,7 @@ struct velo_ctx {
     DevBuf<float> raw_x2, raw_y2, raw_z2;
     DevBuf<uint32_t> keys_alt, perm_alt, nk, nk_sorted, nidx, nidx_sorted, rflags, roffs;
     DevBuf<float4> pts_alt, nrm_alt, nrm_raw;
-    DevBuf<uint8_t> dirty;
+    DevBuf<uint8_t> dirty, vox_occ, vox_near;
     DevBuf<int32_t> work;
     DevBuf<unsigned> work_cnt;
     float map_mx[3] = {0, 0, 0};  // component-wise max of the map points
@@ -195,16 +195,23 @@ int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, unsigned* n_wor
 }
 
 // make `mv` the ctx's map: bookkeeping shared by the full build and the incremental updates
-int publish_map(velo_ctx* c, const MapView& mv, int k_normals, unsigned long long invalid,
+int publish_map(velo_ctx* c, MapView mv, int k_normals, unsigned long long invalid,
                 int last_update, uint64_t n_recomputed)
 {
     hipStream_t s = c->stream;
+    const size_t nvox = (size_t)mv.nx * mv.ny * mv.nz;
+    HIP_TRY(c, reserve_slack(c->vox_occ, nvox));
+    HIP_TRY(c, reserve_slack(c->vox_near, nvox));
+    HIP_TRY(c, launch_vox_near(mv, c->vox_occ.p, c->vox_near.p, s));
+    mv.vox_near = c->vox_near.p;
     c->mv = mv;
     c->has_map = true;
     ++c->map_gen;
     // hints / certificates are indices and radii in the OLD map: forget them
     if (c->hint.p && c->hint.cap)
         HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), s));
+    if (c->rho.p && c->rho.cap)  // 0 = no certificate (negative values certify "no match")
+        HIP_TRY(c, hipMemsetAsync(c->rho.p, 0, c->rho.cap * sizeof(float), s));
     c->info.n_points = (uint64_t)mv.n;
     c->info.n_cells = (uint64_t)mv.fx * mv.fy * mv.fz;
     c->info.origin[0] = mv.ox;
@@ -311,7 +318,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
         HIP_TRY(c, launch_gather(c->raw_x.p, c->raw_y.p, c->raw_z.p, c->perm.p, n, c->pts.p, s));
     }
     HIP_TRY(c, launch_cell_start(c->keys_sorted.p, n, ncell, c->cell_start.p, s));
-    MapView mv;
+    MapView mv{};
     mv.pts = c->pts.p;
     mv.nrm = c->nrm.p;
     mv.cell_start = c->cell_start.p;
@@ -671,6 +678,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             HIP_TRY(c, hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
             hipError_t e = hipMemcpyAsync(c->poses.p, c->h_T0, pose_bytes, hipMemcpyHostToDevice, s);
             if (e == hipSuccess && hint) e = hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s);
+            if (e == hipSuccess && rho) e = hipMemsetAsync(rho, 0, n_all * sizeof(float), s);
             FrameView fv{c->ax, c->ay, c->az, nullptr};
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
                 e = launch_linearize(c->cfg.linearize_variant, c->items.p, ni, fv, c->mv, c->poses.p,
@@ -707,6 +715,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     if (int rc = maybe_sort_frames(c, fv)) return rc;
     // hints never outlive a registration: results do not depend on earlier calls
     if (hint) HIP_TRY(c, hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s));
+    if (rho) HIP_TRY(c, hipMemsetAsync(rho, 0, n_all * sizeof(float), s));
     for (int it = 0; it < iters; ++it) {
         {
             Timed t(c, 0);
@@ -858,6 +867,18 @@ int velo_linearize_hints(velo_ctx* c, int mode)
     c->lin_hints = mode != 0;
     if (c->hint.p && c->hint.cap)  // (re)start from "no hint"
         HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), c->stream));
+    if (c->rho.p && c->rho.cap)
+        HIP_TRY(c, hipMemsetAsync(c->rho.p, 0, c->rho.cap * sizeof(float), c->stream));
+    return VELO_OK;
+}
+
+int velo_debug_search_stats(velo_ctx* c, uint64_t out[8], int reset)
+{
+    if (!c || !out) return VELO_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long v[8];
+    HIP_TRY(c, read_lin_stats(v, reset != 0, c->stream));
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
     return VELO_OK;
 }
 
@@ -1224,7 +1245,10 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
     }
     HIP_TRY(c, c->poses_prev.reserve((size_t)c->cfg.max_batch * 12));
     if (c->lin_hints) {
-        HIP_TRY(c, c->rho.reserve(n_all));
+        if (c->rho.cap < n_all) {
+            HIP_TRY(c, c->rho.reserve(n_all));
+            HIP_TRY(c, hipMemsetAsync(c->rho.p, 0, n_all * sizeof(float), s));
+        }
         // the pose of the previous call is this call's "previous iteration"
         HIP_TRY(c, hipMemcpyAsync(c->poses_prev.p + 12 * (size_t)frame, c->poses.p + 12 * (size_t)frame,
                                   12 * sizeof(double), hipMemcpyDeviceToDevice, s));

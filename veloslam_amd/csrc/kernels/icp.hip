@@ -91,6 +91,21 @@ __constant__ unsigned char c_ia[32] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2,
 __constant__ unsigned char c_ib[32] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3,
                                        4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7};
 
+// Search statistics (only counted in -DVELO_STATS builds, tools/build_variant.sh):
+// [0] live queries, [1] certified (no search), [2] searched, [3] empty-neighbourhood skips,
+// [4] stage-A final, [5] unused, [6] stage-B stragglers, [7] valid pairs
+__device__ unsigned long long g_lin_stats[8];
+#ifdef VELO_STATS
+#define VELO_COUNT(i, pred)                                                                     \
+    do {                                                                                        \
+        const unsigned long long m__ = __ballot(pred);                                          \
+        if (m__ && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m__) - 1))               \
+            atomicAdd(&g_lin_stats[i], (unsigned long long)__popcll(m__));                      \
+    } while (0)
+#else
+#define VELO_COUNT(i, pred) do { } while (0)
+#endif
+
 // ---- fine-grid geometry of a query --------------------------------------------------
 // The map is sorted by FINE cell (S sub-cells per voxel edge, DESIGN.md "ICP semantics");
 // one row of fine cells (fixed Fy,Fz) is one contiguous index range of the map.
@@ -174,7 +189,10 @@ __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float 
 //            x-extent of each row cut to the ball, descending index, '<='.  Compaction keeps
 //            a handful of stragglers from stalling every wavefront of the workgroup.
 constexpr int kMaxRanges = 9;
-constexpr float kCertSlack = 0.05f;  // metres searched beyond the hinted point (tuning only)
+#ifndef VELO_CERT_SLACK
+#define VELO_CERT_SLACK 0.05f
+#endif
+constexpr float kCertSlack = VELO_CERT_SLACK;  // metres searched beyond the hinted point (tuning only)
 #ifndef VELO_WALK_W
 #define VELO_WALK_W 4
 #endif
@@ -248,15 +266,28 @@ struct __attribute__((packed, aligned(4))) Int4U {
 // costs one table request and a couple of candidates instead of nine and ~14.
 // ABL (timing ablations only, results are wrong): 1 = treat stage A as final, 2 = also skip
 // the candidate walk, 3 = also skip the fine-table loads
+constexpr int kFinal = 0, kStraggler = 1;  // stage A outcome
+
+// stage A epilogue: is the block result final, and what radius does it certify
+__device__ __forceinline__ int finish_block(float bd, float sd, float gr, float& cert)
+{
+    const bool final = bd <= gr * gr * 0.99999f;
+    // second-best scanned / pruned-cell bound / block faces, rounded down
+    cert = final ? fmaxf(fminf(sqrtf(sd) * 0.999999f, gr) - 1e-6f, 0.0f) : 0.0f;
+    return final ? kFinal : kStraggler;
+}
+
 template <int ABL>
-__device__ __forceinline__ bool search_block(const MapView& mv, const QueryCell& g, float qx,
-                                             float qy, float qz, float ub0, SearchLds& L,
-                                             int tid, float& bd, int& bj, float& cert)
+__device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& g, float qx,
+                                            float qy, float qz, float ub0, SearchLds& L,
+                                            int tid, float& bd, int& bj, float& cert,
+                                            float& gr_out)
 {
     bd = ub0;
     bj = -1;
     cert = 0.0f;  // radius (m) around the query inside which the winner is the only map point
-    if (!g.near) return true;  // no voxel of the 27 exists: no candidates at all
+    gr_out = 0.0f;
+    if (!g.near) return kFinal;  // no voxel of the 27 exists: no candidates at all
     const float hf = mv.h / (float)mv.S;
     const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
     // conservative distances from the query to the faces of its own fine cell
@@ -299,19 +330,17 @@ __device__ __forceinline__ bool search_block(const MapView& mv, const QueryCell&
         }
     }
     if (ABL >= 2) nr = min(nr, 0);
-    float sd = ub0;  // everything not scanned inside the block is further than sqrt(ub0)
-    walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd);
-    if (ABL >= 1) return true;
     // guaranteed radius of the 3x3x3 block: one fine cell plus the distance to the nearer
     // face of the query's own fine cell, per axis; shrunk for rounding.  Whatever was pruned
     // inside the block is further than sqrt(ub0) >= sqrt(bd).
     const float tmin = fminf(fminf(fminf(g.tx, 1.0f - g.tx), fminf(g.ty, 1.0f - g.ty)),
                              fminf(g.tz, 1.0f - g.tz));
     const float gr = fmaxf(hf * (1.0f + tmin) - mg, 0.0f);
-    const bool final = bd <= gr * gr * 0.99999f;
-    // second-best scanned / pruned-cell bound / block faces, rounded down
-    if (final) cert = fmaxf(fminf(sqrtf(sd) * 0.999999f, gr) - 1e-6f, 0.0f);
-    return final;
+    gr_out = gr;
+    float sd = ub0;  // everything not scanned inside the block is further than sqrt(ub0)
+    walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd);
+    if (ABL >= 1) return kFinal;
+    return finish_block(bd, sd, gr, cert);
 }
 
 // stage B, per-lane form (used when most lanes of a wavefront are stragglers, i.e. the first
@@ -377,11 +406,11 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
 // flight together: a handful of stragglers no longer costs a serial chain of ~50 dependent
 // loads while the other wavefronts of the workgroup wait at the barrier.
 __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, float qy, float qz,
-                                                 float ub, int lane, float& bd, int& bj)
+                                                 float ub, int lane, float& bd, int& bj, float& sd)
 {
     const QueryCell g = locate(mv, qx, qy, qz);
-    bd = ub;
-    bj = -1;
+    float b1 = ub, b2 = ub;  // best and second-best distance seen by this lane
+    int j1 = 0x7fffffff;
     const int S = mv.S;
     const int side = 2 * S + 1, nrows = side * side;
     const float hf = mv.h / (float)S;
@@ -408,20 +437,29 @@ __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, fl
             const float d2 = dist2(mv.pts[j], qx, qy, qz);
             // rows are visited in descending order by each lane, so '<=' keeps the lowest
             // index among equal distances inside the lane; lanes are merged below
-            if (d2 <= bd) {
-                bd = d2;
-                bj = j;
+            if (d2 <= b1) {
+                b2 = b1;
+                b1 = d2;
+                j1 = j;
+            } else {
+                b2 = fminf(b2, d2);
             }
         }
     }
-    float dmin = bd;
+    float dmin = b1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, off, 64));
-    int jm = (bj >= 0 && bd == dmin) ? bj : 0x7fffffff;
+    int jm = (b1 == dmin) ? j1 : 0x7fffffff;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) jm = min(jm, __shfl_xor(jm, off, 64));
+    // second-smallest distance inside the ball (a tie of the minimum counts): every point
+    // within sqrt(ub) has been looked at, so the winner is alone within sqrt(min(sd, ub))
+    float s2 = (b1 == dmin && j1 == jm) ? b2 : b1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s2 = fminf(s2, __shfl_xor(s2, off, 64));
     bd = dmin;
     bj = jm == 0x7fffffff ? -1 : jm;
+    sd = s2;
 }
 
 // One block = one BlockItem = a run of queries of one frame.  Per round of 256
@@ -437,6 +475,9 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
     ReduceLds r;
 };
 
+#ifndef VELO_COOP_MAX
+#define VELO_COOP_MAX 16
+#endif
 template <bool WRITE_CORR, int VARIANT>
 #ifndef VELO_LIN_WAVES
 #define VELO_LIN_WAVES 7  // measured: 8 spills (64 VGPRs), 7 = 72 VGPRs no spill, fastest
@@ -476,6 +517,8 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
         bool state_same = false;   // hint and rho unchanged: nothing to write back
         if (VARIANT >= 1) {
             bool queued = false;
+            int st = kFinal;
+            float blk_gr = 0.0f;  // guaranteed radius of the stage-A block around this query
             float qx = 0.f, qy = 0.f, qz = 0.f;
             if (live) {
                 xform(T, sxq, syq, szq, px, py, pz);
@@ -518,21 +561,28 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
                     const float rs = d1 + kCertSlack;
                     ub0 = fminf(ub0, rs * rs * 1.00001f);
                 }
+                VELO_COUNT(1, certified);
                 if (!certified) {
                     const QueryCell g = locate(mv, qx, qy, qz);
-                    queued = !search_block<(VARIANT >= 11 ? VARIANT - 10 : 0)>(mv, g, qx, qy, qz, ub0,
-                                                                             s_u.s, lane, bd, bj, rho_new_out);
+                    // a query without a previous match whose 27 voxels are all empty has an
+                    // empty candidate set: nothing to search (far-range points over a cropped map)
+                    bool empty = false;
+                    if (hj < 0 && mv.vox_near && g.cx >= 0 && g.cx < mv.nx && g.cy >= 0 &&
+                        g.cy < mv.ny && g.cz >= 0 && g.cz < mv.nz)
+                        empty = mv.vox_near[((size_t)g.cz * mv.ny + g.cy) * mv.nx + g.cx] == 0;
+                    if (!empty)
+                        st = search_block<(VARIANT >= 11 ? VARIANT - 10 : 0)>(
+                            mv, g, qx, qy, qz, ub0, s_u.s, lane, bd, bj, rho_new_out, blk_gr);
+                    VELO_COUNT(3, empty);
+                    VELO_COUNT(2, !empty);
                 }
             }
-            // stage B inside the wavefront: no workgroup barrier, no LDS hand-off.  Each
-            // straggler's query is broadcast from its lane and searched by all 64 lanes;
-            // when most lanes are stragglers (first iterations of a badly aligned frame)
-            // every lane searches its own ball instead.
+            VELO_COUNT(4, live && st == kFinal);
+            queued = st == kStraggler;
             if (queued) rho_new_out = 0.0f;
             unsigned long long need = __ballot(queued);
-#ifndef VELO_COOP_MAX
-#define VELO_COOP_MAX 16
-#endif
+            VELO_COUNT(0, live);
+            VELO_COUNT(6, queued);
             if (__popcll(need) > VELO_COOP_MAX) {
                 if (queued) {
                     const float ub = bd;
@@ -543,13 +593,23 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
                     const int src = __ffsll((long long)need) - 1;
                     need &= need - 1;
                     const float sx = __shfl(qx, src, 64), sy = __shfl(qy, src, 64),
-                                sz = __shfl(qz, src, 64), sub = __shfl(bd, src, 64);
-                    float rbd;
+                                sz = __shfl(qz, src, 64);
+                    // the ball is searched a little beyond the bound (never past one voxel:
+                    // the row window covers that) so that the outcome certifies a radius and
+                    // a far-off correspondence is not searched again at every iteration
+                    const float rsq = sqrtf(__shfl(bd, src, 64)) + kCertSlack;
+                    const float sub = fminf(rsq * rsq, mv.h * mv.h);
+                    float rbd, rsd;
                     int rbj;
-                    search_ball_wave(mv, sx, sy, sz, sub, lane, rbd, rbj);
+                    search_ball_wave(mv, sx, sy, sz, sub, lane, rbd, rbj, rsd);
                     if (lane == src) {
                         bd = rbd;
                         bj = rbj;
+                        // (rows outside the window are further than h - mg: same margin as
+                        // the cell-assignment rounding everywhere else)
+                        const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+                        if (bj >= 0)
+                            rho_new_out = fmaxf(fminf(sqrtf(rsd) * 0.999999f, mv.h - 2.0f * mg) - 1e-6f, 0.0f);
                     }
                 }
             }
@@ -570,6 +630,7 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
                 if (corr) corr[qi] = ok ? bj : -1;
                 if (d2out) d2out[qi] = ok ? bd : INFINITY;
             }
+            VELO_COUNT(7, ok);
             if (ok) {
                 const float4 nf = mv.nrm[bj];
                 const float4 mf = mv.pts[bj];  // issued with the normal: one round trip, not two
@@ -616,6 +677,16 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
         const double t = ((s_w[0][tid] + s_w[1][tid]) + s_w[2][tid]) + s_w[3][tid];
         partials[(size_t)it.slot * kAccStride + tid] = t;
     }
+}
+
+hipError_t read_lin_stats(unsigned long long out[8], bool reset, hipStream_t s)
+{
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin_stats), 8 * sizeof(unsigned long long));
+    if (e != hipSuccess || !reset) return e;
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lin_stats), z, sizeof z);
 }
 
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,

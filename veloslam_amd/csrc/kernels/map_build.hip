@@ -872,4 +872,56 @@ hipError_t launch_mark_dirty_pts(const float4* pts, const float4* nrm, const uin
     return hipGetLastError();
 }
 
+// ---- dilated voxel occupancy: near[v] == 0 <=> the 27 voxels around v hold no point, i.e.
+// the candidate set of any query in v is empty (exact; lets the search of far-range frame
+// points over a cropped map stop after one byte load)
+__global__ __launch_bounds__(256) void k_vox_occ(MapView mv, uint8_t* __restrict__ occ)
+{
+    const size_t nvox = (size_t)mv.nx * mv.ny * mv.nz;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox;
+         v += (size_t)gridDim.x * blockDim.x) {
+        const int vx = (int)(v % (size_t)mv.nx);
+        const size_t t = v / (size_t)mv.nx;
+        const int vy = (int)(t % (size_t)mv.ny), vz = (int)(t / (size_t)mv.ny);
+        const int S = mv.S;
+        // the voxel's S*S fine rows are S runs of S consecutive rows: first and last index of
+        // each row piece; any non-empty piece makes the voxel occupied
+        bool any = false;
+        for (int sz = 0; sz < S && !any; ++sz)
+            for (int sy = 0; sy < S; ++sy) {
+                const size_t row = ((size_t)(vz * S + sz) * mv.fy + (size_t)(vy * S + sy)) * mv.fx;
+                if (mv.cell_start[row + (size_t)(vx + 1) * S] > mv.cell_start[row + (size_t)vx * S]) {
+                    any = true;
+                    break;
+                }
+            }
+        occ[v] = any ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_vox_near(const uint8_t* __restrict__ occ, int nx, int ny,
+                                                  int nz, uint8_t* __restrict__ near)
+{
+    const size_t nvox = (size_t)nx * ny * nz;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox;
+         v += (size_t)gridDim.x * blockDim.x) {
+        const int vx = (int)(v % (size_t)nx);
+        const size_t t = v / (size_t)nx;
+        const int vy = (int)(t % (size_t)ny), vz = (int)(t / (size_t)ny);
+        unsigned any = 0;
+        for (int z = max(vz - 1, 0); z <= min(vz + 1, nz - 1); ++z)
+            for (int y = max(vy - 1, 0); y <= min(vy + 1, ny - 1); ++y)
+                for (int x = max(vx - 1, 0); x <= min(vx + 1, nx - 1); ++x)
+                    any |= occ[((size_t)z * ny + y) * nx + x];
+        near[v] = any ? 1 : 0;
+    }
+}
+hipError_t launch_vox_near(const MapView& mv, uint8_t* occ, uint8_t* near, hipStream_t s)
+{
+    const size_t nvox = (size_t)mv.nx * mv.ny * mv.nz;
+    const int grid = grid_for(nvox, 256, 16384);
+    hipLaunchKernelGGL(k_vox_occ, dim3(grid), dim3(256), 0, s, mv, occ);
+    hipLaunchKernelGGL(k_vox_near, dim3(grid), dim3(256), 0, s, occ, mv.nx, mv.ny, mv.nz, near);
+    return hipGetLastError();
+}
+
 }  // namespace velo

@@ -17,6 +17,7 @@ struct MapView {
     const float4* pts;     // [n] sorted by FINE cell key (stable)
     const float4* nrm;     // [n]
     const int32_t* cell_start;  // [fx*fy*fz + 1] fine-cell table: number of keys < k
+    const uint8_t* vox_near;    // [nx*ny*nz] 0 = no map point in the 27 voxels around (or nullptr)
     float ox, oy, oz, inv_h, h;
     int nx, ny, nz;        // voxels per axis
     int S;                 // sub-cells per voxel edge
@@ -112,6 +113,8 @@ hipError_t launch_gather_nrm(const float4* nrm_raw, const uint32_t* perm, uint32
 hipError_t launch_mark_dirty_pts(const float4* pts, const float4* nrm, const uint32_t* keep,
                                  uint32_t n, const MapView& grid, uint8_t* dirty, hipStream_t s);
 
+hipError_t launch_vox_near(const MapView& mv, uint8_t* occ, uint8_t* near, hipStream_t s);
+
 hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
                       const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
                       hipStream_t s);
@@ -119,6 +122,7 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, int32_t* hint, float* rho,
                             const double* poses_prev, hipStream_t s);
+hipError_t read_lin_stats(unsigned long long out[8], bool reset, hipStream_t s);
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, double* poses_prev,
