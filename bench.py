@@ -111,6 +111,7 @@ def run_stream(args, dev, local):
     inc = torch.empty((3, 200_000), dtype=torch.float32, device=dev)
     stage = dict(decode=0.0, icp=0.0, increment=0.0, append=0.0, evict=0.0)
     counts = dict(pairs=0, inc=0, pts=0, recomputed=0, incremental=0, updates=0, worst=0.0, map=0)
+    upd_ms = {"append_incremental": [], "append_reanchor": [], "evict_incremental": [], "evict_reanchor": []}
 
     def one(f, k, timed):
         t = [time.perf_counter()]
@@ -126,6 +127,8 @@ def run_stream(args, dev, local):
             ctx.map_append_dev(inc[0].data_ptr(), inc[1].data_ptr(), inc[2].data_ptr(), cnt)
             mi = ctx.map_info()
             if timed:
+                upd_ms["append_incremental" if mi.last_update else "append_reanchor"].append(
+                    1e3 * (time.perf_counter() - t[-1]))
                 counts["updates"] += 1
                 counts["incremental"] += int(mi.last_update)
                 counts["recomputed"] += int(mi.n_normals_recomputed)
@@ -134,6 +137,8 @@ def run_stream(args, dev, local):
             ctx.map_evict_outside(*box(f))
             mi = ctx.map_info()
             if timed:
+                upd_ms["evict_incremental" if mi.last_update else "evict_reanchor"].append(
+                    1e3 * (time.perf_counter() - t[-1]))
                 counts["updates"] += 1
                 counts["incremental"] += int(mi.last_update)
                 counts["recomputed"] += int(mi.n_normals_recomputed)
@@ -171,6 +176,8 @@ def run_stream(args, dev, local):
                       "map_margin_voxels": args.map_margin},
            "pairs_per_s": counts["pairs"] / elapsed,
            "stage_ms_per_frame": {k: 1e3 * v / args.steps for k, v in stage.items()},
+           "map_update_ms": {k: {"n": len(v), "mean": float(np.mean(v)), "max": float(np.max(v))}
+                             for k, v in upd_ms.items() if v},
            "increment_points_per_frame": counts["inc"] / max(args.steps, 1),
            "map_updates": counts["updates"], "map_updates_incremental": counts["incremental"],
            "normals_recomputed_per_update": counts["recomputed"] / max(counts["updates"], 1),
