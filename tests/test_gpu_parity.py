@@ -652,6 +652,60 @@ def test_config3_size_10m_map_properties():
         assert np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
 
 
+def test_config4_size_100m_map_knn32_properties():
+    """BASELINE configs[4] size: a 100 M-point map, 32 nearest neighbours.  Far beyond what
+    the CPU oracle finishes in seconds, so it is checked against a float64 brute force over a
+    window of the map: neighbour identities (as append-order indices, through the device's
+    permutation) and order, distances, counts; plus the table's global invariants."""
+    from veloslam_amd import synth
+    rng = np.random.default_rng(44)
+    bx, by, bz = synth.Scene().sample_map(10_000_000)
+    n = 100_000_000
+    mx = np.repeat(bx, 10)
+    my = np.repeat(by, 10)
+    mz = np.repeat(bz, 10)
+    for a in (mx, my, mz):                       # ten jittered copies of every sample (+-2 cm)
+        a += rng.uniform(-0.02, 0.02, n).astype(np.float32)
+    del bx, by, bz
+    k = 32
+    c = capi.Context(0, max_batch=2, map_subdiv=6)
+    try:
+        c.map_reset(mx, my, mz, 1.0, 16)
+        mi = c.map_info()
+        assert mi.n_points == n and mi.k_normals == 16
+        assert mi.n_invalid_normals < n // 100
+        # queries in a 2 m x 2 m window; every neighbour within d_max lies in the 4 m window
+        qn = 400
+        q = np.stack([rng.uniform(11, 13, qn), rng.uniform(11, 13, qn), rng.uniform(-0.1, 0.3, qn)]).astype(np.float32)
+        I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+        c.frames_upload([tuple(q)])
+        for dmax in (1.0, 0.05):
+            idx, d2, cnt = c.knn(0, I, dmax, k, qn)
+            perm = np.empty(n, np.int32)
+            c._chk(capi.lib().velo_map_download(c.h, None, None, None, None, None, None,
+                                                  perm.ctypes.data_as(capi.C.c_void_p), None))
+            win = np.nonzero((mx > 9.9) & (mx < 14.1) & (my > 9.9) & (my < 14.1))[0]
+            wx, wy, wz = (a[win].astype(np.float64) for a in (mx, my, mz))
+            for i in range(qn):
+                e = (wx - float(q[0, i])) ** 2 + (wy - float(q[1, i])) ** 2 + (wz - float(q[2, i])) ** 2
+                inside = np.nonzero(e <= float(np.float32(dmax) * np.float32(dmax)) * (1 + 1e-6))[0]
+                order = inside[np.argsort(e[inside], kind="stable")][:k]
+                m = int(cnt[i])
+                assert abs(m - min(k, inside.size)) <= 1          # a candidate exactly at d_max
+                m = min(m, order.size)
+                got = perm[idx[i, :m]]
+                want = win[order[:m]]
+                same = got == want
+                if not same.all():                                # f32 near-ties may swap neighbours
+                    bad = np.nonzero(~same)[0]
+                    assert np.allclose(d2[i, bad], e[order[bad]], rtol=2e-5, atol=1e-9)
+                assert np.allclose(d2[i, :m], e[order[:m]], rtol=2e-5, atol=1e-9)
+                assert np.all(np.diff(d2[i, :m]) >= 0)
+                assert np.all(idx[i, m:] == -1) if m == cnt[i] else True
+    finally:
+        c.close()
+
+
 def test_huge_extent_lowers_subdivision():
     """A map whose dense fine-cell table would exceed 2^31 entries at the configured
     sub-division is indexed at the largest sub-division that fits (reported in map_info);

@@ -1086,7 +1086,8 @@ int velo_map_download(velo_ctx* c, float* x, float* y, float* z, float* nx, floa
     if (!c) return VELO_E_INVALID;
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
     const size_t n = c->info.n_points;
-    std::vector<float4> h(n);
+    std::vector<float4> h;
+    if (x || y || z || nx || ny || nz) h.resize(n);
     if (x || y || z) {
         HIP_TRY(c, hipMemcpyAsync(h.data(), c->pts.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
