@@ -299,27 +299,62 @@ def main():
     pending = []
     pending_n = 0
 
-    def step(timed):
+    # Exchange step of the path (N > 1), pipelined by one step: the increment of step k is
+    # computed on the device right behind batch k (pose taken from the device, nothing
+    # fetched), and while the GPU works on batch k+1 the host waits for that increment only,
+    # all-gathers it on a side stream and appends it before batch k+2.
+    exchange = world > 1 or args.force_exchange
+    inc2 = [d["inc"], torch.empty_like(d["inc"])] if exchange else None
+    side = torch.cuda.Stream() if exchange else None
+    ev_inc = [torch.cuda.Event(), torch.cuda.Event()] if exchange else None
+    ev_free = [None, None]  # side stream is done reading increment buffer b
+    state = dict(cur=0, prev=None)
+
+    def finish_exchange(buf):
         nonlocal pending, pending_n
+        cnt = ctx.increment_wait()                    # blocks for the increment, not the next batch
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(side):
+            side.wait_event(ev_inc[buf])
+            blocks, counts = exchange_increments(inc2[buf], cnt)
+            got = [b.contiguous() for b in blocks if b.shape[1]]
+            ev_free[buf] = torch.cuda.Event()
+            ev_free[buf].record(side)
+            pending.extend(got)
+            pending_n += sum(counts)
+            if pending_n >= args.rebuild_threshold:
+                allb = torch.cat(pending, dim=1).contiguous()
+                done = torch.cuda.Event()
+                done.record(side)
+                allb.record_stream(main)
+                main.wait_event(done)
+                ctx.map_append_dev(allb[0].data_ptr(), allb[1].data_ptr(), allb[2].data_ptr(),
+                                   allb.shape[1])
+                pending, pending_n = [], 0
+
+    def step(timed):
         ctx.compensate_dev(d["sx"].data_ptr(), d["sy"].data_ptr(), d["sz"].data_ptr(),
                            d["pkt"].data_ptr(), n_q, d["tab"].data_ptr(), d["n_pkt"],
                            d["cx"].data_ptr(), d["cy"].data_ptr(), d["cz"].data_ptr())
         ctx.set_timing(1 if timed else 0)
         ctx.icp_batch_async(d["T0"], args.iters, args.d_max)
-        if world > 1 or args.force_exchange:
-            # exchange step of the path: accepted increment of this rank's first frame of
-            # the round, all-gathered; every replica appends all blocks in rank order
-            res = ctx.icp_batch_fetch()
-            cnt = ctx.increment_dev(0, np.array(list(res[0].T)), 3, d["inc"][0].data_ptr(),
-                                    d["inc"][1].data_ptr(), d["inc"][2].data_ptr())
-            blocks, counts = exchange_increments(d["inc"], cnt)
-            pending.extend(b.contiguous() for b in blocks if b.shape[1])
-            pending_n += sum(counts)
-            if pending_n >= args.rebuild_threshold:
-                allb = torch.cat(pending, dim=1).contiguous()
-                ctx.map_append_dev(allb[0].data_ptr(), allb[1].data_ptr(), allb[2].data_ptr(),
-                                   allb.shape[1])
-                pending, pending_n = [], 0
+        if exchange:
+            if state["prev"] is not None:
+                finish_exchange(state["prev"])        # overlaps with the batch just enqueued
+                state["prev"] = None
+            if not timed:  # (a timed step fetches its events first: see the sampling below)
+                start_increment()
+
+    def start_increment():
+        # accepted increment of this rank's first frame of the round, at its registered pose
+        b = state["cur"]
+        if ev_free[b] is not None:
+            torch.cuda.current_stream().wait_event(ev_free[b])
+        ctx.increment_registered_async(0, 3, inc2[b][0].data_ptr(), inc2[b][1].data_ptr(),
+                                       inc2[b][2].data_ptr())
+        ev_inc[b].record(torch.cuda.current_stream())
+        state["prev"] = b
+        state["cur"] = b ^ 1
 
     for _ in range(args.warmup):
         step(False)
@@ -335,12 +370,17 @@ def main():
             # HIP events on the ctx stream, read back after this step's work is enqueued
             # (fetch synchronises the stream; it is part of the timed region on purpose)
             ctx.icp_batch_fetch()
+            if exchange:
+                start_increment()
             tm_k = ctx.last_timing()
             lin_ms += tm_k["linearize_ms"]
             lin_n += tm_k["linearize_launches"]
             lin_first += tm_k["linearize_first_ms"]
             lin_min = min(lin_min, tm_k["linearize_min_ms"])
             n_samples += 1
+    if exchange and state["prev"] is not None:
+        finish_exchange(state["prev"])                # drain the pipeline inside the timed region
+        state["prev"] = None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -243,6 +243,14 @@ int velo_increment(velo_ctx*, int frame, const double T[12], int min_count, floa
                    float* oz, size_t* n_out);
 int velo_increment_dev(velo_ctx*, int frame, const double T[12], int min_count, float* dox,
                        float* doy, float* doz, size_t* n_out);
+/* Pipelined form for the exchange step: the increment of a frame of the LAST
+ * registration at the pose that registration left on the device -- nothing is fetched, nothing
+ * blocks; outputs are device arrays of at least that frame's size.  velo_increment_wait()
+ * blocks only until the increment itself is done (not for work enqueued after it, e.g. the
+ * next batch) and returns the count. */
+int velo_increment_registered_async(velo_ctx*, int frame, int min_count, float* dox, float* doy,
+                                    float* doz);
+int velo_increment_wait(velo_ctx*, size_t* n_out);
 
 /* per-kernel device time of the last velo_icp_batch* call, HIP events on the ctx
  * stream: [0] linearise kernel total ms, [1] its launch count, [2] solve total ms,

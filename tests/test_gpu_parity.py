@@ -490,6 +490,26 @@ def test_increment_bit_exact(ctx, omap, wl, comp):
         assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gz, oz)
 
 
+def test_increment_of_registered_pose_async(ctx, omap, wl, comp):
+    """Pipelined exchange step: the increment taken at the pose the registration left on the
+    device (no fetch, waits only for itself) equals the oracle's increment at that pose."""
+    import torch
+    ctx.map_reset(*wl["map"], 1.0, 16)
+    ctx.frames_upload(comp)
+    res = ctx.icp_batch([f["T0"] for f in wl["frames"]], 6, 1.0)
+    n = comp[2][0].size
+    buf = torch.empty((3, n), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(capi.VeloError):
+        ctx.increment_wait()                                   # nothing pending
+    ctx.increment_registered_async(2, 3, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr())
+    cnt = ctx.increment_wait()
+    ctx.synchronize()
+    ox, oy, oz = omap.increment(*comp[2], np.array(list(res[2].T)), 3)
+    assert cnt == ox.size and cnt > 0
+    g = buf[:, :cnt].cpu().numpy()
+    assert np.array_equal(g[0], ox) and np.array_equal(g[1], oy) and np.array_equal(g[2], oz)
+
+
 # ------------------------------------------------------ f1: packet decode on the GPU
 def _stream(n_frames, az_start, azimuth_correction=False):
     from veloslam_amd import synth

@@ -69,7 +69,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_evict_outside", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats",
+    "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_wait", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
     "velo_insmeta_write", "velo_insmeta_read", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
@@ -134,6 +134,8 @@ def lib():
     L.velo_decode_to_frames.argtypes = [vp]
     L.velo_increment.argtypes = [vp, C.c_int, dp, C.c_int, vp, vp, vp, C.POINTER(C.c_size_t)]
     L.velo_increment_dev.argtypes = L.velo_increment.argtypes
+    L.velo_increment_registered_async.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.velo_increment_wait.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.velo_last_timing.argtypes = [vp, dp]
     L.velo_set_timing.argtypes = [vp, C.c_int]
     L.velo_matrix_from_pose.argtypes = [dp, dp]
@@ -489,6 +491,14 @@ class Context:
                                        C.byref(cnt)))
         k = cnt.value
         return ox[:k].copy(), oy[:k].copy(), oz[:k].copy()
+
+    def increment_registered_async(self, frame, min_count, pox, poy, poz):
+        self._chk(lib().velo_increment_registered_async(self.h, frame, min_count, pox, poy, poz))
+
+    def increment_wait(self):
+        cnt = C.c_size_t()
+        self._chk(lib().velo_increment_wait(self.h, C.byref(cnt)))
+        return cnt.value
 
     def increment_dev(self, frame, T, min_count, pox, poy, poz):
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)

@@ -101,6 +101,10 @@ struct velo_ctx {
     DevBuf<float> d2;
     DevBuf<uint32_t> flags, offs;
     DevBuf<float> inc_x, inc_y, inc_z;
+    DevBuf<double> inc_pose;
+    uint32_t* h_inc_total = nullptr;  // pinned: count of the asynchronous increment
+    hipEvent_t ev_inc = nullptr;
+    bool inc_pending = false;
     int last_iters = 0;
     // hipGraph replay of the per-registration launch sequence (cfg.use_graph)
     hipGraphExec_t graph_exec = nullptr;
@@ -839,6 +843,8 @@ void velo_destroy(velo_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->h_T0) (void)hipHostFree(c->h_T0);
+    if (c->h_inc_total) (void)hipHostFree(c->h_inc_total);
+    if (c->ev_inc) (void)hipEventDestroy(c->ev_inc);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_call0) (void)hipEventDestroy(c->ev_call0);
     if (c->ev_call1) (void)hipEventDestroy(c->ev_call1);
@@ -1561,6 +1567,28 @@ int velo_knn(velo_ctx* c, int frame, const double T[12], float d_max, int k, int
 }
 
 // ----------------------------------------------------------------- increment
+// flags -> exclusive scan -> order-preserving scatter, all enqueued on the ctx stream; the
+// count lands in *h_total (host memory the caller keeps alive until the stream reaches it)
+static int enqueue_increment(velo_ctx* c, int frame, const double* d_pose, int min_count, float* tx,
+                             float* ty, float* tz, uint32_t* h_total)
+{
+    hipStream_t s = c->stream;
+    const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
+    HIP_TRY(c, c->flags.reserve(n + 1));
+    HIP_TRY(c, c->offs.reserve(n + 1));
+    HIP_TRY(c, launch_increment_flags(c->ax + q0, c->ay + q0, c->az + q0, n, c->mv, d_pose, min_count,
+                                      c->flags.p, s));
+    HIP_TRY(c, hipMemsetAsync(c->flags.p + n, 0, sizeof(uint32_t), s));
+    size_t tb = 0;
+    HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->flags.p, c->offs.p, n + 1, s));
+    if (int rc = ensure_temp(c, tb)) return rc;
+    HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->flags.p, c->offs.p, n + 1, s));
+    HIP_TRY(c, hipMemcpyAsync(h_total, c->offs.p + n, sizeof *h_total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, launch_increment_scatter(c->ax + q0, c->ay + q0, c->az + q0, n, d_pose, c->flags.p,
+                                        c->offs.p, tx, ty, tz, s));
+    return VELO_OK;
+}
+
 static int increment_impl(velo_ctx* c, int frame, const double T[12], int min_count, float* ox,
                           float* oy, float* oz, size_t* n_out, bool dev)
 {
@@ -1569,23 +1597,11 @@ static int increment_impl(velo_ctx* c, int frame, const double T[12], int min_co
     if (frame < 0 || frame >= c->n_frames) return c->fail(VELO_E_INVALID, "frame index out of range");
     if (!T || !n_out) return c->fail(VELO_E_INVALID, "null argument");
     hipStream_t s = c->stream;
-    const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
+    const size_t n = (size_t)(c->frame_start[frame + 1] - c->frame_start[frame]);
     *n_out = 0;
     if (n == 0) return VELO_OK;
-    HIP_TRY(c, c->flags.reserve(n + 1));
-    HIP_TRY(c, c->offs.reserve(n + 1));
-    DevBuf<double> dT;
-    HIP_TRY(c, dT.reserve(12));
-    HIP_TRY(c, hipMemcpyAsync(dT.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, launch_increment_flags(c->ax + q0, c->ay + q0, c->az + q0, n, c->mv, dT.p, min_count,
-                                      c->flags.p, s));
-    HIP_TRY(c, hipMemsetAsync(c->flags.p + n, 0, sizeof(uint32_t), s));
-    size_t tb = 0;
-    HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->flags.p, c->offs.p, n + 1, s));
-    if (int rc = ensure_temp(c, tb)) return rc;
-    HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->flags.p, c->offs.p, n + 1, s));
-    uint32_t total = 0;
-    HIP_TRY(c, hipMemcpyAsync(&total, c->offs.p + n, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, c->inc_pose.reserve(12));
+    HIP_TRY(c, hipMemcpyAsync(c->inc_pose.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
     float *tx = ox, *ty = oy, *tz = oz;
     if (!dev) {
         HIP_TRY(c, c->inc_x.reserve(n));
@@ -1596,8 +1612,8 @@ static int increment_impl(velo_ctx* c, int frame, const double T[12], int min_co
         tz = c->inc_z.p;
     }
     if (!tx || !ty || !tz) return c->fail(VELO_E_INVALID, "null output array");
-    HIP_TRY(c, launch_increment_scatter(c->ax + q0, c->ay + q0, c->az + q0, n, dT.p, c->flags.p,
-                                        c->offs.p, tx, ty, tz, s));
+    uint32_t total = 0;
+    if (int rc = enqueue_increment(c, frame, c->inc_pose.p, min_count, tx, ty, tz, &total)) return rc;
     HIP_TRY(c, hipStreamSynchronize(s));
     if (!dev && total) {
         if (!ox || !oy || !oz) return c->fail(VELO_E_INVALID, "null output array");
@@ -1606,6 +1622,42 @@ static int increment_impl(velo_ctx* c, int frame, const double T[12], int min_co
         HIP_TRY(c, hipMemcpy(oz, tz, total * sizeof(float), hipMemcpyDeviceToHost));
     }
     *n_out = total;
+    return VELO_OK;
+}
+
+int velo_increment_registered_async(velo_ctx* c, int frame, int min_count, float* dox, float* doy,
+                                    float* doz)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
+    if (frame < 0 || frame >= c->n_frames) return c->fail(VELO_E_INVALID, "frame index out of range");
+    if (c->last_iters < 1) return c->fail(VELO_E_INVALID, "no registration has run");
+    if (!dox || !doy || !doz) return c->fail(VELO_E_INVALID, "null output array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->h_inc_total) {
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_inc_total, sizeof(uint32_t), 0));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_inc, hipEventDisableTiming));
+    }
+    *c->h_inc_total = 0;
+    c->inc_pending = false;
+    if (c->frame_start[frame + 1] > c->frame_start[frame]) {
+        // the pose the registration left on the device: no host round trip before the increment
+        if (int rc = enqueue_increment(c, frame, c->poses.p + 12 * (size_t)frame, min_count, dox, doy,
+                                       doz, c->h_inc_total))
+            return rc;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_inc, c->stream));
+    c->inc_pending = true;
+    return VELO_OK;
+}
+
+int velo_increment_wait(velo_ctx* c, size_t* n_out)
+{
+    if (!c || !n_out) return VELO_E_INVALID;
+    if (!c->inc_pending) return c->fail(VELO_E_INVALID, "no asynchronous increment is pending");
+    HIP_TRY(c, hipEventSynchronize(c->ev_inc));  // only this event: later work keeps running
+    c->inc_pending = false;
+    *n_out = *c->h_inc_total;
     return VELO_OK;
 }
 
