@@ -316,7 +316,7 @@ class Context:
         out = (C.c_uint64 * 8)()
         self._chk(lib().velo_debug_search_stats(self.h, out, int(reset)))
         return dict(zip(("live", "certified", "searched", "empty_skips", "stage_a_final",
-                         "stage_b_lane", "stage_b_coop", "valid_pairs"), [int(v) for v in out]))
+                         "unused", "stage_b", "valid_pairs"), [int(v) for v in out]))
 
     def synchronize(self):
         self._chk(lib().velo_synchronize(self.h))
