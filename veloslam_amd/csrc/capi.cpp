@@ -72,7 +72,8 @@ struct velo_ctx {
     DevBuf<float4> pts_alt, nrm_alt, nrm_raw;
     DevBuf<uint8_t> dirty, vox_occ, vox_near;
     DevBuf<int32_t> work;
-    DevBuf<unsigned> work_cnt;
+    DevBuf<unsigned> work_cnt;  // [0] work-list length, [1] normals re-estimated
+    unsigned n_done_host = 0;
     float map_mx[3] = {0, 0, 0};  // component-wise max of the map points
     DevBuf<char> temp;
     MapView mv{};
@@ -183,18 +184,25 @@ hipError_t reserve_slack(DevBuf<T>& b, size_t n)
 }
 
 // normals of the points in dirty voxels, after the sorted arrays were updated in place
-int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, unsigned* n_work_out)
+// chg_keys: sorted fine keys of the added / removed points (nullptr: re-estimate every point of
+// the dirty voxels).  The number of normals really re-estimated lands in c->n_done_host once
+// the stream has been synchronised.
+int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, const uint32_t* chg_keys,
+                          uint32_t n_chg)
 {
     hipStream_t s = c->stream;
     HIP_TRY(c, reserve_slack(c->work, (size_t)mv.n));
-    HIP_TRY(c, c->work_cnt.reserve(1));
+    HIP_TRY(c, c->work_cnt.reserve(2));
+    HIP_TRY(c, hipMemsetAsync(c->work_cnt.p, 0, 2 * sizeof(unsigned), s));
     HIP_TRY(c, launch_select_dirty(c->keys_sorted.p, (uint32_t)mv.n, mv, c->dirty.p, c->work.p,
                                    c->work_cnt.p, s));
     unsigned n_work = 0;
     HIP_TRY(c, hipMemcpyAsync(&n_work, c->work_cnt.p, sizeof n_work, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    HIP_TRY(c, launch_normals_subset(mv, c->perm.p, k, c->work.p, (int)n_work, c->nrm.p, c->invalid_cnt.p, s));
-    *n_work_out = n_work;
+    HIP_TRY(c, launch_normals_subset(mv, c->perm.p, k, c->work.p, (int)n_work, chg_keys, n_chg,
+                                     c->nrm.p, c->invalid_cnt.p, c->work_cnt.p + 1, s));
+    HIP_TRY(c, hipMemcpyAsync(&c->n_done_host, c->work_cnt.p + 1, sizeof(unsigned),
+                              hipMemcpyDeviceToHost, s));
     return VELO_OK;
 }
 
@@ -348,12 +356,11 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
         if (carry->removed_keep)
             HIP_TRY(c, launch_mark_dirty_pts(old_pts, nullptr, carry->removed_keep, carry->removed_n,
                                              mv, c->dirty.p, s));
-        unsigned n_work = 0;
-        if (int rc = refresh_dirty_normals(c, mv, k_normals, &n_work)) return rc;
+        if (int rc = refresh_dirty_normals(c, mv, k_normals, nullptr, 0)) return rc;
         HIP_TRY(c, launch_count_invalid(c->nrm.p, (uint32_t)n, c->invalid_cnt.p, s));
         HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
-        return publish_map(c, mv, k_normals, invalid, 0, n_work);
+        return publish_map(c, mv, k_normals, invalid, 0, c->n_done_host);
     }
     if (k_normals > 0) {
         HIP_TRY(c, launch_normals(mv, c->perm.p, k_normals, c->nrm.p, c->invalid_cnt.p, s));
@@ -472,19 +479,19 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     g.cell_start = c->cell_start.p;
     g.n = (int)total;
     unsigned long long invalid = total;
-    unsigned n_work = 0;
+    c->n_done_host = 0;
     if (k > 0) {
         const size_t nvox = (size_t)dims[0] * dims[1] * dims[2];
         HIP_TRY(c, reserve_slack(c->dirty, nvox));
         HIP_TRY(c, hipMemsetAsync(c->dirty.p, 0, nvox, s));
         HIP_TRY(c, launch_mark_dirty(c->nk_sorted.p, (uint32_t)m, nullptr, g, c->dirty.p, s));
-        if (int rc = refresh_dirty_normals(c, g, k, &n_work)) return rc;
+        if (int rc = refresh_dirty_normals(c, g, k, c->nk_sorted.p, (uint32_t)m)) return rc;
         HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     for (int a = 0; a < 3; ++a) c->map_mx[a] = mx[a];
     *done = 1;
-    return publish_map(c, g, k, invalid, 1, n_work);
+    return publish_map(c, g, k, invalid, 1, c->n_done_host);
 }
 
 
@@ -1045,6 +1052,8 @@ int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
         HIP_TRY(c, reserve_slack(c->dirty, nvox));
         HIP_TRY(c, hipMemsetAsync(c->dirty.p, 0, nvox, s));
         HIP_TRY(c, launch_mark_dirty(c->keys_sorted.p, n, c->flags.p, old, c->dirty.p, s));
+        HIP_TRY(c, reserve_slack(c->nk_sorted, n - kept));  // sorted keys of the removed points
+        HIP_TRY(c, launch_removed_keys(c->keys_sorted.p, c->flags.p, c->offs.p, n, c->nk_sorted.p, s));
     }
     HIP_TRY(c, launch_compact_sorted(c->pts.p, c->nrm.p, c->perm.p, c->keys_sorted.p, n, c->flags.p,
                                      c->offs.p, c->roffs.p, c->pts_alt.p, c->nrm_alt.p,
@@ -1067,15 +1076,15 @@ int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
     g.cell_start = c->cell_start.p;
     g.n = (int)kept;
     unsigned long long invalid = kept;
-    unsigned n_work = 0;
+    c->n_done_host = 0;
     if (k > 0) {
-        if (int rc = refresh_dirty_normals(c, g, k, &n_work)) return rc;
+        if (int rc = refresh_dirty_normals(c, g, k, c->nk_sorted.p, n - kept)) return rc;
         HIP_TRY(c, launch_count_invalid(c->nrm.p, kept, c->invalid_cnt.p, s));
         HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     for (int a = 0; a < 3; ++a) c->map_mx[a] = mm.mx[a];
-    return publish_map(c, g, k, invalid, 1, n_work);
+    return publish_map(c, g, k, invalid, 1, c->n_done_host);
 }
 
 int velo_map_info_get(velo_ctx* c, velo_map_info* out)

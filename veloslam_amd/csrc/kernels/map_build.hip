@@ -287,14 +287,18 @@ __device__ __forceinline__ int collect_knn(const MapView& mv, const uint32_t* __
     return cnt;
 }
 
-// PCA normal of sorted point s: {0,0,0,0} = invalid (fewer than kMinNb neighbours within h)
+// PCA normal of sorted point s: xyz = {0,0,0} = invalid (fewer than kMinNb neighbours within
+// h).  w carries the squared distance of the k-th neighbour used (h^2 when the list is not
+// full): a point added or removed further away than that cannot change this normal, which is
+// what the incremental update tests before re-estimating (w < 0 marks "no normal yet").
 __device__ __forceinline__ float4 point_normal(const MapView& mv, const uint32_t* __restrict__ perm,
                                                int s, int k, float (*s_d)[kNrmThreads],
                                                int (*s_i)[kNrmThreads], int tid)
 {
     const float4 q = mv.pts[s];
     const int cnt = collect_knn<true>(mv, perm, q.x, q.y, q.z, mv.h * mv.h, k, s_d, s_i, tid);
-    if (cnt < kMinNb) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float rk2 = cnt == k ? s_d[k - 1][tid] : mv.h * mv.h;
+    if (cnt < kMinNb) return make_float4(0.f, 0.f, 0.f, rk2);
     double mx = 0, my = 0, mz = 0;
     for (int i = 0; i < cnt; ++i) {
         const float4 p = mv.pts[s_i[i][tid]];
@@ -338,7 +342,7 @@ __device__ __forceinline__ float4 point_normal(const MapView& mv, const uint32_t
         vy = -vy;
         vz = -vz;
     }
-    return make_float4((float)vx, (float)vy, (float)vz, 0.0f);
+    return make_float4((float)vx, (float)vy, (float)vz, rk2);
 }
 
 __device__ __forceinline__ bool is_zero3(const float4& v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f; }
@@ -358,12 +362,45 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv,
     if (is_zero3(nv)) atomicAdd(invalid, 1ull);
 }
 
-// Incremental update: recompute the normals of the listed sorted points only.  nrm[] holds
-// the previous normal of every surviving point and {0,0,0,1} for points that are new, so
-// the invalid-normal count is maintained by difference (two's complement add).
+// Is a changed (added / removed) point possibly within sqrt(rk2) of p?  chg = sorted fine keys
+// of the changed points; one binary search per fine row that the ball touches.  Conservative.
+__device__ __forceinline__ bool near_changed(const MapView& mv, const float4& p, float rk2,
+                                             const uint32_t* __restrict__ chg, uint32_t m)
+{
+    const float inv_hf = mv.inv_h * (float)mv.S;
+    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+    const float r = (sqrtf(rk2) * 1.00001f + 2.0f * mg) * inv_hf;  // fine-cell units
+    const float ux = (p.x - mv.ox) * inv_hf, uy = (p.y - mv.oy) * inv_hf, uz = (p.z - mv.oz) * inv_hf;
+    const int x0 = max((int)floorf(ux - r), 0), x1 = min((int)floorf(ux + r), mv.fx - 1);
+    const int y0 = max((int)floorf(uy - r), 0), y1 = min((int)floorf(uy + r), mv.fy - 1);
+    const int z0 = max((int)floorf(uz - r), 0), z1 = min((int)floorf(uz + r), mv.fz - 1);
+    if (x0 > x1) return false;
+    for (int fz = z0; fz <= z1; ++fz)
+        for (int fy = y0; fy <= y1; ++fy) {
+            const uint32_t klo = (uint32_t)(((size_t)fz * mv.fy + fy) * mv.fx + x0);
+            const uint32_t khi = klo + (uint32_t)(x1 - x0);
+            uint32_t lo = 0, hi = m;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (chg[mid] < klo)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            if (lo < m && chg[lo] <= khi) return true;
+        }
+    return false;
+}
+
+// Incremental update: re-estimate the normals of the listed sorted points only.  nrm[] holds
+// the previous normal of every surviving point (w = squared reach of its neighbour list) and
+// w < 0 for points that are new.  A listed point whose reach no changed point can touch keeps
+// its normal untouched (chg == nullptr: no such test).  The invalid-normal count is
+// maintained by difference (two's complement add).
 __global__ __launch_bounds__(kNrmThreads) void k_normals_subset(
     MapView mv, const uint32_t* __restrict__ perm, int k, const int32_t* __restrict__ work,
-    int n_work, float4* __restrict__ nrm, unsigned long long* __restrict__ invalid)
+    int n_work, const uint32_t* __restrict__ chg, uint32_t n_chg, float4* __restrict__ nrm,
+    unsigned long long* __restrict__ invalid, unsigned* __restrict__ n_done)
 {
     __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
     __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
@@ -372,11 +409,24 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals_subset(
     if (w >= n_work) return;
     const int s = work[w];
     const float4 old = nrm[s];
+    if (chg && old.w >= 0.0f && !near_changed(mv, mv.pts[s], old.w, chg, n_chg)) return;
     const float4 nv = point_normal(mv, perm, s, k, s_d, s_i, tid);
     nrm[s] = nv;
-    const int was = (old.w == 0.0f && is_zero3(old)) ? 1 : 0;
+    const int was = (old.w >= 0.0f && is_zero3(old)) ? 1 : 0;
     const int now = is_zero3(nv) ? 1 : 0;
     if (now != was) atomicAdd(invalid, (unsigned long long)(long long)(now - was));
+    if (n_done) atomicAdd(n_done, 1u);
+}
+
+// sorted fine keys of the points an eviction removes (keep == 0), compacted in order
+__global__ __launch_bounds__(256) void k_removed_keys(const uint32_t* __restrict__ keys,
+                                                      const uint32_t* __restrict__ keep,
+                                                      const uint32_t* __restrict__ offs, uint32_t n,
+                                                      uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || keep[i]) return;
+    out[i - offs[i]] = keys[i];  // offs = kept points before i
 }
 
 // a10 with k > 1: the k nearest map points of every (transformed) query within d_max,
@@ -504,7 +554,7 @@ __global__ __launch_bounds__(256) void k_merge_new(
     const uint32_t d = upper_bound_u32(keys_old, n, key) + j;
     const uint32_t r = raw_base + nidx[j];
     pts2[d] = make_float4(rx[r], ry[r], rz[r], 0.0f);
-    nrm2[d] = make_float4(0.f, 0.f, 0.f, 1.0f);  // w = 1: "no previous normal"
+    nrm2[d] = make_float4(0.f, 0.f, 0.f, -1.0f);  // w < 0: "no normal yet"
     perm2[d] = r;
     keys2[d] = key;
 }
@@ -724,12 +774,23 @@ hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& 
 }
 
 hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
-                                 const int32_t* work, int n_work, float4* nrm,
-                                 unsigned long long* d_invalid, hipStream_t s)
+                                 const int32_t* work, int n_work, const uint32_t* chg_keys,
+                                 uint32_t n_chg, float4* nrm, unsigned long long* d_invalid,
+                                 unsigned* d_done, hipStream_t s)
 {
     if (n_work <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_normals_subset, dim3((n_work + kNrmThreads - 1) / kNrmThreads),
-                       dim3(kNrmThreads), 0, s, mv, perm, k, work, n_work, nrm, d_invalid);
+                       dim3(kNrmThreads), 0, s, mv, perm, k, work, n_work, chg_keys, n_chg, nrm,
+                       d_invalid, d_done);
+    return hipGetLastError();
+}
+
+hipError_t launch_removed_keys(const uint32_t* keys, const uint32_t* keep, const uint32_t* offs,
+                               uint32_t n, uint32_t* out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_removed_keys, dim3((n + 255) / 256), dim3(256), 0, s, keys, keep, offs, n,
+                       out);
     return hipGetLastError();
 }
 
@@ -801,7 +862,7 @@ __global__ __launch_bounds__(256) void k_scatter_nrm_raw(const float4* __restric
 __global__ __launch_bounds__(256) void k_fill_fresh(float4* __restrict__ nrm_raw, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) nrm_raw[i] = make_float4(0.f, 0.f, 0.f, 1.0f);
+    if (i < n) nrm_raw[i] = make_float4(0.f, 0.f, 0.f, -1.0f);
 }
 __global__ __launch_bounds__(256) void k_gather_nrm(const float4* __restrict__ nrm_raw,
                                                     const uint32_t* __restrict__ perm, uint32_t n,
@@ -810,7 +871,7 @@ __global__ __launch_bounds__(256) void k_gather_nrm(const float4* __restrict__ n
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < n) nrm[s] = nrm_raw[perm[s]];
 }
-// mark the 27 voxels around points chosen by position: mode 0 = nrm[i].w == 1 (fresh points
+// mark the 27 voxels around points chosen by position: mode 0 = nrm[i].w < 0 (fresh points
 // of the new order), mode 1 = keep[i] == 0 (removed points of the old order; they may lie
 // outside the new grid)
 __global__ __launch_bounds__(256) void k_mark_dirty_pts(const float4* __restrict__ pts,
@@ -821,7 +882,7 @@ __global__ __launch_bounds__(256) void k_mark_dirty_pts(const float4* __restrict
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (nrm ? nrm[i].w != 1.0f : keep[i] != 0u) return;
+    if (nrm ? nrm[i].w >= 0.0f : keep[i] != 0u) return;
     const float4 p = pts[i];
     const int vx = cell_coord(p.x, g.ox, g.inv_h, g.nx);
     const int vy = cell_coord(p.y, g.oy, g.inv_h, g.ny);

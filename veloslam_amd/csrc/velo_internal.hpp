@@ -87,8 +87,11 @@ hipError_t launch_mark_dirty(const uint32_t* keys, uint32_t m, const uint32_t* s
 hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& grid,
                                const uint8_t* dirty, int32_t* work, unsigned* count, hipStream_t s);
 hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
-                                 const int32_t* work, int n_work, float4* nrm,
-                                 unsigned long long* d_invalid, hipStream_t s);
+                                 const int32_t* work, int n_work, const uint32_t* chg_keys,
+                                 uint32_t n_chg, float4* nrm, unsigned long long* d_invalid,
+                                 unsigned* d_done, hipStream_t s);
+hipError_t launch_removed_keys(const uint32_t* keys, const uint32_t* keep, const uint32_t* offs,
+                               uint32_t n, uint32_t* out, hipStream_t s);
 hipError_t launch_count_invalid(const float4* nrm, uint32_t n, unsigned long long* d_invalid,
                                 hipStream_t s);
 hipError_t launch_keep_flags(const float4* pts, const float* x, const float* y, const float* z,
