@@ -72,7 +72,8 @@ def parse():
     ap.add_argument("--stream-frames", type=int, default=24, help="distinct synthetic frames (cycled)")
     ap.add_argument("--half-box", type=float, default=45.0, help="rolling map: kept half-extent in x around the sensor (m)")
     ap.add_argument("--evict-every", type=int, default=5)
-    ap.add_argument("--map-margin", type=int, default=16)
+    ap.add_argument("--map-margin", type=int, default=16, help="stream: grid slack in x/y, voxels")
+    ap.add_argument("--map-margin-z", type=int, default=2, help="stream: grid slack in z, voxels")
     ap.add_argument("--full-rebuild", action="store_true", help="stream: re-sort the whole map on every update (A/B)")
     return ap.parse_args()
 
@@ -100,6 +101,7 @@ def run_stream(args, dev, local):
                        use_hints=0 if args.no_hints else args.hints,
                        use_graph=0 if args.no_graph else 1)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.map_set_margins(args.map_margin, args.map_margin, args.map_margin_z)
 
     def box(f):
         cx = f["Tt"][3]
@@ -173,7 +175,7 @@ def run_stream(args, dev, local):
                                   "the sensor" % (args.iters, args.evict_every, args.half_box),
                       "map_points_mean": counts["map"] / max(args.steps, 1),
                       "map_update": "full rebuild" if args.full_rebuild else "incremental",
-                      "map_margin_voxels": args.map_margin},
+                      "map_margin_voxels": [args.map_margin, args.map_margin, args.map_margin_z]},
            "pairs_per_s": counts["pairs"] / elapsed,
            "stage_ms_per_frame": {k: 1e3 * v / args.steps for k, v in stage.items()},
            "map_update_ms": {k: {"n": len(v), "mean": float(np.mean(v)), "max": float(np.max(v))}

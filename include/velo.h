@@ -145,6 +145,10 @@ int velo_map_append_dev(velo_ctx*, const float* dx, const float* dy, const float
  * survivors is kept.  Refused (VELO_E_INVALID, map unchanged) if nothing would remain.  The
  * grid is re-anchored when the lowest survivor is >= 2*margin+2 voxels above the origin. */
 int velo_map_evict_outside(velo_ctx*, const float lo[3], const float hi[3]);
+/* Per-axis grid slack in voxels (cfg.map_margin sets all three): a vehicle wants tens of
+ * voxels in x/y and one or two in z -- the dense fine-cell table grows with the product.
+ * Takes effect at the next (re-)anchoring: velo_map_reset, or the rules above. */
+int velo_map_set_margins(velo_ctx*, const int32_t margin[3]);
 int velo_map_info_get(velo_ctx*, velo_map_info* out);
 /* Test / inspection: copy the voxel-sorted map back.  Any pointer may be NULL.
  * perm[s] = index of sorted point s in append order; cell_start has n_cells+1 entries. */

@@ -349,7 +349,7 @@ size_t vo_map_num_cells(const vo_map* m) { return m->ncell; }
 
 /* ---- rolling map (BASELINE configs[2]) ---------------------------------------
  * State: the raw point list in insertion order, a sticky grid (origin o, voxel dims) and a
- * margin of M voxels.  After every operation the map equals
+ * margin of M voxels (one value per axis: a vehicle needs slack in x/y, hardly any in z).  After every operation the map equals
  * vo_map_build_grid(raw list, o, dims): the GPU's incremental update is held to that.
  *   anchor   o = min - M*h (float), dims = floorf((max - o)*inv_h) + 1 + M
  *   append   if a new point lies below o on some axis -> anchor on the whole list; else o
@@ -362,7 +362,7 @@ struct vo_roll {
     float *x, *y, *z;
     size_t n, cap;
     float h;
-    int k, S, M;
+    int k, S, M[3]; /* margin per axis, voxels */
     float o[3];
     int dims[3];
     vo_map* map;
@@ -387,8 +387,8 @@ static void roll_anchor(vo_roll* r, const float mn[3], const float mx[3])
 {
     const float inv_h = 1.0f / r->h;
     for (int a = 0; a < 3; ++a) {
-        r->o[a] = mn[a] - (float)r->M * r->h;
-        r->dims[a] = (int)floorf((mx[a] - r->o[a]) * inv_h) + 1 + r->M;
+        r->o[a] = mn[a] - (float)r->M[a] * r->h;
+        r->dims[a] = (int)floorf((mx[a] - r->o[a]) * inv_h) + 1 + r->M[a];
     }
 }
 
@@ -415,12 +415,19 @@ static void roll_reserve(vo_roll* r, size_t n)
 vo_roll* vo_roll_new(const float* x, const float* y, const float* z, size_t n, float voxel,
                      int k_normals, int subdiv, int margin)
 {
-    if (n == 0 || margin < 0) return NULL;
+    const int m3[3] = {margin, margin, margin};
+    return vo_roll_new3(x, y, z, n, voxel, k_normals, subdiv, m3);
+}
+
+vo_roll* vo_roll_new3(const float* x, const float* y, const float* z, size_t n, float voxel,
+                      int k_normals, int subdiv, const int margin[3])
+{
+    if (n == 0 || margin[0] < 0 || margin[1] < 0 || margin[2] < 0) return NULL;
     vo_roll* r = (vo_roll*)calloc(1, sizeof *r);
     r->h = voxel;
     r->k = k_normals;
     r->S = subdiv;
-    r->M = margin;
+    memcpy(r->M, margin, sizeof r->M);
     roll_reserve(r, n);
     memcpy(r->x, x, n * sizeof(float));
     memcpy(r->y, y, n * sizeof(float));
@@ -468,7 +475,7 @@ int vo_roll_append(vo_roll* r, const float* x, const float* y, const float* z, s
         const float inv_h = 1.0f / r->h;
         for (int a = 0; a < 3; ++a) {
             const int need = (int)floorf((mx[a] - r->o[a]) * inv_h) + 1;
-            if (need > r->dims[a]) r->dims[a] = need + r->M;
+            if (need > r->dims[a]) r->dims[a] = need + r->M[a];
         }
     }
     if (roll_rebuild(r)) return -1;
@@ -499,7 +506,7 @@ int vo_roll_evict_outside(vo_roll* r, const float lo[3], const float hi[3])
     const float inv_h = 1.0f / r->h;
     int anchor = 0;
     for (int a = 0; a < 3; ++a)
-        if (floorf((mn[a] - r->o[a]) * inv_h) >= (float)(2 * r->M + 2)) anchor = 1;
+        if (floorf((mn[a] - r->o[a]) * inv_h) >= (float)(2 * r->M[a] + 2)) anchor = 1;
     if (anchor) roll_anchor(r, mn, mx);
     if (roll_rebuild(r)) return -1;
     return anchor ? 1 : 2;

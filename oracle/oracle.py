@@ -111,6 +111,8 @@ def lib():
     L.vo_map_build_grid.restype = C.c_void_p
     L.vo_roll_new.argtypes = [fp, fp, fp, C.c_size_t, C.c_float, C.c_int, C.c_int, C.c_int]
     L.vo_roll_new.restype = C.c_void_p
+    L.vo_roll_new3.argtypes = [fp, fp, fp, C.c_size_t, C.c_float, C.c_int, C.c_int, ip]
+    L.vo_roll_new3.restype = C.c_void_p
     L.vo_roll_free.argtypes = [C.c_void_p]
     L.vo_roll_map.argtypes = [C.c_void_p]
     L.vo_roll_map.restype = C.c_void_p
@@ -435,8 +437,9 @@ class RollingMap:
 
     def __init__(self, x, y, z, voxel=1.0, k_normals=16, subdiv=3, margin=0):
         x, y, z = _f32(x), _f32(y), _f32(z)
-        self.r = lib().vo_roll_new(_f(x), _f(y), _f(z), x.size, float(voxel), int(k_normals),
-                                   int(subdiv), int(margin))
+        m3 = np.ascontiguousarray(np.broadcast_to(np.asarray(margin, np.int32), (3,)))
+        self.r = lib().vo_roll_new3(_f(x), _f(y), _f(z), x.size, float(voxel), int(k_normals),
+                                    int(subdiv), _i(m3))
         if not self.r:
             raise ValueError("vo_roll_new failed")
 

@@ -134,6 +134,8 @@ void vo_map_free(vo_map*);
 typedef struct vo_roll vo_roll;
 vo_roll* vo_roll_new(const float* x, const float* y, const float* z, size_t n, float voxel,
                      int k_normals, int subdiv, int margin);
+vo_roll* vo_roll_new3(const float* x, const float* y, const float* z, size_t n, float voxel,
+                      int k_normals, int subdiv, const int margin[3]);
 void vo_roll_free(vo_roll*);
 const vo_map* vo_roll_map(const vo_roll*);
 size_t vo_roll_size(const vo_roll*);

@@ -159,7 +159,8 @@ def _assert_map_equal(ctx, om):
     assert mi.n_invalid_normals == int(((nn[0] == 0) & (nn[1] == 0) & (nn[2] == 0)).sum())
 
 
-@pytest.mark.parametrize("margin,full,k", [(0, 0, 8), (2, 0, 8), (2, 1, 8), (5, 0, 16), (3, 0, 0)])
+@pytest.mark.parametrize("margin,full,k", [(0, 0, 8), (2, 0, 8), (2, 1, 8), (5, 0, 16), (3, 0, 0),
+                                           ((3, 3, 1), 0, 8)])
 def test_rolling_map_incremental_equals_fresh_build(oracle, margin, full, k):
     """f3 / BASELINE configs[2]: appends and evictions update the sorted map in place (merge,
     shifted cell table, normals re-estimated only near changed points).  After every
@@ -171,10 +172,16 @@ def test_rolling_map_incremental_equals_fresh_build(oracle, margin, full, k):
     q = rng.uniform(-1, 14, (3, 3000)).astype(np.float32)
     q[2] *= 0.25
     I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
-    c = capi.Context(0, max_batch=2, map_margin=margin, map_full_rebuild=full)
+    margins = margin
+    if isinstance(margin, tuple):        # per-axis slack; the scenario below moves along x only
+        c = capi.Context(0, max_batch=2, map_full_rebuild=full)
+        c.map_set_margins(*margin)
+        margin = margin[0]
+    else:
+        c = capi.Context(0, max_batch=2, map_margin=margin, map_full_rebuild=full)
     try:
         c.map_reset(*base, 1.0, k)
-        roll = oracle.RollingMap(*base, 1.0, k, 3, margin=margin)
+        roll = oracle.RollingMap(*base, 1.0, k, 3, margin=margins)
         _assert_map_equal(c, roll.map)
         assert c.map_info().last_update == 0
 

@@ -66,7 +66,7 @@ class MapInfo(C.Structure):
 EXPORTS = [
     "velo_create", "velo_destroy", "velo_last_error", "velo_abi_version", "velo_set_stream",
     "velo_synchronize", "velo_map_reset", "velo_map_reset_dev", "velo_map_append",
-    "velo_map_append_dev", "velo_map_evict_outside", "velo_map_info_get", "velo_map_download", "velo_compensate",
+    "velo_map_append_dev", "velo_map_evict_outside", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
     "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_wait", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats",
@@ -113,6 +113,7 @@ def lib():
     L.velo_map_append.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.velo_map_append_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.velo_map_evict_outside.argtypes = [vp, vp, vp]
+    L.velo_map_set_margins.argtypes = [vp, vp]
     L.velo_debug_search_stats.argtypes = [vp, vp, C.c_int]
     L.velo_map_info_get.argtypes = [vp, C.POINTER(MapInfo)]
     L.velo_map_download.argtypes = [vp] + [vp] * 8
@@ -345,6 +346,10 @@ class Context:
 
     def map_append_dev(self, px, py, pz, n):
         self._chk(lib().velo_map_append_dev(self.h, px, py, pz, n))
+
+    def map_set_margins(self, mx, my, mz):
+        m = np.array([mx, my, mz], np.int32)
+        self._chk(lib().velo_map_set_margins(self.h, _p(m)))
 
     def map_evict_outside(self, lo, hi):
         lo = np.ascontiguousarray(lo, np.float32)

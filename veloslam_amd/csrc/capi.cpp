@@ -75,6 +75,7 @@ struct velo_ctx {
     DevBuf<unsigned> work_cnt;  // [0] work-list length, [1] normals re-estimated
     unsigned n_done_host = 0;
     float map_mx[3] = {0, 0, 0};  // component-wise max of the map points
+    int margin[3] = {0, 0, 0};    // grid slack per axis, voxels (cfg.map_margin / velo_map_set_margins)
     DevBuf<char> temp;
     MapView mv{};
     bool has_map = false;
@@ -271,8 +272,8 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     int dims[3];
     float org[3];
     double ncell_d = 1.0;
-    const int M = c->cfg.map_margin;
     for (int a = 0; a < 3; ++a) {
+        const int M = c->margin[a];
         if (!std::isfinite(mm.mn[a]) || !std::isfinite(mm.mx[a]))
             return c->fail(VELO_E_INVALID, "map points must be finite");
         // anchor (oracle/icp.c roll_anchor): M voxels of slack below the lowest point and above
@@ -397,7 +398,6 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     hipStream_t s = c->stream;
     const MapView old = c->mv;
     const int k = c->info.k_normals;
-    const int M = c->cfg.map_margin;
     if (n_old + m >= (size_t)INT32_MAX) return c->fail(VELO_E_RANGE, "map larger than 2^31-1 points");
     HIP_TRY(c, c->mm_scratch.reserve(8));
     MinMax mm;
@@ -416,7 +416,7 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
         if (!(ext < 2.0e9f)) return c->fail(VELO_E_RANGE, "map extent / voxel too large");
         const int need = (int)ext + 1;
         if (need > dims[a]) {
-            dims[a] = need + M;
+            dims[a] = need + c->margin[a];
             grew = true;
         }
     }
@@ -833,6 +833,8 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
         c->cfg.use_hints = 2;
         c->cfg.use_graph = 1;
     }
+    if (c->cfg.map_margin < 0) c->cfg.map_margin = 0;
+    for (int a = 0; a < 3; ++a) c->margin[a] = c->cfg.map_margin;
     if (c->cfg.map_subdiv <= 0) c->cfg.map_subdiv = 3;
     if (c->cfg.map_subdiv > 16) c->cfg.map_subdiv = 16;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -981,7 +983,6 @@ int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
     const MapView old = c->mv;
     const uint32_t n = (uint32_t)c->raw_n;
     const int k = c->info.k_normals;
-    const int M = c->cfg.map_margin;
     // keep flags + exclusive scans, in sorted order and in append order
     HIP_TRY(c, reserve_slack(c->flags, n));
     HIP_TRY(c, reserve_slack(c->offs, n));
@@ -1013,7 +1014,7 @@ int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
     const float org[3] = {old.ox, old.oy, old.oz};
     bool anchor = false;
     for (int a = 0; a < 3; ++a)
-        if (floorf((mm.mn[a] - org[a]) * old.inv_h) >= (float)(2 * M + 2)) anchor = true;
+        if (floorf((mm.mn[a] - org[a]) * old.inv_h) >= (float)(2 * c->margin[a] + 2)) anchor = true;
     auto swap_raw = [&]() {
         std::swap(c->raw_x.p, c->raw_x2.p);
         std::swap(c->raw_x.cap, c->raw_x2.cap);
@@ -1085,6 +1086,15 @@ int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
     HIP_TRY(c, hipStreamSynchronize(s));
     for (int a = 0; a < 3; ++a) c->map_mx[a] = mm.mx[a];
     return publish_map(c, g, k, invalid, 1, c->n_done_host);
+}
+
+int velo_map_set_margins(velo_ctx* c, const int32_t margin[3])
+{
+    if (!c || !margin) return VELO_E_INVALID;
+    for (int a = 0; a < 3; ++a)
+        if (margin[a] < 0 || margin[a] > 100000) return c->fail(VELO_E_INVALID, "margin out of range");
+    for (int a = 0; a < 3; ++a) c->margin[a] = margin[a];
+    return VELO_OK;
 }
 
 int velo_map_info_get(velo_ctx* c, velo_map_info* out)
