@@ -276,11 +276,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    # (functional check of the N > 1 path on a one-GPU box: VELO_BENCH_ONE_DEVICE=1 puts every
+    # rank on device 0 and uses gloo -- RCCL refuses two ranks on one device.  Not a measurement.)
+    one_dev = os.environ.get("VELO_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.workload == "stream":
         if world > 1:

@@ -18,15 +18,18 @@ def exchange_increments(inc_xyz, count, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return [inc_xyz[:, :count]], [int(count)]
     world = dist.get_world_size(group)
-    cnt = torch.tensor([int(count)], dtype=torch.int32, device=inc_xyz.device)
-    counts = torch.zeros(world, dtype=torch.int32, device=inc_xyz.device)
+    # gloo (CPU tests, one-GPU functional checks) gathers host tensors; nccl = RCCL gathers in HBM
+    cdev = inc_xyz.device if dist.get_backend(group) != "gloo" else torch.device("cpu")
+    cnt = torch.tensor([int(count)], dtype=torch.int32, device=cdev)
+    counts = torch.zeros(world, dtype=torch.int32, device=cdev)
     dist.all_gather_into_tensor(counts, cnt, group=group)
     counts_h = [int(v) for v in counts.cpu().tolist()]
     pad = max(max(counts_h), 1)
-    send = torch.zeros((3, pad), dtype=torch.float32, device=inc_xyz.device)
-    send[:, :count] = inc_xyz[:, :count]
-    recv = torch.empty((world, 3, pad), dtype=torch.float32, device=inc_xyz.device)
+    send = torch.zeros((3, pad), dtype=torch.float32, device=cdev)
+    send[:, :count] = inc_xyz[:, :count].to(cdev)
+    recv = torch.empty((world, 3, pad), dtype=torch.float32, device=cdev)
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    recv = recv.to(inc_xyz.device)
     return [recv[r, :, :counts_h[r]] for r in range(world)], counts_h
 
 
