@@ -25,9 +25,9 @@
  *           The CANDIDATE SET of a query is still defined on voxels: all points of
  *           the 27 voxels around the query's voxel (81 fine rows for S = 3).
  *  normals  for sorted point s: the k smallest (d2, append-order index) among all points
- *           of the 27 neighbouring cells with d2 <= h*h (self included) -- that ball lies
- *           inside the 27 voxels wherever the grid is anchored, so a normal is a function
- *           of the point list alone; fewer than 5 -> normal = 0 (invalid).  Covariance
+ *           of the 27 neighbouring cells with d2 <= (0.99 h)^2 (self included) -- that ball
+ *           lies strictly inside the 27 voxels wherever the grid is anchored, float rounding
+ *           of the cell assignment included, so a normal is a function of the point list alone; fewer than 5 -> normal = 0 (invalid).  Covariance
  *           about the mean in fp64, summed in that (d2, append index) order; eigenvector of the smallest
  *           eigenvalue by 8 fixed cyclic Jacobi sweeps (only + - * / sqrt);
  *           sign: last non-zero of (nz, ny, nx) made positive; stored as float.
@@ -153,12 +153,18 @@ static void smallest_eigvec(const double C[6] /* xx xy xz yy yz zz */, double n[
 }
 
 #define VO_KMAX 32
+#define VO_NORMAL_RADIUS 0.99f
 #define VO_MIN_NB 5
 
 static void point_normal(const vo_map* m, size_t s, int k, float out[3])
 {
     const float qx = m->x[s], qy = m->y[s], qz = m->z[s];
-    const float r2 = m->h * m->h;
+    /* neighbour radius 0.99 h, strictly inside one voxel: a neighbour's voxel index then
+     * differs by at most one from the point's on every axis whatever the float rounding of the
+     * cell assignment does (up to ~4e4 voxels per axis), so the neighbour set -- and with the
+     * append-order tie-break the whole normal -- does not depend on where the grid is anchored */
+    const float rn = VO_NORMAL_RADIUS * m->h;
+    const float r2 = rn * rn;
     const int cx = cell_coord(qx, m->o[0], m->inv_h, m->dims[0]);
     const int cy = cell_coord(qy, m->o[1], m->inv_h, m->dims[1]);
     const int cz = cell_coord(qz, m->o[2], m->inv_h, m->dims[2]);

@@ -170,6 +170,7 @@ hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell
 // dynamically indexed per-thread array would otherwise go to scratch memory.
 constexpr int kNrmThreads = 128;
 constexpr int kMinNb = 5;
+constexpr float kNormalRadius = 0.99f;
 
 __device__ __forceinline__ void jacobi_rot(double A[3][3], double V[3][3], int p, int q)
 {
@@ -296,8 +297,11 @@ __device__ __forceinline__ float4 point_normal(const MapView& mv, const uint32_t
                                                int (*s_i)[kNrmThreads], int tid)
 {
     const float4 q = mv.pts[s];
-    const int cnt = collect_knn<true>(mv, perm, q.x, q.y, q.z, mv.h * mv.h, k, s_d, s_i, tid);
-    const float rk2 = cnt == k ? s_d[k - 1][tid] : mv.h * mv.h;
+    // neighbour radius 0.99 h: strictly inside one voxel, see oracle/icp.c point_normal
+    const float rn = kNormalRadius * mv.h;
+    const float r2 = rn * rn;
+    const int cnt = collect_knn<true>(mv, perm, q.x, q.y, q.z, r2, k, s_d, s_i, tid);
+    const float rk2 = cnt == k ? s_d[k - 1][tid] : r2;
     if (cnt < kMinNb) return make_float4(0.f, 0.f, 0.f, rk2);
     double mx = 0, my = 0, mz = 0;
     for (int i = 0; i < cnt; ++i) {
@@ -337,11 +341,14 @@ __device__ __forceinline__ float4 point_normal(const MapView& mv, const uint32_t
     vy *= inv;
     vz *= inv;
     const bool flip = (vz < 0.0) || (vz == 0.0 && (vy < 0.0 || (vy == 0.0 && vx < 0.0)));
-    if (flip) {
-        vx = -vx;
-        vy = -vy;
-        vz = -vz;
-    }
+    // The sign is flipped on the bits.  Written as `if (flip) { vx = -vx; ... }` this is
+    // miscompiled by the ROCm 7.2 compiler at -O3 for gfx950: the negation survives only on
+    // the `vz < 0` path and is dropped on the `vz == 0 && vy < 0` path (found by
+    // tools/fuzz_parity.py on a lattice map; tools/dbg/eig.hip reproduces it in 40 lines).
+    const long long sb = flip ? (long long)0x8000000000000000ull : 0ll;
+    vx = __longlong_as_double(__double_as_longlong(vx) ^ sb);
+    vy = __longlong_as_double(__double_as_longlong(vy) ^ sb);
+    vz = __longlong_as_double(__double_as_longlong(vz) ^ sb);
     return make_float4((float)vx, (float)vy, (float)vz, rk2);
 }
 
