@@ -189,6 +189,18 @@ int velo_decode(velo_ctx*, const uint8_t* packets, const int64_t* pkt_t_us, size
                 const velo_laser_corr corr[64], int n_lasers, const velo_pose* poses,
                 size_t n_poses, int flush, const double* crop_region, int crop_inside,
                 int32_t* n_frames, size_t* n_points);
+/* The same parser, stateful across calls like the reference's (HDLSource feeds HDLParser one
+ * packet at a time, HDLSource.cxx:209-225): packets may arrive in chunks of any size, a call
+ * emits the frames whose closing split lies in its packets, and the packets that still hold
+ * firing blocks of the unfinished frame are kept inside the ctx for the next call (n_pkt may be
+ * 0 with flush != 0 to drain).  Emitted frames are identical to one velo_decode over the whole
+ * sequence; packet_index counts from the first packet still in flight.  flush or
+ * velo_decode_stream_reset() return the parser to its initial state. */
+int velo_decode_stream(velo_ctx*, const uint8_t* packets, const int64_t* pkt_t_us, size_t n_pkt,
+                       const velo_laser_corr corr[64], int n_lasers, const velo_pose* poses,
+                       size_t n_poses, int flush, const double* crop_region, int crop_inside,
+                       int32_t* n_frames, size_t* n_points);
+int velo_decode_stream_reset(velo_ctx*);
 /* Copy the last decode back; any pointer may be NULL.  frame_start: n_frames+1; beam_start:
  * n_frames x 65 (absolute offsets); packet_index: index of the source packet of each point. */
 int velo_decode_fetch(velo_ctx*, float* x, float* y, float* z, float* intensity, uint16_t* azimuth,

@@ -574,6 +574,54 @@ def test_gpu_decode_matches_oracle_parser(ctx, oracle, az_start, azcorr, with_po
     assert g["n_points"] == sum(dec.beam(f, b)[0].size for f in range(dec.num_frames) for b in range(64))
 
 
+@pytest.mark.parametrize("seed,az_start", [(1, 0), (2, 17000), (3, 35990)])
+def test_gpu_decode_stream_chunks_equal_one_shot(ctx, oracle, seed, az_start):
+    """The parser is stateful across calls (velo_decode_stream): the same packet sequence fed
+    in chunks of arbitrary size -- single packets, chunks that end right on a frame split,
+    chunks spanning several frames -- yields exactly the frames of one call over the whole
+    sequence, which are the oracle parser's frames."""
+    pk, ts, cal, mo = _stream(4, az_start)
+    track = mo.ins_track(ts[0], ts[-1])
+    poses, n = capi.make_poses(track)
+    ref = ctx.decode(pk, ts, cal, 64, poses, n, flush=True)
+    tl = oracle.Timeline()
+    for (T, R, V, t) in track:
+        tl.add(T, R, V, t)
+    dec = oracle.Decoder(cal, 64, tl)
+    for p, t in zip(pk, ts):
+        dec.packet(p, t)
+    dec.flush()
+    _check_decode(oracle, ref, dec, ref["n_frames"])
+    rng = np.random.default_rng(seed)
+    ctx.decode_stream_reset()
+    frames = []
+    i = 0
+    while i < len(pk):
+        m = int(rng.choice([1, 1, 2, 7, 60, 299, 300, 301, 750]))
+        j = min(i + m, len(pk))
+        g = ctx.decode(pk[i:j], ts[i:j], cal, 64, poses, n, flush=(j == len(pk)), stream=True)
+        for f in range(g["n_frames"]):
+            a, b = g["frame_start"][f], g["frame_start"][f + 1]
+            frames.append(dict(x=g["x"][a:b], y=g["y"][a:b], z=g["z"][a:b], i=g["intensity"][a:b],
+                               az=g["azimuth"][a:b], d=g["distance"][a:b],
+                               beams=g["beam_start"][f] - g["beam_start"][f][0],
+                               car=g["carposes"][f], t=g["frame_t_us"][f], np=g["frame_packets"][f]))
+        i = j
+    assert len(frames) == ref["n_frames"]
+    for f, fr in enumerate(frames):
+        a, b = ref["frame_start"][f], ref["frame_start"][f + 1]
+        for key, rk in (("x", "x"), ("y", "y"), ("z", "z"), ("i", "intensity"), ("d", "distance")):
+            assert np.array_equal(fr[key].view(np.uint32), ref[rk][a:b].view(np.uint32)), (f, key)
+        assert np.array_equal(fr["az"], ref["azimuth"][a:b])
+        assert np.array_equal(fr["beams"], ref["beam_start"][f] - ref["beam_start"][f][0])
+        assert fr["t"] == ref["frame_t_us"][f] and fr["np"] == ref["frame_packets"][f]
+        assert list(fr["car"].T) == list(ref["carposes"][f].T)
+        assert list(fr["car"].R) == list(ref["carposes"][f].R)
+    # drained: nothing in flight, an empty flush emits nothing
+    g = ctx.decode([], [], cal, 64, poses, n, flush=True, stream=True)
+    assert g["n_frames"] == 0
+
+
 def test_gpu_decode_crop_and_registration(ctx, oracle, wl):
     pk, ts, cal, mo = _stream(1, 0)
     track = mo.ins_track(ts[0], ts[-1])

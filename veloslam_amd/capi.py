@@ -69,7 +69,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_evict_outside", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_wait", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats",
+    "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_wait", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
     "velo_insmeta_write", "velo_insmeta_read", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
@@ -131,6 +131,8 @@ def lib():
     L.velo_knn.argtypes = [vp, C.c_int, dp, C.c_float, C.c_int, vp, vp, vp]
     L.velo_decode.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_int, C.POINTER(Pose), C.c_size_t, C.c_int,
                               vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
+    L.velo_decode_stream.argtypes = L.velo_decode.argtypes
+    L.velo_decode_stream_reset.argtypes = [vp]
     L.velo_decode_fetch.argtypes = [vp] * 13
     L.velo_decode_to_frames.argtypes = [vp]
     L.velo_increment.argtypes = [vp, C.c_int, dp, C.c_int, vp, vp, vp, C.POINTER(C.c_size_t)]
@@ -441,18 +443,20 @@ class Context:
         return idx, d2, cnt
 
     def decode(self, packets, times_us, calib, n_lasers=64, poses=None, n_poses=0, flush=True,
-               crop_region=None, crop_inside=False):
+               crop_region=None, crop_inside=False, stream=False):
         """packets: list of 1206-byte strings; calib: (64, 9) float64.  Returns a dict with the
-        decoded frames (beam-major SoA) fetched back to the host."""
-        buf = np.frombuffer(b"".join(packets), dtype=np.uint8)
+        decoded frames (beam-major SoA) fetched back to the host.  stream=True keeps the parser
+        state inside the ctx between calls (velo_decode_stream)."""
+        buf = np.frombuffer(b"".join(packets), dtype=np.uint8) if len(packets) else np.zeros(0, np.uint8)
         t = np.ascontiguousarray(times_us, dtype=np.int64)
         cal = np.ascontiguousarray(calib, dtype=np.float64).reshape(64, 9)
         crop = None if crop_region is None else np.ascontiguousarray(crop_region, dtype=np.float64)
         nf = C.c_int32()
         npts = C.c_size_t()
-        self._chk(lib().velo_decode(self.h, _p(buf), _p(t), len(packets), _p(cal), n_lasers,
-                                    poses, n_poses, int(bool(flush)), _p(crop), int(bool(crop_inside)),
-                                    C.byref(nf), C.byref(npts)))
+        fn = lib().velo_decode_stream if stream else lib().velo_decode
+        self._chk(fn(self.h, _p(buf), _p(t), len(packets), _p(cal), n_lasers,
+                     poses, n_poses, int(bool(flush)), _p(crop), int(bool(crop_inside)),
+                     C.byref(nf), C.byref(npts)))
         F, n = nf.value, npts.value
         self._decoded_frames = F
         out = dict(n_frames=F, n_points=n,
@@ -468,6 +472,9 @@ class Context:
             C.cast(car, C.c_void_p), _p(out["frame_t_us"]), _p(out["frame_packets"])))
         out["carposes"] = car
         return out
+
+    def decode_stream_reset(self):
+        self._chk(lib().velo_decode_stream_reset(self.h))
 
     def decode_resident(self, buf, times_us, calib, poses, n_poses, n_lasers=64, flush=True):
         """velo_decode without the host fetch: buf = contiguous uint8 packets (n x 1206),

@@ -141,6 +141,22 @@ struct velo_ctx {
     std::vector<int32_t> dk_beam_start, dk_frame_packets;
     std::vector<velo_pose> dk_carposes;
 
+    // parser state carried across velo_decode_stream calls (HDLParser is stateful across packets)
+    struct DecodeStream {
+        int last_az = -1, firing_skip = 0;
+        bool inited = false, is_hdl64 = false, open = false;
+        veloslam::PoseTransform carpose;
+        velo_pose carpose0{};      // header of the unfinished frame
+        int64_t frame_t = VELO_TIME_INVALID;
+        int32_t frame_packets = 0;
+        // the packets that still hold firing blocks of the unfinished frame
+        std::vector<uint8_t> bytes, tvalid;
+        std::vector<int64_t> t;
+        std::vector<double> table;
+        std::vector<int32_t> azdiff;
+        std::vector<int16_t> blk;  // 12 per packet: 0 = unfinished frame, -1 = emitted earlier
+    } dstream;
+
     // ---- timing
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -1354,34 +1370,48 @@ int upload_calibration(velo_ctx* c, const velo_laser_corr corr[64])
 
 }  // namespace
 
-int velo_decode(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, size_t n_pkt,
-                const velo_laser_corr corr[64], int n_lasers, const velo_pose* poses,
-                size_t n_poses, int flush, const double* crop_region, int crop_inside,
-                int32_t* n_frames, size_t* n_points)
+// Host half of the decode: the sequential part of the parser (12 integers per packet,
+// HDLParser.cxx:980-1055) run over [pending packets of the unfinished frame] + [new packets],
+// continuing from the parser state `st` carries; then the device half over the same packet set.
+static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* packets,
+                       const int64_t* pkt_t_us, size_t n_new, const velo_laser_corr corr[64],
+                       int n_lasers, const velo_pose* poses, size_t n_poses, int flush,
+                       const double* crop_region, int crop_inside, bool keep_state,
+                       int32_t* n_frames, size_t* n_points)
 {
-    if (!c) return VELO_E_INVALID;
-    if (!packets || !pkt_t_us || !corr || (n_poses && !poses))
+    if ((n_new && (!packets || !pkt_t_us)) || !corr || (n_poses && !poses))
         return c->fail(VELO_E_INVALID, "velo_decode: null argument");
     if (n_lasers != 64 && n_lasers != 32 && n_lasers != 16)
         return c->fail(VELO_E_INVALID, "n_lasers must be 64, 32 or 16");
-    if (n_pkt == 0 || n_pkt > 60000) return c->fail(VELO_E_RANGE, "n_pkt must be in [1, 60000]");
+    velo_ctx::DecodeStream st_next_;
+    const size_t n_pend = st.t.size();
+    const size_t n_pkt = n_pend + n_new;
+    if (n_pkt == 0 || n_pkt > 60000) return c->fail(VELO_E_RANGE, "packets in flight must be in [1, 60000]");
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = upload_calibration(c, corr)) return rc;
     hipStream_t s = c->stream;
 
-    // ---- the sequential part of the parser, 12 integers per packet (HDLParser.cxx:980-1055)
     veloslam::TransformManager tm;
     for (size_t i = 0; i < n_poses; ++i) tm.addTransform(veloslam::PoseTransform::fromC(poses[i]));
-    std::vector<int16_t> blk((size_t)n_pkt * 12, -1);
-    std::vector<double> table((size_t)n_pkt * 12, 0.0);
-    std::vector<uint8_t> tvalid(n_pkt, 0), perm;
-    std::vector<int32_t> azdiff(n_pkt, 0);
+    // working set = what the unfinished frame still needs + the new packets
+    std::vector<uint8_t> bytes(st.bytes);
+    bytes.insert(bytes.end(), packets, packets + n_new * 1206);
+    std::vector<int64_t> times(st.t);
+    times.insert(times.end(), pkt_t_us, pkt_t_us + n_new);
+    std::vector<int16_t> blk(st.blk);
+    blk.resize(n_pkt * 12, -1);
+    std::vector<double> table(st.table);
+    table.resize(n_pkt * 12, 0.0);
+    std::vector<uint8_t> tvalid(st.tvalid), perm;
+    tvalid.resize(n_pkt, 0);
+    std::vector<int32_t> azdiff(st.azdiff);
+    azdiff.resize(n_pkt, 0);
     c->dk_carposes.clear();
     c->dk_frame_t.clear();
     c->dk_frame_packets.clear();
-    int last_az = -1, firing_skip = 0, cur = 0;
-    bool inited = false, is_hdl64 = false;
-    veloslam::PoseTransform carpose;
+    int last_az = st.last_az, firing_skip = st.firing_skip, cur = 0;
+    bool inited = st.inited, is_hdl64 = st.is_hdl64;
+    veloslam::PoseTransform carpose = st.carpose;
     auto open_frame = [&]() {
         c->dk_carposes.push_back(veloslam::PoseTransform().toC());
         c->dk_frame_t.push_back(VELO_TIME_INVALID);
@@ -1389,18 +1419,23 @@ int velo_decode(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, si
         perm.push_back(0);
     };
     open_frame();
-    for (size_t p = 0; p < n_pkt; ++p) {
-        const uint8_t* d = packets + p * 1206;
+    if (st.open) {  // header of the frame the previous call left unfinished
+        c->dk_carposes[0] = st.carpose0;
+        c->dk_frame_t[0] = st.frame_t;
+        c->dk_frame_packets[0] = st.frame_packets;
+    }
+    for (size_t p = n_pend; p < n_pkt; ++p) {
+        const uint8_t* d = bytes.data() + p * 1206;
         veloslam::PoseTransform tr;
-        tm.interpolateTransform(pkt_t_us[p], &tr);
+        tm.interpolateTransform(times[p], &tr);
         if (!inited) {  // :992-1001
             carpose = tr;
             c->dk_carposes[cur] = tr.toC();
-            c->dk_frame_t[cur] = pkt_t_us[p];
+            c->dk_frame_t[cur] = times[p];
             c->dk_frame_packets[cur]++;
             inited = true;
         }
-        tr.timestamp = pkt_t_us[p];
+        tr.timestamp = times[p];
         if (tr.seconds_pos != -1) {  // :1004-1007 (+ :1057-1062)
             for (int a = 0; a < 3; ++a) tr.T[a] -= carpose.T[a];
             const veloslam::Affine3x4 M = tr.getMatrix();
@@ -1436,6 +1471,35 @@ int velo_decode(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, si
         }
     }
     int nfr = cur;
+    if (keep_state && !flush) {
+        // carry the parser on: keep the packets that hold blocks of the unfinished frame `cur`
+        velo_ctx::DecodeStream nx;
+        nx.last_az = last_az;
+        nx.firing_skip = firing_skip;
+        nx.inited = inited;
+        nx.is_hdl64 = is_hdl64;
+        nx.carpose = carpose;
+        nx.open = true;
+        nx.carpose0 = c->dk_carposes[cur];
+        nx.frame_t = c->dk_frame_t[cur];
+        nx.frame_packets = c->dk_frame_packets[cur];
+        size_t p0 = n_pkt;
+        for (size_t p = 0; p < n_pkt && p0 == n_pkt; ++p)
+            for (int k = 0; k < 12; ++k)
+                if (blk[p * 12 + k] == cur) {
+                    p0 = p;
+                    break;
+                }
+        for (size_t p = p0; p < n_pkt; ++p) {
+            nx.bytes.insert(nx.bytes.end(), bytes.begin() + p * 1206, bytes.begin() + (p + 1) * 1206);
+            nx.t.push_back(times[p]);
+            nx.table.insert(nx.table.end(), table.begin() + p * 12, table.begin() + (p + 1) * 12);
+            nx.tvalid.push_back(tvalid[p]);
+            nx.azdiff.push_back(azdiff[p]);
+            for (int k = 0; k < 12; ++k) nx.blk.push_back(blk[p * 12 + k] == cur ? (int16_t)0 : (int16_t)-1);
+        }
+        st_next_ = std::move(nx);
+    }
     if (flush) {
         perm[cur] = is_hdl64 ? 1 : 0;
         nfr = cur + 1;
@@ -1446,7 +1510,7 @@ int velo_decode(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, si
         c->dk_frame_t.resize((size_t)nfr);
         c->dk_frame_packets.resize((size_t)nfr);
     }
-
+    const uint8_t* packets_all = bytes.data();
     // ---- device side
     const size_t n_ret = n_pkt * 384;
     HIP_TRY(c, c->dk_pkts.reserve(n_pkt * 1206));
@@ -1461,7 +1525,7 @@ int velo_decode(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, si
     HIP_TRY(c, c->dk_order.reserve(n_ret));
     const uint32_t n_keys = (uint32_t)std::max(nfr, 1) * 64u;
     HIP_TRY(c, c->dk_starts.reserve((size_t)n_keys + 1));
-    HIP_TRY(c, hipMemcpyAsync(c->dk_pkts.p, packets, n_pkt * 1206, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->dk_pkts.p, packets_all, n_pkt * 1206, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->dk_blk.p, blk.data(), blk.size() * sizeof(int16_t), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->dk_perm.p, perm.data(), perm.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->dk_table.p, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1516,6 +1580,48 @@ int velo_decode(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, si
     c->dk_frame_start[nfr] = (int64_t)n_valid;
     if (n_frames) *n_frames = nfr;
     if (n_points) *n_points = n_valid;
+    if (keep_state) {
+        if (flush)
+            st = velo_ctx::DecodeStream();  // everything emitted: the next packet starts afresh
+        else
+            st = std::move(st_next_);
+    }
+    return VELO_OK;
+}
+
+int velo_decode(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, size_t n_pkt,
+                const velo_laser_corr corr[64], int n_lasers, const velo_pose* poses,
+                size_t n_poses, int flush, const double* crop_region, int crop_inside,
+                int32_t* n_frames, size_t* n_points)
+{
+    if (!c) return VELO_E_INVALID;
+    if (n_pkt == 0) return c->fail(VELO_E_RANGE, "n_pkt must be in [1, 60000]");
+    velo_ctx::DecodeStream fresh;
+    return decode_impl(c, fresh, packets, pkt_t_us, n_pkt, corr, n_lasers, poses, n_poses, flush,
+                       crop_region, crop_inside, false, n_frames, n_points);
+}
+
+int velo_decode_stream(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, size_t n_pkt,
+                       const velo_laser_corr corr[64], int n_lasers, const velo_pose* poses,
+                       size_t n_poses, int flush, const double* crop_region, int crop_inside,
+                       int32_t* n_frames, size_t* n_points)
+{
+    if (!c) return VELO_E_INVALID;
+    if (n_pkt == 0 && c->dstream.t.empty()) {  // nothing in flight: nothing to emit
+        c->dk_frames = 0;
+        c->dk_points = 0;
+        if (n_frames) *n_frames = 0;
+        if (n_points) *n_points = 0;
+        return VELO_OK;
+    }
+    return decode_impl(c, c->dstream, packets, pkt_t_us, n_pkt, corr, n_lasers, poses, n_poses, flush,
+                       crop_region, crop_inside, true, n_frames, n_points);
+}
+
+int velo_decode_stream_reset(velo_ctx* c)
+{
+    if (!c) return VELO_E_INVALID;
+    c->dstream = velo_ctx::DecodeStream();
     return VELO_OK;
 }
 
