@@ -324,6 +324,11 @@ int velo_ins_to_pose(const velo_inspva* ins, const double orig_xyz[3], int64_t t
 /* pose-store persistence: the record layout of type_defs.cxx:4-33 (ptime -> int64 us) */
 int velo_insmeta_write(const char* path, const velo_pose* poses, size_t n);
 int velo_insmeta_read(const char* path, velo_pose* poses, size_t cap, size_t* n_out);
+/* Velodyne calibration file (db.xml) -> the 64 laser corrections velo_decode takes.  Replaces
+ * HDLParser::vsInternal::loadCorrectionsFile (HDLParser.cxx:771-858): same element names, same
+ * units (centimetres in the file, metres afterwards) and derived sin/cos fields; n_enabled
+ * (optional) = number of `enabled_` items equal to 1 (calibFileReportedNumLasers). */
+int velo_load_corrections(const char* path, velo_laser_corr corr[64], int32_t* n_enabled);
 
 /* ---- CoordiTran (CoordiTran.h:7-15): reference names and signatures verbatim -------- */
 void eulr2dcm(double eul_vect[3], double DCMbn[3][3]);

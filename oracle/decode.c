@@ -15,6 +15,7 @@
  *   - the crop flag named pointOutsideOfBox is true INSIDE the box (:629-639).
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "velo_oracle.h"
@@ -304,3 +305,123 @@ void vo_frame_carpose(const vo_decoder* d, int f, vo_pose* out, int64_t* t_us, i
     if (skips) *skips = d->frames[f].skips;
 }
 size_t vo_frame_num_packets(const vo_decoder* d, int f) { return d->frames[f].n_packets; }
+
+/* ---- calibration file, HDLParser.cxx:771-858 ------------------------------------------------
+ * Restated without boost::property_tree: the reference looks elements up by name only
+ * (boost_serialization.DB.enabled_ / .points_ > item > px > <field>), atoi/atof on the text.
+ * PARITY UNPINNED (Boost absent here); product and oracle are two independent scanners held
+ * to each other and to the numbers a generated file was written from. */
+static const char* find_elem(const char* s, const char* end, const char* name, const char** content_end)
+{
+    const size_t nl = strlen(name);
+    const char* p = s;
+    while (p < end) {
+        p = memchr(p, '<', (size_t)(end - p));
+        if (!p) return NULL;
+        if ((size_t)(end - p) > nl + 1 && strncmp(p + 1, name, nl) == 0 &&
+            (p[1 + nl] == '>' || p[1 + nl] == ' ' || p[1 + nl] == '\t' || p[1 + nl] == '\n' || p[1 + nl] == '\r')) {
+            const char* gt = memchr(p, '>', (size_t)(end - p));
+            if (!gt) return NULL;
+            /* closing tag */
+            const char* q = gt + 1;
+            while (q < end) {
+                q = memchr(q, '<', (size_t)(end - q));
+                if (!q) return NULL;
+                if ((size_t)(end - q) > nl + 2 && q[1] == '/' && strncmp(q + 2, name, nl) == 0 && q[2 + nl] == '>') {
+                    *content_end = q;
+                    return gt + 1;
+                }
+                ++q;
+            }
+            return NULL;
+        }
+        ++p;
+    }
+    return NULL;
+}
+
+static int elem_number(const char* s, const char* end, const char* name, double* out)
+{
+    const char* ce;
+    const char* c = find_elem(s, end, name, &ce);
+    if (!c) return 0;
+    char buf[64];
+    size_t n = (size_t)(ce - c);
+    if (n >= sizeof buf) n = sizeof buf - 1;
+    memcpy(buf, c, n);
+    buf[n] = 0;
+    *out = atof(buf);
+    return 1;
+}
+
+int vo_load_corrections(const char* path, vo_laser_corr corr[64], int* n_enabled)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return -1;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char* s = (char*)malloc((size_t)sz + 1);
+    if (fread(s, 1, (size_t)sz, f) != (size_t)sz) {
+        fclose(f);
+        free(s);
+        return -1;
+    }
+    fclose(f);
+    s[sz] = 0;
+    const char* end = s + sz;
+    memset(corr, 0, 64 * sizeof(vo_laser_corr));
+    const char *db_e, *db = find_elem(s, end, "DB", &db_e);
+    if (!db) {
+        free(s);
+        return -1;
+    }
+    int enabled = 0;
+    const char *en_e, *en = find_elem(db, db_e, "enabled_", &en_e);
+    if (en) {
+        const char* p = en;
+        for (;;) {
+            const char *ie, *it = find_elem(p, en_e, "item", &ie);
+            if (!it) break;
+            if (atoi(it) == 1 && it != ie) ++enabled;
+            p = ie + 1;
+        }
+    }
+    if (n_enabled) *n_enabled = enabled;
+    const char *pt_e, *pt = find_elem(db, db_e, "points_", &pt_e);
+    if (!pt) {
+        free(s);
+        return -1;
+    }
+    const char* p = pt;
+    for (;;) {
+        const char *xe, *x = find_elem(p, pt_e, "px", &xe);
+        if (!x) break;
+        p = xe + 1;
+        double id = -1, az = 0, vert = 0, dist = 0, voff = 0, hoff = 0;
+        const char* ce;
+        const char* c = find_elem(x, xe, "id_", &ce);
+        if (c) id = (double)atoi(c);
+        elem_number(x, xe, "rotCorrection_", &az);
+        elem_number(x, xe, "vertCorrection_", &vert);
+        elem_number(x, xe, "distCorrection_", &dist);
+        elem_number(x, xe, "vertOffsetCorrection_", &voff);
+        elem_number(x, xe, "horizOffsetCorrection_", &hoff);
+        const int index = (int)id;
+        if (index < 0 || index >= 64) continue;
+        vo_laser_corr* k = &corr[index];
+        k->azimuthCorrection = az;
+        k->verticalCorrection = vert;
+        k->distanceCorrection = dist / 100.0;          /* :836 */
+        k->verticalOffsetCorrection = voff / 100.0;    /* :837 */
+        k->horizontalOffsetCorrection = hoff / 100.0;  /* :838 */
+        k->cosVertCorrection = cos(k->verticalCorrection * M_PI / 180.0); /* :840 */
+        k->sinVertCorrection = sin(k->verticalCorrection * M_PI / 180.0); /* :841 */
+    }
+    for (int i = 0; i < 64; ++i) { /* :848-855 */
+        corr[i].sinVertOffsetCorrection = corr[i].verticalOffsetCorrection * corr[i].sinVertCorrection;
+        corr[i].cosVertOffsetCorrection = corr[i].verticalOffsetCorrection * corr[i].cosVertCorrection;
+    }
+    free(s);
+    return 0;
+}

@@ -87,6 +87,7 @@ def lib():
     L.vo_interpolate_transform.argtypes = [C.c_void_p, C.c_int64, pp]
     L.vo_compensate.argtypes = [fp, fp, fp, C.POINTER(C.c_uint16), C.c_size_t, dp, C.c_size_t,
                                 fp, fp, fp]
+    L.vo_load_corrections.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]
     L.vo_decoder_new.argtypes = [C.POINTER(LaserCorr), C.c_int, C.c_void_p]
     L.vo_decoder_new.restype = C.c_void_p
     L.vo_decoder_free.argtypes = [C.c_void_p]
@@ -464,6 +465,15 @@ class RollingMap:
         lo = np.ascontiguousarray(lo, np.float32)
         hi = np.ascontiguousarray(hi, np.float32)
         return lib().vo_roll_evict_outside(self.r, _f(lo), _f(hi))
+
+
+def load_corrections(path):
+    """HDLParser.cxx:771-858 -> ((64, 9) float64 in LaserCorr field order, enabled count)."""
+    corr = np.zeros((64, 9))
+    n = C.c_int()
+    if lib().vo_load_corrections(str(path).encode(), corr.ctypes.data_as(C.c_void_p), C.byref(n)):
+        raise ValueError("cannot read " + str(path))
+    return corr, n.value
 
 
 def solve_update(acc, T):

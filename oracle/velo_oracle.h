@@ -95,6 +95,8 @@ typedef struct vo_laser_corr { /* HDLParser.cxx:89-100 */
 
 typedef struct vo_decoder vo_decoder;
 /* n_lasers: calibFileReportedNumLasers (64/32/16) */
+/* HDLParser.cxx:771-858 loadCorrectionsFile; 0 ok, -1 unreadable */
+int vo_load_corrections(const char* path, vo_laser_corr corr[64], int* n_enabled);
 vo_decoder* vo_decoder_new(const vo_laser_corr corr[64], int n_lasers, const vo_timeline* tl);
 void vo_decoder_free(vo_decoder*);
 void vo_decoder_set_crop(vo_decoder*, int enable, int crop_inside, const double region[6]);

@@ -205,3 +205,66 @@ def test_ins_to_pose_and_insmeta(tmp_path, oracle):
     assert capi.lib().velo_insmeta_read(path.encode(), back, 5, C.byref(n)) == 0 and n.value == 5
     for a, b in zip(poses, back):
         assert bytes(a)[:72] == bytes(b)[:72] and a.t_us == b.t_us and a.seconds_pos == b.seconds_pos
+
+
+def _write_db_xml(path, cal, enabled=64, shuffle=False):
+    """A calibration file in Velodyne's boost-serialisation layout (the element names are all
+    HDLParser::loadCorrectionsFile looks at, HDLParser.cxx:771-858); distances in centimetres."""
+    ids = list(range(64))
+    if shuffle:
+        ids = ids[::-1]
+    px = []
+    for i in ids:
+        r = cal[i]
+        px.append("""\t\t<item class_id="2" tracking_level="0" version="1">
+\t\t\t<px class_id="3" tracking_level="1" version="1" object_id="_%d">
+\t\t\t\t<id_>%d</id_>
+\t\t\t\t<rotCorrection_>%r</rotCorrection_>
+\t\t\t\t<vertCorrection_>%r</vertCorrection_>
+\t\t\t\t<distCorrection_>%r</distCorrection_>
+\t\t\t\t<distCorrectionX_>0</distCorrectionX_>
+\t\t\t\t<vertOffsetCorrection_>%r</vertOffsetCorrection_>
+\t\t\t\t<horizOffsetCorrection_>%r</horizOffsetCorrection_>
+\t\t\t\t<focalDistance_>0</focalDistance_>
+\t\t\t</px>
+\t\t</item>""" % (i, i, float(r[0]), float(r[1]), float(r[2]) * 100.0, float(r[3]) * 100.0, float(r[4]) * 100.0))
+    en = "\n".join("\t\t<item>%d</item>" % (1 if i < enabled else 0) for i in range(64))
+    with open(path, "w") as f:
+        f.write("""<?xml version="1.0" encoding="UTF-8" standalone="yes" ?>
+<!DOCTYPE boost_serialization>
+<boost_serialization signature="serialization::archive" version="4">
+<DB class_id="0" tracking_level="1" version="0" object_id="_0">
+\t<distLSB_>0.2</distLSB_>
+\t<enabled_ class_id="4" tracking_level="0" version="0">
+\t\t<count>64</count>
+%s
+\t</enabled_>
+\t<points_ class_id="1" tracking_level="0" version="0">
+\t\t<count>64</count>
+\t\t<item_version>1</item_version>
+%s
+\t</points_>
+</DB>
+</boost_serialization>
+""" % (en, "\n".join(px)))
+
+
+@pytest.mark.parametrize("azcorr,enabled,shuffle", [(False, 64, False), (True, 32, True)])
+def test_calibration_file_loader(tmp_path, oracle, azcorr, enabled, shuffle):
+    """db.xml -> laser corrections (HDLParser.cxx:771-858): product == oracle bit for bit, and
+    both reproduce the table the file was written from (angles exactly, the centimetre fields
+    after their round trip through /100)."""
+    from veloslam_amd import synth
+    cal = synth.hdl64_calibration(azcorr)
+    path = tmp_path / "db.xml"
+    _write_db_xml(path, cal, enabled, shuffle)
+    g, gn = capi.load_corrections(path)
+    o, on = oracle.load_corrections(path)
+    assert gn == on == enabled
+    assert np.array_equal(g.view(np.uint64), o.view(np.uint64))
+    assert np.array_equal(g[:, :2], cal[:, :2])                       # degrees: untouched
+    assert np.allclose(g[:, 2:5], cal[:, 2:5], rtol=0, atol=1e-15)    # cm -> m
+    assert np.allclose(g[:, 5:], cal[:, 5:], rtol=0, atol=1e-15)      # sin/cos/offset products
+    with pytest.raises(capi.VeloError):
+        capi.load_corrections(tmp_path / "missing.xml")
+

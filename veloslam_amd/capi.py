@@ -72,7 +72,7 @@ EXPORTS = [
     "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_wait", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
-    "velo_insmeta_write", "velo_insmeta_read", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
+    "velo_insmeta_write", "velo_insmeta_read", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
     "llh2enu", "MappingAngle",
 ]
 
@@ -151,6 +151,7 @@ def lib():
     L.velo_ins_to_pose.argtypes = [C.POINTER(InsPVA), dp, C.c_int64, C.POINTER(Pose)]
     L.velo_insmeta_write.argtypes = [C.c_char_p, C.POINTER(Pose), C.c_size_t]
     L.velo_insmeta_read.argtypes = [C.c_char_p, C.POINTER(Pose), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.velo_load_corrections.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_int32)]
     for nm in ("llh2xyz", "xyz2llh"):
         getattr(L, nm).argtypes = [dp, dp]
     for nm in ("xyz2enu", "enu2xyz", "enu2llh", "llh2enu"):
@@ -219,6 +220,17 @@ def packet_transforms(poses, n, pkt_times):
     if rc:
         raise VeloError(rc, "velo_packet_transforms")
     return tab, valid, car
+
+
+def load_corrections(path):
+    """Velodyne db.xml -> ((64, 9) float64 laser corrections in velo_laser_corr field order,
+    number of enabled lasers)."""
+    corr = np.zeros((64, 9))
+    n = C.c_int32()
+    rc = lib().velo_load_corrections(str(path).encode(), corr.ctypes.data_as(C.c_void_p), C.byref(n))
+    if rc:
+        raise VeloError(rc, "velo_load_corrections: cannot read %s" % path)
+    return corr, n.value
 
 
 def pcap_write(path, packets, times_us):

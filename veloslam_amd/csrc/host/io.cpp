@@ -6,6 +6,9 @@
 //     type_defs.h:39-58) and the pose-store file formats (carposes.txt is in pose.cpp;
 //     .insmeta record = type_defs.cxx:4-33 with ptime flattened to int64 microseconds).
 #include <cmath>
+#include <cstdlib>
+#include <iterator>
+#include <string>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -210,6 +213,121 @@ int velo_insmeta_read(const char* path, velo_pose* poses, size_t cap, size_t* n_
         ++n;
     }
     *n_out = n;
+    return VELO_OK;
+}
+
+// ---- calibration file (HDLParser::vsInternal::loadCorrectionsFile, HDLParser.cxx:771-858) ----
+// The reference reads Velodyne's db.xml through boost::property_tree; only the element names
+// matter to it, so a plain tag scanner is enough: boost_serialization.DB.enabled_ (items equal
+// to 1 are counted) and boost_serialization.DB.points_ (item > px > id_, rotCorrection_,
+// vertCorrection_, distCorrection_, vertOffsetCorrection_, horizOffsetCorrection_).  Units and
+// derived fields as there: the three distances are centimetres in the file and metres
+// afterwards (:836-838), sin/cos of the vertical angle (:840-841), the two offset products
+// (:848-855).  Lasers the file does not mention stay zero.
+namespace {
+
+// text of the first <name ...>...</name> inside [from, to); empty if absent
+bool tag_text(const std::string& s, size_t from, size_t to, const char* name, std::string* out,
+              size_t* after = nullptr)
+{
+    const std::string open = std::string("<") + name;
+    size_t a = from;
+    for (;;) {
+        a = s.find(open, a);
+        if (a == std::string::npos || a >= to) return false;
+        const char c = a + open.size() < s.size() ? s[a + open.size()] : '\0';
+        if (c == '>' || c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '/') break;
+        a += open.size();  // a longer tag name that merely starts the same
+    }
+    const size_t gt = s.find('>', a);
+    if (gt == std::string::npos || gt >= to) return false;
+    if (s[gt - 1] == '/') {  // <name/>
+        out->clear();
+        if (after) *after = gt + 1;
+        return true;
+    }
+    const std::string close = std::string("</") + name + ">";
+    const size_t b = s.find(close, gt + 1);
+    if (b == std::string::npos || b > to) return false;
+    *out = s.substr(gt + 1, b - gt - 1);
+    if (after) *after = b + close.size();
+    return true;
+}
+
+// [start of content, start of closing tag) of the first <name> element inside [from, to)
+bool tag_span(const std::string& s, size_t from, size_t to, const char* name, size_t* a, size_t* b)
+{
+    const std::string open = std::string("<") + name;
+    size_t p = from;
+    for (;;) {
+        p = s.find(open, p);
+        if (p == std::string::npos || p >= to) return false;
+        const char c = p + open.size() < s.size() ? s[p + open.size()] : '\0';
+        if (c == '>' || c == ' ' || c == '\t' || c == '\n' || c == '\r') break;
+        p += open.size();
+    }
+    const size_t gt = s.find('>', p);
+    const std::string close = std::string("</") + name + ">";
+    const size_t e = gt == std::string::npos ? std::string::npos : s.find(close, gt + 1);
+    if (e == std::string::npos || e > to) return false;
+    *a = gt + 1;
+    *b = e;
+    return true;
+}
+
+}  // namespace
+
+int velo_load_corrections(const char* path, velo_laser_corr corr[64], int32_t* n_enabled)
+{
+    if (!path || !corr) return VELO_E_INVALID;
+    std::ifstream is(path, std::ios::binary);
+    if (!is) return VELO_E_NODATA;
+    const std::string s((std::istreambuf_iterator<char>(is)), std::istreambuf_iterator<char>());
+    std::memset(corr, 0, 64 * sizeof(velo_laser_corr));
+    size_t da, db;
+    if (!tag_span(s, 0, s.size(), "DB", &da, &db)) return VELO_E_NODATA;
+    int enabled = 0;
+    size_t ea, eb;
+    if (tag_span(s, da, db, "enabled_", &ea, &eb)) {
+        size_t p = ea;
+        std::string t;
+        while (tag_text(s, p, eb, "item", &t, &p)) {
+            char* end = nullptr;
+            const long v = std::strtol(t.c_str(), &end, 10);
+            if (end != t.c_str() && v == 1) ++enabled;
+        }
+    }
+    if (n_enabled) *n_enabled = enabled;
+    size_t pa, pb;
+    if (!tag_span(s, da, db, "points_", &pa, &pb)) return VELO_E_NODATA;
+    size_t p = pa;
+    for (;;) {
+        size_t xa, xb;
+        if (!tag_span(s, p, pb, "px", &xa, &xb)) break;
+        p = xb + 5;  // past </px>
+        std::string t;
+        int index = -1;
+        double az = 0, vert = 0, dist = 0, voff = 0, hoff = 0;
+        if (tag_text(s, xa, xb, "id_", &t)) index = std::atoi(t.c_str());
+        if (tag_text(s, xa, xb, "rotCorrection_", &t)) az = std::atof(t.c_str());
+        if (tag_text(s, xa, xb, "vertCorrection_", &t)) vert = std::atof(t.c_str());
+        if (tag_text(s, xa, xb, "distCorrection_", &t)) dist = std::atof(t.c_str());
+        if (tag_text(s, xa, xb, "vertOffsetCorrection_", &t)) voff = std::atof(t.c_str());
+        if (tag_text(s, xa, xb, "horizOffsetCorrection_", &t)) hoff = std::atof(t.c_str());
+        if (index < 0 || index >= 64) continue;  // (the reference would index out of bounds)
+        velo_laser_corr& c = corr[index];
+        c.azimuthCorrection = az;
+        c.verticalCorrection = vert;
+        c.distanceCorrection = dist / 100.0;
+        c.verticalOffsetCorrection = voff / 100.0;
+        c.horizontalOffsetCorrection = hoff / 100.0;
+        c.cosVertCorrection = std::cos(c.verticalCorrection * M_PI / 180.0);
+        c.sinVertCorrection = std::sin(c.verticalCorrection * M_PI / 180.0);
+    }
+    for (int i = 0; i < 64; ++i) {
+        corr[i].sinVertOffsetCorrection = corr[i].verticalOffsetCorrection * corr[i].sinVertCorrection;
+        corr[i].cosVertOffsetCorrection = corr[i].verticalOffsetCorrection * corr[i].cosVertCorrection;
+    }
     return VELO_OK;
 }
 
