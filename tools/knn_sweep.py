@@ -16,6 +16,7 @@ from veloslam_amd import capi, synth  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--points", type=int, default=100_000_000)
 ap.add_argument("--subdivs", type=int, nargs="+", default=[2, 3, 4, 6, 8, 10])
+ap.add_argument("--voxels", type=float, nargs="+", default=[1.0], help="voxel edge h = d_max sweep")
 ap.add_argument("--k", type=int, default=32)
 a = ap.parse_args()
 rng = np.random.default_rng(44)
@@ -33,11 +34,11 @@ tab, valid, car = capi.packet_transforms(poses, n, ts)
 Tt = np.array([1, 0, 0, car.T[0], 0, 1, 0, car.T[1], 0, 0, 1, car.T[2]], np.float64)
 T0 = synth.perturbed_guess(Tt, dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))
 print("map points %d, frame points %d, k = %d" % (mx.size, fr["x"].size, a.k))
-for S in a.subdivs:
+for h, S in [(h, S) for h in a.voxels for S in a.subdivs]:
     c = capi.Context(0, max_batch=2, map_subdiv=S)
     try:
         t0 = time.perf_counter()
-        c.map_reset(mx, my, mz, 1.0, 16)
+        c.map_reset(mx, my, mz, h, 16)
         t_build = time.perf_counter() - t0
         mi = c.map_info()
         cs = np.empty(mi.n_cells + 1, np.int32)
@@ -48,21 +49,21 @@ for S in a.subdivs:
         comp = c.compensate(fr["x"], fr["y"], fr["z"], fr["pkt"], tab)
         c.frames_upload([comp])
         nq = comp[0].size
-        c.knn(0, Tt, 1.0, a.k, nq)
+        c.knn(0, Tt, h, a.k, nq)
         t0 = time.perf_counter()
         for _ in range(3):
-            idx, d2, cnt = c.knn(0, Tt, 1.0, a.k, nq)
+            idx, d2, cnt = c.knn(0, Tt, h, a.k, nq)
         t_knn = (time.perf_counter() - t0) / 3
-        c.icp_batch([T0], 20, 1.0)
+        c.icp_batch([T0], 20, min(h, 1.0))
         t0 = time.perf_counter()
         for _ in range(3):
-            r = c.icp_batch([T0], 20, 1.0)
+            r = c.icp_batch([T0], 20, min(h, 1.0))
         t_icp = (time.perf_counter() - t0) / 3
         err = float(np.linalg.norm(np.array(list(r[0].T)).reshape(3, 4)[:, 3] - Tt.reshape(3, 4)[:, 3]))
-        print("S=%2d (used %2d) build %.2f s  table %.0f M cells (%.2f GB) occupancy %.1f %%  "
+        print("h=%.2f S=%2d (used %2d) build %.2f s  table %.0f M cells (%.2f GB) occupancy %.1f %%  "
               "pts/occupied cell mean %.1f max %d | knn%d %.1f ms/frame incl. %0.f MB D2H (mean found %.1f) | "
               "20-iter registration %.2f ms (pose err %.4f m)"
-              % (S, mi.subdiv, t_build, mi.n_cells / 1e6, 4 * mi.n_cells / 1e9,
+              % (h, S, mi.subdiv, t_build, mi.n_cells / 1e6, 4 * mi.n_cells / 1e9,
                  100.0 * nz.size / occ.size, nz.mean(), nz.max(), a.k, 1e3 * t_knn,
                  (idx.nbytes + d2.nbytes) / 1e6, cnt.mean(), 1e3 * t_icp, err))
     finally:
