@@ -261,23 +261,32 @@ __device__ __forceinline__ int collect_knn(const MapView& mv, const uint32_t* __
                     const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
                     const int j0 = mv.cell_start[row + (size_t)fa];
                     const int j1 = mv.cell_start[row + (size_t)fb + 1];
-                    for (int j = j0; j < j1; ++j) {
-                        const float d2 = dist2(mv.pts[j], qx, qy, qz);
-                        if (!(d2 <= r2)) continue;
-                        if (cnt == k && !before(d2, j, s_d[k - 1][tid], s_i[k - 1][tid])) continue;
-                        int pos = cnt < k ? cnt : k - 1;
-                        while (pos > 0) {
-                            const float pd = s_d[pos - 1][tid];
-                            const int pi = s_i[pos - 1][tid];
-                            if (!before(d2, j, pd, pi)) break;
-                            s_d[pos][tid] = pd;
-                            s_i[pos][tid] = pi;
-                            --pos;
+                    // four candidate loads in flight per trip (the walk is a latency chain);
+                    // a slot past the end repeats the last index and is masked
+                    for (int jb = j0; jb < j1; jb += 4) {
+                        float4 cpt[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) cpt[u] = mv.pts[min(jb + u, j1 - 1)];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int j = jb + u;
+                            const float d2 = dist2(cpt[u], qx, qy, qz);
+                            if (j >= j1 || !(d2 <= r2)) continue;
+                            if (cnt == k && !before(d2, j, s_d[k - 1][tid], s_i[k - 1][tid])) continue;
+                            int pos = cnt < k ? cnt : k - 1;
+                            while (pos > 0) {
+                                const float pd = s_d[pos - 1][tid];
+                                const int pi = s_i[pos - 1][tid];
+                                if (!before(d2, j, pd, pi)) break;
+                                s_d[pos][tid] = pd;
+                                s_i[pos][tid] = pi;
+                                --pos;
+                            }
+                            s_d[pos][tid] = d2;
+                            s_i[pos][tid] = j;
+                            if (cnt < k) ++cnt;
+                            if (cnt == k) bound = fminf(r2, s_d[k - 1][tid]);
                         }
-                        s_d[pos][tid] = d2;
-                        s_i[pos][tid] = j;
-                        if (cnt < k) ++cnt;
-                        if (cnt == k) bound = fminf(r2, s_d[k - 1][tid]);
                     }
                 }
                 if (!any_y) break;  // gaps only grow with dy and the bound only shrinks
@@ -354,13 +363,17 @@ __device__ __forceinline__ float4 point_normal(const MapView& mv, const uint32_t
 
 __device__ __forceinline__ bool is_zero3(const float4& v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f; }
 
+// KMAX = capacity of the per-thread neighbour list in LDS (8, 16 or 32 slots: 8 bytes x KMAX x
+// 128 threads per workgroup); the launcher picks the smallest that holds k, which doubles or
+// quadruples the workgroups a CU can hold for the usual k = 16 / k = 8.
+template <int KMAX>
 __global__ __launch_bounds__(kNrmThreads) void k_normals(MapView mv,
                                                          const uint32_t* __restrict__ perm, int k,
                                                          float4* __restrict__ nrm,
                                                          unsigned long long* __restrict__ invalid)
 {
-    __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
-    __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
+    __shared__ float s_d[KMAX][kNrmThreads];
+    __shared__ int s_i[KMAX][kNrmThreads];
     const int tid = threadIdx.x;
     const int s = blockIdx.x * kNrmThreads + tid;
     if (s >= mv.n) return;
@@ -404,13 +417,14 @@ __device__ __forceinline__ bool near_changed(const MapView& mv, const float4& p,
 // w < 0 for points that are new.  A listed point whose reach no changed point can touch keeps
 // its normal untouched (chg == nullptr: no such test).  The invalid-normal count is
 // maintained by difference (two's complement add).
+template <int KMAX>
 __global__ __launch_bounds__(kNrmThreads) void k_normals_subset(
     MapView mv, const uint32_t* __restrict__ perm, int k, const int32_t* __restrict__ work,
     int n_work, const uint32_t* __restrict__ chg, uint32_t n_chg, float4* __restrict__ nrm,
     unsigned long long* __restrict__ invalid, unsigned* __restrict__ n_done)
 {
-    __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
-    __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
+    __shared__ float s_d[KMAX][kNrmThreads];
+    __shared__ int s_i[KMAX][kNrmThreads];
     const int tid = threadIdx.x;
     const int w = blockIdx.x * kNrmThreads + tid;
     if (w >= n_work) return;
@@ -438,6 +452,7 @@ __global__ __launch_bounds__(256) void k_removed_keys(const uint32_t* __restrict
 
 // a10 with k > 1: the k nearest map points of every (transformed) query within d_max,
 // ascending (d2, sorted index); rows of idx/d2 are padded with -1 / +inf.
+template <int KMAX>
 __global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __restrict__ x,
                                                      const float* __restrict__ y,
                                                      const float* __restrict__ z, int n,
@@ -446,8 +461,8 @@ __global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __
                                                      float* __restrict__ d2o,
                                                      int32_t* __restrict__ count)
 {
-    __shared__ float s_d[VELO_MAX_KNORMALS][kNrmThreads];
-    __shared__ int s_i[VELO_MAX_KNORMALS][kNrmThreads];
+    __shared__ float s_d[KMAX][kNrmThreads];
+    __shared__ int s_i[KMAX][kNrmThreads];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kNrmThreads + tid;
     if (i >= n) return;
@@ -468,8 +483,15 @@ hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const f
 {
     if (n == 0) return hipSuccess;
     const int grid = (int)((n + kNrmThreads - 1) / kNrmThreads);
-    hipLaunchKernelGGL(k_knn, dim3(grid), dim3(kNrmThreads), 0, s, mv, x, y, z, (int)n, T, dmax2, k,
-                       idx, d2, count);
+    if (k <= 8)
+        hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(kNrmThreads), 0, s, mv, x, y, z, (int)n, T, dmax2,
+                           k, idx, d2, count);
+    else if (k <= 16)
+        hipLaunchKernelGGL(k_knn<16>, dim3(grid), dim3(kNrmThreads), 0, s, mv, x, y, z, (int)n, T, dmax2,
+                           k, idx, d2, count);
+    else
+        hipLaunchKernelGGL(k_knn<VELO_MAX_KNORMALS>, dim3(grid), dim3(kNrmThreads), 0, s, mv, x, y, z,
+                           (int)n, T, dmax2, k, idx, d2, count);
     return hipGetLastError();
 }
 
@@ -479,7 +501,13 @@ hipError_t launch_normals(const MapView& mv, const uint32_t* perm, int k, float4
     hipError_t e = hipMemsetAsync(d_invalid, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     const int grid = (mv.n + kNrmThreads - 1) / kNrmThreads;
-    hipLaunchKernelGGL(k_normals, dim3(grid), dim3(kNrmThreads), 0, s, mv, perm, k, nrm, d_invalid);
+    if (k <= 8)
+        hipLaunchKernelGGL(k_normals<8>, dim3(grid), dim3(kNrmThreads), 0, s, mv, perm, k, nrm, d_invalid);
+    else if (k <= 16)
+        hipLaunchKernelGGL(k_normals<16>, dim3(grid), dim3(kNrmThreads), 0, s, mv, perm, k, nrm, d_invalid);
+    else
+        hipLaunchKernelGGL(k_normals<VELO_MAX_KNORMALS>, dim3(grid), dim3(kNrmThreads), 0, s, mv, perm, k,
+                           nrm, d_invalid);
     return hipGetLastError();
 }
 
@@ -786,9 +814,16 @@ hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
                                  unsigned* d_done, hipStream_t s)
 {
     if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_normals_subset, dim3((n_work + kNrmThreads - 1) / kNrmThreads),
-                       dim3(kNrmThreads), 0, s, mv, perm, k, work, n_work, chg_keys, n_chg, nrm,
-                       d_invalid, d_done);
+    const dim3 g((n_work + kNrmThreads - 1) / kNrmThreads), b(kNrmThreads);
+    if (k <= 8)
+        hipLaunchKernelGGL(k_normals_subset<8>, g, b, 0, s, mv, perm, k, work, n_work, chg_keys, n_chg,
+                           nrm, d_invalid, d_done);
+    else if (k <= 16)
+        hipLaunchKernelGGL(k_normals_subset<16>, g, b, 0, s, mv, perm, k, work, n_work, chg_keys, n_chg,
+                           nrm, d_invalid, d_done);
+    else
+        hipLaunchKernelGGL(k_normals_subset<VELO_MAX_KNORMALS>, g, b, 0, s, mv, perm, k, work, n_work,
+                           chg_keys, n_chg, nrm, d_invalid, d_done);
     return hipGetLastError();
 }
 
