@@ -118,5 +118,18 @@ int main(int argc, char** argv)
     for (int k = 0; k < 12; ++k) std::printf(" %.17g", res.T[k]);
     std::printf("\npairs %u\n", res.iter[9].n_pairs);
     std::printf("trdeg %.12g %.12g %.12g %.12g %.12g %.12g\n", out.T[0], out.T[1], out.T[2], out.R[0], out.R[1], out.R[2]);
+    // integrate: the accepted increment goes into the host tiles AND is merged into the device
+    // map in place; the next registration must not re-upload the ROI
+    velo_map_info mi0, mi1, mi2;
+    velo_map_info_get(mgr.context(), &mi0);
+    opt.integrate = true;
+    PoseTransform out2, out3;
+    if (!mgr.registerFrame(frame, prior, opt, &out2)) return 6;
+    velo_map_info_get(mgr.context(), &mi1);
+    if (!mgr.registerFrame(frame, prior, opt, &out3)) return 7;
+    velo_map_info_get(mgr.context(), &mi2);
+    std::printf("integrate %llu %llu %llu %d %d %zu\n", (unsigned long long)mi0.n_points,
+                (unsigned long long)mi1.n_points, (unsigned long long)mi2.n_points, mi1.last_update,
+                mi2.last_update, mgr.numPoints());
     return 0;
 }

@@ -88,3 +88,8 @@ def test_cpp_register_frame_matches_c_abi(tmp_path, oracle):
     dpos, drot = pose_delta(T, np.array(list(ref.T)))
     assert dpos <= 1e-4 and drot <= 1e-5
     assert abs(int(lines["pairs"]) - int(ref.iter[9].n_pairs)) <= 2
+    # integrate keeps host tiles and device map in step, incrementally (no ROI re-upload)
+    n0, n1, n2, u1, u2, host = (int(v) for v in lines["integrate"].split())
+    assert n1 > n0 and n2 >= n1 and host == n2
+    assert u1 == 1 and u2 in (0, 1)   # the first append cannot lower the map's minimum here
+

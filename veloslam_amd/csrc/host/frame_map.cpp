@@ -297,6 +297,11 @@ bool MapManager::registerFrame(const HDLFrame& frame, const PoseTransform& init,
             return false;
         }
         addPoints(ix.data(), iy.data(), iz.data(), n_inc);
+        // keep the device map in step instead of re-uploading the ROI at the next frame: the
+        // increment is merged into the sorted map in place (velo_map_append is incremental).  If
+        // the ROI's tile set changes, syncDeviceMap rebuilds from the tiles as before.
+        if (n_inc == 0 || velo_map_append(ctx_, ix.data(), iy.data(), iz.data(), n_inc) == VELO_OK)
+            dirty_ = false;
     }
     return true;
 }
