@@ -460,6 +460,13 @@ def main():
                                "bytes_per_query": bytes_per_query,
                                "compulsory_bytes_per_launch": 16.0 * n_q + 32.0 * args.map_points,
                                "traffic_GBps": (traffic / avg_s / 1e9) if traffic else None,
+                               # a converged iteration moves, per query: xyz 12 B + hint 4 B +
+                               # certificate 4 B + one 16-B point gather + one 16-B normal gather
+                               "steady_state": {"bytes_per_query": 52.0,
+                                                "launch_us": 1e3 * tm["linearize_min_ms"],
+                                                "GBps": 52.0 * n_q / (1e-3 * tm["linearize_min_ms"]) / 1e9,
+                                                "frac": 52.0 * n_q / (1e-3 * tm["linearize_min_ms"]) / 1e9 / HBM_PEAK_GBPS}
+                               if tm["linearize_min_ms"] > 0 else None,
                                "note": "achieved = SURVEY 8(d) algorithmic bytes (232+12*Cbar+24 per "
                                        "query, exhaustive 27-voxel definition) / mean launch time; the "
                                        "map is cache-resident and the exact ball search never touches "
