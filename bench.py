@@ -435,7 +435,7 @@ def main():
             if tm["linearize_ms"] > 0 else None,
         }
         cbar = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 at N = 1 only
             cb, cbar = cpu_baseline(args, d)
             out["cpu_baseline"] = cb
         if tm["linearize_launches"] > 0:
