@@ -268,3 +268,15 @@ def test_calibration_file_loader(tmp_path, oracle, azcorr, enabled, shuffle):
     with pytest.raises(capi.VeloError):
         capi.load_corrections(tmp_path / "missing.xml")
 
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/velo.h is the drop-in boundary: it has to compile as C99 with nothing but the
+    standard headers (cgo / JNI / ctypes-style bindings include it as C)."""
+    import subprocess
+    src = tmp_path / "chk.c"
+    src.write_text('#include "velo.h"\nint main(void) { return velo_abi_version() > 0 ? 0 : 1; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
