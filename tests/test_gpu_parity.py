@@ -486,6 +486,33 @@ def test_sorted_query_order_gives_same_pose(omap, wl, comp, variant):
 
 
 # ------------------------------------------------------------- increment (8e)
+@pytest.mark.parametrize("kw", [dict(use_graph=0), dict(use_hints=0), dict(use_hints=1),
+                                dict(rounds_per_block=3), dict(rounds_per_block=64, use_graph=0),
+                                dict(sort_frames=2), dict(use_hints=0, use_graph=0, rounds_per_block=2)])
+def test_cfg_switches_do_not_change_the_registration(omap, wl, comp, kw):
+    """Every tuning switch of velo_cfg is performance-only: with hipGraph replay off, hints or
+    certificates off, several rounds per workgroup or cell-sorted queries, the registration has
+    the same per-iteration pair counts and the same pose (summation order may differ)."""
+    ref = capi.Context(0, max_batch=4)
+    alt = capi.Context(0, max_batch=4, **kw)
+    try:
+        out = []
+        for c in (ref, alt):
+            c.map_reset(*wl["map"], 1.0, 16)
+            c.frames_upload(comp)
+            out.append(c.icp_batch([f["T0"] for f in wl["frames"]], 12, 1.0))
+        for a, b in zip(*out):
+            assert [a.iter[i].n_pairs for i in range(12)] == [b.iter[i].n_pairs for i in range(12)]
+            dpos, drot = pose_delta(a.T, b.T)
+            assert dpos <= 1e-9 and drot <= 1e-7   # (arccos floor of the rotation metric: ~4e-8)
+        To, st, _ = omap.icp(*comp[0], wl["frames"][0]["T0"], 12, 1.0)
+        dpos, drot = pose_delta(out[1][0].T, To)
+        assert dpos <= POS_TOL and drot <= ROT_TOL
+    finally:
+        ref.close()
+        alt.close()
+
+
 def test_increment_bit_exact(ctx, omap, wl, comp):
     ctx.map_reset(*wl["map"], 1.0, 16)
     ctx.frames_upload(comp)
