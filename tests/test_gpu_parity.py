@@ -601,6 +601,32 @@ def test_gpu_decode_matches_oracle_parser(ctx, oracle, az_start, azcorr, with_po
     assert g["n_points"] == sum(dec.beam(f, b)[0].size for f in range(dec.num_frames) for b in range(64))
 
 
+@pytest.mark.parametrize("n_lasers", [32, 16])
+def test_gpu_decode_32_and_16_laser_timing(ctx, oracle, n_lasers):
+    """HDL-32 / VLP-16 packets (every firing block carries the 0xeeff id): the per-laser
+    azimuth adjustment from the packet's median azimuth step (HDLParser.cxx:946-962,
+    1021-1026) is on the device too -- same frames as the oracle parser, bit for bit."""
+    pk, ts, cal, mo = _stream(2, 9000)
+    pk32 = []
+    for p in pk:
+        b = bytearray(p)
+        for k in range(12):
+            b[100 * k], b[100 * k + 1] = 0xFF, 0xEE
+        pk32.append(bytes(b))
+    track = mo.ins_track(ts[0], ts[-1])
+    tl = oracle.Timeline()
+    for (T, R, V, t) in track:
+        tl.add(T, R, V, t)
+    dec = oracle.Decoder(cal, n_lasers, tl)
+    for p, t in zip(pk32, ts):
+        dec.packet(p, t)
+    dec.flush()
+    poses, n = capi.make_poses(track)
+    g = ctx.decode(pk32, ts, cal, n_lasers, poses, n, flush=True)
+    _check_decode(oracle, g, dec, dec.num_frames)
+    assert g["n_points"] > 50_000
+
+
 @pytest.mark.parametrize("seed,az_start", [(1, 0), (2, 17000), (3, 35990)])
 def test_gpu_decode_stream_chunks_equal_one_shot(ctx, oracle, seed, az_start):
     """The parser is stateful across calls (velo_decode_stream): the same packet sequence fed
