@@ -49,6 +49,60 @@ uint32_t get32(const uint8_t* p, bool swap)
 
 }  // namespace
 
+// ---- tag scanner for the calibration file (velo_load_corrections below)
+namespace {
+
+// text of the first <name ...>...</name> inside [from, to); empty if absent
+bool tag_text(const std::string& s, size_t from, size_t to, const char* name, std::string* out,
+              size_t* after = nullptr)
+{
+    const std::string open = std::string("<") + name;
+    size_t a = from;
+    for (;;) {
+        a = s.find(open, a);
+        if (a == std::string::npos || a >= to) return false;
+        const char c = a + open.size() < s.size() ? s[a + open.size()] : '\0';
+        if (c == '>' || c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '/') break;
+        a += open.size();  // a longer tag name that merely starts the same
+    }
+    const size_t gt = s.find('>', a);
+    if (gt == std::string::npos || gt >= to) return false;
+    if (s[gt - 1] == '/') {  // <name/>
+        out->clear();
+        if (after) *after = gt + 1;
+        return true;
+    }
+    const std::string close = std::string("</") + name + ">";
+    const size_t b = s.find(close, gt + 1);
+    if (b == std::string::npos || b > to) return false;
+    *out = s.substr(gt + 1, b - gt - 1);
+    if (after) *after = b + close.size();
+    return true;
+}
+
+// [start of content, start of closing tag) of the first <name> element inside [from, to)
+bool tag_span(const std::string& s, size_t from, size_t to, const char* name, size_t* a, size_t* b)
+{
+    const std::string open = std::string("<") + name;
+    size_t p = from;
+    for (;;) {
+        p = s.find(open, p);
+        if (p == std::string::npos || p >= to) return false;
+        const char c = p + open.size() < s.size() ? s[p + open.size()] : '\0';
+        if (c == '>' || c == ' ' || c == '\t' || c == '\n' || c == '\r') break;
+        p += open.size();
+    }
+    const size_t gt = s.find('>', p);
+    const std::string close = std::string("</") + name + ">";
+    const size_t e = gt == std::string::npos ? std::string::npos : s.find(close, gt + 1);
+    if (e == std::string::npos || e > to) return false;
+    *a = gt + 1;
+    *b = e;
+    return true;
+}
+
+}  // namespace
+
 extern "C" {
 
 int velo_pcap_write(const char* path, const uint8_t* packets, const int64_t* t_us, size_t n_pkt)
@@ -224,59 +278,6 @@ int velo_insmeta_read(const char* path, velo_pose* poses, size_t cap, size_t* n_
 // derived fields as there: the three distances are centimetres in the file and metres
 // afterwards (:836-838), sin/cos of the vertical angle (:840-841), the two offset products
 // (:848-855).  Lasers the file does not mention stay zero.
-namespace {
-
-// text of the first <name ...>...</name> inside [from, to); empty if absent
-bool tag_text(const std::string& s, size_t from, size_t to, const char* name, std::string* out,
-              size_t* after = nullptr)
-{
-    const std::string open = std::string("<") + name;
-    size_t a = from;
-    for (;;) {
-        a = s.find(open, a);
-        if (a == std::string::npos || a >= to) return false;
-        const char c = a + open.size() < s.size() ? s[a + open.size()] : '\0';
-        if (c == '>' || c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '/') break;
-        a += open.size();  // a longer tag name that merely starts the same
-    }
-    const size_t gt = s.find('>', a);
-    if (gt == std::string::npos || gt >= to) return false;
-    if (s[gt - 1] == '/') {  // <name/>
-        out->clear();
-        if (after) *after = gt + 1;
-        return true;
-    }
-    const std::string close = std::string("</") + name + ">";
-    const size_t b = s.find(close, gt + 1);
-    if (b == std::string::npos || b > to) return false;
-    *out = s.substr(gt + 1, b - gt - 1);
-    if (after) *after = b + close.size();
-    return true;
-}
-
-// [start of content, start of closing tag) of the first <name> element inside [from, to)
-bool tag_span(const std::string& s, size_t from, size_t to, const char* name, size_t* a, size_t* b)
-{
-    const std::string open = std::string("<") + name;
-    size_t p = from;
-    for (;;) {
-        p = s.find(open, p);
-        if (p == std::string::npos || p >= to) return false;
-        const char c = p + open.size() < s.size() ? s[p + open.size()] : '\0';
-        if (c == '>' || c == ' ' || c == '\t' || c == '\n' || c == '\r') break;
-        p += open.size();
-    }
-    const size_t gt = s.find('>', p);
-    const std::string close = std::string("</") + name + ">";
-    const size_t e = gt == std::string::npos ? std::string::npos : s.find(close, gt + 1);
-    if (e == std::string::npos || e > to) return false;
-    *a = gt + 1;
-    *b = e;
-    return true;
-}
-
-}  // namespace
-
 int velo_load_corrections(const char* path, velo_laser_corr corr[64], int32_t* n_enabled)
 {
     if (!path || !corr) return VELO_E_INVALID;
