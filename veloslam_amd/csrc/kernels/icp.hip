@@ -38,8 +38,19 @@ __global__ __launch_bounds__(256) void k_compensate_v4(
         const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w},
                     zs[4] = {z.x, z.y, z.z, z.w};
         float rx[4], ry[4], rz[4];
+        if (k[0] == k[3] && k[1] == k[2] && k[0] == k[1]) {
+            // four consecutive returns of a beam almost always share their packet: fetch its
+            // 3x4 matrix once (the table loads, not HBM, were what bounded this kernel)
+            double M[12];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) apply_affine(tab + 12 * (size_t)k[j], xs[j], ys[j], zs[j], rx[j], ry[j], rz[j]);
+            for (int e = 0; e < 12; ++e) M[e] = tab[12 * (size_t)k[0] + e];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) apply_affine(M, xs[j], ys[j], zs[j], rx[j], ry[j], rz[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                apply_affine(tab + 12 * (size_t)k[j], xs[j], ys[j], zs[j], rx[j], ry[j], rz[j]);
+        }
         ox4[i] = make_float4(rx[0], rx[1], rx[2], rx[3]);
         oy4[i] = make_float4(ry[0], ry[1], ry[2], ry[3]);
         oz4[i] = make_float4(rz[0], rz[1], rz[2], rz[3]);
@@ -69,7 +80,7 @@ hipError_t launch_compensate(const float* x, const float* y, const float* z, con
         (reinterpret_cast<uintptr_t>(pkt) & 7u) == 0 && n >= 4) {
         const size_t n4 = n / 4;
         size_t g = (n4 + 255) / 256;
-        const int grid = (int)(g > 2048 ? 2048 : g);
+        const int grid = (int)(g > 16384 ? 16384 : g);
         hipLaunchKernelGGL(k_compensate_v4, dim3(grid), dim3(256), 0, s, (const float4*)x,
                            (const float4*)y, (const float4*)z, (const ushort4*)pkt, n4, T3x4,
                            (unsigned)n_pkt, (float4*)ox, (float4*)oy, (float4*)oz);
