@@ -123,6 +123,7 @@ struct velo_ctx {
         }
     } graph_key;
     uint64_t map_gen = 0, frames_gen = 0;
+    uint64_t seen_map_gen = ~0ull, seen_frames_gen = ~0ull;  // of the previous registration
     double* h_T0 = nullptr;  // pinned staging of the initial poses (stable address for the graph)
     bool lin_hints = false;  // velo_linearize keeps/uses hints across calls (tests)
 
@@ -678,7 +679,14 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         }
     }
     HIP_TRY(c, c->poses_prev.reserve((size_t)c->cfg.max_batch * 12));
-    const bool graph_ok = c->cfg.use_graph && !c->timing && !c->cfg.sort_frames;
+    // A graph is only worth capturing for a launch sequence that will be replayed: when the map
+    // or the frames changed since the previous registration (a stream: every frame appends to the
+    // map) the sequence is launched directly, and captured only once the same map and frames come
+    // back (capture + instantiate cost more than the launches they would save once).
+    const bool stable = c->seen_map_gen == c->map_gen && c->seen_frames_gen == c->frames_gen;
+    c->seen_map_gen = c->map_gen;
+    c->seen_frames_gen = c->frames_gen;
+    const bool graph_ok = c->cfg.use_graph && !c->timing && !c->cfg.sort_frames && stable;
     if (graph_ok) {
         // Replay the whole registration (pose upload, hint reset, iters x (linearise, solve)) as
         // one hipGraph: the kernels are tens of microseconds long, so per-launch host cost and
