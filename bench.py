@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--hints", type=int, default=2, help="1 = radius hints, 2 = + uniqueness certificates")
     ap.add_argument("--rounds", type=int, default=0, help="rounds of 256 queries per workgroup (0=auto)")
     ap.add_argument("--no-graph", action="store_true", help="plain stream launches, no hipGraph replay")
-    ap.add_argument("--variant", type=int, default=1, help="1 = fine-grid ball search (default), 0 = exhaustive validation kernel")
+    ap.add_argument("--variant", type=int, default=1, help="1 = fine-grid ball search (default), 100 = exhaustive validation kernel")
     ap.add_argument("--rebuild-threshold", type=int, default=20000,
                     help="pending increment points that trigger a map re-index (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -36,6 +36,8 @@ extern "C" {
 #define VELO_ABI_VERSION 1
 #define VELO_MAX_ITERS 64
 #define VELO_MAX_KNORMALS 32
+#define VELO_VARIANT_BALL 1
+#define VELO_VARIANT_SCAN 100
 
 enum {
     VELO_OK = 0,
@@ -52,7 +54,9 @@ typedef struct velo_ctx velo_ctx;
 typedef struct velo_cfg {
     uint32_t struct_size;   /* = sizeof(velo_cfg) */
     int32_t max_batch;      /* frames registered per launch (default 64) */
-    int32_t linearize_variant; /* 0 = default kernel; others are tuning variants */
+    int32_t linearize_variant; /* 0 = default = VELO_VARIANT_BALL (exact pruned ball search);
+                               VELO_VARIANT_SCAN = the exhaustive 27-voxel validation kernel
+                               (same results, ~10x slower); 11..13 timing ablations */
     int32_t sort_frames;    /* 1: order each frame's queries by map cell once per registration */
     int32_t use_graph;      /* 1: replay a registration's launch sequence as one hipGraph
                                (cfg == NULL enables it) */
@@ -119,6 +123,9 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg);
 void velo_destroy(velo_ctx*);
 const char* velo_last_error(const velo_ctx*); /* ctx may be NULL: creation errors */
 int velo_abi_version(void);
+/* The configuration in effect (defaults filled in: e.g. linearize_variant 0 reads back as
+ * VELO_VARIANT_BALL, map_subdiv 0 as 3). */
+int velo_cfg_get(const velo_ctx*, velo_cfg* out);
 /* Run all work of this ctx on `hip_stream` (a hipStream_t, e.g. torch's current
  * stream).  NULL = the ctx's own stream. */
 int velo_set_stream(velo_ctx*, void* hip_stream);
@@ -207,7 +214,10 @@ int velo_decode_fetch(velo_ctx*, float* x, float* y, float* z, float* intensity,
                       float* distance, uint16_t* packet_index, int64_t* frame_start,
                       int32_t* beam_start, velo_pose* carposes, int64_t* frame_t_us,
                       int32_t* frame_packets);
-/* The decoded frames become the resident frames of velo_icp_batch (no host round-trip). */
+/* The decoded frames become the resident frames of velo_icp_batch (no host round-trip).  They
+ * stay resident until the next velo_decode / velo_decode_stream on this ctx, which rewrites
+ * those buffers: that call ends the adoption (registration then fails with VELO_E_INVALID until
+ * velo_decode_to_frames / velo_frames_upload / velo_frames_adopt_dev is called again). */
 int velo_decode_to_frames(velo_ctx*);
 
 /* ---- K2+K3+solve: scan-to-map ICP (no reference counterpart) -----------
@@ -244,6 +254,12 @@ int velo_linearize(velo_ctx*, int frame, const double T[12], float d_max, int32_
  * number found per query.  No reference counterpart. */
 int velo_knn(velo_ctx*, int frame, const double T[12], float d_max, int k, int32_t* idx, float* d2,
              int32_t* count);
+
+/* a12 alone, on the device (the kernel every registration iteration runs): the 29 sums of one
+ * linearisation -> 6x6 LDLt (diagonal guard on a non-positive pivot) -> T <- exp(xi^) T.
+ * T is updated in place; solve_flag (may be NULL): 0 ok, 1 guard used, 2 no update (fewer than
+ * 6 pairs or singular).  No reference counterpart. */
+int velo_solve_update(velo_ctx*, const double acc[29], double T[12], int32_t* solve_flag);
 
 /* mode 1: velo_linearize remembers each query's correspondence and uses it as the search-
  * radius hint of the next call (what velo_icp_batch does between iterations); mode 0: every

@@ -67,7 +67,7 @@ private:
     std::set<std::shared_ptr<MapPatch>> resident_;
     float residentVoxel_;
     int residentK_;
-    std::string err_;
+    mutable std::string err_;
 };
 
 }  // namespace veloslam

@@ -95,6 +95,11 @@ int main(int argc, char** argv)
         std::cerr << "no context: " << mgr.lastError() << std::endl;
         return 4;
     }
+    // MapManager creates its ctx with cfg == NULL: that must select the fast (pruned) kernel,
+    // hints + certificates and graph replay -- not the validation kernel
+    velo_cfg eff;
+    velo_cfg_get(mgr.context(), &eff);
+    std::printf("cfg %d %d %d %d\n", eff.linearize_variant, eff.use_hints, eff.use_graph, eff.map_subdiv);
     const auto mx = slurp<float>(dir + "/mx.f32"), my = slurp<float>(dir + "/my.f32"),
                mz = slurp<float>(dir + "/mz.f32");
     mgr.addPoints(mx.data(), my.data(), mz.data(), mx.size());

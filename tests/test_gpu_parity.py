@@ -14,10 +14,13 @@ POS_TOL = 1e-4  # metres   (BASELINE.json north_star)
 ROT_TOL = 1e-5  # radians
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["scan", "pruned"])
+SCAN, BALL = 100, 1  # VELO_VARIANT_SCAN / VELO_VARIANT_BALL (include/velo.h)
+
+
+@pytest.fixture(scope="module", params=[SCAN, BALL], ids=["scan", "pruned"])
 def ctx(request):
-    """Both linearise kernels are held to the same oracle: variant 0 = exhaustive 27-cell
-    scan, variant 1 = pruned exact search."""
+    """Both linearise kernels are held to the same oracle: VELO_VARIANT_SCAN = exhaustive
+    27-cell scan, VELO_VARIANT_BALL = pruned exact search, the default."""
     c = capi.Context(0, max_batch=16, linearize_variant=request.param)
     yield c
     c.close()
@@ -107,7 +110,7 @@ def test_map_build_and_search_other_grids(oracle, voxel, k, subdiv):
     q = rng.uniform(-22, 22, (3, 6000)).astype(np.float32)
     q[2] *= 0.05
     I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)
-    for variant in (0, 1):
+    for variant in (SCAN, BALL):
         c = capi.Context(0, max_batch=2, linearize_variant=variant, map_subdiv=subdiv)
         try:
             c.map_reset(x, y, z, voxel, k)
@@ -470,7 +473,7 @@ def test_icp_ragged_batch_with_empty_frame(ctx, omap, wl, comp):
     assert r[2].iter[4].n_pairs == st[4]["n_pairs"]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [SCAN, BALL])
 def test_sorted_query_order_gives_same_pose(omap, wl, comp, variant):
     c2 = capi.Context(0, max_batch=4, sort_frames=1, linearize_variant=variant)
     try:
@@ -756,7 +759,7 @@ def test_config3_size_10m_map_properties():
     f = wl["frames"][0]
     s = f["sensor"]
     res = {}
-    for variant in (1, 0):
+    for variant in (BALL, SCAN):
         c = capi.Context(0, max_batch=2, linearize_variant=variant, map_subdiv=6)
         try:
             cx, cy, cz = c.compensate(s["x"], s["y"], s["z"], s["pkt"], f["table"])
@@ -766,7 +769,7 @@ def test_config3_size_10m_map_properties():
             sub = tuple(a[::5].copy() for a in (cx, cy, cz))
             c.frames_upload([sub])
             res[variant] = [c.linearize(0, T, 1.0, sub[0].size)[:2] for T in (f["T0"], f["T_true"])]
-            if variant == 1:
+            if variant == BALL:
                 g = c.map_download()
                 assert g["cell_start"][0] == 0 and g["cell_start"][-1] == 10_000_000
                 assert np.all(np.diff(g["cell_start"]) >= 0)
@@ -775,7 +778,7 @@ def test_config3_size_10m_map_properties():
                 assert dpos < 0.01 and drot < 2e-4
         finally:
             c.close()
-    for (c1, d1), (c0, d0) in zip(res[1], res[0]):
+    for (c1, d1), (c0, d0) in zip(res[BALL], res[SCAN]):
         assert np.array_equal(c1, c0)
         assert np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
 

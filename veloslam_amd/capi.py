@@ -15,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("VELO_LIB") or os.path.join(CSRC, "libveloslam_amd.so")  # VELO_LIB: A/B builds
 
 VELO_MAX_ITERS = 64
+VARIANT_BALL, VARIANT_SCAN = 1, 100  # velo_cfg.linearize_variant (0 = default = BALL)
 VELO_TIME_INVALID = -(2 ** 63)
 
 
@@ -64,12 +65,12 @@ class MapInfo(C.Structure):
 
 # every symbol include/velo.h declares (tests check the library exports them all)
 EXPORTS = [
-    "velo_create", "velo_destroy", "velo_last_error", "velo_abi_version", "velo_set_stream",
+    "velo_create", "velo_destroy", "velo_last_error", "velo_abi_version", "velo_cfg_get", "velo_set_stream",
     "velo_synchronize", "velo_map_reset", "velo_map_reset_dev", "velo_map_append",
     "velo_map_append_dev", "velo_map_evict_outside", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_wait", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats",
+    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_wait", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
     "velo_insmeta_write", "velo_insmeta_read", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
@@ -107,6 +108,7 @@ def lib():
     L.velo_last_error.restype = C.c_char_p
     L.velo_last_error.argtypes = [vp]
     L.velo_set_stream.argtypes = [vp, vp]
+    L.velo_cfg_get.argtypes = [vp, C.POINTER(Cfg)]
     L.velo_synchronize.argtypes = [vp]
     L.velo_map_reset.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_int]
     L.velo_map_reset_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_int]
@@ -128,6 +130,7 @@ def lib():
     L.velo_icp_batch_fetch.argtypes = [vp, C.POINTER(IcpResult)]
     L.velo_linearize.argtypes = [vp, C.c_int, dp, C.c_float, vp, vp, dp]
     L.velo_linearize_hints.argtypes = [vp, C.c_int]
+    L.velo_solve_update.argtypes = [vp, dp, dp, C.POINTER(C.c_int32)]
     L.velo_knn.argtypes = [vp, C.c_int, dp, C.c_float, C.c_int, vp, vp, vp]
     L.velo_decode.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_int, C.POINTER(Pose), C.c_size_t, C.c_int,
                               vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
@@ -324,6 +327,11 @@ class Context:
         if rc != 0:
             raise VeloError(rc, lib().velo_last_error(self.h).decode())
 
+    def cfg(self):
+        out = Cfg()
+        self._chk(lib().velo_cfg_get(self.h, C.byref(out)))
+        return out
+
     def set_stream(self, stream_ptr):
         self._chk(lib().velo_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
 
@@ -445,6 +453,14 @@ class Context:
         acc = np.zeros(29)
         self._chk(lib().velo_linearize(self.h, frame, _d(T), d_max, _p(corr), _p(d2), _d(acc)))
         return corr, d2, acc
+
+    def solve_update(self, acc, T):
+        """a12 on the device: (29 sums, pose) -> (solve_flag, updated pose)."""
+        acc = np.ascontiguousarray(acc, dtype=np.float64).reshape(29)
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(12).copy()
+        flag = C.c_int32()
+        self._chk(lib().velo_solve_update(self.h, _d(acc), _d(T), C.byref(flag)))
+        return flag.value, T
 
     def knn(self, frame, T, d_max, k, n):
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)

@@ -124,7 +124,12 @@ struct velo_ctx {
     } graph_key;
     uint64_t map_gen = 0, frames_gen = 0;
     uint64_t seen_map_gen = ~0ull, seen_frames_gen = ~0ull;  // of the previous registration
-    double* h_T0 = nullptr;  // pinned staging of the initial poses (stable address for the graph)
+    // pinned staging of the initial poses, double-buffered: buffer b is reused only after the
+    // upload that read it has completed (its event), so an _async call never waits for the
+    // batch in flight
+    double* h_T0[2] = {nullptr, nullptr};
+    hipEvent_t ev_T0[2] = {nullptr, nullptr};
+    int t0_next = 0;
     bool lin_hints = false;  // velo_linearize keeps/uses hints across calls (tests)
 
     // ---- f1 decode
@@ -645,6 +650,24 @@ int maybe_sort_frames(velo_ctx* c, FrameView& fv)
     return VELO_OK;
 }
 
+// initial poses -> device through the pinned double buffer (never blocks on queued work
+// younger than two uploads ago; a pageable-source hipMemcpyAsync would block every time)
+int upload_T0(velo_ctx* c, const double* T0, size_t pose_bytes)
+{
+    const int b = c->t0_next;
+    if (!c->h_T0[b]) {
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_T0[b], (size_t)c->cfg.max_batch * 12 * sizeof(double), 0));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_T0[b], hipEventDisableTiming));
+    } else {
+        HIP_TRY(c, hipEventSynchronize(c->ev_T0[b]));
+    }
+    std::memcpy(c->h_T0[b], T0, pose_bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->poses.p, c->h_T0[b], pose_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_T0[b], c->stream));
+    c->t0_next = b ^ 1;
+    return VELO_OK;
+}
+
 int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
 {
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map: call velo_map_reset first");
@@ -654,6 +677,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         return c->fail(VELO_E_INVALID, "iters must be in [1,%d]", VELO_MAX_ITERS);
     if (!(d_max > 0.0f) || !(d_max <= c->mv.h))
         return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv.h);
+    HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->ev_used = 0;
     c->ev_kind.clear();
@@ -688,10 +712,9 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     c->seen_frames_gen = c->frames_gen;
     const bool graph_ok = c->cfg.use_graph && !c->timing && !c->cfg.sort_frames && stable;
     if (graph_ok) {
-        // Replay the whole registration (pose upload, hint reset, iters x (linearise, solve)) as
+        // Replay the whole registration (hint reset, iters x (linearise, solve)) as
         // one hipGraph: the kernels are tens of microseconds long, so per-launch host cost and
         // inter-kernel gaps are a visible share of an iteration.
-        if (!c->h_T0) HIP_TRY(c, hipHostMalloc((void**)&c->h_T0, (size_t)c->cfg.max_batch * 12 * sizeof(double), 0));
         velo_ctx::GraphKey key;
         key.iters = iters;
         key.ni = ni;
@@ -711,8 +734,8 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             }
             HIP_TRY(c, hipStreamSynchronize(s));
             HIP_TRY(c, hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-            hipError_t e = hipMemcpyAsync(c->poses.p, c->h_T0, pose_bytes, hipMemcpyHostToDevice, s);
-            if (e == hipSuccess && hint) e = hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s);
+            hipError_t e = hipSuccess;  // (the pose upload stays outside the graph: its source alternates)
+            if (hint) e = hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s);
             if (e == hipSuccess && rho) e = hipMemsetAsync(rho, 0, n_all * sizeof(float), s);
             FrameView fv{c->ax, c->ay, c->az, nullptr};
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
@@ -738,14 +761,12 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             }
             c->graph_key = key;
         }
-        // the previous replay may still be reading h_T0
-        HIP_TRY(c, hipStreamSynchronize(s));
-        std::memcpy(c->h_T0, T0, pose_bytes);
+        if (int rc = upload_T0(c, T0, pose_bytes)) return rc;
         HIP_TRY(c, hipGraphLaunch(c->graph_exec, s));
         c->last_iters = iters;
         return VELO_OK;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->poses.p, T0, pose_bytes, hipMemcpyHostToDevice, s));
+    if (int rc = upload_T0(c, T0, pose_bytes)) return rc;
     FrameView fv{c->ax, c->ay, c->az, nullptr};
     if (int rc = maybe_sort_frames(c, fv)) return rc;
     // hints never outlive a registration: results do not depend on earlier calls
@@ -774,6 +795,7 @@ int fetch_icp(velo_ctx* c, velo_icp_result* out)
 {
     if (!out) return c->fail(VELO_E_INVALID, "out is null");
     if (c->last_iters < 1) return c->fail(VELO_E_INVALID, "no registration has run");
+    HIP_TRY(c, hipSetDevice(c->device));
     const int F = c->n_frames, iters = c->last_iters;
     std::vector<double> T((size_t)F * 12);
     std::vector<velo_icp_iter> st((size_t)F * VELO_MAX_ITERS);
@@ -853,6 +875,9 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     if (cfg) std::memcpy(&c->cfg, cfg, std::min<size_t>(cfg->struct_size, sizeof(velo_cfg)));
     c->cfg.struct_size = sizeof(velo_cfg);
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 64;
+    // 0 = the default (fast, pruned) kernel for every consumer -- C, C++ MapManager and Python
+    // alike; the exhaustive validation kernel has to be asked for by name
+    if (c->cfg.linearize_variant == 0) c->cfg.linearize_variant = VELO_VARIANT_BALL;
     if (!cfg) {
         c->cfg.use_hints = 2;
         c->cfg.use_graph = 1;
@@ -875,7 +900,10 @@ void velo_destroy(velo_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
-    if (c->h_T0) (void)hipHostFree(c->h_T0);
+    for (int b = 0; b < 2; ++b) {
+        if (c->h_T0[b]) (void)hipHostFree(c->h_T0[b]);
+        if (c->ev_T0[b]) (void)hipEventDestroy(c->ev_T0[b]);
+    }
     if (c->h_inc_total) (void)hipHostFree(c->h_inc_total);
     if (c->ev_inc) (void)hipEventDestroy(c->ev_inc);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -885,9 +913,17 @@ void velo_destroy(velo_ctx* c)
     delete c;
 }
 
+int velo_cfg_get(const velo_ctx* c, velo_cfg* out)
+{
+    if (!c || !out) return VELO_E_INVALID;
+    *out = c->cfg;
+    return VELO_OK;
+}
+
 int velo_set_stream(velo_ctx* c, void* hip_stream)
 {
     if (!c) return VELO_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return VELO_OK;
@@ -896,6 +932,7 @@ int velo_set_stream(velo_ctx* c, void* hip_stream)
 int velo_synchronize(velo_ctx* c)
 {
     if (!c) return VELO_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VELO_OK;
 }
@@ -903,6 +940,7 @@ int velo_synchronize(velo_ctx* c)
 int velo_linearize_hints(velo_ctx* c, int mode)
 {
     if (!c) return VELO_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
     c->lin_hints = mode != 0;
     if (c->hint.p && c->hint.cap)  // (re)start from "no hint"
         HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), c->stream));
@@ -1134,6 +1172,7 @@ int velo_map_download(velo_ctx* c, float* x, float* y, float* z, float* nx, floa
 {
     if (!c) return VELO_E_INVALID;
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
+    HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = c->info.n_points;
     std::vector<float4> h;
     if (x || y || z || nx || ny || nz) h.resize(n);
@@ -1172,6 +1211,7 @@ int velo_compensate_dev(velo_ctx* c, const float* dx, const float* dy, const flo
     if (n == 0) return VELO_OK;
     if (!dx || !dy || !dz || !dpkt || !dT || !dox || !doy || !doz || n_pkt == 0)
         return c->fail(VELO_E_INVALID, "velo_compensate: null argument or empty transform table");
+    HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, launch_compensate(dx, dy, dz, dpkt, n, dT, n_pkt, dox, doy, doz, c->stream));
     return VELO_OK;
 }
@@ -1284,6 +1324,7 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
     if (!T) return c->fail(VELO_E_INVALID, "T is null");
     if (!(d_max > 0.0f) || !(d_max <= c->mv.h))
         return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv.h);
+    HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const size_t n_all = (size_t)c->frame_start[c->n_frames];
     const size_t q0 = (size_t)c->frame_start[frame], q1 = (size_t)c->frame_start[frame + 1];
@@ -1323,6 +1364,37 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
     HIP_TRY(c, hipMemcpyAsync(a, c->acc.p, sizeof a, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     if (acc) std::memcpy(acc, a, kAccN * sizeof(double));
+    return VELO_OK;
+}
+
+// a12 on its own (parity tests): the 29 sums -> LDLt solve -> T <- exp(xi^) T, on the device
+// (k_reduce_solve over one partial row, the kernel every registration iteration runs)
+int velo_solve_update(velo_ctx* c, const double acc[29], double T[12], int32_t* solve_flag)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!acc || !T) return c->fail(VELO_E_INVALID, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    DevBuf<double> part, pose;
+    DevBuf<int32_t> fbs;
+    DevBuf<velo_icp_iter> st;
+    HIP_TRY(c, part.reserve(kAccStride));
+    HIP_TRY(c, pose.reserve(12));
+    HIP_TRY(c, fbs.reserve(2));
+    HIP_TRY(c, st.reserve(VELO_MAX_ITERS));
+    double row[kAccStride] = {0};
+    std::memcpy(row, acc, kAccN * sizeof(double));
+    const int32_t range[2] = {0, 1};
+    HIP_TRY(c, hipMemcpyAsync(part.p, row, sizeof row, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(pose.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(fbs.p, range, sizeof range, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));  // the sources are stack arrays
+    HIP_TRY(c, launch_reduce_solve(part.p, fbs.p, 1, pose.p, st.p, 0, 1, nullptr, 1, nullptr, s));
+    velo_icp_iter it0;
+    HIP_TRY(c, hipMemcpyAsync(T, pose.p, 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&it0, st.p, sizeof it0, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (solve_flag) *solve_flag = (int32_t)it0.solve_flag;
     return VELO_OK;
 }
 
@@ -1396,6 +1468,15 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     const size_t n_pkt = n_pend + n_new;
     if (n_pkt == 0 || n_pkt > 60000) return c->fail(VELO_E_RANGE, "packets in flight must be in [1, 60000]");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->ax && c->ax == c->dk_x.p) {
+        // the resident frames ARE the previous decode's output (velo_decode_to_frames): this
+        // decode rewrites (and may reallocate) those buffers, so the adoption ends here --
+        // registration calls fail with VELO_E_INVALID until frames are uploaded/adopted again
+        c->ax = c->ay = c->az = nullptr;
+        c->n_frames = 0;
+        c->last_iters = 0;
+        ++c->frames_gen;
+    }
     if (int rc = upload_calibration(c, corr)) return rc;
     hipStream_t s = c->stream;
 
@@ -1639,6 +1720,7 @@ int velo_decode_fetch(velo_ctx* c, float* x, float* y, float* z, float* intensit
                       int32_t* frame_packets)
 {
     if (!c) return VELO_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = c->dk_points;
     hipStream_t s = c->stream;
     if (n) {
@@ -1679,6 +1761,7 @@ int velo_knn(velo_ctx* c, int frame, const double T[12], float d_max, int k, int
     if (k < 1 || k > VELO_MAX_KNORMALS) return c->fail(VELO_E_INVALID, "k must be in [1,%d]", VELO_MAX_KNORMALS);
     if (!(d_max > 0.0f) || !(d_max <= c->mv.h))
         return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv.h);
+    HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
     if (n == 0) return VELO_OK;
@@ -1729,6 +1812,7 @@ static int increment_impl(velo_ctx* c, int frame, const double T[12], int min_co
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
     if (frame < 0 || frame >= c->n_frames) return c->fail(VELO_E_INVALID, "frame index out of range");
     if (!T || !n_out) return c->fail(VELO_E_INVALID, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const size_t n = (size_t)(c->frame_start[frame + 1] - c->frame_start[frame]);
     *n_out = 0;
@@ -1788,6 +1872,7 @@ int velo_increment_wait(velo_ctx* c, size_t* n_out)
 {
     if (!c || !n_out) return VELO_E_INVALID;
     if (!c->inc_pending) return c->fail(VELO_E_INVALID, "no asynchronous increment is pending");
+    HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipEventSynchronize(c->ev_inc));  // only this event: later work keeps running
     c->inc_pending = false;
     *n_out = *c->h_inc_total;

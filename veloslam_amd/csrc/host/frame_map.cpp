@@ -150,10 +150,30 @@ size_t MapManager::evictOutside(double x, double y, double radius)
 
 bool MapManager::save(const std::string& filename) const
 {
+    // the reference header counts tiles in an unsigned short (MapManager.cxx:81-96)
+    if (patches_.size() > 65535) {
+        err_ = "map has more than 65535 tiles: the reference record layout cannot count them";
+        return false;
+    }
     std::ofstream os(filename, std::ios::binary);
-    if (!os) return false;
-    const double cx = 0, cy = 0;
-    const float range = 0;
+    if (!os) {
+        err_ = "cannot open " + filename;
+        return false;
+    }
+    // centre and half-extent of the tiled area (the reference writes its own centerX/Y, range)
+    double x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    bool first = true;
+    for (const auto& kv : patches_) {
+        const MapPatch& p = *kv.second;
+        const double h = 0.5 * p.range;
+        if (first || p.centerX - h < x0) x0 = p.centerX - h;
+        if (first || p.centerX + h > x1) x1 = p.centerX + h;
+        if (first || p.centerY - h < y0) y0 = p.centerY - h;
+        if (first || p.centerY + h > y1) y1 = p.centerY + h;
+        first = false;
+    }
+    const double cx = 0.5 * (x0 + x1), cy = 0.5 * (y0 + y1);
+    const float range = (float)std::max(x1 - x0, y1 - y0);
     os.write(reinterpret_cast<const char*>(&cx), sizeof(double));
     os.write(reinterpret_cast<const char*>(&cy), sizeof(double));
     os.write(reinterpret_cast<const char*>(&range), sizeof(float));

@@ -710,16 +710,16 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
 #define VELO_LAUNCH_LIN(WC, V)                                                                   \
     hipLaunchKernelGGL((k_linearize<WC, V>), dim3(n_items), dim3(kLinThreads), 0, s, items, fv, \
                        mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev)
-    if (variant == 1) {
-        if (wc) VELO_LAUNCH_LIN(true, 1); else VELO_LAUNCH_LIN(false, 1);
+    if (variant == VELO_VARIANT_SCAN) {
+        if (wc) VELO_LAUNCH_LIN(true, 0); else VELO_LAUNCH_LIN(false, 0);
     } else if (variant == 11) {  // timing ablations (wrong results by design)
         VELO_LAUNCH_LIN(false, 11);
     } else if (variant == 12) {
         VELO_LAUNCH_LIN(false, 12);
     } else if (variant == 13) {
         VELO_LAUNCH_LIN(false, 13);
-    } else {
-        if (wc) VELO_LAUNCH_LIN(true, 0); else VELO_LAUNCH_LIN(false, 0);
+    } else {  // VELO_VARIANT_BALL and anything unknown: the default kernel
+        if (wc) VELO_LAUNCH_LIN(true, 1); else VELO_LAUNCH_LIN(false, 1);
     }
 #undef VELO_LAUNCH_LIN
     return hipGetLastError();
