@@ -12,11 +12,27 @@ of F frames that are ALREADY RESIDENT in HBM: K1 motion compensation of the batc
 Frames are independent units: with N ranks every rank registers its own F frames
 against its own replica of the map (weak scaling, no data-path collective inside
 the registration); the one exchange step of the path -- the RCCL all-gather of the
-accepted map increments -- runs after every step when N > 1, and the replicas
-re-index the map once enough increment points are pending.
+accepted map increments of EVERY frame of the batch -- runs after every step when
+N > 1, pipelined behind the next batch.
 
-`value` = valid correspondence pairs processed by all ranks / wall time of the K
-timed steps (max over ranks).  Rank 0 prints ONE JSON line.
+`value` = valid correspondence pairs processed by all ranks (counted on the device,
+exact) / wall time of the K timed steps (max over ranks).  Rank 0 prints ONE JSON line.
+At N = 1 the same line carries, measured in this run:
+  roofline      dominant kernel k_linearize: bytes the kernel REQUESTED from memory (its
+                counting instantiation, velo_set_stats) / mean launch time (HIP events on
+                the ctx stream) / 8 TB/s; `traffic` = PMC bytes from profiles/ (same
+                batch and map) or null; the SURVEY 8(d) exhaustive-definition figure is
+                kept under `exhaustive_equivalent_GBps`
+  dense         the same kernel on a working set far beyond the 256 MB Infinity Cache
+                (10 M-point map, 16 frames): the HBM-roofline record proper
+  single_frame  F = 1 latency (BASELINE configs[1] read literally)
+  stream        BASELINE configs[2]: packets -> decode -> register -> increment ->
+                rolling map (evicted by ROI_RANGE around the pose), frames/s
+  incl_h2d      batch frames/s with the sensor frames uploaded from pinned host memory
+                inside the timed region
+  cpu_baseline  oracle/icp.c on this box's host cores: 1 thread and all-core (best
+                OpenMP width), median of 5 after one warm-up
+  parity        GPU poses of the timed batch vs the oracle's poses for the same frames
 """
 import argparse
 import json
@@ -36,6 +52,8 @@ from veloslam_amd import capi, synth  # noqa: E402
 from veloslam_amd.dist import exchange_increments  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+ROI_RANGE = 100.0       # MapManager.h:13
+POS_TOL, ROT_TOL = 1e-4, 1e-5  # north star: GPU pose vs CPU path
 
 
 def parse():
@@ -56,9 +74,11 @@ def parse():
     ap.add_argument("--rounds", type=int, default=0, help="rounds of 256 queries per workgroup (0=auto)")
     ap.add_argument("--no-graph", action="store_true", help="plain stream launches, no hipGraph replay")
     ap.add_argument("--variant", type=int, default=1, help="1 = fine-grid ball search (default), 100 = exhaustive validation kernel")
-    ap.add_argument("--rebuild-threshold", type=int, default=20000,
-                    help="pending increment points that trigger a map re-index (N>1)")
+    ap.add_argument("--rebuild-threshold", type=int, default=1,
+                    help="pending increment points that trigger a map append (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-subrecords", action="store_true", help="skip dense / single_frame / stream / incl_h2d")
+    ap.add_argument("--only", default="", help="comma list of sub-records to run (dense,single_frame,stream,incl_h2d)")
     ap.add_argument("--time-every", type=int, default=4,
                     help="bracket the linearise launches with HIP events in every k-th timed step")
     ap.add_argument("--force-exchange", action="store_true",
@@ -70,24 +90,112 @@ def parse():
                          "packets -> decode -> register -> increment -> rolling-map update, "
                          "frame after frame")
     ap.add_argument("--stream-frames", type=int, default=24, help="distinct synthetic frames (cycled)")
-    ap.add_argument("--half-box", type=float, default=45.0, help="rolling map: kept half-extent in x around the sensor (m)")
+    ap.add_argument("--stream-steps", type=int, default=100, help="stream sub-record: timed frames")
+    ap.add_argument("--stream-map-points", type=int, default=12_000_000,
+                    help="points of the whole scene the rolling map is cut from")
+    ap.add_argument("--stream-subdiv", type=int, default=3)
+    ap.add_argument("--roi-range", type=float, default=ROI_RANGE, help="rolling map: kept radius around the pose (m)")
     ap.add_argument("--evict-every", type=int, default=5)
     ap.add_argument("--map-margin", type=int, default=16, help="stream: grid slack in x/y, voxels")
     ap.add_argument("--map-margin-z", type=int, default=2, help="stream: grid slack in z, voxels")
     ap.add_argument("--full-rebuild", action="store_true", help="stream: re-sort the whole map on every update (A/B)")
+    ap.add_argument("--dense-map-points", type=int, default=10_000_000)
+    ap.add_argument("--dense-frames", type=int, default=16)
+    ap.add_argument("--dense-subdiv", type=int, default=6)
     return ap.parse_args()
 
 
-def run_stream(args, dev, local):
+def trace(msg):
+    if os.environ.get("VELO_BENCH_TRACE"):
+        sys.stderr.write("[bench %.1fs] %s\n" % (time.perf_counter() - T_START, msg))
+        sys.stderr.flush()
+
+
+T_START = time.perf_counter()
+
+
+def want(args, name):
+    if args.no_subrecords:
+        return False
+    return (not args.only) or name in args.only.split(",")
+
+
+# ------------------------------------------------------------------------- byte accounting
+def measured_bytes(ctx, T0, iters, d_max):
+    """Bytes k_linearize requests from memory, counted by its counting instantiation on the
+    resident frames: mean per launch over a whole registration, first launch, last launch."""
+    def run(k):
+        ctx.search_stats(reset=True)
+        ctx.icp_batch(T0, k, d_max)
+        return ctx.search_stats(reset=True)
+    ctx.set_stats(1)
+    try:
+        full = run(iters)
+        first = run(1)
+        prev = run(iters - 1) if iters > 1 else dict.fromkeys(full, 0)
+    finally:
+        ctx.set_stats(0)
+    last = {k: full[k] - prev[k] for k in full}
+    return dict(mean_bytes_per_launch=full["bytes"] / max(full["launches"], 1),
+                first_launch_bytes=first["bytes"], last_launch_bytes=last["bytes"],
+                per_registration={k: full[k] for k in ("live", "certified", "searched", "stage_a_final",
+                                                       "stage_b", "stage_b_per_lane", "candidates",
+                                                       "table_requests", "valid_pairs", "launches")},
+                first_launch={k: first[k] for k in ("searched", "stage_b", "stage_b_per_lane", "candidates",
+                                                    "table_requests")})
+
+
+def traffic_for(key):
+    """PMC (2 x FETCH_SIZE + WRITE_SIZE) bytes per k_linearize launch taken under rocprofv3 at
+    the SAME batch and map (profiles/traffic.json, written by profiles/summarize.py)."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(p)).get(key)
+    except Exception:
+        return None
+
+
+def roofline_record(ctx, T0, iters, d_max, n_q, avg_launch_s, first_us, min_us, key, cbar=None):
+    mb = measured_bytes(ctx, T0, iters, d_max)
+    ach = mb["mean_bytes_per_launch"] / avg_launch_s / 1e9
+    tr = traffic_for(key)
+    rec = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": ach / HBM_PEAK_GBPS,
+           "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+           "traffic_source": tr["source"] if tr else None,
+           "traffic_GBps": (tr["hbm_bytes_per_launch"] / avg_launch_s / 1e9) if tr else None,
+           "kernel": "k_linearize", "avg_launch_us": 1e6 * avg_launch_s,
+           "first_launch_us": first_us, "min_launch_us": min_us, "queries_per_launch": n_q,
+           "bytes_per_launch": mb["mean_bytes_per_launch"],
+           "bytes_per_query": mb["mean_bytes_per_launch"] / max(n_q, 1),
+           "first_launch_bytes": mb["first_launch_bytes"],
+           "last_launch_bytes": mb["last_launch_bytes"],
+           "last_launch_GBps": (mb["last_launch_bytes"] / (1e-6 * min_us) / 1e9) if min_us > 0 else None,
+           "search": mb["per_registration"], "search_first_launch": mb["first_launch"],
+           "note": "achieved = bytes the kernel requested from memory (16 B per candidate / hinted / "
+                   "matched point and per normal, 16 or 8 B per fine-table request, 20 B query + hint "
+                   "+ certificate read, 8 B written back), counted by the kernel's counting "
+                   "instantiation in this run, / mean launch time of the timed steps (HIP events on "
+                   "the ctx stream) / 8 TB/s.  16-B gathers move whole 64/128-B lines: `traffic` "
+                   "(PMC, fabric side of L2, includes Infinity-Cache hits) is the physical figure"}
+    if cbar is not None:
+        exh = (232.0 + 12.0 * cbar + 24.0) * n_q
+        rec["exhaustive_equivalent_GBps"] = exh / avg_launch_s / 1e9
+        rec["cbar"] = cbar
+    return rec
+
+
+# ------------------------------------------------------------------------- stream (configs[2])
+def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct):
     """BASELINE configs[2]: an HDL-64E packet stream against a rolling map, one frame at a
     time (each frame sees the map the previous one updated).  Per frame: 300 packets H2D ->
     GPU decode + motion compensation -> 20 ICP iterations -> accepted increment ->
-    incremental map append; every `evict_every` frames the map is cropped to a box that
-    follows the sensor.  Reports sustained frames/s and where the time goes."""
+    incremental map append; every `evict_every` frames everything further than ROI_RANGE
+    (MapManager.h:13) from the current pose is evicted.  Returns the record."""
     sc, mo, cal = synth.Scene(), synth.Motion(), synth.hdl64_calibration()
-    mx, my, mz = sc.sample_map(args.map_points)
+    mx, my, mz = sc.sample_map_device(scene_points, dev)
     frames = []
-    for k in range(args.stream_frames):
+    for k in range(n_distinct):
         pk, ts, _ = synth.make_frame_packets(sc, mo, 3 + k, cal, seed=42)
         poses, n = capi.make_poses(mo.ins_track(ts[0], ts[-1]))
         _, _, car = capi.packet_transforms(poses, n, ts)
@@ -96,23 +204,20 @@ def run_stream(args, dev, local):
                            ts=np.ascontiguousarray(ts, dtype=np.int64), poses=poses, n=n, Tt=Tt,
                            T0=synth.perturbed_guess(Tt, dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))))
     calc = np.ascontiguousarray(cal, dtype=np.float64).reshape(64, 9)
-    ctx = capi.Context(local, max_batch=2, map_margin=args.map_margin, map_subdiv=args.subdiv,
+    ctx = capi.Context(local, max_batch=2, map_margin=args.map_margin, map_subdiv=args.stream_subdiv,
                        map_full_rebuild=1 if args.full_rebuild else 0, sort_frames=args.sort_frames,
                        use_hints=0 if args.no_hints else args.hints,
                        use_graph=0 if args.no_graph else 1)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.map_set_margins(args.map_margin, args.map_margin, args.map_margin_z)
-
-    def box(f):
-        cx = f["Tt"][3]
-        return (np.float32([cx - args.half_box, -1e4, -1e4]), np.float32([cx + args.half_box, 1e4, 1e4]))
-
-    lo, hi = box(frames[0])
-    keep = (mx >= lo[0]) & (mx <= hi[0])
-    ctx.map_reset(mx[keep], my[keep], mz[keep], args.voxel, args.k_normals)
+    c0 = frames[0]["Tt"]
+    keep = ((mx - float(c0[3])) ** 2 + (my - float(c0[7])) ** 2) <= args.roi_range ** 2
+    kx, ky, kz = mx[keep].contiguous(), my[keep].contiguous(), mz[keep].contiguous()
+    ctx.map_reset_dev(kx.data_ptr(), ky.data_ptr(), kz.data_ptr(), kx.numel(), args.voxel, args.k_normals)
+    del mx, my, mz, keep
     inc = torch.empty((3, 200_000), dtype=torch.float32, device=dev)
     stage = dict(decode=0.0, icp=0.0, increment=0.0, append=0.0, evict=0.0)
-    counts = dict(pairs=0, inc=0, pts=0, recomputed=0, incremental=0, updates=0, worst=0.0, map=0)
+    counts = dict(pairs=0, inc=0, recomputed=0, incremental=0, updates=0, worst=0.0, map=0)
     upd_ms = {"append_incremental": [], "append_reanchor": [], "evict_incremental": [], "evict_reanchor": []}
 
     def one(f, k, timed):
@@ -127,8 +232,8 @@ def run_stream(args, dev, local):
         t.append(time.perf_counter())
         if cnt:
             ctx.map_append_dev(inc[0].data_ptr(), inc[1].data_ptr(), inc[2].data_ptr(), cnt)
-            mi = ctx.map_info()
             if timed:
+                mi = ctx.map_info()
                 upd_ms["append_incremental" if mi.last_update else "append_reanchor"].append(
                     1e3 * (time.perf_counter() - t[-1]))
                 counts["updates"] += 1
@@ -136,9 +241,10 @@ def run_stream(args, dev, local):
                 counts["recomputed"] += int(mi.n_normals_recomputed)
         t.append(time.perf_counter())
         if (k + 1) % max(args.evict_every, 1) == 0:
-            ctx.map_evict_outside(*box(f))
+            n_before = ctx.map_info().n_points
+            ctx.map_evict_radius(float(T[3]), float(T[7]), args.roi_range)
             mi = ctx.map_info()
-            if timed:
+            if timed and mi.n_points != n_before:
                 upd_ms["evict_incremental" if mi.last_update else "evict_reanchor"].append(
                     1e3 * (time.perf_counter() - t[-1]))
                 counts["updates"] += 1
@@ -155,39 +261,36 @@ def run_stream(args, dev, local):
             counts["worst"] = max(counts["worst"], err)
 
     nfr = len(frames)
-    for k in range(args.warmup):
+    for k in range(warmup):
         one(frames[k % nfr], k, False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        one(frames[(args.warmup + k) % nfr], args.warmup + k, True)
+    for k in range(steps):
+        one(frames[(warmup + k) % nfr], warmup + k, True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    mi = ctx.map_info()
+    ctx.close()
     if counts["worst"] > 0.05:
         raise SystemExit("bench stream: registration diverged (%.3f m)" % counts["worst"])
-    out = {"metric": "rolling-map registered frames/s", "value": args.steps / elapsed,
-           "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32 points, f64 pose/accumulators", "data": "synthetic",
-           "config": {"workload": "BASELINE configs[2]: HDL-64E packet stream, one frame per step: decode "
-                                  "+ compensate + %d ICP iters + increment + rolling-map update "
-                                  "(append every frame, evict every %d), map cropped to +-%.0f m around "
-                                  "the sensor" % (args.iters, args.evict_every, args.half_box),
-                      "map_points_mean": counts["map"] / max(args.steps, 1),
-                      "map_update": "full rebuild" if args.full_rebuild else "incremental",
-                      "map_margin_voxels": [args.map_margin, args.map_margin, args.map_margin_z]},
-           "pairs_per_s": counts["pairs"] / elapsed,
-           "stage_ms_per_frame": {k: 1e3 * v / args.steps for k, v in stage.items()},
-           "map_update_ms": {k: {"n": len(v), "mean": float(np.mean(v)), "max": float(np.max(v))}
-                             for k, v in upd_ms.items() if v},
-           "increment_points_per_frame": counts["inc"] / max(args.steps, 1),
-           "map_updates": counts["updates"], "map_updates_incremental": counts["incremental"],
-           "normals_recomputed_per_update": counts["recomputed"] / max(counts["updates"], 1),
-           "worst_pose_error_m": counts["worst"]}
-    print(json.dumps(out))
-    ctx.close()
+    return {"frames_per_s": steps / elapsed, "ms_per_frame": 1e3 * elapsed / steps, "frames": steps,
+            "workload": "BASELINE configs[2]: HDL-64E packet stream, one frame per step: 300 packets H2D + "
+                        "decode + compensate + %d ICP iters + increment + rolling-map append every frame; "
+                        "every %d frames evict everything beyond ROI_RANGE %.0f m of the pose "
+                        "(MapManager.h:13)" % (args.iters, args.evict_every, args.roi_range),
+            "map_points_mean": counts["map"] / max(steps, 1), "map_subdiv": int(mi.subdiv),
+            "map_update": "full rebuild" if args.full_rebuild else "incremental",
+            "pairs_per_s": counts["pairs"] / elapsed,
+            "stage_ms_per_frame": {k: 1e3 * v / steps for k, v in stage.items()},
+            "map_update_ms": {k: {"n": len(v), "mean": float(np.mean(v)), "max": float(np.max(v))}
+                              for k, v in upd_ms.items() if v},
+            "increment_points_per_frame": counts["inc"] / max(steps, 1),
+            "map_updates": counts["updates"], "map_updates_incremental": counts["incremental"],
+            "normals_recomputed_per_update": counts["recomputed"] / max(counts["updates"], 1),
+            "worst_pose_error_m": counts["worst"]}
 
 
+# ------------------------------------------------------------------------- inputs
 def build_inputs(args, rank, dev):
     """Seeded synthetic inputs; everything the step reads ends up in device tensors."""
     sc = synth.Scene()
@@ -214,27 +317,28 @@ def build_inputs(args, rank, dev):
         host_frames.append((fr, tab, Ttrue))
     assert pkt_base < 65536, "uint16 packet index overflow: lower --frames"
 
-    def dv(a, dt):
-        return torch.from_numpy(np.ascontiguousarray(np.concatenate(a)).astype(dt, copy=False)).to(dev)
+    def cat(a, dt):
+        return np.ascontiguousarray(np.concatenate(a)).astype(dt, copy=False)
 
-    d = dict(
-        sx=dv(xs, np.float32), sy=dv(ys, np.float32), sz=dv(zs, np.float32),
-        pkt=torch.from_numpy(np.concatenate(pk).view(np.int16)).to(dev),
-        tab=torch.from_numpy(np.concatenate(tabs).astype(np.float64)).to(dev),
-        map=(mx, my, mz), T0=np.stack(T0), Ttrue=np.stack(Tt),
-        frame_start=np.array(fs, dtype=np.int64), n_pkt=pkt_base, host_frames=host_frames)
+    host = dict(sx=cat(xs, np.float32), sy=cat(ys, np.float32), sz=cat(zs, np.float32),
+                pkt=np.concatenate(pk).view(np.int16), tab=np.concatenate(tabs).astype(np.float64))
+    d = {k: torch.from_numpy(v).to(dev) for k, v in host.items()}
+    d.update(host=host, map=(mx, my, mz), T0=np.stack(T0), Ttrue=np.stack(Tt),
+             frame_start=np.array(fs, dtype=np.int64), n_pkt=pkt_base, host_frames=host_frames, scene=sc)
     n = int(fs[-1])
-    d["cx"] = torch.empty(n, dtype=torch.float32, device=dev)
-    d["cy"] = torch.empty(n, dtype=torch.float32, device=dev)
-    d["cz"] = torch.empty(n, dtype=torch.float32, device=dev)
-    d["inc"] = torch.empty((3, int(np.diff(fs).max())), dtype=torch.float32, device=dev)
+    for k in ("cx", "cy", "cz"):
+        d[k] = torch.empty(n, dtype=torch.float32, device=dev)
     return d
 
 
-def cpu_baseline(args, d):
-    """The oracle (a port: the reference has no ICP) timed on this box's host cores on a
-    bounded sample: `cpu_frames` of the same frames, same map, same 20 iterations."""
+# ------------------------------------------------------------------------- CPU leg + parity
+def cpu_baseline(args, d, gpu_res):
+    """The oracle (a port: the reference has no ICP) timed on this box's host cores on a bounded
+    sample -- frame 0 of the timed batch, same map, same 20 iterations -- single-threaded and
+    with OpenMP at the fastest width found by a short probe; median of 5 runs after one warm-up
+    (SURVEY 8d).  The poses it computes are also the parity check of the timed GPU batch."""
     from oracle import oracle as orc
+    from tests.util_scene import pose_delta
     ncpu = os.cpu_count() or 1
     om = orc.Map(*d["map"], args.voxel, args.k_normals)
     nf = min(args.cpu_frames, len(d["host_frames"]))
@@ -242,33 +346,200 @@ def cpu_baseline(args, d):
     for k in range(nf):
         fr, tab, _ = d["host_frames"][k]
         comp.append(orc.compensate(fr["x"], fr["y"], fr["z"], fr["pkt"], tab))
-    # pick the OpenMP width that is fastest on this host (115k queries per iteration do not
-    # feed hundreds of threads); the chosen width is what "cores" reports
-    best_t, threads = None, 1
-    for th in sorted({1, min(8, ncpu), min(32, ncpu), min(64, ncpu)}):
+
+    def timed(th, frame=0):
+        t0 = time.perf_counter()
+        T, st, _ = om.icp(*comp[frame], d["T0"][frame], args.iters, args.d_max, threads=th)
+        return time.perf_counter() - t0, T, st
+
+    best_t, width = None, 1
+    for th in sorted({w for w in (8, 16, 32, 64, 128, ncpu) if w <= ncpu}):
         t0 = time.perf_counter()
         om.icp(*comp[0], d["T0"][0], 2, args.d_max, threads=th)
         dt = time.perf_counter() - t0
         if best_t is None or dt < best_t:
-            best_t, threads = dt, th
-    pairs, cand, queries, t = 0, 0, 0, 0.0
-    reps = 0
-    while t < 10.0 and reps < 50:  # bounded: ~10 s of CPU work
-        for k in range(nf):
-            cx, cy, cz = comp[k]
-            t0 = time.perf_counter()
-            _, st, _ = om.icp(cx, cy, cz, d["T0"][k], args.iters, args.d_max, threads=threads)
-            t += time.perf_counter() - t0
-            pairs += sum(s["n_pairs"] for s in st)
-            cand += sum(s["candidates"] for s in st)
-            queries += cx.size * args.iters
-        reps += 1
-    return dict(value=pairs / t, unit="pairs/s", cores=threads, kind="port",
-                sample="%d frame(s) x %d ICP iterations x %d repetitions of the same workload, "
-                       "%.1f s of CPU (oracle/icp.c, OpenMP, %d of %d host cores)"
-                       % (nf, args.iters, reps, t, threads, ncpu)), cand / max(queries, 1)
+            best_t, width = dt, th
+
+    def median5(th):
+        timed(th)  # warm-up
+        runs = [timed(th) for _ in range(5)]
+        ts = sorted(r[0] for r in runs)
+        return ts[2], runs[0][1], runs[0][2]
+
+    t_all, T_all, st_all = median5(width)
+    t_one, T_one, st_one = median5(1)
+    pairs = sum(s["n_pairs"] for s in st_all)
+    cbar = sum(s["candidates"] for s in st_all) / float(comp[0][0].size * args.iters)
+    # parity of the timed GPU batch against the CPU path, frames 0..nf-1
+    max_dpos, max_drot, pairs_equal = 0.0, 0.0, True
+    for k in range(nf):
+        if k == 0:
+            T, st = T_all, st_all
+        else:
+            _, T, st = timed(width, k)
+        dpos, drot = pose_delta(np.array(list(gpu_res[k].T)), T)
+        max_dpos, max_drot = max(max_dpos, dpos), max(max_drot, drot)
+        pairs_equal &= all(int(gpu_res[k].iter[i].n_pairs) == int(st[i]["n_pairs"]) for i in range(args.iters))
+    cb = dict(value=pairs / t_all, unit="pairs/s", cores=width, kind="port",
+              single_thread_value=pairs / t_one, host_cores=ncpu,
+              seconds_per_registration={"threads_%d" % width: t_all, "threads_1": t_one},
+              sample="frame 0 of the timed batch (115 200-pt frame vs the same %d-pt map, %d ICP "
+                     "iterations = %d pairs), median of 5 runs after 1 warm-up: oracle/icp.c with "
+                     "OpenMP on %d threads (fastest of a 2-iteration probe over widths up to the box's "
+                     "%d host cores) and on 1 thread" % (args.map_points, args.iters, pairs, width, ncpu))
+    parity = dict(frames=nf, max_dpos_m=max_dpos, max_drot_rad=max_drot, pairs_equal=bool(pairs_equal),
+                  tol_m=POS_TOL, tol_rad=ROT_TOL, against="oracle/icp.c vo_icp on the same frames, map and T0")
+    return cb, cbar, parity
 
 
+# ------------------------------------------------------------------------- sub-records
+def timed_registrations(ctx, T0, iters, d_max, reps):
+    """reps registrations of the resident frames with per-launch HIP events -> launch statistics"""
+    ctx.set_timing(1)
+    lin_ms = lin_n = 0
+    first, mn = [], 1e30
+    call_ms = []
+    for _ in range(reps):
+        ctx.icp_batch(T0, iters, d_max)
+        tm = ctx.last_timing()
+        lin_ms += tm["linearize_ms"]
+        lin_n += tm["linearize_launches"]
+        first.append(tm["linearize_first_ms"])
+        mn = min(mn, tm["linearize_min_ms"])
+        call_ms.append(tm["call_ms"])
+    ctx.set_timing(0)
+    return dict(avg_s=1e-3 * lin_ms / max(lin_n, 1), first_us=1e3 * float(np.median(first)),
+                min_us=1e3 * mn, call_ms=float(np.median(call_ms)))
+
+
+def dense_record(args, d, dev, local):
+    """The HBM-roofline record: same frames, a map whose working set (points + normals + fine
+    table + queries) is several times the 256 MB Infinity Cache."""
+    F = min(args.dense_frames, args.frames)
+    M = args.dense_map_points
+    mx, my, mz = d["scene"].sample_map_device(M, dev)
+    ctx = capi.Context(local, max_batch=max(F, 1), map_subdiv=args.dense_subdiv,
+                       use_hints=0 if args.no_hints else args.hints, use_graph=0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    t0 = time.perf_counter()
+    ctx.map_reset_dev(mx.data_ptr(), my.data_ptr(), mz.data_ptr(), M, args.voxel, args.k_normals)
+    ctx.synchronize()
+    build_s = time.perf_counter() - t0
+    mi = ctx.map_info()
+    fs = d["frame_start"][:F + 1]
+    n_q = int(fs[-1])
+    ctx.frames_adopt_dev(d["cx"].data_ptr(), d["cy"].data_ptr(), d["cz"].data_ptr(), fs)
+    T0 = d["T0"][:F]
+    res = ctx.icp_batch(T0, args.iters, args.d_max)  # warm-up + sanity
+    worst = max(float(np.linalg.norm(np.array(list(r.T)).reshape(3, 4)[:, 3] - d["Ttrue"][i].reshape(3, 4)[:, 3]))
+                for i, r in enumerate(res))
+    if worst > 0.05:
+        raise SystemExit("bench dense: registration diverged (%.3f m)" % worst)
+    tm = timed_registrations(ctx, T0, args.iters, args.d_max, 3)
+    # whole registrations back to back, no events: the throughput figure
+    torch.cuda.synchronize()
+    ctx.pairs_total(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.icp_batch_async(T0, args.iters, args.d_max)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    pairs = ctx.pairs_total(reset=True)
+    key = "F%d_M%d" % (F, M)
+    rec = roofline_record(ctx, T0, args.iters, args.d_max, n_q, tm["avg_s"], tm["first_us"], tm["min_us"], key)
+    ws = 32.0 * M + 4.0 * (mi.n_cells + 1) + 20.0 * n_q
+    rec.update(workload="%d frames x 115200 pts vs a %d-pt map of the same scene (%d x %d x %d voxels of %.1f m, "
+                        "sub-division %d), %d ICP iters" % (F, M, mi.dims[0], mi.dims[1], mi.dims[2], args.voxel,
+                                                           mi.subdiv, args.iters),
+               map_points=M, frames=F, map_subdiv=int(mi.subdiv), fine_cells=int(mi.n_cells),
+               working_set_bytes=ws, working_set_over_infinity_cache=ws / (256.0 * 2 ** 20),
+               pairs_per_s=pairs / el, ms_per_registration_batch=1e3 * el / 3,
+               map_build_s=build_s, worst_pose_error_m=worst, traffic_key=key)
+    ctx.close()
+    return rec
+
+
+def single_frame_record(args, d, local):
+    """BASELINE configs[1] read literally: ONE 115 200-point frame against the 1 M-point map."""
+    ctx = capi.Context(local, max_batch=2, map_subdiv=args.subdiv,
+                       use_hints=0 if args.no_hints else args.hints, use_graph=0 if args.no_graph else 1)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.map_reset(*d["map"], args.voxel, args.k_normals)
+    fs = d["frame_start"][:2]
+    ctx.frames_adopt_dev(d["cx"].data_ptr(), d["cy"].data_ptr(), d["cz"].data_ptr(), fs)
+    T0 = d["T0"][:1]
+    for _ in range(5):
+        ctx.icp_batch(T0, args.iters, args.d_max)
+    lat = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        res = ctx.icp_batch(T0, args.iters, args.d_max)  # upload pose, 20 iterations, fetch result
+        lat.append(time.perf_counter() - t0)
+    med = float(np.median(lat))
+    tm = timed_registrations(ctx, T0, args.iters, args.d_max, 5)
+    pairs = int(res[0].total_pairs)
+    ctx.close()
+    return dict(workload="1 frame x %d pts vs %d-pt map, %d ICP iters, pose upload to result fetch"
+                         % (int(fs[1]), args.map_points, args.iters),
+                ms_per_registration=1e3 * med, ms_min=1e3 * float(np.min(lat)), pairs_per_s=pairs / med,
+                frames_per_s=1.0 / med, linearize_avg_launch_us=1e6 * tm["avg_s"],
+                linearize_first_launch_us=tm["first_us"], linearize_min_launch_us=tm["min_us"])
+
+
+def incl_h2d_record(args, d, dev, ctx, steps):
+    """Batch throughput with the inputs coming from the HOST inside the timed region: sensor-frame
+    SoA + packet indices + per-packet transforms are uploaded from pinned memory on a copy stream,
+    double-buffered against the registration of the previous batch (the C ABI takes device
+    pointers; PCIe-inclusive rate, never `value`)."""
+    names = ("sx", "sy", "sz", "pkt", "tab")
+    pinned = {k: torch.from_numpy(d["host"][k]).pin_memory() for k in names}
+    bufs = [{k: torch.empty_like(d[k]) for k in names} for _ in range(2)]
+    copy = torch.cuda.Stream()
+    ev_up = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_done = [None, None]
+    main = torch.cuda.current_stream()
+    n_q = int(d["frame_start"][-1])
+    nbytes = sum(int(pinned[k].numel() * pinned[k].element_size()) for k in names)
+
+    def upload(b):
+        with torch.cuda.stream(copy):
+            if ev_done[b] is not None:
+                copy.wait_event(ev_done[b])
+            for k in names:
+                bufs[b][k].copy_(pinned[k], non_blocking=True)
+            ev_up[b].record(copy)
+
+    def compute(b):
+        main.wait_event(ev_up[b])
+        s = bufs[b]
+        ctx.compensate_dev(s["sx"].data_ptr(), s["sy"].data_ptr(), s["sz"].data_ptr(), s["pkt"].data_ptr(),
+                           n_q, s["tab"].data_ptr(), d["n_pkt"], d["cx"].data_ptr(), d["cy"].data_ptr(),
+                           d["cz"].data_ptr())
+        ev_done[b] = torch.cuda.Event()
+        ev_done[b].record(main)   # K1 has consumed the upload buffer
+        ctx.icp_batch_async(d["T0"], args.iters, args.d_max)
+
+    upload(0)
+    compute(0)  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    upload(0)
+    for k in range(steps):
+        if k + 1 < steps:
+            upload((k + 1) & 1)
+        compute(k & 1)
+    ctx.icp_batch_fetch()  # poses and statistics back on the host: end of the job
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    F = args.frames
+    return dict(frames_per_s=F * steps / el, ms_per_step=1e3 * el / steps, steps=steps,
+                h2d_bytes_per_step=nbytes, h2d_GBps=nbytes * steps / el / 1e9,
+                note="sensor frames (x,y,z f32 + u16 packet index) and per-packet 3x4 tables uploaded from "
+                     "pinned host memory every step, overlapped with the previous batch; K1 + %d ICP "
+                     "iterations + result fetch" % args.iters)
+
+
+# ------------------------------------------------------------------------- main
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -283,6 +554,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # One explicit stream carries torch's work AND the ctx's kernels (velo_set_stream): torch's
+    # default stream is the NULL stream, which velo_set_stream reads as "use the ctx's own
+    # non-blocking stream" -- events recorded on torch's side would then order nothing.
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_dev:
@@ -293,9 +568,20 @@ def main():
     if args.workload == "stream":
         if world > 1:
             raise SystemExit("the stream workload is one sequence on one GPU (run N replicas for N GPUs)")
-        return run_stream(args, dev, local)
+        rec = run_stream(args, dev, local, args.steps, args.warmup, args.stream_map_points, args.stream_frames)
+        out = {"metric": "rolling-map registered frames/s", "value": rec["frames_per_s"],
+               "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": rec["ms_per_frame"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32 points, f64 pose/accumulators", "data": "synthetic",
+               "config": {"workload": rec["workload"], "map_points_mean": rec["map_points_mean"],
+                          "map_update": rec["map_update"],
+                          "map_margin_voxels": [args.map_margin, args.map_margin, args.map_margin_z]}}
+        out.update({k: v for k, v in rec.items() if k not in ("workload", "frames_per_s", "ms_per_frame")})
+        print(json.dumps(out))
+        return
 
     d = build_inputs(args, rank, dev)
+    trace("inputs built")
     F = args.frames
     ctx = capi.Context(local, max_batch=max(F, 1), sort_frames=args.sort_frames,
                        linearize_variant=args.variant, map_subdiv=args.subdiv,
@@ -309,16 +595,16 @@ def main():
     pending = []
     pending_n = 0
 
-    # Exchange step of the path (N > 1), pipelined by one step: the increment of step k is
-    # computed on the device right behind batch k (pose taken from the device, nothing
-    # fetched), and while the GPU works on batch k+1 the host waits for that increment only,
-    # all-gathers it on a side stream and appends it before batch k+2.
+    # Exchange step of the path (N > 1), pipelined by one step: the increments of ALL frames of
+    # step k are computed on the device right behind batch k (poses taken from the device,
+    # nothing fetched), and while the GPU works on batch k+1 the host waits for that increment
+    # only, all-gathers it on a side stream and appends it before batch k+2.
     exchange = world > 1 or args.force_exchange
-    inc2 = [d["inc"], torch.empty_like(d["inc"])] if exchange else None
+    inc2 = [torch.empty((3, n_q), dtype=torch.float32, device=dev) for _ in range(2)] if exchange else None
     side = torch.cuda.Stream() if exchange else None
     ev_inc = [torch.cuda.Event(), torch.cuda.Event()] if exchange else None
     ev_free = [None, None]  # side stream is done reading increment buffer b
-    state = dict(cur=0, prev=None)
+    state = dict(cur=0, prev=None, exchanged_points=0, appends=0)
 
     def finish_exchange(buf):
         nonlocal pending, pending_n
@@ -332,14 +618,16 @@ def main():
             ev_free[buf].record(side)
             pending.extend(got)
             pending_n += sum(counts)
-            if pending_n >= args.rebuild_threshold:
-                allb = torch.cat(pending, dim=1).contiguous()
+            state["exchanged_points"] += sum(counts)
+            if pending_n >= max(args.rebuild_threshold, 1):
+                allb = torch.cat(pending, dim=1).contiguous()   # rank order: replicas stay identical
                 done = torch.cuda.Event()
                 done.record(side)
                 allb.record_stream(main)
                 main.wait_event(done)
                 ctx.map_append_dev(allb[0].data_ptr(), allb[1].data_ptr(), allb[2].data_ptr(),
                                    allb.shape[1])
+                state["appends"] += 1
                 pending, pending_n = [], 0
 
     def step(timed):
@@ -356,19 +644,23 @@ def main():
                 start_increment()
 
     def start_increment():
-        # accepted increment of this rank's first frame of the round, at its registered pose
+        # accepted increments of every frame of this rank's batch, at their registered poses
         b = state["cur"]
         if ev_free[b] is not None:
             torch.cuda.current_stream().wait_event(ev_free[b])
-        ctx.increment_registered_async(0, 3, inc2[b][0].data_ptr(), inc2[b][1].data_ptr(),
-                                       inc2[b][2].data_ptr())
+        ctx.increment_all_registered_async(3, inc2[b][0].data_ptr(), inc2[b][1].data_ptr(),
+                                           inc2[b][2].data_ptr())
         ev_inc[b].record(torch.cuda.current_stream())
         state["prev"] = b
         state["cur"] = b ^ 1
 
+    trace("map + frames resident")
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
+    trace("warm-up done")
+    ctx.pairs_total(reset=True)
+    state["exchanged_points"] = state["appends"] = 0
     if world > 1:
         dist.barrier()
     lin_ms, lin_n, lin_first, lin_min, n_samples = 0.0, 0, 0.0, 1e30, 0
@@ -395,19 +687,18 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    # kernel time of the LAST step (HIP events on the ctx stream) -- same launches every step
+    trace("timed region done")
+    pairs_rank = ctx.pairs_total(reset=True)          # counted on the device over the K timed steps
     res = ctx.icp_batch_fetch()
+    ctx.set_timing(0)
     ns = max(n_samples, 1)
-    tm = dict(linearize_ms=lin_ms, linearize_launches=lin_n, linearize_first_ms=lin_first / ns,
-              linearize_min_ms=(lin_min if lin_n else 0.0), solve_ms=0.0)
-    pairs_step = sum(int(r.total_pairs) for r in res)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    pr = torch.tensor([float(pairs_step)], dtype=torch.float64, device=dev)
+    pr = torch.tensor([float(pairs_rank)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(pr, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
-    total_pairs = float(pr.item()) * args.steps
+    total_pairs = float(pr.item())
 
     # sanity: the timed work really registered the frames
     worst = max(float(np.linalg.norm(np.array(list(r.T)).reshape(3, 4)[:, 3] - d["Ttrue"][i].reshape(3, 4)[:, 3]))
@@ -415,7 +706,9 @@ def main():
     if worst > 0.05 and args.variant < 10:
         raise SystemExit("bench: registration diverged (%.3f m from truth)" % worst)
 
+    rc = 0
     if rank == 0:
+        mi = ctx.map_info()
         out = {
             "metric": "ICP correspondence-pairs/s", "value": total_pairs / elapsed,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -427,57 +720,57 @@ def main():
                                    "per GPU, resident in HBM" % (args.map_points, args.iters,
                                                                  args.d_max, args.voxel, F),
                        "frames_per_step_per_gpu": F, "points_per_frame": n_q // F,
-                       "map_points": args.map_points, "iters": args.iters,
+                       "map_points": args.map_points, "iters": args.iters, "map_subdiv": int(mi.subdiv),
                        "parallelism": "frame-parallel x%d" % world},
             "frames_per_s": world * F * args.steps / elapsed,
+            "total_pairs": total_pairs,
             "worst_pose_error_m": worst,
-            "linearize_pairs_per_s": (pairs_step * ns / (1e-3 * tm["linearize_ms"]))
-            if tm["linearize_ms"] > 0 else None,
         }
+        if exchange:
+            out["exchange"] = {"increments": "every frame of every batch", "transport": "torch.distributed " +
+                               (dist.get_backend() if world > 1 else "(single rank)"),
+                               "points_exchanged": state["exchanged_points"], "map_appends": state["appends"],
+                               "map_points_after": int(mi.n_points)}
+        single = world == 1
+        avg_s = (1e-3 * lin_ms / lin_n) if lin_n else None
+        if avg_s:
+            out["linearize_pairs_per_s"] = total_pairs / world / args.steps * ns / (1e-3 * lin_ms)
         cbar = None
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 at N = 1 only
-            cb, cbar = cpu_baseline(args, d)
+        if single and not args.no_cpu_baseline:  # the CPU leg runs on rank 0 at N = 1 only
+            cb, cbar, parity = cpu_baseline(args, d, res)
+            trace("cpu leg done")
             out["cpu_baseline"] = cb
-        if tm["linearize_launches"] > 0:
-            avg_s = 1e-3 * tm["linearize_ms"] / tm["linearize_launches"]
-            if cbar is None:
-                cbar = float(os.environ.get("VELO_CBAR", "247.0"))
-            bytes_per_query = 232.0 + 12.0 * cbar + 24.0  # SURVEY 8(d), fused K2+K3, k=1
-            ach = bytes_per_query * n_q / avg_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                               "kernel": "k_linearize", "avg_launch_us": 1e6 * avg_s,
-                               "first_launch_us": 1e3 * tm["linearize_first_ms"],
-                               "min_launch_us": 1e3 * tm["linearize_min_ms"],
-                               "queries_per_launch": n_q, "cbar": cbar,
-                               "bytes_per_query": bytes_per_query,
-                               "compulsory_bytes_per_launch": 16.0 * n_q + 32.0 * args.map_points,
-                               "traffic_GBps": (traffic / avg_s / 1e9) if traffic else None,
-                               # a converged iteration moves, per query: xyz 12 B + hint 4 B +
-                               # certificate 4 B + one 16-B point gather + one 16-B normal gather
-                               "steady_state": {"bytes_per_query": 52.0,
-                                                "launch_us": 1e3 * tm["linearize_min_ms"],
-                                                "GBps": 52.0 * n_q / (1e-3 * tm["linearize_min_ms"]) / 1e9,
-                                                "frac": 52.0 * n_q / (1e-3 * tm["linearize_min_ms"]) / 1e9 / HBM_PEAK_GBPS}
-                               if tm["linearize_min_ms"] > 0 else None,
-                               "note": "achieved = SURVEY 8(d) algorithmic bytes (232+12*Cbar+24 per "
-                                       "query, exhaustive 27-voxel definition) / mean launch time; the "
-                                       "map is cache-resident and the exact ball search never touches "
-                                       "most of those candidates, so frac > 1 is a throughput figure in "
-                                       "HBM-equivalent bytes, not HBM saturation. traffic = PMC "
-                                       "(2*FETCH_SIZE+WRITE_SIZE) per launch from profiles/"
-                                       "traffic_latest.json (taken at its own batch size)"}
+            out["parity"] = parity
+            if parity["max_dpos_m"] > POS_TOL or parity["max_drot_rad"] > ROT_TOL:
+                rc = 3
+        if single and avg_s and args.variant < 10 and not exchange:
+            out["roofline"] = roofline_record(ctx, d["T0"], args.iters, args.d_max, n_q, avg_s,
+                                              1e3 * lin_first / ns, 1e3 * lin_min,
+                                              "F%d_M%d" % (F, args.map_points), cbar)
+        trace("roofline done")
+        if single and not exchange:
+            if want(args, "incl_h2d"):
+                trace("incl_h2d ...")
+                out["incl_h2d"] = incl_h2d_record(args, d, dev, ctx, max(args.steps, 4))
+            if want(args, "single_frame"):
+                trace("single_frame ...")
+                out["single_frame"] = single_frame_record(args, d, local)
+            if want(args, "dense"):
+                trace("dense ...")
+                out["dense"] = dense_record(args, d, dev, local)
+            if want(args, "stream"):
+                trace("stream ...")
+                out["stream"] = run_stream(args, dev, local, args.stream_steps, 10,
+                                           args.stream_map_points, args.stream_frames)
         print(json.dumps(out))
+        if rc:
+            sys.stderr.write("bench: GPU pose differs from the CPU path beyond the north-star tolerance: %r\n"
+                             % (out.get("parity"),))
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -152,6 +152,10 @@ int velo_map_append_dev(velo_ctx*, const float* dx, const float* dy, const float
  * survivors is kept.  Refused (VELO_E_INVALID, map unchanged) if nothing would remain.  The
  * grid is re-anchored when the lowest survivor is >= 2*margin+2 voxels above the origin. */
 int velo_map_evict_outside(velo_ctx*, const float lo[3], const float hi[3]);
+/* The same with the region the reference names: keep what lies within `radius` of (x, y) in the
+ * ground plane (z free) -- ROI_RANGE, "sensor detecting range" (MapManager.h:13) around the
+ * current pose.  Same grid rules and refusal as velo_map_evict_outside. */
+int velo_map_evict_radius(velo_ctx*, const float center_xy[2], float radius);
 /* Per-axis grid slack in voxels (cfg.map_margin sets all three): a vehicle wants tens of
  * voxels in x/y and one or two in z -- the dense fine-cell table grows with the product.
  * Takes effect at the next (re-)anchoring: velo_map_reset, or the rules above. */
@@ -282,7 +286,16 @@ int velo_increment_dev(velo_ctx*, int frame, const double T[12], int min_count, 
  * next batch) and returns the count. */
 int velo_increment_registered_async(velo_ctx*, int frame, int min_count, float* dox, float* doy,
                                     float* doz);
+/* The same for EVERY resident frame of the last registration in one pass: the concatenation, in
+ * frame order, of the per-frame increments (each frame at its own registered pose, all against
+ * the same map snapshot).  Outputs: device arrays with room for all resident points. */
+int velo_increment_all_registered_async(velo_ctx*, int min_count, float* dox, float* doy, float* doz);
 int velo_increment_wait(velo_ctx*, size_t* n_out);
+
+/* Valid correspondence pairs processed by every registration iteration of this ctx since the
+ * last reset, counted on the device (exact; lets a caller that never fetches per-batch results
+ * -- the bench loop -- report pairs/s).  Synchronises the ctx stream. */
+int velo_pairs_total(velo_ctx*, uint64_t* out, int reset);
 
 /* per-kernel device time of the last velo_icp_batch* call, HIP events on the ctx
  * stream: [0] linearise kernel total ms, [1] its launch count, [2] solve total ms,
@@ -290,12 +303,18 @@ int velo_increment_wait(velo_ctx*, size_t* n_out);
  * [6] fastest linearise launch ms */
 int velo_last_timing(velo_ctx*, double out[8]);
 /* enable (1) / disable (0) per-launch event timing (adds event records) */
-/* Search statistics of the linearise kernel since the last reset, for tuning; all zero unless
- * the library was built with -DVELO_STATS (tools/build_variant.sh).  out[8]: live queries,
- * certified without search, searched, empty-neighbourhood skips, stage-A final, stage-B per
- * lane, stage-B cooperative, valid pairs. */
-int velo_debug_search_stats(velo_ctx*, uint64_t out[8], int reset);
 int velo_set_timing(velo_ctx*, int on);
+/* Search statistics and byte accounting of the linearise kernel.  velo_set_stats(ctx, 1) makes
+ * every following linearise launch use the COUNTING instantiation of the kernel (same results,
+ * slower; the production instantiation carries no counters); velo_search_stats reads the
+ * process-wide totals since the last reset: [0] live queries, [1] certified without search,
+ * [2] searched, [3] empty-neighbourhood skips, [4] stage-A final, [5] stragglers searched per
+ * lane, [6] stage-B stragglers (all), [7] valid pairs, [8] BYTES the kernel requested from
+ * memory (loads + stores: the roofline numerator bench.py uses), [9] candidate points examined,
+ * [10] fine-table requests, [11] launches.  velo_debug_search_stats = the first 8. */
+int velo_set_stats(velo_ctx*, int on);
+int velo_search_stats(velo_ctx*, uint64_t out[16], int reset);
+int velo_debug_search_stats(velo_ctx*, uint64_t out[8], int reset);
 
 /* ---- host-side pose plumbing -------------------------------------------------------- */
 /* PoseTransform::getMatrix (type_defs.h:134-146) and its inverse. TRdeg = T[3] + R[3]. */

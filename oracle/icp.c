@@ -488,19 +488,30 @@ int vo_roll_append(vo_roll* r, const float* x, const float* y, const float* z, s
     return below;
 }
 
-int vo_roll_evict_outside(vo_roll* r, const float lo[3], const float hi[3])
+/* keep region = closed box, optionally intersected with the vertical cylinder of radius `radius`
+ * around (cx, cy) (radius < 0: box only).  The cylinder is the rolling-map policy behind
+ * ROI_RANGE (MapManager.h:13: "sensor detecting range"): distance in the ground plane, z free. */
+static inline int roll_keep(const vo_roll* r, size_t i, const float lo[3], const float hi[3],
+                            float cx, float cy, float radius)
+{
+    if (!(r->x[i] >= lo[0] && r->x[i] <= hi[0] && r->y[i] >= lo[1] && r->y[i] <= hi[1] &&
+          r->z[i] >= lo[2] && r->z[i] <= hi[2]))
+        return 0;
+    if (radius < 0.0f) return 1;
+    const float dx = r->x[i] - cx, dy = r->y[i] - cy;
+    return fmaf(dy, dy, dx * dx) <= radius * radius;
+}
+
+int vo_roll_evict_region(vo_roll* r, const float lo[3], const float hi[3], float cx, float cy,
+                         float radius)
 {
     size_t kept = 0;
-    for (size_t i = 0; i < r->n; ++i)
-        if (r->x[i] >= lo[0] && r->x[i] <= hi[0] && r->y[i] >= lo[1] && r->y[i] <= hi[1] &&
-            r->z[i] >= lo[2] && r->z[i] <= hi[2])
-            ++kept;
+    for (size_t i = 0; i < r->n; ++i) kept += (size_t)roll_keep(r, i, lo, hi, cx, cy, radius);
     if (kept == 0) return -1;
     if (kept == r->n) return 0;
     size_t w = 0;
     for (size_t i = 0; i < r->n; ++i)
-        if (r->x[i] >= lo[0] && r->x[i] <= hi[0] && r->y[i] >= lo[1] && r->y[i] <= hi[1] &&
-            r->z[i] >= lo[2] && r->z[i] <= hi[2]) {
+        if (roll_keep(r, i, lo, hi, cx, cy, radius)) {
             r->x[w] = r->x[i];
             r->y[w] = r->y[i];
             r->z[w] = r->z[i];
@@ -516,6 +527,11 @@ int vo_roll_evict_outside(vo_roll* r, const float lo[3], const float hi[3])
     if (anchor) roll_anchor(r, mn, mx);
     if (roll_rebuild(r)) return -1;
     return anchor ? 1 : 2;
+}
+
+int vo_roll_evict_outside(vo_roll* r, const float lo[3], const float hi[3])
+{
+    return vo_roll_evict_region(r, lo, hi, 0.0f, 0.0f, -1.0f);
 }
 
 /* p' = T*p in fp64 with a fixed fma nesting (shared with the HIP kernels) */

@@ -121,6 +121,7 @@ def lib():
     L.vo_roll_size.restype = C.c_size_t
     L.vo_roll_append.argtypes = [C.c_void_p, fp, fp, fp, C.c_size_t]
     L.vo_roll_evict_outside.argtypes = [C.c_void_p, fp, fp]
+    L.vo_roll_evict_region.argtypes = [C.c_void_p, fp, fp, C.c_float, C.c_float, C.c_float]
     L.vo_map_free.argtypes = [C.c_void_p]
     L.vo_map_size.argtypes = [C.c_void_p]
     L.vo_map_subdiv.argtypes = [C.c_void_p]
@@ -465,6 +466,16 @@ class RollingMap:
         lo = np.ascontiguousarray(lo, np.float32)
         hi = np.ascontiguousarray(hi, np.float32)
         return lib().vo_roll_evict_outside(self.r, _f(lo), _f(hi))
+
+
+def _evict_radius(self, cx, cy, radius):
+    big = np.float32(3.0e38)
+    lo = np.array([-big, -big, -big], np.float32)
+    hi = np.array([big, big, big], np.float32)
+    return lib().vo_roll_evict_region(self.r, _f(lo), _f(hi), float(cx), float(cy), float(radius))
+
+
+RollingMap.evict_radius = _evict_radius
 
 
 def load_corrections(path):

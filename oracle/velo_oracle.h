@@ -143,6 +143,10 @@ const vo_map* vo_roll_map(const vo_roll*);
 size_t vo_roll_size(const vo_roll*);
 int vo_roll_append(vo_roll*, const float* x, const float* y, const float* z, size_t m);
 int vo_roll_evict_outside(vo_roll*, const float lo[3], const float hi[3]);
+/* box intersected with the cylinder of `radius` around (cx, cy) in the ground plane (radius < 0:
+ * box only): eviction by ROI_RANGE (MapManager.h:13) */
+int vo_roll_evict_region(vo_roll* r, const float lo[3], const float hi[3], float cx, float cy,
+                         float radius);
 size_t vo_map_size(const vo_map*);
 void vo_map_grid(const vo_map*, float origin[3], int dims[3], float* inv_h);
 /* sorted SoA arrays (length n), perm[s] = original index; cell_start = the FINE cell

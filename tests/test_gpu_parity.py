@@ -238,6 +238,36 @@ def test_rolling_map_incremental_equals_fresh_build(oracle, margin, full, k):
         c.close()
 
 
+@pytest.mark.parametrize("margin", [0, 3])
+def test_rolling_map_evict_radius_equals_fresh_build(oracle, margin):
+    """Eviction by ROI_RANGE (MapManager.h:13; velo_map_evict_radius): a cylinder around the
+    pose in the ground plane.  Device map == oracle's fresh build afterwards, incrementally or
+    re-anchored; refused when nothing would remain."""
+    rng = np.random.default_rng(33)
+    base = rng.uniform(-15, 15, (3, 12000)).astype(np.float32)
+    base[2] *= 0.1
+    c = capi.Context(0, max_batch=2, map_margin=margin)
+    try:
+        c.map_reset(*base, 1.0, 8)
+        roll = oracle.RollingMap(*base, 1.0, 8, 3, margin=margin)
+        for (cx, cy, r) in ((0.0, 0.0, 19.0), (2.0, -1.0, 12.0), (6.0, 3.0, 7.5), (6.0, 3.0, 100.0)):
+            rc = roll.evict_radius(cx, cy, r)
+            c.map_evict_radius(cx, cy, r)
+            assert rc in (0, 1, 2)
+            _assert_map_equal(c, roll.map)
+            if rc:
+                assert c.map_info().last_update == (1 if rc == 2 else 0)
+        more = rng.uniform(4, 8, (3, 300)).astype(np.float32); more[2] *= 0.1
+        c.map_append(*more); roll.append(*more)
+        _assert_map_equal(c, roll.map)
+        with pytest.raises(capi.VeloError):
+            c.map_evict_radius(500.0, 500.0, 1.0)
+        assert roll.evict_radius(500.0, 500.0, 1.0) == -1
+        _assert_map_equal(c, roll.map)
+    finally:
+        c.close()
+
+
 def test_rolling_map_registration_after_updates(oracle, wl, comp):
     """ICP against a map that was appended to and evicted from incrementally gives the pose of
     the oracle's ICP on the fresh build (hints of the previous map are forgotten)."""

@@ -63,3 +63,31 @@ def test_roll_rules_and_grid_independence(oracle):
     sx, sy, sz = wide.map.sorted_xyz()
     perm = wide.map.perm()
     assert np.array_equal(sx, keep[0][perm]) and np.array_equal(sz, keep[2][perm])
+
+
+def test_roll_evict_radius_is_a_cylinder_in_the_ground_plane(oracle):
+    """Eviction by ROI_RANGE (MapManager.h:13): keep what lies within `radius` of the pose in
+    x/y, whatever its height; order preserving; same refusal / anchoring rules as the box."""
+    rng = np.random.default_rng(9)
+    p = rng.uniform(-20, 20, (3, 5000)).astype(np.float32)
+    p[2] = rng.uniform(-50, 50, 5000).astype(np.float32)
+    roll = oracle.RollingMap(*p, 1.0, 8, 3, margin=2)
+    cx, cy, r = 3.0, -2.0, 12.5
+    d2 = (p[0].astype(np.float64) - cx) ** 2 + (p[1].astype(np.float64) - cy) ** 2
+    sure_in, sure_out = d2 <= r * r * (1 - 1e-6), d2 > r * r * (1 + 1e-6)
+    assert roll.evict_radius(cx, cy, r) in (1, 2)
+    sx, sy, sz = roll.map.sorted_xyz()
+    raw = np.stack([sx, sy, sz])[:, np.argsort(roll.map.perm())]   # survivors in append order
+    assert sure_in.sum() <= roll.n <= (~sure_out).sum()
+    assert np.abs(raw[2]).max() > 40.0                              # z is free
+    # the survivors are a subsequence of the original list (order preserving), they contain
+    # every point surely inside and none surely outside
+    k, taken = 0, np.zeros(p.shape[1], bool)
+    for i in range(p.shape[1]):
+        if k < raw.shape[1] and np.array_equal(p[:, i], raw[:, k]):
+            taken[i] = True
+            k += 1
+    assert k == raw.shape[1] and np.all(taken[sure_in]) and not np.any(taken[sure_out])
+    n = roll.n
+    assert roll.evict_radius(cx, cy, 1e4) == 0 and roll.n == n
+    assert roll.evict_radius(500.0, 500.0, 1.0) == -1 and roll.n == n

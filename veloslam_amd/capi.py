@@ -67,10 +67,10 @@ class MapInfo(C.Structure):
 EXPORTS = [
     "velo_create", "velo_destroy", "velo_last_error", "velo_abi_version", "velo_cfg_get", "velo_set_stream",
     "velo_synchronize", "velo_map_reset", "velo_map_reset_dev", "velo_map_append",
-    "velo_map_append_dev", "velo_map_evict_outside", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
+    "velo_map_append_dev", "velo_map_evict_outside", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_wait", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats",
+    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
     "velo_insmeta_write", "velo_insmeta_read", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
@@ -115,8 +115,12 @@ def lib():
     L.velo_map_append.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.velo_map_append_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.velo_map_evict_outside.argtypes = [vp, vp, vp]
+    L.velo_map_evict_radius.argtypes = [vp, vp, C.c_float]
     L.velo_map_set_margins.argtypes = [vp, vp]
     L.velo_debug_search_stats.argtypes = [vp, vp, C.c_int]
+    L.velo_search_stats.argtypes = [vp, vp, C.c_int]
+    L.velo_set_stats.argtypes = [vp, C.c_int]
+    L.velo_pairs_total.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.velo_map_info_get.argtypes = [vp, C.POINTER(MapInfo)]
     L.velo_map_download.argtypes = [vp] + [vp] * 8
     L.velo_compensate.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp]
@@ -141,6 +145,7 @@ def lib():
     L.velo_increment.argtypes = [vp, C.c_int, dp, C.c_int, vp, vp, vp, C.POINTER(C.c_size_t)]
     L.velo_increment_dev.argtypes = L.velo_increment.argtypes
     L.velo_increment_registered_async.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.velo_increment_all_registered_async.argtypes = [vp, C.c_int, vp, vp, vp]
     L.velo_increment_wait.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.velo_last_timing.argtypes = [vp, dp]
     L.velo_set_timing.argtypes = [vp, C.c_int]
@@ -335,11 +340,21 @@ class Context:
     def set_stream(self, stream_ptr):
         self._chk(lib().velo_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
 
+    def pairs_total(self, reset=False):
+        v = C.c_uint64()
+        self._chk(lib().velo_pairs_total(self.h, C.byref(v), int(reset)))
+        return v.value
+
+    def set_stats(self, on):
+        """1: launch the counting instantiation of the linearise kernel (same results)."""
+        self._chk(lib().velo_set_stats(self.h, int(on)))
+
     def search_stats(self, reset=True):
-        out = (C.c_uint64 * 8)()
-        self._chk(lib().velo_debug_search_stats(self.h, out, int(reset)))
+        out = (C.c_uint64 * 16)()
+        self._chk(lib().velo_search_stats(self.h, out, int(reset)))
         return dict(zip(("live", "certified", "searched", "empty_skips", "stage_a_final",
-                         "unused", "stage_b", "valid_pairs"), [int(v) for v in out]))
+                         "stage_b_per_lane", "stage_b", "valid_pairs", "bytes", "candidates",
+                         "table_requests", "launches"), [int(v) for v in out[:12]]))
 
     def synchronize(self):
         self._chk(lib().velo_synchronize(self.h))
@@ -377,6 +392,10 @@ class Context:
         lo = np.ascontiguousarray(lo, np.float32)
         hi = np.ascontiguousarray(hi, np.float32)
         self._chk(lib().velo_map_evict_outside(self.h, _p(lo), _p(hi)))
+
+    def map_evict_radius(self, cx, cy, radius):
+        c = np.array([cx, cy], np.float32)
+        self._chk(lib().velo_map_evict_radius(self.h, _p(c), float(radius)))
 
     def map_info(self):
         mi = MapInfo()
@@ -534,6 +553,9 @@ class Context:
 
     def increment_registered_async(self, frame, min_count, pox, poy, poz):
         self._chk(lib().velo_increment_registered_async(self.h, frame, min_count, pox, poy, poz))
+
+    def increment_all_registered_async(self, min_count, pox, poy, poz):
+        self._chk(lib().velo_increment_all_registered_async(self.h, min_count, pox, poy, poz))
 
     def increment_wait(self):
         cnt = C.c_size_t()

@@ -100,6 +100,7 @@ struct velo_ctx {
     DevBuf<int32_t> hint;  // last correspondence per query slot (search-radius hint), -1 = none
     DevBuf<float> rho;     // certified uniqueness radius per query slot (valid with hint >= 0)
     DevBuf<double> poses_prev;  // pose each frame was linearised at in the previous iteration
+    DevBuf<unsigned long long> pairs_total;  // pairs processed by every registration iteration so far
     DevBuf<float> d2;
     DevBuf<uint32_t> flags, offs;
     DevBuf<float> inc_x, inc_y, inc_z;
@@ -131,6 +132,7 @@ struct velo_ctx {
     hipEvent_t ev_T0[2] = {nullptr, nullptr};
     int t0_next = 0;
     bool lin_hints = false;  // velo_linearize keeps/uses hints across calls (tests)
+    bool stats_on = false;   // launch the counting instantiation of the linearise kernel
 
     // ---- f1 decode
     DevBuf<uint8_t> dk_pkts, dk_perm, dk_tvalid, dk_invlut;
@@ -703,6 +705,10 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         }
     }
     HIP_TRY(c, c->poses_prev.reserve((size_t)c->cfg.max_batch * 12));
+    if (!c->pairs_total.p) {
+        HIP_TRY(c, c->pairs_total.reserve(1));
+        HIP_TRY(c, hipMemsetAsync(c->pairs_total.p, 0, sizeof(unsigned long long), s));
+    }
     // A graph is only worth capturing for a launch sequence that will be replayed: when the map
     // or the frames changed since the previous registration (a stream: every frame appends to the
     // map) the sequence is launched directly, and captured only once the same map and frames come
@@ -710,7 +716,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     const bool stable = c->seen_map_gen == c->map_gen && c->seen_frames_gen == c->frames_gen;
     c->seen_map_gen = c->map_gen;
     c->seen_frames_gen = c->frames_gen;
-    const bool graph_ok = c->cfg.use_graph && !c->timing && !c->cfg.sort_frames && stable;
+    const bool graph_ok = c->cfg.use_graph && !c->timing && !c->stats_on && !c->cfg.sort_frames && stable;
     if (graph_ok) {
         // Replay the whole registration (hint reset, iters x (linearise, solve)) as
         // one hipGraph: the kernels are tens of microseconds long, so per-launch host cost and
@@ -741,10 +747,11 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
                 e = launch_linearize(c->cfg.linearize_variant, c->items.p, ni, fv, c->mv, c->poses.p,
                                      dmax2, c->partials.p, nullptr, nullptr, hint, rho,
-                                     c->poses_prev.p, s);
+                                     c->poses_prev.p, false, s);
                 if (e == hipSuccess)
                     e = launch_reduce_solve(c->partials.p, c->fbs.p, c->n_frames, c->poses.p,
-                                            c->stats.p, it, iters, nullptr, 1, c->poses_prev.p, s);
+                                            c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
+                                            c->pairs_total.p, s);
             }
             hipGraph_t g = nullptr;
             hipError_t e2 = hipStreamEndCapture(s, &g);
@@ -778,12 +785,13 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             HIP_TRY(c, launch_linearize(c->cfg.linearize_variant,
                                         (fv.order && c->cfg.sort_frames == 1) ? c->items_xcd.p : c->items.p, ni, fv, c->mv,
                                         c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, rho,
-                                        c->poses_prev.p, s));
+                                        c->poses_prev.p, c->stats_on, s));
         }
         {
             Timed t(c, 1);
             HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p, c->n_frames, c->poses.p,
-                                           c->stats.p, it, iters, nullptr, 1, c->poses_prev.p, s));
+                                           c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
+                                           c->pairs_total.p, s));
         }
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev_call1, s));
@@ -949,12 +957,42 @@ int velo_linearize_hints(velo_ctx* c, int mode)
     return VELO_OK;
 }
 
-int velo_debug_search_stats(velo_ctx* c, uint64_t out[8], int reset)
+int velo_pairs_total(velo_ctx* c, uint64_t* out, int reset)
 {
     if (!c || !out) return VELO_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    unsigned long long v[8];
+    unsigned long long v = 0;
+    if (c->pairs_total.p) {
+        HIP_TRY(c, hipMemcpyAsync(&v, c->pairs_total.p, sizeof v, hipMemcpyDeviceToHost, c->stream));
+        if (reset) HIP_TRY(c, hipMemsetAsync(c->pairs_total.p, 0, sizeof v, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    *out = v;
+    return VELO_OK;
+}
+
+int velo_set_stats(velo_ctx* c, int on)
+{
+    if (!c) return VELO_E_INVALID;
+    c->stats_on = on != 0;
+    return VELO_OK;
+}
+
+int velo_search_stats(velo_ctx* c, uint64_t out[16], int reset)
+{
+    if (!c || !out) return VELO_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long v[16];
     HIP_TRY(c, read_lin_stats(v, reset != 0, c->stream));
+    for (int i = 0; i < 16; ++i) out[i] = v[i];
+    return VELO_OK;
+}
+
+int velo_debug_search_stats(velo_ctx* c, uint64_t out[8], int reset)
+{
+    uint64_t v[16];
+    if (!out) return VELO_E_INVALID;
+    if (int rc = velo_search_stats(c, v, reset)) return rc;
     for (int i = 0; i < 8; ++i) out[i] = v[i];
     return VELO_OK;
 }
@@ -1035,11 +1073,40 @@ int velo_map_append_dev(velo_ctx* c, const float* x, const float* y, const float
     return map_append_impl(c, x, y, z, n, true);
 }
 
+static int evict_impl(velo_ctx* c, const KeepRegion& region);
+
 int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
 {
     if (!c) return VELO_E_INVALID;
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "velo_map_evict_outside before velo_map_reset");
     if (!lo || !hi) return c->fail(VELO_E_INVALID, "null box");
+    KeepRegion g{};
+    for (int a = 0; a < 3; ++a) {
+        g.lo[a] = lo[a];
+        g.hi[a] = hi[a];
+    }
+    return evict_impl(c, g);
+}
+
+int velo_map_evict_radius(velo_ctx* c, const float center_xy[2], float radius)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "velo_map_evict_radius before velo_map_reset");
+    if (!center_xy || !(radius >= 0.0f)) return c->fail(VELO_E_INVALID, "null centre or negative radius");
+    KeepRegion g{};
+    for (int a = 0; a < 3; ++a) {
+        g.lo[a] = -3.0e38f;
+        g.hi[a] = 3.0e38f;
+    }
+    g.cx = center_xy[0];
+    g.cy = center_xy[1];
+    g.r2 = radius * radius;
+    g.use_radius = 1;
+    return evict_impl(c, g);
+}
+
+static int evict_impl(velo_ctx* c, const KeepRegion& region)
+{
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const MapView old = c->mv;
@@ -1050,8 +1117,8 @@ int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
     HIP_TRY(c, reserve_slack(c->offs, n));
     HIP_TRY(c, reserve_slack(c->rflags, n));
     HIP_TRY(c, reserve_slack(c->roffs, n));
-    HIP_TRY(c, launch_keep_flags(c->pts.p, nullptr, nullptr, nullptr, n, lo, hi, c->flags.p, s));
-    HIP_TRY(c, launch_keep_flags(nullptr, c->raw_x.p, c->raw_y.p, c->raw_z.p, n, lo, hi, c->rflags.p, s));
+    HIP_TRY(c, launch_keep_flags(c->pts.p, nullptr, nullptr, nullptr, n, region, c->flags.p, s));
+    HIP_TRY(c, launch_keep_flags(nullptr, c->raw_x.p, c->raw_y.p, c->raw_z.p, n, region, c->rflags.p, s));
     size_t tb = 0;
     HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->flags.p, c->offs.p, n, s));
     if (int rc = ensure_temp(c, tb)) return rc;
@@ -1062,7 +1129,7 @@ int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
     HIP_TRY(c, hipMemcpyAsync(&last[1], c->flags.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     const uint32_t kept = last[0] + last[1];
-    if (kept == 0) return c->fail(VELO_E_INVALID, "eviction box would remove every map point");
+    if (kept == 0) return c->fail(VELO_E_INVALID, "eviction region would remove every map point");
     if (kept == n) return VELO_OK;
     // append-order arrays first: they decide whether the grid keeps
     HIP_TRY(c, reserve_slack(c->raw_x2, kept));
@@ -1353,9 +1420,9 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
                                 c->poses.p, d_max * d_max, c->partials.p, c->corr.p, c->d2.p,
                                 c->lin_hints ? c->hint.p : nullptr,
                                 (c->lin_hints && c->cfg.use_hints >= 2) ? c->rho.p : nullptr,
-                                c->poses_prev.p, s));
+                                c->poses_prev.p, c->stats_on, s));
     HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p + frame, 1, c->poses.p, nullptr, 0, 1,
-                                   c->acc.p, 0, nullptr, s));
+                                   c->acc.p, 0, nullptr, nullptr, s));
     if (corr)
         HIP_TRY(c, hipMemcpyAsync(corr, c->corr.p + q0, (q1 - q0) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (d2)
@@ -1389,7 +1456,7 @@ int velo_solve_update(velo_ctx* c, const double acc[29], double T[12], int32_t* 
     HIP_TRY(c, hipMemcpyAsync(pose.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(fbs.p, range, sizeof range, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));  // the sources are stack arrays
-    HIP_TRY(c, launch_reduce_solve(part.p, fbs.p, 1, pose.p, st.p, 0, 1, nullptr, 1, nullptr, s));
+    HIP_TRY(c, launch_reduce_solve(part.p, fbs.p, 1, pose.p, st.p, 0, 1, nullptr, 1, nullptr, nullptr, s));
     velo_icp_iter it0;
     HIP_TRY(c, hipMemcpyAsync(T, pose.p, 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&it0, st.p, sizeof it0, hipMemcpyDeviceToHost, s));
@@ -1864,6 +1931,43 @@ int velo_increment_registered_async(velo_ctx* c, int frame, int min_count, float
             return rc;
     }
     HIP_TRY(c, hipEventRecord(c->ev_inc, c->stream));
+    c->inc_pending = true;
+    return VELO_OK;
+}
+
+// every resident frame of the last registration at once ("every GPU contributes its
+// accepted map increment"): concatenation, in frame order, of the per-frame increments
+int velo_increment_all_registered_async(velo_ctx* c, int min_count, float* dox, float* doy, float* doz)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
+    if (c->n_frames < 1 || c->last_iters < 1) return c->fail(VELO_E_INVALID, "no registration has run");
+    if (!dox || !doy || !doz) return c->fail(VELO_E_INVALID, "null output array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->h_inc_total) {
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_inc_total, sizeof(uint32_t), 0));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_inc, hipEventDisableTiming));
+    }
+    *c->h_inc_total = 0;
+    c->inc_pending = false;
+    hipStream_t s = c->stream;
+    const size_t n = (size_t)c->frame_start[c->n_frames];
+    const int ni = (int)c->items_h.size();
+    if (n) {
+        HIP_TRY(c, c->flags.reserve(n + 1));
+        HIP_TRY(c, c->offs.reserve(n + 1));
+        FrameView fv{c->ax, c->ay, c->az, nullptr};
+        HIP_TRY(c, launch_increment_flags_items(c->items.p, ni, fv, c->mv, c->poses.p, min_count, c->flags.p, s));
+        HIP_TRY(c, hipMemsetAsync(c->flags.p + n, 0, sizeof(uint32_t), s));
+        size_t tb = 0;
+        HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->flags.p, c->offs.p, n + 1, s));
+        if (int rc = ensure_temp(c, tb)) return rc;
+        HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->flags.p, c->offs.p, n + 1, s));
+        HIP_TRY(c, hipMemcpyAsync(c->h_inc_total, c->offs.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, launch_increment_scatter_items(c->items.p, ni, fv, c->poses.p, c->flags.p, c->offs.p,
+                                                  dox, doy, doz, s));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_inc, s));
     c->inc_pending = true;
     return VELO_OK;
 }

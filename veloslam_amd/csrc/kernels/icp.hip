@@ -102,20 +102,56 @@ __constant__ unsigned char c_ia[32] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2,
 __constant__ unsigned char c_ib[32] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3,
                                        4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7};
 
-// Search statistics (only counted in -DVELO_STATS builds, tools/build_variant.sh):
+// Search statistics and byte accounting: counted only by the STATS instantiation of the kernel
+// (velo_set_stats), the production instantiation carries none of it.
 // [0] live queries, [1] certified (no search), [2] searched, [3] empty-neighbourhood skips,
-// [4] stage-A final, [5] unused, [6] stage-B stragglers, [7] valid pairs
-__device__ unsigned long long g_lin_stats[8];
-#ifdef VELO_STATS
+// [4] stage-A final, [5] stragglers searched per lane, [6] stage-B stragglers (all),
+// [7] valid pairs, [8] bytes requested from memory (loads + stores, see Tally),
+// [9] candidate points examined, [10] fine-table requests, [11] launches
+__device__ unsigned long long g_lin_stats[16];
+
+// Bytes this lane asked the memory system for: the roofline numerator of the pruned kernel
+// (bench.py "roofline.achieved" = these bytes / launch time).  16 B per candidate / hinted /
+// matched point, 16 B per normal, 16 B (stage A) or 2 x 4 B (stage B) per fine-table request,
+// 12 B query + 4 B hint + 4 B certificate read, 4 + 4 B written back, 1 B voxel flag.
+template <bool STATS>
+struct Tally {
+    unsigned bytes = 0, cand = 0, tab = 0;
+    __device__ __forceinline__ void add(unsigned b)
+    {
+        if constexpr (STATS) bytes += b;
+    }
+    __device__ __forceinline__ void candidates(unsigned n)
+    {
+        if constexpr (STATS) {
+            cand += n;
+            bytes += 16u * n;
+        }
+    }
+    __device__ __forceinline__ void table(unsigned n_req, unsigned bytes_each)
+    {
+        if constexpr (STATS) {
+            tab += n_req;
+            bytes += n_req * bytes_each;
+        }
+    }
+};
+
+__device__ __forceinline__ void stat_add(int slot, unsigned v)
+{
+    unsigned t = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(&g_lin_stats[slot], (unsigned long long)t);
+}
 #define VELO_COUNT(i, pred)                                                                     \
     do {                                                                                        \
-        const unsigned long long m__ = __ballot(pred);                                          \
-        if (m__ && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m__) - 1))               \
-            atomicAdd(&g_lin_stats[i], (unsigned long long)__popcll(m__));                      \
+        if constexpr (STATS) {                                                                  \
+            const unsigned long long m__ = __ballot(pred);                                      \
+            if (m__ && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m__) - 1))           \
+                atomicAdd(&g_lin_stats[i], (unsigned long long)__popcll(m__));                  \
+        }                                                                                       \
     } while (0)
-#else
-#define VELO_COUNT(i, pred) do { } while (0)
-#endif
 
 // ---- fine-grid geometry of a query --------------------------------------------------
 // The map is sorted by FINE cell (S sub-cells per voxel edge, DESIGN.md "ICP semantics");
@@ -220,10 +256,10 @@ struct SearchLds {
 // flight together; indices are clamped to the range start (a candidate evaluated twice is
 // harmless under '<=').  (Carrying the winner's coordinates through the walk to save the
 // later re-fetch was measured: the extra selects and registers cost more than the fetch.)
-template <int W>
+template <int W, bool STATS>
 __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float qy, float qz,
                                             SearchLds& L, int tid, int nr, float& bd, int& bj,
-                                            float& sd)
+                                            float& sd, Tally<STATS>& tl)
 {
     // W candidates per trip drawn ACROSS ranges: a lane with three short ranges needs one or
     // two trips instead of three (measured 54 vs 57.5 us per launch against one range per
@@ -243,6 +279,7 @@ __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float q
                 ++k;
             }
             live[u] = j > lo;
+            if (live[u]) tl.candidates(1);
             if (live[u]) last = --j;
             jj[u] = last;
             c[u] = mv.pts[last];
@@ -288,11 +325,11 @@ __device__ __forceinline__ int finish_block(float bd, float sd, float gr, float&
     return final ? kFinal : kStraggler;
 }
 
-template <int ABL>
+template <int ABL, bool STATS>
 __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& g, float qx,
                                             float qy, float qz, float ub0, SearchLds& L,
                                             int tid, float& bd, int& bj, float& cert,
-                                            float& gr_out)
+                                            float& gr_out, Tally<STATS>& tl)
 {
     bd = ub0;
     bj = -1;
@@ -329,6 +366,7 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
                 if (x0 > x1) continue;
                 const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
                 const Int4U e = *reinterpret_cast<const Int4U*>(mv.cell_start + row + xb);
+                tl.table(1, 16);
                 const int a = x0 - xb, b = x1 + 1 - xb;  // both in [0,3]
                 const int jlo = a == 0 ? e.v[0] : (a == 1 ? e.v[1] : (a == 2 ? e.v[2] : e.v[3]));
                 const int jhi = b == 1 ? e.v[1] : (b == 2 ? e.v[2] : (b == 3 ? e.v[3] : e.v[0]));
@@ -349,7 +387,7 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
     const float gr = fmaxf(hf * (1.0f + tmin) - mg, 0.0f);
     gr_out = gr;
     float sd = ub0;  // everything not scanned inside the block is further than sqrt(ub0)
-    walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd);
+    walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd, tl);
     if (ABL >= 1) return kFinal;
     return finish_block(bd, sd, gr, cert);
 }
@@ -359,8 +397,9 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
 // descending order in chunks of kMaxRanges.  Per chunk the table entries of all its rows are
 // requested together, the surviving ranges staged in LDS and walked like stage A -- two
 // memory round trips per nine rows instead of two per row.
+template <bool STATS>
 __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, float ub,
-                            SearchLds& L, int tid, float& bd, int& bj)
+                            SearchLds& L, int tid, float& bd, int& bj, Tally<STATS>& tl)
 {
     const QueryCell g = locate(mv, qx, qy, qz);
     bd = ub;
@@ -391,6 +430,7 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
                     if (x0 <= x1) {
                         const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
                         const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
+                        tl.table(2, 4);
                         if (jhi > jlo) {
                             L.hi[nr][tid] = jhi;
                             L.lo[nr][tid] = jlo;
@@ -405,7 +445,7 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
             }
         }
         float sd_unused = bd;
-        walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd_unused);
+        walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd_unused, tl);
     }
 }
 
@@ -416,8 +456,10 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
 // Every lane returns the same winner.  Rows are independent, so all their loads are in
 // flight together: a handful of stragglers no longer costs a serial chain of ~50 dependent
 // loads while the other wavefronts of the workgroup wait at the barrier.
+template <bool STATS>
 __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, float qy, float qz,
-                                                 float ub, int lane, float& bd, int& bj, float& sd)
+                                                 float ub, int lane, float& bd, int& bj, float& sd,
+                                                 Tally<STATS>& tl)
 {
     const QueryCell g = locate(mv, qx, qy, qz);
     float b1 = ub, b2 = ub;  // best and second-best distance seen by this lane
@@ -443,6 +485,8 @@ __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, fl
         if (x0 > x1) continue;
         const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
         const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
+        tl.table(2, 4);
+        tl.candidates((unsigned)max(jhi - jlo, 0));
 #pragma unroll 4
         for (int j = jhi - 1; j >= jlo; --j) {
             const float d2 = dist2(mv.pts[j], qx, qy, qz);
@@ -489,7 +533,7 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 #ifndef VELO_COOP_MAX
 #define VELO_COOP_MAX 16
 #endif
-template <bool WRITE_CORR, int VARIANT>
+template <bool WRITE_CORR, int VARIANT, bool STATS>
 #ifndef VELO_LIN_WAVES
 #define VELO_LIN_WAVES 7  // measured: 8 spills (64 VGPRs), 7 = 72 VGPRs no spill, fastest
 #endif
@@ -509,6 +553,11 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
     LinLds& s_u = s_uw[wave];
     const int ia = c_ia[col], ib = c_ib[col];
     double colsum = 0.0;
+    Tally<STATS> tl;
+    if constexpr (STATS) {
+        if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_lin_stats[11], 1ull);
+        if (tid == 0) tl.add(16 + 96 + kAccN * 8);  // work item, pose, partial sums
+    }
 
     for (int base = it.q0; base < it.q1; base += kLinThreads) {
         const int q = base + tid;
@@ -520,6 +569,7 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
             syq = fv.y[q];
             szq = fv.z[q];
             if (hint) hj = hint[q];
+            tl.add(hint ? 16 : 12);
         }
         double px = 0, py = 0, pz = 0;
         float bd = INFINITY;
@@ -547,6 +597,8 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
                 float ub0 = dmax2;
                 bool certified = false;
                 if (hj >= 0) {
+                    tl.candidates(1);
+                    tl.add(rho ? 4 : 0);
                     const float d1sq = dist2(mv.pts[hj], qx, qy, qz);
                     const float d1 = sqrtf(d1sq) * 1.000001f + 1e-7f;
                     if (rho) {
@@ -581,9 +633,10 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
                     if (hj < 0 && mv.vox_near && g.cx >= 0 && g.cx < mv.nx && g.cy >= 0 &&
                         g.cy < mv.ny && g.cz >= 0 && g.cz < mv.nz)
                         empty = mv.vox_near[((size_t)g.cz * mv.ny + g.cy) * mv.nx + g.cx] == 0;
+                    tl.add(hj < 0 && mv.vox_near ? 1 : 0);
                     if (!empty)
                         st = search_block<(VARIANT >= 11 ? VARIANT - 10 : 0)>(
-                            mv, g, qx, qy, qz, ub0, s_u.s, lane, bd, bj, rho_new_out, blk_gr);
+                            mv, g, qx, qy, qz, ub0, s_u.s, lane, bd, bj, rho_new_out, blk_gr, tl);
                     VELO_COUNT(3, empty);
                     VELO_COUNT(2, !empty);
                 }
@@ -595,9 +648,10 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
             VELO_COUNT(0, live);
             VELO_COUNT(6, queued);
             if (__popcll(need) > VELO_COOP_MAX) {
+                VELO_COUNT(5, queued);
                 if (queued) {
                     const float ub = bd;
-                    search_ball(mv, qx, qy, qz, ub, s_u.s, lane, bd, bj);
+                    search_ball(mv, qx, qy, qz, ub, s_u.s, lane, bd, bj, tl);
                 }
             } else {
                 while (need) {
@@ -612,7 +666,7 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
                     const float sub = fminf(rsq * rsq, mv.h * mv.h);
                     float rbd, rsd;
                     int rbj;
-                    search_ball_wave(mv, sx, sy, sz, sub, lane, rbd, rbj, rsd);
+                    search_ball_wave(mv, sx, sy, sz, sub, lane, rbd, rbj, rsd, tl);
                     if (lane == src) {
                         bd = rbd;
                         bj = rbj;
@@ -635,6 +689,7 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
             if (!(state_same && ok)) {
                 if (hint) hint[q] = ok ? bj : -1;
                 if (VARIANT >= 1 && rho) rho[q] = rho_new_out;
+                tl.add((hint ? 4 : 0) + ((VARIANT >= 1 && rho) ? 4 : 0));
             }
             if (WRITE_CORR) {
                 const int qi = fv.order ? fv.order[q] : q;
@@ -643,6 +698,7 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
             }
             VELO_COUNT(7, ok);
             if (ok) {
+                tl.add(32);
                 const float4 nf = mv.nrm[bj];
                 const float4 mf = mv.pts[bj];  // issued with the normal: one round trip, not two
                 if (!(nf.x == 0.0f && nf.y == 0.0f && nf.z == 0.0f)) {
@@ -680,6 +736,11 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    if constexpr (STATS) {
+        stat_add(8, tl.bytes);
+        stat_add(9, tl.cand);
+        stat_add(10, tl.tab);
+    }
     // halves -> wave (shuffle), waves -> block (LDS), fixed order
     const double other = __shfl_down(colsum, 32, 64);
     if (half == 0) s_w[wave][col] = colsum + other;
@@ -690,27 +751,30 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
     }
 }
 
-hipError_t read_lin_stats(unsigned long long out[8], bool reset, hipStream_t s)
+hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)
 {
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
-    e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin_stats), 8 * sizeof(unsigned long long));
+    e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin_stats), 16 * sizeof(unsigned long long));
     if (e != hipSuccess || !reset) return e;
-    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long z[16] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_lin_stats), z, sizeof z);
 }
 
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, int32_t* hint, float* rho,
-                            const double* poses_prev, hipStream_t s)
+                            const double* poses_prev, bool stats, hipStream_t s)
 {
     if (n_items == 0) return hipSuccess;
     const bool wc = corr || d2;
 #define VELO_LAUNCH_LIN(WC, V)                                                                   \
-    hipLaunchKernelGGL((k_linearize<WC, V>), dim3(n_items), dim3(kLinThreads), 0, s, items, fv, \
-                       mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev)
-    if (variant == VELO_VARIANT_SCAN) {
+    hipLaunchKernelGGL((k_linearize<WC, V, false>), dim3(n_items), dim3(kLinThreads), 0, s,     \
+                       items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev)
+    if (stats && variant != VELO_VARIANT_SCAN && variant < 10) {  // counting instantiation
+        hipLaunchKernelGGL((k_linearize<true, 1, true>), dim3(n_items), dim3(kLinThreads), 0, s,
+                           items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+    } else if (variant == VELO_VARIANT_SCAN) {
         if (wc) VELO_LAUNCH_LIN(true, 0); else VELO_LAUNCH_LIN(false, 0);
     } else if (variant == 11) {  // timing ablations (wrong results by design)
         VELO_LAUNCH_LIN(false, 11);
@@ -801,7 +865,8 @@ constexpr int kSolveGroups = kSolveThreads / 32;
 __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     const double* __restrict__ partials, const int32_t* __restrict__ fbs,
     double* __restrict__ poses, velo_icp_iter* __restrict__ stats, int iter,
-    double* __restrict__ acc_out, int do_update, double* __restrict__ poses_prev)
+    double* __restrict__ acc_out, int do_update, double* __restrict__ poses_prev,
+    unsigned long long* __restrict__ pairs_total)
 {
     __shared__ double s_g[kSolveGroups][32];
     __shared__ double s_acc[32];
@@ -840,6 +905,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     st.n_pairs = (uint32_t)cnt;
     st.rmse = cnt > 0.0 ? sqrt(s_acc[27] / cnt) : 0.0;
     st.solve_flag = 0;
+    // running count of the pairs every registration iteration on this ctx has processed
+    // (integer adds: exact and order independent)
+    if (pairs_total && do_update) atomicAdd(pairs_total, (unsigned long long)cnt);
     if (do_update) {
         if (cnt < 6.0) {
             st.solve_flag = 2;
@@ -871,12 +939,13 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, double* poses_prev,
-                               hipStream_t s)
+                               unsigned long long* pairs_total, hipStream_t s)
 {
     (void)iters_total;
     if (n_frames == 0) return hipSuccess;
     hipLaunchKernelGGL(k_reduce_solve, dim3(n_frames), dim3(kSolveThreads), 0, s, partials,
-                       frame_block_start, poses, stats, iter, acc_out, do_update, poses_prev);
+                       frame_block_start, poses, stats, iter, acc_out, do_update, poses_prev,
+                       pairs_total);
     return hipGetLastError();
 }
 
@@ -1021,6 +1090,78 @@ hipError_t launch_increment_scatter(const float* x, const float* y, const float*
     const int grid = (int)(g > 4096 ? 4096 : g);
     hipLaunchKernelGGL(k_increment_scatter, dim3(grid), dim3(256), 0, s, x, y, z, n, pose, flags,
                        offs, ox, oy, oz);
+    return hipGetLastError();
+}
+
+// ---- the same for every resident frame at once (one workgroup per work item of the
+// linearise decomposition, each frame at its own pose): the concatenation, in frame order,
+// of the per-frame increments against the same map snapshot
+__device__ __forceinline__ int voxel_count(const MapView& mv, int cx, int cy, int cz)
+{
+    int occ = 0;
+    for (int fz = cz * mv.S; fz < (cz + 1) * mv.S; ++fz)
+        for (int fy = cy * mv.S; fy < (cy + 1) * mv.S; ++fy) {
+            const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
+            occ += mv.cell_start[row + (size_t)(cx + 1) * mv.S] - mv.cell_start[row + (size_t)cx * mv.S];
+        }
+    return occ;
+}
+
+__global__ __launch_bounds__(kLinThreads) void k_increment_flags_items(
+    const BlockItem* __restrict__ items, FrameView fv, MapView mv, const double* __restrict__ poses,
+    int min_count, uint32_t* __restrict__ flags)
+{
+    const BlockItem it = items[blockIdx.x];
+    const double* __restrict__ T = poses + 12 * (size_t)it.frame;
+    for (int q = it.q0 + (int)threadIdx.x; q < it.q1; q += kLinThreads) {
+        double px, py, pz;
+        xform(T, fv.x[q], fv.y[q], fv.z[q], px, py, pz);
+        const int cx = cell_coord((float)px, mv.ox, mv.inv_h, mv.nx);
+        const int cy = cell_coord((float)py, mv.oy, mv.inv_h, mv.ny);
+        const int cz = cell_coord((float)pz, mv.oz, mv.inv_h, mv.nz);
+        int occ = 0;
+        if (cx >= 0 && cx < mv.nx && cy >= 0 && cy < mv.ny && cz >= 0 && cz < mv.nz)
+            occ = voxel_count(mv, cx, cy, cz);
+        flags[q] = occ < min_count ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(kLinThreads) void k_increment_scatter_items(
+    const BlockItem* __restrict__ items, FrameView fv, const double* __restrict__ poses,
+    const uint32_t* __restrict__ flags, const uint32_t* __restrict__ offs, float* __restrict__ ox,
+    float* __restrict__ oy, float* __restrict__ oz)
+{
+    const BlockItem it = items[blockIdx.x];
+    const double* __restrict__ T = poses + 12 * (size_t)it.frame;
+    for (int q = it.q0 + (int)threadIdx.x; q < it.q1; q += kLinThreads) {
+        if (!flags[q]) continue;
+        double px, py, pz;
+        xform(T, fv.x[q], fv.y[q], fv.z[q], px, py, pz);
+        const uint32_t o = offs[q];
+        ox[o] = (float)px;
+        oy[o] = (float)py;
+        oz[o] = (float)pz;
+    }
+}
+
+hipError_t launch_increment_flags_items(const BlockItem* items, int n_items, const FrameView& fv,
+                                        const MapView& mv, const double* poses, int min_count,
+                                        uint32_t* flags, hipStream_t s)
+{
+    if (n_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_increment_flags_items, dim3(n_items), dim3(kLinThreads), 0, s, items, fv, mv,
+                       poses, min_count, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_increment_scatter_items(const BlockItem* items, int n_items, const FrameView& fv,
+                                          const double* poses, const uint32_t* flags,
+                                          const uint32_t* offs, float* ox, float* oy, float* oz,
+                                          hipStream_t s)
+{
+    if (n_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_increment_scatter_items, dim3(n_items), dim3(kLinThreads), 0, s, items, fv,
+                       poses, flags, offs, ox, oy, oz);
     return hipGetLastError();
 }
 

@@ -678,25 +678,33 @@ __global__ __launch_bounds__(256) void k_select_dirty(const uint32_t* __restrict
 }
 
 // ---- eviction: keep the points inside the closed box [lo, hi]
-__global__ __launch_bounds__(256) void k_keep4(const float4* __restrict__ pts, uint32_t n, float lx,
-                                               float ly, float lz, float hx, float hy, float hz,
-                                               uint32_t* __restrict__ flags)
+// keep region: closed box, optionally intersected with a vertical cylinder (ground-plane
+// distance to (cx, cy) <= radius) -- same float expression as the oracle's roll_keep
+__device__ __forceinline__ bool keep_pt(const KeepRegion& g, float px, float py, float pz)
+{
+    if (!(px >= g.lo[0] && px <= g.hi[0] && py >= g.lo[1] && py <= g.hi[1] && pz >= g.lo[2] &&
+          pz <= g.hi[2]))
+        return false;
+    if (!g.use_radius) return true;
+    const float dx = px - g.cx, dy = py - g.cy;
+    return fmaf(dy, dy, dx * dx) <= g.r2;
+}
+__global__ __launch_bounds__(256) void k_keep4(const float4* __restrict__ pts, uint32_t n,
+                                               KeepRegion g, uint32_t* __restrict__ flags)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = pts[i];
-    flags[i] = (p.x >= lx && p.x <= hx && p.y >= ly && p.y <= hy && p.z >= lz && p.z <= hz) ? 1u : 0u;
+    flags[i] = keep_pt(g, p.x, p.y, p.z) ? 1u : 0u;
 }
 __global__ __launch_bounds__(256) void k_keep3(const float* __restrict__ x,
                                                const float* __restrict__ y,
-                                               const float* __restrict__ z, uint32_t n, float lx,
-                                               float ly, float lz, float hx, float hy, float hz,
-                                               uint32_t* __restrict__ flags)
+                                               const float* __restrict__ z, uint32_t n,
+                                               KeepRegion g, uint32_t* __restrict__ flags)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float px = x[i], py = y[i], pz = z[i];
-    flags[i] = (px >= lx && px <= hx && py >= ly && py <= hy && pz >= lz && pz <= hz) ? 1u : 0u;
+    flags[i] = keep_pt(g, x[i], y[i], z[i]) ? 1u : 0u;
 }
 __global__ __launch_bounds__(256) void k_compact_sorted(
     const float4* __restrict__ pts, const float4* __restrict__ nrm,
@@ -847,16 +855,13 @@ hipError_t launch_count_invalid(const float4* nrm, uint32_t n, unsigned long lon
 }
 
 hipError_t launch_keep_flags(const float4* pts, const float* x, const float* y, const float* z,
-                             uint32_t n, const float lo[3], const float hi[3], uint32_t* flags,
-                             hipStream_t s)
+                             uint32_t n, const KeepRegion& g, uint32_t* flags, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     if (pts)
-        hipLaunchKernelGGL(k_keep4, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, lo[0], lo[1],
-                           lo[2], hi[0], hi[1], hi[2], flags);
+        hipLaunchKernelGGL(k_keep4, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, g, flags);
     else
-        hipLaunchKernelGGL(k_keep3, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, lo[0], lo[1],
-                           lo[2], hi[0], hi[1], hi[2], flags);
+        hipLaunchKernelGGL(k_keep3, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, g, flags);
     return hipGetLastError();
 }
 

@@ -94,9 +94,13 @@ hipError_t launch_removed_keys(const uint32_t* keys, const uint32_t* keep, const
                                uint32_t n, uint32_t* out, hipStream_t s);
 hipError_t launch_count_invalid(const float4* nrm, uint32_t n, unsigned long long* d_invalid,
                                 hipStream_t s);
+struct KeepRegion {  // closed box, optionally intersected with a vertical cylinder
+    float lo[3], hi[3];
+    float cx, cy, r2;
+    int use_radius;
+};
 hipError_t launch_keep_flags(const float4* pts, const float* x, const float* y, const float* z,
-                             uint32_t n, const float lo[3], const float hi[3], uint32_t* flags,
-                             hipStream_t s);
+                             uint32_t n, const KeepRegion& g, uint32_t* flags, hipStream_t s);
 hipError_t launch_compact_sorted(const float4* pts, const float4* nrm, const uint32_t* perm,
                                  const uint32_t* keys, uint32_t n, const uint32_t* flags,
                                  const uint32_t* offs, const uint32_t* raw_offs, float4* pts2,
@@ -124,12 +128,12 @@ hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const f
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, int32_t* hint, float* rho,
-                            const double* poses_prev, hipStream_t s);
-hipError_t read_lin_stats(unsigned long long out[8], bool reset, hipStream_t s);
+                            const double* poses_prev, bool stats, hipStream_t s);
+hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s);
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, double* poses_prev,
-                               hipStream_t s);
+                               unsigned long long* pairs_total, hipStream_t s);
 hipError_t launch_frame_cellkeys(const FrameView& fv, const int64_t* d_frame_start, int n_frames,
                                  size_t n_total, const MapView& mv, const double* poses,
                                  uint32_t* keys, uint32_t* idx, hipStream_t s);
@@ -144,6 +148,14 @@ hipError_t launch_increment_scatter(const float* x, const float* y, const float*
                                     const double* pose, const uint32_t* flags,
                                     const uint32_t* offs, float* ox, float* oy, float* oz,
                                     hipStream_t s);
+
+hipError_t launch_increment_flags_items(const BlockItem* items, int n_items, const FrameView& fv,
+                                        const MapView& mv, const double* poses, int min_count,
+                                        uint32_t* flags, hipStream_t s);
+hipError_t launch_increment_scatter_items(const BlockItem* items, int n_items, const FrameView& fv,
+                                          const double* poses, const uint32_t* flags,
+                                          const uint32_t* offs, float* ox, float* oy, float* oz,
+                                          hipStream_t s);
 
 // ---- f1: packet decode (kernels/decode.hip)
 struct DecodeView {
