@@ -89,7 +89,7 @@ def parse():
                     help="batch = BASELINE configs[1] (the headline line); stream = configs[2]: "
                          "packets -> decode -> register -> increment -> rolling-map update, "
                          "frame after frame")
-    ap.add_argument("--stream-frames", type=int, default=24, help="distinct synthetic frames (cycled)")
+    ap.add_argument("--stream-frames", type=int, default=64, help="distinct synthetic frames (played forwards and backwards)")
     ap.add_argument("--stream-steps", type=int, default=100, help="stream sub-record: timed frames")
     ap.add_argument("--stream-map-points", type=int, default=12_000_000,
                     help="points of the whole scene the rolling map is cut from")
@@ -186,23 +186,37 @@ def roofline_record(ctx, T0, iters, d_max, n_q, avg_launch_s, first_us, min_us, 
 
 
 # ------------------------------------------------------------------------- stream (configs[2])
-def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct):
-    """BASELINE configs[2]: an HDL-64E packet stream against a rolling map, one frame at a
-    time (each frame sees the map the previous one updated).  Per frame: 300 packets H2D ->
-    GPU decode + motion compensation -> 20 ICP iterations -> accepted increment ->
-    incremental map append; every `evict_every` frames everything further than ROI_RANGE
-    (MapManager.h:13) from the current pose is evicted.  Returns the record."""
+def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct, src=None):
+    """BASELINE configs[2]: an HDL-64E packet stream against a rolling map, one frame at a time
+    (each frame sees the map the previous one updated).  The car drives through a pre-mapped
+    world of `scene_points` points (10 m/s, one frame per metre; the distinct frames are played
+    forwards then backwards, so the pose never jumps).  Per frame: 300 packets H2D -> GPU decode +
+    motion compensation -> 20 ICP iterations -> accepted increment -> incremental map append.
+    Every `evict_every` frames the map rolls: everything further than ROI_RANGE (MapManager.h:13)
+    from the registered pose is evicted, and the world tiles that came within range are appended
+    (what MapManager::getROI + patch loading feed the device map with).  Returns the record."""
     sc, mo, cal = synth.Scene(), synth.Motion(), synth.hdl64_calibration()
-    mx, my, mz = sc.sample_map_device(scene_points, dev)
+    wx, wy, wz = sc.sample_map_device(scene_points, dev)
+    if src is None:
+        src = []
+        for k in range(n_distinct):
+            pk, ts, _ = synth.make_frame_packets(sc, mo, 3 + k, cal, seed=42)
+            poses, n = capi.make_poses(mo.ins_track(ts[0], ts[-1]))
+            src.append(dict(packets=pk, ts=ts, poses=poses, n=n))
     frames = []
-    for k in range(n_distinct):
-        pk, ts, _ = synth.make_frame_packets(sc, mo, 3 + k, cal, seed=42)
-        poses, n = capi.make_poses(mo.ins_track(ts[0], ts[-1]))
-        _, _, car = capi.packet_transforms(poses, n, ts)
+    for f in src:
+        _, _, car = capi.packet_transforms(f["poses"], f["n"], f["ts"])
         Tt = np.array([1, 0, 0, car.T[0], 0, 1, 0, car.T[1], 0, 0, 1, car.T[2]], np.float64)
-        frames.append(dict(buf=np.frombuffer(b"".join(pk), dtype=np.uint8).copy(),
-                           ts=np.ascontiguousarray(ts, dtype=np.int64), poses=poses, n=n, Tt=Tt,
+        frames.append(dict(buf=np.frombuffer(b"".join(f["packets"]), dtype=np.uint8).copy(),
+                           ts=np.ascontiguousarray(f["ts"], dtype=np.int64), poses=f["poses"], n=f["n"], Tt=Tt,
                            T0=synth.perturbed_guess(Tt, dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))))
+    nfr = len(frames)
+    period = max(2 * nfr - 2, 1)
+
+    def frame_at(k):  # forwards, then backwards: 0 1 .. n-1 n-2 .. 1 0 1 ..
+        j = k % period
+        return frames[j if j < nfr else period - j]
+
     calc = np.ascontiguousarray(cal, dtype=np.float64).reshape(64, 9)
     ctx = capi.Context(local, max_batch=2, map_margin=args.map_margin, map_subdiv=args.stream_subdiv,
                        map_full_rebuild=1 if args.full_rebuild else 0, sort_frames=args.sort_frames,
@@ -210,17 +224,35 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct):
                        use_graph=0 if args.no_graph else 1)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.map_set_margins(args.map_margin, args.map_margin, args.map_margin_z)
-    c0 = frames[0]["Tt"]
-    keep = ((mx - float(c0[3])) ** 2 + (my - float(c0[7])) ** 2) <= args.roi_range ** 2
-    kx, ky, kz = mx[keep].contiguous(), my[keep].contiguous(), mz[keep].contiguous()
+    R = float(args.roi_range)
+    R_in = R - 0.5  # tiles enter half a metre inside the eviction radius: no point flaps at the rim
+
+    def dist2(T):
+        return (wx - float(T[3])) ** 2 + (wy - float(T[7])) ** 2
+
+    resident = dist2(frames[0]["Tt"]) <= R_in * R_in
+    kx, ky, kz = wx[resident].contiguous(), wy[resident].contiguous(), wz[resident].contiguous()
     ctx.map_reset_dev(kx.data_ptr(), ky.data_ptr(), kz.data_ptr(), kx.numel(), args.voxel, args.k_normals)
-    del mx, my, mz, keep
+    del kx, ky, kz
     inc = torch.empty((3, 200_000), dtype=torch.float32, device=dev)
-    stage = dict(decode=0.0, icp=0.0, increment=0.0, append=0.0, evict=0.0)
-    counts = dict(pairs=0, inc=0, recomputed=0, incremental=0, updates=0, worst=0.0, map=0)
-    upd_ms = {"append_incremental": [], "append_reanchor": [], "evict_incremental": [], "evict_reanchor": []}
+    stage = dict(decode=0.0, icp=0.0, increment=0.0, append=0.0, roll=0.0)
+    counts = dict(pairs=0, inc=0, recomputed=0, incremental=0, updates=0, worst=0.0, map=0, tiles_in=0,
+                  evicted=0, rolls=0)
+    upd_ms = {"append_incremental": [], "append_reanchor": [], "evict_incremental": [], "evict_reanchor": [],
+              "tiles_incremental": [], "tiles_reanchor": []}
+
+    def note(kind, t_from, timed):
+        mi = ctx.map_info()
+        if timed:
+            upd_ms[kind + ("_incremental" if mi.last_update else "_reanchor")].append(
+                1e3 * (time.perf_counter() - t_from))
+            counts["updates"] += 1
+            counts["incremental"] += int(mi.last_update)
+            counts["recomputed"] += int(mi.n_normals_recomputed)
+        return mi
 
     def one(f, k, timed):
+        nonlocal resident
         t = [time.perf_counter()]
         ctx.decode_resident(f["buf"], f["ts"], calc, f["poses"], f["n"])
         ctx.decode_to_frames()
@@ -232,24 +264,27 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct):
         t.append(time.perf_counter())
         if cnt:
             ctx.map_append_dev(inc[0].data_ptr(), inc[1].data_ptr(), inc[2].data_ptr(), cnt)
-            if timed:
-                mi = ctx.map_info()
-                upd_ms["append_incremental" if mi.last_update else "append_reanchor"].append(
-                    1e3 * (time.perf_counter() - t[-1]))
-                counts["updates"] += 1
-                counts["incremental"] += int(mi.last_update)
-                counts["recomputed"] += int(mi.n_normals_recomputed)
+            note("append", t[-1], timed)
         t.append(time.perf_counter())
         if (k + 1) % max(args.evict_every, 1) == 0:
-            n_before = ctx.map_info().n_points
-            ctx.map_evict_radius(float(T[3]), float(T[7]), args.roi_range)
+            n0 = ctx.map_info().n_points
+            t1 = time.perf_counter()
+            ctx.map_evict_radius(float(T[3]), float(T[7]), R)
             mi = ctx.map_info()
-            if timed and mi.n_points != n_before:
-                upd_ms["evict_incremental" if mi.last_update else "evict_reanchor"].append(
-                    1e3 * (time.perf_counter() - t[-1]))
-                counts["updates"] += 1
-                counts["incremental"] += int(mi.last_update)
-                counts["recomputed"] += int(mi.n_normals_recomputed)
+            if mi.n_points != n0:
+                note("evict", t1, timed)
+            d2 = dist2(T)
+            entering = (d2 <= R_in * R_in) & ~resident
+            resident = (resident & (d2 <= R * R)) | entering
+            ex, ey, ez = wx[entering].contiguous(), wy[entering].contiguous(), wz[entering].contiguous()
+            t2 = time.perf_counter()
+            if ex.numel():
+                ctx.map_append_dev(ex.data_ptr(), ey.data_ptr(), ez.data_ptr(), ex.numel())
+                note("tiles", t2, timed)
+            if timed:
+                counts["tiles_in"] += int(ex.numel())
+                counts["evicted"] += int(n0 - mi.n_points)
+                counts["rolls"] += 1
         t.append(time.perf_counter())
         if timed:
             for name, a, b in zip(stage, t[:-1], t[1:]):
@@ -260,24 +295,26 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct):
             err = float(np.linalg.norm(T.reshape(3, 4)[:, 3] - f["Tt"].reshape(3, 4)[:, 3]))
             counts["worst"] = max(counts["worst"], err)
 
-    nfr = len(frames)
     for k in range(warmup):
-        one(frames[k % nfr], k, False)
+        one(frame_at(k), k, False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
-        one(frames[(warmup + k) % nfr], warmup + k, True)
+        one(frame_at(warmup + k), warmup + k, True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     mi = ctx.map_info()
     ctx.close()
     if counts["worst"] > 0.05:
         raise SystemExit("bench stream: registration diverged (%.3f m)" % counts["worst"])
+    rolls = max(counts["rolls"], 1)
     return {"frames_per_s": steps / elapsed, "ms_per_frame": 1e3 * elapsed / steps, "frames": steps,
-            "workload": "BASELINE configs[2]: HDL-64E packet stream, one frame per step: 300 packets H2D + "
-                        "decode + compensate + %d ICP iters + increment + rolling-map append every frame; "
-                        "every %d frames evict everything beyond ROI_RANGE %.0f m of the pose "
-                        "(MapManager.h:13)" % (args.iters, args.evict_every, args.roi_range),
+            "workload": "BASELINE configs[2]: HDL-64E packet stream through a pre-mapped world of %d points, "
+                        "one frame per step (%d distinct frames, 1 m apart, played forwards and backwards): "
+                        "300 packets H2D + decode + compensate + %d ICP iters + increment + map append; every "
+                        "%d frames the map rolls: evict beyond ROI_RANGE %.0f m of the pose (MapManager.h:13), "
+                        "append the world tiles that came within range"
+                        % (scene_points, nfr, args.iters, args.evict_every, R),
             "map_points_mean": counts["map"] / max(steps, 1), "map_subdiv": int(mi.subdiv),
             "map_update": "full rebuild" if args.full_rebuild else "incremental",
             "pairs_per_s": counts["pairs"] / elapsed,
@@ -285,6 +322,8 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct):
             "map_update_ms": {k: {"n": len(v), "mean": float(np.mean(v)), "max": float(np.max(v))}
                               for k, v in upd_ms.items() if v},
             "increment_points_per_frame": counts["inc"] / max(steps, 1),
+            "tile_points_in_per_roll": counts["tiles_in"] / rolls,
+            "points_evicted_per_roll": counts["evicted"] / rolls, "rolls": counts["rolls"],
             "map_updates": counts["updates"], "map_updates_incremental": counts["incremental"],
             "normals_recomputed_per_update": counts["recomputed"] / max(counts["updates"], 1),
             "worst_pose_error_m": counts["worst"]}
@@ -299,13 +338,16 @@ def build_inputs(args, rank, dev):
     cal = synth.hdl64_calibration()
     F = args.frames
     xs, ys, zs, pk, tabs, T0, Tt, fs = [], [], [], [], [], [], [], [0]
-    host_frames = []
+    host_frames, stream_src = [], []
     pkt_base = 0
     for k in range(F):
-        fi = 3 + (rank * F + k) % 40  # distinct frames per rank; wraps inside the scene
+        # 64 consecutive frames of the drive (6.4 s, all inside the walled scene); every rank
+        # takes the same set, rotated, so that rank r starts 17 frames further down the road
+        fi = 3 + (rank * 17 + k) % 64
         packets, ts, _ = synth.make_frame_packets(sc, mo, fi, cal, seed=42)
         fr = synth.decode_sensor_frame(packets, cal)
         poses, n = capi.make_poses(mo.ins_track(ts[0], ts[-1]))
+        stream_src.append(dict(fi=fi, packets=packets, ts=ts, poses=poses, n=n))
         tab, valid, car = capi.packet_transforms(poses, n, ts)  # product host code (a4..a6)
         Ttrue = np.array([1, 0, 0, car.T[0], 0, 1, 0, car.T[1], 0, 0, 1, car.T[2]], np.float64)
         xs.append(fr["x"]); ys.append(fr["y"]); zs.append(fr["z"])
@@ -324,7 +366,8 @@ def build_inputs(args, rank, dev):
                 pkt=np.concatenate(pk).view(np.int16), tab=np.concatenate(tabs).astype(np.float64))
     d = {k: torch.from_numpy(v).to(dev) for k, v in host.items()}
     d.update(host=host, map=(mx, my, mz), T0=np.stack(T0), Ttrue=np.stack(Tt),
-             frame_start=np.array(fs, dtype=np.int64), n_pkt=pkt_base, host_frames=host_frames, scene=sc)
+             frame_start=np.array(fs, dtype=np.int64), n_pkt=pkt_base, host_frames=host_frames, scene=sc,
+             stream_src=sorted({f["fi"]: f for f in stream_src}.values(), key=lambda f: f["fi"]))
     n = int(fs[-1])
     for k in ("cx", "cy", "cz"):
         d[k] = torch.empty(n, dtype=torch.float32, device=dev)
@@ -761,7 +804,8 @@ def main():
             if want(args, "stream"):
                 trace("stream ...")
                 out["stream"] = run_stream(args, dev, local, args.stream_steps, 10,
-                                           args.stream_map_points, args.stream_frames)
+                                           args.stream_map_points, args.stream_frames,
+                                           src=d["stream_src"] if rank == 0 and F >= 24 else None)
         print(json.dumps(out))
         if rc:
             sys.stderr.write("bench: GPU pose differs from the CPU path beyond the north-star tolerance: %r\n"

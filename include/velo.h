@@ -302,6 +302,9 @@ int velo_pairs_total(velo_ctx*, uint64_t* out, int reset);
  * [3] solve launches, [4] whole call ms, [5] first linearise launch ms (no hints yet),
  * [6] fastest linearise launch ms */
 int velo_last_timing(velo_ctx*, double out[8]);
+/* Device time (microseconds) of every linearise launch of that call, in launch order; returns
+ * the number of launches (>= 0; may exceed cap, only cap values are written). */
+int velo_last_linearize_us(velo_ctx*, float* out, int cap);
 /* enable (1) / disable (0) per-launch event timing (adds event records) */
 int velo_set_timing(velo_ctx*, int on);
 /* Search statistics and byte accounting of the linearise kernel.  velo_set_stats(ctx, 1) makes

@@ -70,7 +70,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_evict_outside", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_last_timing", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
+    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
     "velo_insmeta_write", "velo_insmeta_read", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
@@ -149,6 +149,7 @@ def lib():
     L.velo_increment_wait.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.velo_last_timing.argtypes = [vp, dp]
     L.velo_set_timing.argtypes = [vp, C.c_int]
+    L.velo_last_linearize_us.argtypes = [vp, vp, C.c_int]
     L.velo_matrix_from_pose.argtypes = [dp, dp]
     L.velo_pose_from_matrix.argtypes = [dp, dp]
     L.velo_interp_pose.argtypes = [C.POINTER(Pose), C.c_size_t, C.c_int64, C.POINTER(Pose)]
@@ -368,6 +369,11 @@ class Context:
         return dict(linearize_ms=t[0], linearize_launches=int(t[1]), solve_ms=t[2],
                     solve_launches=int(t[3]), call_ms=t[4], linearize_first_ms=t[5],
                     linearize_min_ms=t[6])
+
+    def last_linearize_us(self):
+        buf = np.zeros(VELO_MAX_ITERS, np.float32)
+        n = lib().velo_last_linearize_us(self.h, _p(buf), buf.size)
+        return buf[:max(min(n, buf.size), 0)].copy()
 
     # ---- map
     def map_reset(self, x, y, z, voxel=1.0, k_normals=16):

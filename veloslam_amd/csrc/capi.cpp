@@ -172,6 +172,7 @@ struct velo_ctx {
     std::vector<int> ev_kind;  // per pair: 0 linearise, 1 solve
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;
     double last_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<float> last_lin_us;  // every linearise launch of the last timed registration
 
     int fail(int code, const char* fmt, ...)
     {
@@ -825,10 +826,12 @@ int fetch_icp(velo_ctx* c, velo_icp_result* out)
     if (c->timing) {
         double lin = 0, sol = 0, lin_first = 0, lin_min = 1e30;
         int nl = 0, ns = 0;
+        c->last_lin_us.clear();
         for (size_t k = 0; k < c->ev_kind.size(); ++k) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) != hipSuccess) continue;
             if (c->ev_kind[k] == 0) {
+                c->last_lin_us.push_back(1e3f * ms);
                 lin += ms;
                 if (nl == 0) lin_first = ms;
                 if (ms < lin_min) lin_min = ms;
@@ -955,6 +958,14 @@ int velo_linearize_hints(velo_ctx* c, int mode)
     if (c->rho.p && c->rho.cap)
         HIP_TRY(c, hipMemsetAsync(c->rho.p, 0, c->rho.cap * sizeof(float), c->stream));
     return VELO_OK;
+}
+
+int velo_last_linearize_us(velo_ctx* c, float* out, int cap)
+{
+    if (!c || (cap > 0 && !out)) return VELO_E_INVALID;
+    const int n = (int)c->last_lin_us.size();
+    for (int i = 0; i < n && i < cap; ++i) out[i] = c->last_lin_us[(size_t)i];
+    return n;
 }
 
 int velo_pairs_total(velo_ctx* c, uint64_t* out, int reset)
