@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--voxel", type=float, default=1.0)
     ap.add_argument("--k-normals", type=int, default=16)
     ap.add_argument("--sort-frames", type=int, default=0)
-    ap.add_argument("--subdiv", type=int, default=3, help="sub-cells per voxel edge of the map order")
+    ap.add_argument("--subdiv", type=int, default=0, help="sub-cells per voxel edge of the map order (0 = from the map's density)")
     ap.add_argument("--no-hints", action="store_true")
     ap.add_argument("--hints", type=int, default=2, help="1 = radius hints, 2 = + uniqueness certificates")
     ap.add_argument("--rounds", type=int, default=0, help="rounds of 256 queries per workgroup (0=auto)")
@@ -93,7 +93,7 @@ def parse():
     ap.add_argument("--stream-steps", type=int, default=100, help="stream sub-record: timed frames")
     ap.add_argument("--stream-map-points", type=int, default=12_000_000,
                     help="points of the whole scene the rolling map is cut from")
-    ap.add_argument("--stream-subdiv", type=int, default=3)
+    ap.add_argument("--stream-subdiv", type=int, default=0)
     ap.add_argument("--roi-range", type=float, default=ROI_RANGE, help="rolling map: kept radius around the pose (m)")
     ap.add_argument("--evict-every", type=int, default=5)
     ap.add_argument("--map-margin", type=int, default=16, help="stream: grid slack in x/y, voxels")
@@ -101,7 +101,7 @@ def parse():
     ap.add_argument("--full-rebuild", action="store_true", help="stream: re-sort the whole map on every update (A/B)")
     ap.add_argument("--dense-map-points", type=int, default=10_000_000)
     ap.add_argument("--dense-frames", type=int, default=16)
-    ap.add_argument("--dense-subdiv", type=int, default=6)
+    ap.add_argument("--dense-subdiv", type=int, default=0)
     return ap.parse_args()
 
 

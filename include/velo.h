@@ -60,7 +60,10 @@ typedef struct velo_cfg {
     int32_t sort_frames;    /* 1: order each frame's queries by map cell once per registration */
     int32_t use_graph;      /* 1: replay a registration's launch sequence as one hipGraph
                                (cfg == NULL enables it) */
-    int32_t map_subdiv;     /* sub-cells per voxel edge of the map sort order (default 3) */
+    int32_t map_subdiv;     /* sub-cells per voxel edge of the map sort order; 0 (default) = chosen
+                               at velo_map_reset from the map's density: round(sqrt(points per
+                               occupied voxel / 2.8)) clamped to [2, 6]; velo_map_info.subdiv
+                               reports the value in use */
     int32_t use_hints;      /* temporal coherence, exact either way.  1: bound each query's search by
                                its previous correspondence; 2: also skip the search when last
                                iteration certified that correspondence as the unique nearest
@@ -124,7 +127,7 @@ void velo_destroy(velo_ctx*);
 const char* velo_last_error(const velo_ctx*); /* ctx may be NULL: creation errors */
 int velo_abi_version(void);
 /* The configuration in effect (defaults filled in: e.g. linearize_variant 0 reads back as
- * VELO_VARIANT_BALL, map_subdiv 0 as 3). */
+ * VELO_VARIANT_BALL; map_subdiv 0 stays 0 = automatic, see velo_map_info.subdiv). */
 int velo_cfg_get(const velo_ctx*, velo_cfg* out);
 /* Run all work of this ctx on `hip_stream` (a hipStream_t, e.g. torch's current
  * stream).  NULL = the ctx's own stream. */

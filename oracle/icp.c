@@ -234,9 +234,49 @@ vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, f
     return vo_map_build_ex(x, y, z, n, voxel, k_normals, 3);
 }
 
+/* Sub-division chosen from the map's density (subdiv == 0 in the calls below): rho = points per
+ * OCCUPIED voxel (voxels anchored on the component-wise minimum; the count does not depend on a
+ * whole-voxel margin), S = round(sqrt(rho / 2.8)) clamped to [2, 6] -- about 2-3 points per
+ * occupied fine cell on surfaces, the optimum measured on the 1 M- and 10 M-point maps
+ * (DESIGN.md).  Resolved once, when a map is reset. */
+int vo_auto_subdiv(const float* x, const float* y, const float* z, size_t n, float voxel)
+{
+    if (n == 0 || !(voxel > 0)) return 3;
+    const float inv_h = 1.0f / voxel;
+    float mn[3] = {x[0], y[0], z[0]}, mx[3] = {x[0], y[0], z[0]};
+    for (size_t i = 1; i < n; ++i) {
+        if (x[i] < mn[0]) mn[0] = x[i];
+        if (y[i] < mn[1]) mn[1] = y[i];
+        if (z[i] < mn[2]) mn[2] = z[i];
+        if (x[i] > mx[0]) mx[0] = x[i];
+        if (y[i] > mx[1]) mx[1] = y[i];
+        if (z[i] > mx[2]) mx[2] = z[i];
+    }
+    size_t d[3], nv = 1;
+    for (int a = 0; a < 3; ++a) {
+        d[a] = (size_t)floorf((mx[a] - mn[a]) * inv_h) + 1;
+        nv *= d[a];
+    }
+    if (nv >= ((size_t)1 << 31)) return 1;
+    unsigned char* occ = (unsigned char*)calloc(nv, 1);
+    size_t n_occ = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t cx = (size_t)floorf((x[i] - mn[0]) * inv_h), cy = (size_t)floorf((y[i] - mn[1]) * inv_h),
+                     cz = (size_t)floorf((z[i] - mn[2]) * inv_h);
+        unsigned char* o = &occ[(cz * d[1] + cy) * d[0] + cx];
+        n_occ += (size_t)(*o == 0);
+        *o = 1;
+    }
+    free(occ);
+    const double rho = (double)n / (double)n_occ;
+    int S = (int)floor(sqrt(rho / 2.8) + 0.5);
+    return S < 2 ? 2 : (S > 6 ? 6 : S);
+}
+
 vo_map* vo_map_build_ex(const float* x, const float* y, const float* z, size_t n, float voxel,
                         int k_normals, int subdiv)
 {
+    if (subdiv == 0) subdiv = vo_auto_subdiv(x, y, z, n, voxel);
     return vo_map_build_grid(x, y, z, n, voxel, k_normals, subdiv, NULL, NULL);
 }
 
@@ -432,7 +472,7 @@ vo_roll* vo_roll_new3(const float* x, const float* y, const float* z, size_t n, 
     vo_roll* r = (vo_roll*)calloc(1, sizeof *r);
     r->h = voxel;
     r->k = k_normals;
-    r->S = subdiv;
+    r->S = subdiv ? subdiv : vo_auto_subdiv(x, y, z, n, voxel);  /* resolved once, kept for life */
     memcpy(r->M, margin, sizeof r->M);
     roll_reserve(r, n);
     memcpy(r->x, x, n * sizeof(float));

@@ -108,6 +108,7 @@ def lib():
     L.vo_map_build.restype = C.c_void_p
     L.vo_map_build_ex.argtypes = [fp, fp, fp, C.c_size_t, C.c_float, C.c_int, C.c_int]
     L.vo_map_build_ex.restype = C.c_void_p
+    L.vo_auto_subdiv.argtypes = [fp, fp, fp, C.c_size_t, C.c_float]
     L.vo_map_build_grid.argtypes = [fp, fp, fp, C.c_size_t, C.c_float, C.c_int, C.c_int, fp, ip]
     L.vo_map_build_grid.restype = C.c_void_p
     L.vo_roll_new.argtypes = [fp, fp, fp, C.c_size_t, C.c_float, C.c_int, C.c_int, C.c_int]
@@ -326,6 +327,8 @@ class Map:
     def __init__(self, x, y, z, voxel=1.0, k_normals=16, subdiv=3, origin=None, dims_min=None):
         x, y, z = _f32(x), _f32(y), _f32(z)
         self._owned = True
+        if int(subdiv) == 0:  # chosen from the density
+            subdiv = lib().vo_auto_subdiv(_f(x), _f(y), _f(z), x.size, float(voxel))
         if origin is None and dims_min is None:
             self.h = lib().vo_map_build_ex(_f(x), _f(y), _f(z), x.size, float(voxel),
                                            int(k_normals), int(subdiv))

@@ -119,6 +119,8 @@ typedef struct vo_map vo_map;
 vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, float voxel,
                      int k_normals);
 /* subdiv: sub-cells per voxel edge (part of the sort order, hence of the spec); 3 above */
+/* density-chosen sub-division (subdiv == 0 in vo_map_build_ex / vo_roll_new*): see oracle/icp.c */
+int vo_auto_subdiv(const float* x, const float* y, const float* z, size_t n, float voxel);
 vo_map* vo_map_build_ex(const float* x, const float* y, const float* z, size_t n, float voxel,
                         int k_normals, int subdiv);
 /* fresh build on an explicit grid: origin (<= min of the points, NULL = min) and a lower

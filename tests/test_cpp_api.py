@@ -82,7 +82,7 @@ def test_cpp_register_frame_matches_c_abi(tmp_path, oracle):
     assert int(lines["beam3"]) == int(s["beam_start"][4] - s["beam_start"][3])
     assert int(lines["patches"]) >= 1
     # cfg == NULL (what MapManager passes) runs the default pruned kernel, not the validation scan
-    assert [int(v) for v in lines["cfg"].split()] == [capi.VARIANT_BALL, 2, 1, 3]
+    assert [int(v) for v in lines["cfg"].split()] == [capi.VARIANT_BALL, 2, 1, 0]  # 0 = S from density
     T = np.array([float(v) for v in lines["pose"].split()])
     # the map went through MapPatch tiles (different append order than the direct upload), so
     # the sorted order -- and with it last-bit summation -- may differ: compare at the north

@@ -144,6 +144,31 @@ def test_map_append_equals_rebuild(ctx, oracle):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("n,expect", [(30_000, 2), (400_000, None), (2_500_000, None)])
+def test_auto_subdivision_matches_oracle(oracle, n, expect):
+    """cfg.map_subdiv = 0: the sub-division is chosen from the map's density (points per occupied
+    voxel) by the same rule on both sides; the map built with it is bit-identical."""
+    from veloslam_amd import synth
+    m = synth.Scene().sample_map(n)
+    S = oracle.lib().vo_auto_subdiv(oracle._f(m[0]), oracle._f(m[1]), oracle._f(m[2]), n, 1.0)
+    assert 2 <= S <= 6 and (expect is None or S == expect)
+    c = capi.Context(0, max_batch=2, map_subdiv=0)
+    try:
+        c.map_reset(*m, 1.0, 0)
+        assert c.map_info().subdiv == S
+        om = oracle.Map(*m, 1.0, 0, subdiv=0)
+        assert om.subdiv == S
+        g = c.map_download()
+        assert np.array_equal(g["cell_start"], om.cell_start()) and np.array_equal(g["perm"], om.perm())
+        # an append keeps the resolved value; a reset resolves again
+        c.map_append(*(a[:100] + np.float32(0.01) for a in m))
+        assert c.map_info().subdiv == S
+        c.map_reset(*(a[:2000] for a in m), 1.0, 0)
+        assert c.map_info().subdiv == 2
+    finally:
+        c.close()
+
+
 def _assert_map_equal(ctx, om):
     g = ctx.map_download()
     mi = ctx.map_info()

@@ -76,6 +76,8 @@ struct velo_ctx {
     unsigned n_done_host = 0;
     float map_mx[3] = {0, 0, 0};  // component-wise max of the map points
     int margin[3] = {0, 0, 0};    // grid slack per axis, voxels (cfg.map_margin / velo_map_set_margins)
+    int map_S = 3;                // sub-division of the current map: cfg.map_subdiv, or chosen from
+                                  // the density when that is 0; resolved at velo_map_reset
     DevBuf<char> temp;
     MapView mv{};
     bool has_map = false;
@@ -314,7 +316,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     }
     // sub-division: as configured, lowered (never raised) until the dense fine-cell table fits
     // 2^31 entries; the value actually used is reported in velo_map_info.subdiv
-    int S = c->cfg.map_subdiv;
+    int S = c->map_S;
     while (S > 1 && ncell_d * (double)S * S * S >= 2147483648.0) --S;
     ncell_d *= (double)S * S * S;
     if (ncell_d >= 2147483648.0)
@@ -396,6 +398,49 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     return publish_map(c, mv, k_normals, invalid, 0, k_normals > 0 ? n : 0);
+}
+
+// Sub-division of a freshly reset map: as configured, or (cfg.map_subdiv == 0) chosen from the
+// density exactly as oracle/icp.c vo_auto_subdiv does: rho = points per occupied voxel,
+// S = round(sqrt(rho / 2.8)) clamped to [2, 6].  Kept until the next velo_map_reset.
+int resolve_subdiv(velo_ctx* c, float voxel)
+{
+    if (c->cfg.map_subdiv > 0) {
+        c->map_S = c->cfg.map_subdiv;
+        return VELO_OK;
+    }
+    c->map_S = 3;
+    if (c->raw_n == 0 || !(voxel > 0.0f)) return VELO_OK;  // rebuild_map reports these
+    hipStream_t s = c->stream;
+    HIP_TRY(c, c->mm_scratch.reserve(8));
+    MinMax mm;
+    HIP_TRY(c, launch_minmax(c->raw_x.p, c->raw_y.p, c->raw_z.p, c->raw_n, c->mm_scratch.p, &mm, s));
+    const float inv_h = 1.0f / voxel;
+    size_t d[3];
+    double nv = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        if (!std::isfinite(mm.mn[a]) || !std::isfinite(mm.mx[a])) return VELO_OK;
+        const float ext = floorf((mm.mx[a] - mm.mn[a]) * inv_h);
+        if (!(ext < 2.0e9f)) return VELO_OK;
+        d[a] = (size_t)ext + 1;
+        nv *= (double)d[a];
+    }
+    if (nv >= 2147483648.0) {
+        c->map_S = 1;
+        return VELO_OK;
+    }
+    HIP_TRY(c, reserve_slack(c->vox_occ, (size_t)nv));
+    HIP_TRY(c, c->invalid_cnt.reserve(1));
+    HIP_TRY(c, launch_count_occupied_voxels(c->raw_x.p, c->raw_y.p, c->raw_z.p, c->raw_n, mm.mn, inv_h, d,
+                                            c->vox_occ.p, c->invalid_cnt.p, s));
+    unsigned long long occ = 0;
+    HIP_TRY(c, hipMemcpyAsync(&occ, c->invalid_cnt.p, sizeof occ, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (occ == 0) return VELO_OK;
+    const double rho = (double)c->raw_n / (double)occ;
+    const int S = (int)std::floor(std::sqrt(rho / 2.8) + 0.5);
+    c->map_S = S < 2 ? 2 : (S > 6 ? 6 : S);
+    return VELO_OK;
 }
 
 int stage_raw(velo_ctx* c, const float* x, const float* y, const float* z, size_t n, bool dev,
@@ -895,7 +940,7 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     }
     if (c->cfg.map_margin < 0) c->cfg.map_margin = 0;
     for (int a = 0; a < 3; ++a) c->margin[a] = c->cfg.map_margin;
-    if (c->cfg.map_subdiv <= 0) c->cfg.map_subdiv = 3;
+    if (c->cfg.map_subdiv < 0) c->cfg.map_subdiv = 0;  // 0 = chosen from the map's density
     if (c->cfg.map_subdiv > 16) c->cfg.map_subdiv = 16;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
@@ -1031,6 +1076,7 @@ static int map_reset_impl(velo_ctx* c, const float* x, const float* y, const flo
     c->has_map = false;
     if (n == 0) return c->fail(VELO_E_INVALID, "map needs at least one point");
     if (int rc = stage_raw(c, x, y, z, n, dev, false)) return rc;
+    if (int rc = resolve_subdiv(c, voxel)) return rc;
     return rebuild_map(c, voxel, k);
 }
 int velo_map_reset(velo_ctx* c, const float* x, const float* y, const float* z, size_t n,

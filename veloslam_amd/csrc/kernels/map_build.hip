@@ -1023,6 +1023,47 @@ __global__ __launch_bounds__(256) void k_vox_near(const uint8_t* __restrict__ oc
         near[v] = any ? 1 : 0;
     }
 }
+// ---- density probe for the automatic sub-division (oracle/icp.c vo_auto_subdiv): number of
+// distinct voxels (anchored on the component-wise minimum) that hold a point
+__global__ __launch_bounds__(256) void k_mark_voxels(const float* __restrict__ x,
+                                                     const float* __restrict__ y,
+                                                     const float* __restrict__ z, size_t n, float ox,
+                                                     float oy, float oz, float inv_h, size_t dx,
+                                                     size_t dy, uint8_t* __restrict__ occ)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t cx = (size_t)floorf((x[i] - ox) * inv_h), cy = (size_t)floorf((y[i] - oy) * inv_h),
+                     cz = (size_t)floorf((z[i] - oz) * inv_h);
+        occ[(cz * dy + cy) * dx + cx] = 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_count_bytes(const uint8_t* __restrict__ occ, size_t n,
+                                                     unsigned long long* __restrict__ total)
+{
+    unsigned c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        c += occ[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, (unsigned long long)c);
+}
+hipError_t launch_count_occupied_voxels(const float* x, const float* y, const float* z, size_t n,
+                                        const float mn[3], float inv_h, const size_t dims[3],
+                                        uint8_t* occ, unsigned long long* d_count, hipStream_t s)
+{
+    const size_t nv = dims[0] * dims[1] * dims[2];
+    hipError_t e = hipMemsetAsync(occ, 0, nv, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_mark_voxels, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, y, z, n, mn[0],
+                       mn[1], mn[2], inv_h, dims[0], dims[1], occ);
+    hipLaunchKernelGGL(k_count_bytes, dim3(grid_for(nv, 256, 4096)), dim3(256), 0, s, occ, nv, d_count);
+    return hipGetLastError();
+}
+
 hipError_t launch_vox_near(const MapView& mv, uint8_t* occ, uint8_t* near, hipStream_t s)
 {
     const size_t nvox = (size_t)mv.nx * mv.ny * mv.nz;

@@ -121,6 +121,9 @@ hipError_t launch_mark_dirty_pts(const float4* pts, const float4* nrm, const uin
                                  uint32_t n, const MapView& grid, uint8_t* dirty, hipStream_t s);
 
 hipError_t launch_vox_near(const MapView& mv, uint8_t* occ, uint8_t* near, hipStream_t s);
+hipError_t launch_count_occupied_voxels(const float* x, const float* y, const float* z, size_t n,
+                                        const float mn[3], float inv_h, const size_t dims[3],
+                                        uint8_t* occ, unsigned long long* d_count, hipStream_t s);
 
 hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
                       const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
