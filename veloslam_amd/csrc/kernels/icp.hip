@@ -236,12 +236,16 @@ __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float 
 //            x-extent of each row cut to the ball, descending index, '<='.  Compaction keeps
 //            a handful of stragglers from stalling every wavefront of the workgroup.
 constexpr int kMaxRanges = 9;
+constexpr int kLatItems = 2048;  // launches below this many workgroups use the latency kernel
 #ifndef VELO_CERT_SLACK
 #define VELO_CERT_SLACK 0.05f
 #endif
 constexpr float kCertSlack = VELO_CERT_SLACK;  // metres searched beyond the hinted point (tuning only)
 #ifndef VELO_WALK_W
 #define VELO_WALK_W 4
+#endif
+#ifndef VELO_WALK_W_LAT
+#define VELO_WALK_W_LAT 8  // latency kernel: twice the candidate loads in flight per trip
 #endif
 
 
@@ -325,7 +329,7 @@ __device__ __forceinline__ int finish_block(float bd, float sd, float gr, float&
     return final ? kFinal : kStraggler;
 }
 
-template <int ABL, bool STATS>
+template <int ABL, bool STATS, int W>
 __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& g, float qx,
                                             float qy, float qz, float ub0, SearchLds& L,
                                             int tid, float& bd, int& bj, float& cert,
@@ -387,7 +391,7 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
     const float gr = fmaxf(hf * (1.0f + tmin) - mg, 0.0f);
     gr_out = gr;
     float sd = ub0;  // everything not scanned inside the block is further than sqrt(ub0)
-    walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd, tl);
+    walk_ranges<W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd, tl);
     if (ABL >= 1) return kFinal;
     return finish_block(bd, sd, gr, cert);
 }
@@ -517,6 +521,190 @@ __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, fl
     sd = s2;
 }
 
+// ---- stage B for the LATENCY kernel (k_linearize_lat: a single frame, a few hundred
+// workgroups -- nothing hides a memory round trip, and registers are plentiful) -------------
+// lower bound (rounded down) of the distance from the query to fine row offset d along one axis
+__device__ __forceinline__ float axis_gap(int d, float t, float hf, float mg)
+{
+    return d == 0 ? 0.0f : fmaxf(((float)(abs(d) - 1) + (d > 0 ? 1.0f - t : t)) * hf - mg, 0.0f);
+}
+
+// index range of fine row (Fz+dz, Fy+dy) inside the ball of squared radius `bound` around the
+// query (conservative: rounded outwards); clip1: only the cells Fx-1..Fx+1.  false = nothing.
+template <bool STATS>
+__device__ __forceinline__ bool ball_row(const MapView& mv, const QueryCell& g, int dz, int dy,
+                                         float bound, float xf, float hf, float inv_hf, float mg,
+                                         bool clip1, int& jlo, int& jhi, Tally<STATS>& tl)
+{
+    const int zz = g.Fz + dz, yy = g.Fy + dy;
+    if (zz < 0 || zz >= mv.fz || yy < 0 || yy >= mv.fy) return false;
+    const float bz = axis_gap(dz, g.tz, hf, mg), by = axis_gap(dy, g.ty, hf, mg);
+    const float rb2 = (bz * bz + by * by) * 0.99999f;
+    if (rb2 > bound) return false;
+    // half-width of the ball in this row, in fine cells, rounded outwards
+    const float w = (sqrtf(fmaxf(bound - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
+    int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
+    if (clip1) {
+        x0 = max(x0, g.Fx - 1);
+        x1 = min(x1, g.Fx + 1);
+    }
+    if (x0 > x1) return false;
+    const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
+    jlo = mv.cell_start[row + x0];
+    jhi = mv.cell_start[row + x1 + 1];
+    tl.table(2, 4);
+    return jhi > jlo;
+}
+
+// rows of the (2R+1)^2 window a ball of squared radius b can reach (R <= S since b <= h^2)
+__device__ __forceinline__ int ball_window(float b, float inv_hf, int S)
+{
+    return min(S, (int)floorf(sqrtf(b) * 1.00001f * inv_hf + 1.001f));
+}
+
+// per-lane form.  Called by every lane of the wavefront (`active` = this lane is a straggler):
+// the loops synchronise with __any.
+template <bool STATS>
+__device__ void search_ball_lat(const MapView& mv, float qx, float qy, float qz, float ub, bool active,
+                                bool probe, SearchLds& L, int tid, float& bd, int& bj, Tally<STATS>& tl)
+{
+    const QueryCell g = locate(mv, qx, qy, qz);
+    bd = ub;
+    bj = -1;
+    const int S = mv.S;
+    const float hf = mv.h / (float)S;
+    const float inv_hf = (float)S * mv.inv_h;
+    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+    const float xf = (float)g.Fx + g.tx;  // fine coordinate of the query along x
+    // Phase 1, only for a query whose 3x3x3 block held nothing: a bound.  The ball of an
+    // unmatched query is a whole voxel wide, and on a dense map the rows through the surface it
+    // eventually finds hold hundreds of candidates each.  Probe the cells straight above /
+    // below / beside the query first (rows (0, +-k) and (+-k, 0), cells Fx-1..Fx+1, nearest
+    // first): a frame that is slightly off hangs a fraction of a metre over the ground or in
+    // front of a wall, and the foot point is there.  The probe only tightens `bd` as a BOUND
+    // (some map point at that distance exists, so the winner is no further); the search proper
+    // below still visits everything within it in index order, so ties resolve as ever.
+    if (__any(probe)) {
+        float pb = bd;
+        int k = 2, side = 0;  // next probe row: offset k in direction `side` (+z, -z, +y, -y)
+#pragma unroll 1
+        while (__any(probe && k <= S)) {
+            int nr = 0;
+            while (probe && nr < kMaxRanges - 1 && k <= S) {
+                const int dz = side == 0 ? k : (side == 1 ? -k : 0);
+                const int dy = side == 2 ? k : (side == 3 ? -k : 0);
+                int jlo, jhi;
+                if (ball_row(mv, g, dz, dy, pb, xf, hf, inv_hf, mg, true, jlo, jhi, tl)) {
+                    L.hi[nr][tid] = jhi;
+                    L.lo[nr][tid] = jlo;
+                    ++nr;
+                }
+                if (++side == 4) {
+                    side = 0;
+                    ++k;
+                }
+            }
+            int pj = -1;
+            float sd_unused = pb;
+            walk_ranges<VELO_WALK_W_LAT>(mv, qx, qy, qz, L, tid, nr, pb, pj, sd_unused, tl);
+            const float far = axis_gap(k, 1.0f, hf, mg);  // nearest any row at offset >= k can be
+            if (probe && far * far * 0.99999f > pb) k = S + 1;
+        }
+        bd = fminf(bd, pb);
+    }
+    // Phase 2: every row the ball can reach, descending (the tie rule), the surviving rows
+    // packed nine to a trip: table entries requested together, ranges staged in LDS, one walk.
+    const int R = ball_window(bd, inv_hf, S);
+    int dz = active ? R : -R - 1, dy = R;
+#pragma unroll 1
+    do {
+        int nr = 0;
+        while (nr < kMaxRanges && dz >= -R) {
+            int jlo, jhi;
+            if (ball_row(mv, g, dz, dy, bd, xf, hf, inv_hf, mg, false, jlo, jhi, tl)) {
+                L.hi[nr][tid] = jhi;
+                L.lo[nr][tid] = jlo;
+                ++nr;
+            }
+            if (--dy < -R) {
+                dy = R;
+                --dz;
+            }
+        }
+        float sd_unused = bd;
+        walk_ranges<VELO_WALK_W_LAT>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd_unused, tl);
+    } while (__any(dz >= -R));
+}
+
+// cooperative form: as search_ball_wave, over the rows the ball can actually reach, a wide ball
+// bounded first by the axis probe (one probe row per lane)
+template <bool STATS>
+__device__ __forceinline__ void search_ball_wave_lat(const MapView& mv, float qx, float qy, float qz,
+                                                     float ub, int lane, float& bd, int& bj, float& sd,
+                                                     Tally<STATS>& tl)
+{
+    const QueryCell g = locate(mv, qx, qy, qz);
+    const int S = mv.S;
+    const float hf = mv.h / (float)S;
+    const float inv_hf = (float)S * mv.inv_h;
+    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+    const float xf = (float)g.Fx + g.tx;
+    int R = ball_window(ub, inv_hf, S);
+    if (R >= 3) {
+        float pb = ub;
+        if (lane < 4 * (R - 1)) {
+            const int k = 2 + lane / 4, side = lane & 3;
+            const int dz = side == 0 ? k : (side == 1 ? -k : 0);
+            const int dy = side == 2 ? k : (side == 3 ? -k : 0);
+            int jlo, jhi;
+            if (ball_row(mv, g, dz, dy, ub, xf, hf, inv_hf, mg, true, jlo, jhi, tl)) {
+                tl.candidates((unsigned)(jhi - jlo));
+                for (int j = jhi - 1; j >= jlo; --j) pb = fminf(pb, dist2(mv.pts[j], qx, qy, qz));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pb = fminf(pb, __shfl_xor(pb, off, 64));
+        if (pb < ub) {
+            // a map point at sqrt(pb): search that far plus the certificate slack, no further
+            const float rs = sqrtf(pb) * 1.000001f + 1e-7f + kCertSlack;
+            ub = fminf(ub, rs * rs * 1.00001f);
+            R = ball_window(ub, inv_hf, S);
+        }
+    }
+    float b1 = ub, b2 = ub;  // best and second-best distance seen by this lane
+    int j1 = 0x7fffffff;
+    const int side = 2 * R + 1, nrows = side * side;
+    for (int r = lane; r < nrows; r += 64) {
+        const int dz = R - r / side, dy = R - r % side;
+        int jlo, jhi;
+        if (!ball_row(mv, g, dz, dy, ub, xf, hf, inv_hf, mg, false, jlo, jhi, tl)) continue;
+        tl.candidates((unsigned)(jhi - jlo));
+#pragma unroll 4
+        for (int j = jhi - 1; j >= jlo; --j) {
+            const float d2 = dist2(mv.pts[j], qx, qy, qz);
+            if (d2 <= b1) {
+                b2 = b1;
+                b1 = d2;
+                j1 = j;
+            } else {
+                b2 = fminf(b2, d2);
+            }
+        }
+    }
+    float dmin = b1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, off, 64));
+    int jm = (b1 == dmin) ? j1 : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) jm = min(jm, __shfl_xor(jm, off, 64));
+    float s2 = (b1 == dmin && j1 == jm) ? b2 : b1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s2 = fminf(s2, __shfl_xor(s2, off, 64));
+    bd = dmin;
+    bj = jm == 0x7fffffff ? -1 : jm;
+    sd = fminf(s2, ub);
+}
+
 // One block = one BlockItem = a run of queries of one frame.  Per round of 256
 // queries every thread writes its 8 values {J, r, valid} to LDS; then lane k<29 of
 // each 32-lane half sums column k over that half's 32 entries (ascending), the two
@@ -533,18 +721,20 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 #ifndef VELO_COOP_MAX
 #define VELO_COOP_MAX 16
 #endif
-template <bool WRITE_CORR, int VARIANT, bool STATS>
 #ifndef VELO_LIN_WAVES
 #define VELO_LIN_WAVES 7  // measured: 8 spills (64 VGPRs), 7 = 72 VGPRs no spill, fastest
 #endif
-__global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
-    const BlockItem* __restrict__ items, FrameView fv, MapView mv,
+// LAT = false: the throughput kernel (batches: tens of thousands of workgroups, bound by VALU
+// issue and occupancy: 72 registers, 7 waves per SIMD).  LAT = true: the latency kernel (a
+// single frame: < 2 workgroups per CU, bound by dependent memory round trips: registers are
+// free, stage B is the packed / probed form above).  Same results bit for bit.
+template <bool WRITE_CORR, int VARIANT, bool STATS, bool LAT>
+__device__ __forceinline__ void linearize_body(
+    const BlockItem* __restrict__ items, const FrameView& fv, const MapView& mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
     int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint,
-    float* __restrict__ rho, const double* __restrict__ poses_prev)
+    float* __restrict__ rho, const double* __restrict__ poses_prev, LinLds* s_uw, double (*s_w)[32])
 {
-    __shared__ LinLds s_uw[kLinThreads / 64];
-    __shared__ double s_w[4][32];
     const BlockItem it = items[blockIdx.x];
     const double* __restrict__ T = poses + 12 * (size_t)it.frame;
     const int tid = threadIdx.x;
@@ -635,7 +825,7 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
                         empty = mv.vox_near[((size_t)g.cz * mv.ny + g.cy) * mv.nx + g.cx] == 0;
                     tl.add(hj < 0 && mv.vox_near ? 1 : 0);
                     if (!empty)
-                        st = search_block<(VARIANT >= 11 ? VARIANT - 10 : 0)>(
+                        st = search_block<(VARIANT >= 11 ? VARIANT - 10 : 0), STATS, (LAT ? VELO_WALK_W_LAT : VELO_WALK_W)>(
                             mv, g, qx, qy, qz, ub0, s_u.s, lane, bd, bj, rho_new_out, blk_gr, tl);
                     VELO_COUNT(3, empty);
                     VELO_COUNT(2, !empty);
@@ -649,7 +839,16 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
             VELO_COUNT(6, queued);
             if (__popcll(need) > VELO_COOP_MAX) {
                 VELO_COUNT(5, queued);
-                if (queued) {
+                if constexpr (LAT) {
+                    float rbd = bd;
+                    int rbj = bj;
+                    search_ball_lat(mv, qx, qy, qz, queued ? bd : 0.0f, queued, queued && bj < 0, s_u.s, lane,
+                                    rbd, rbj, tl);
+                    if (queued) {
+                        bd = rbd;
+                        bj = rbj;
+                    }
+                } else if (queued) {
                     const float ub = bd;
                     search_ball(mv, qx, qy, qz, ub, s_u.s, lane, bd, bj, tl);
                 }
@@ -666,7 +865,10 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
                     const float sub = fminf(rsq * rsq, mv.h * mv.h);
                     float rbd, rsd;
                     int rbj;
-                    search_ball_wave(mv, sx, sy, sz, sub, lane, rbd, rbj, rsd, tl);
+                    if constexpr (LAT)
+                        search_ball_wave_lat(mv, sx, sy, sz, sub, lane, rbd, rbj, rsd, tl);
+                    else
+                        search_ball_wave(mv, sx, sy, sz, sub, lane, rbd, rbj, rsd, tl);
                     if (lane == src) {
                         bd = rbd;
                         bj = rbj;
@@ -751,6 +953,32 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
     }
 }
 
+template <bool WRITE_CORR, int VARIANT, bool STATS>
+__global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
+    const BlockItem* __restrict__ items, FrameView fv, MapView mv,
+    const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
+    int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint,
+    float* __restrict__ rho, const double* __restrict__ poses_prev)
+{
+    __shared__ LinLds s_uw[kLinThreads / 64];
+    __shared__ double s_w[4][32];
+    linearize_body<WRITE_CORR, VARIANT, STATS, false>(items, fv, mv, poses, dmax2, partials, corr, d2out,
+                                                      hint, rho, poses_prev, s_uw, s_w);
+}
+
+template <bool WRITE_CORR, bool STATS>
+__global__ __launch_bounds__(kLinThreads, 4) void k_linearize_lat(
+    const BlockItem* __restrict__ items, FrameView fv, MapView mv,
+    const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
+    int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint,
+    float* __restrict__ rho, const double* __restrict__ poses_prev)
+{
+    __shared__ LinLds s_uw[kLinThreads / 64];
+    __shared__ double s_w[4][32];
+    linearize_body<WRITE_CORR, 1, STATS, true>(items, fv, mv, poses, dmax2, partials, corr, d2out, hint,
+                                               rho, poses_prev, s_uw, s_w);
+}
+
 hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)
 {
     hipError_t e = hipStreamSynchronize(s);
@@ -771,9 +999,23 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
 #define VELO_LAUNCH_LIN(WC, V)                                                                   \
     hipLaunchKernelGGL((k_linearize<WC, V, false>), dim3(n_items), dim3(kLinThreads), 0, s,     \
                        items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev)
+    // a launch that leaves most of the chip idle is a latency problem: fewer than kLatItems
+    // workgroups (~4 frames) go to the latency kernel
+    const bool lat = variant == VELO_VARIANT_BALL && n_items < kLatItems;
     if (stats && variant != VELO_VARIANT_SCAN && variant < 10) {  // counting instantiation
-        hipLaunchKernelGGL((k_linearize<true, 1, true>), dim3(n_items), dim3(kLinThreads), 0, s,
-                           items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+        if (lat)
+            hipLaunchKernelGGL((k_linearize_lat<true, true>), dim3(n_items), dim3(kLinThreads), 0, s,
+                               items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+        else
+            hipLaunchKernelGGL((k_linearize<true, 1, true>), dim3(n_items), dim3(kLinThreads), 0, s,
+                               items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+    } else if (lat) {
+        if (wc)
+            hipLaunchKernelGGL((k_linearize_lat<true, false>), dim3(n_items), dim3(kLinThreads), 0, s,
+                               items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+        else
+            hipLaunchKernelGGL((k_linearize_lat<false, false>), dim3(n_items), dim3(kLinThreads), 0, s,
+                               items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
     } else if (variant == VELO_VARIANT_SCAN) {
         if (wc) VELO_LAUNCH_LIN(true, 0); else VELO_LAUNCH_LIN(false, 0);
     } else if (variant == 11) {  // timing ablations (wrong results by design)
