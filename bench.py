@@ -96,6 +96,9 @@ def parse():
     ap.add_argument("--stream-subdiv", type=int, default=0)
     ap.add_argument("--roi-range", type=float, default=ROI_RANGE, help="rolling map: kept radius around the pose (m)")
     ap.add_argument("--evict-every", type=int, default=5)
+    ap.add_argument("--append-threshold", type=int, default=512,
+                    help="stream: accepted increments are collected on the device and appended to the map "
+                         "once this many points are pending (and always before the map rolls)")
     ap.add_argument("--map-margin", type=int, default=16, help="stream: grid slack in x/y, voxels")
     ap.add_argument("--map-margin-z", type=int, default=2, help="stream: grid slack in z, voxels")
     ap.add_argument("--full-rebuild", action="store_true", help="stream: re-sort the whole map on every update (A/B)")
@@ -234,7 +237,8 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct, src=No
     kx, ky, kz = wx[resident].contiguous(), wy[resident].contiguous(), wz[resident].contiguous()
     ctx.map_reset_dev(kx.data_ptr(), ky.data_ptr(), kz.data_ptr(), kx.numel(), args.voxel, args.k_normals)
     del kx, ky, kz
-    inc = torch.empty((3, 200_000), dtype=torch.float32, device=dev)
+    inc = torch.empty((3, 400_000), dtype=torch.float32, device=dev)  # pending increments, then this frame's
+    pend = dict(n=0)
     stage = dict(decode=0.0, icp=0.0, increment=0.0, append=0.0, roll=0.0)
     counts = dict(pairs=0, inc=0, recomputed=0, incremental=0, updates=0, worst=0.0, map=0, tiles_in=0,
                   evicted=0, rolls=0)
@@ -260,13 +264,18 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct, src=No
         res = ctx.icp_batch(f["T0"].reshape(1, 12), args.iters, args.d_max)[0]
         t.append(time.perf_counter())
         T = np.array(list(res.T))
-        cnt = ctx.increment_dev(0, T, 3, inc[0].data_ptr(), inc[1].data_ptr(), inc[2].data_ptr())
+        base = pend["n"]
+        cnt = ctx.increment_dev(0, T, 3, inc[0, base:].data_ptr(), inc[1, base:].data_ptr(),
+                                inc[2, base:].data_ptr())
+        pend["n"] += cnt
         t.append(time.perf_counter())
-        if cnt:
-            ctx.map_append_dev(inc[0].data_ptr(), inc[1].data_ptr(), inc[2].data_ptr(), cnt)
+        rolling = (k + 1) % max(args.evict_every, 1) == 0
+        if pend["n"] >= args.append_threshold and not rolling:  # (a roll appends them with its tiles)
+            ctx.map_append_dev(inc[0].data_ptr(), inc[1].data_ptr(), inc[2].data_ptr(), pend["n"])
+            pend["n"] = 0
             note("append", t[-1], timed)
         t.append(time.perf_counter())
-        if (k + 1) % max(args.evict_every, 1) == 0:
+        if rolling:
             n0 = ctx.map_info().n_points
             t1 = time.perf_counter()
             ctx.map_evict_radius(float(T[3]), float(T[7]), R)
@@ -276,13 +285,18 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct, src=No
             d2 = dist2(T)
             entering = (d2 <= R_in * R_in) & ~resident
             resident = (resident & (d2 <= R * R)) | entering
-            ex, ey, ez = wx[entering].contiguous(), wy[entering].contiguous(), wz[entering].contiguous()
+            # one append for the pending increments and the tiles that came into range
+            np_ = pend["n"]
+            ex = torch.cat([inc[0, :np_], wx[entering]])
+            ey = torch.cat([inc[1, :np_], wy[entering]])
+            ez = torch.cat([inc[2, :np_], wz[entering]])
+            pend["n"] = 0
             t2 = time.perf_counter()
             if ex.numel():
                 ctx.map_append_dev(ex.data_ptr(), ey.data_ptr(), ez.data_ptr(), ex.numel())
                 note("tiles", t2, timed)
             if timed:
-                counts["tiles_in"] += int(ex.numel())
+                counts["tiles_in"] += int(ex.numel()) - np_
                 counts["evicted"] += int(n0 - mi.n_points)
                 counts["rolls"] += 1
         t.append(time.perf_counter())
@@ -311,10 +325,11 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct, src=No
     return {"frames_per_s": steps / elapsed, "ms_per_frame": 1e3 * elapsed / steps, "frames": steps,
             "workload": "BASELINE configs[2]: HDL-64E packet stream through a pre-mapped world of %d points, "
                         "one frame per step (%d distinct frames, 1 m apart, played forwards and backwards): "
-                        "300 packets H2D + decode + compensate + %d ICP iters + increment + map append; every "
+                        "300 packets H2D + decode + compensate + %d ICP iters + increment (appended once %d points are "
+                        "pending); every "
                         "%d frames the map rolls: evict beyond ROI_RANGE %.0f m of the pose (MapManager.h:13), "
                         "append the world tiles that came within range"
-                        % (scene_points, nfr, args.iters, args.evict_every, R),
+                        % (scene_points, nfr, args.iters, args.append_threshold, args.evict_every, R),
             "map_points_mean": counts["map"] / max(steps, 1), "map_subdiv": int(mi.subdiv),
             "map_update": "full rebuild" if args.full_rebuild else "incremental",
             "pairs_per_s": counts["pairs"] / elapsed,

@@ -242,7 +242,7 @@ int publish_map(velo_ctx* c, MapView mv, int k_normals, unsigned long long inval
     const size_t nvox = (size_t)mv.nx * mv.ny * mv.nz;
     HIP_TRY(c, reserve_slack(c->vox_occ, nvox));
     HIP_TRY(c, reserve_slack(c->vox_near, nvox));
-    HIP_TRY(c, launch_vox_near(mv, c->vox_occ.p, c->vox_near.p, s));
+    HIP_TRY(c, launch_vox_near(mv, c->keys_sorted.p, c->vox_occ.p, c->vox_near.p, s));
     mv.vox_near = c->vox_near.p;
     c->mv = mv;
     c->has_map = true;

@@ -120,7 +120,8 @@ hipError_t launch_gather_nrm(const float4* nrm_raw, const uint32_t* perm, uint32
 hipError_t launch_mark_dirty_pts(const float4* pts, const float4* nrm, const uint32_t* keep,
                                  uint32_t n, const MapView& grid, uint8_t* dirty, hipStream_t s);
 
-hipError_t launch_vox_near(const MapView& mv, uint8_t* occ, uint8_t* near, hipStream_t s);
+hipError_t launch_vox_near(const MapView& mv, const uint32_t* keys_sorted, uint8_t* occ, uint8_t* near,
+                           hipStream_t s);
 hipError_t launch_count_occupied_voxels(const float* x, const float* y, const float* z, size_t n,
                                         const float mn[3], float inv_h, const size_t dims[3],
                                         uint8_t* occ, unsigned long long* d_count, hipStream_t s);
