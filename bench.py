@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the increment exchange + map append path even with one rank")
     ap.add_argument("--no-timing", action="store_true", help="skip per-launch HIP events (A/B their overhead)")
+    ap.add_argument("--exchange", choices=["capi", "torch"], default="capi",
+                    help="N > 1 transport of the increments: RCCL behind the C ABI, or torch.distributed")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--workload", choices=["batch", "stream"], default="batch",
                     help="batch = BASELINE configs[1] (the headline line); stream = configs[2]: "
@@ -600,6 +602,15 @@ def incl_h2d_record(args, d, dev, ctx, steps):
 # ------------------------------------------------------------------------- main
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: anything else that writes to fd 1 (RCCL prints a
+    # version banner there when its first communicator comes up) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -635,7 +646,7 @@ def main():
                           "map_update": rec["map_update"],
                           "map_margin_voxels": [args.map_margin, args.map_margin, args.map_margin_z]}}
         out.update({k: v for k, v in rec.items() if k not in ("workload", "frames_per_s", "ms_per_frame")})
-        print(json.dumps(out))
+        emit(out)
         return
 
     d = build_inputs(args, rank, dev)
@@ -659,13 +670,47 @@ def main():
     # only, all-gathers it on a side stream and appends it before batch k+2.
     exchange = world > 1 or args.force_exchange
     inc2 = [torch.empty((3, n_q), dtype=torch.float32, device=dev) for _ in range(2)] if exchange else None
+    # Transport: RCCL behind the C ABI (velo_comm_init + velo_exchange_increments: what a C++
+    # MapManager host would call); torch.distributed only carries the 128-byte id.  The torch
+    # collective path stays for gloo (one-device functional runs) and as the recorded fallback
+    # should the communicator fail to come up -- the line says which one ran.
+    transport = "torch.distributed"
+    gathered = None
+    if exchange and not one_dev and args.exchange == "capi":
+        try:
+            if world > 1:
+                box = [capi.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ctx.comm_init(box[0], rank, world)
+            else:
+                ctx.comm_init(capi.comm_unique_id(), 0, 1)
+            transport = "velo_exchange_increments (RCCL via the C ABI)"
+            gathered = torch.empty((3, n_q * world), dtype=torch.float32, device=dev)
+        except capi.VeloError as e:
+            sys.stderr.write("bench: C-ABI communicator unavailable (%s); using torch.distributed\n" % e)
     side = torch.cuda.Stream() if exchange else None
     ev_inc = [torch.cuda.Event(), torch.cuda.Event()] if exchange else None
     ev_free = [None, None]  # side stream is done reading increment buffer b
-    state = dict(cur=0, prev=None, exchanged_points=0, appends=0)
+    state = dict(cur=0, prev=None, exchanged_points=0, appends=0, appended_points=0)
+
+    def finish_exchange_capi(buf):
+        cnt = ctx.increment_wait()                    # blocks for the increment, not the next batch
+        counts, total = ctx.exchange_increments(inc2[buf][0].data_ptr(), inc2[buf][1].data_ptr(),
+                                                inc2[buf][2].data_ptr(), cnt, gathered[0].data_ptr(),
+                                                gathered[1].data_ptr(), gathered[2].data_ptr(),
+                                                gathered.shape[1], after_async_increment=True)
+        state["exchanged_points"] += total
+        if total:   # stream-ordered behind the exchange; lands before the batch after next
+            # voxel-downsampled: F frames x W ranks see the same under-filled voxels
+            kept = ctx.map_append_sparse_dev(gathered[0].data_ptr(), gathered[1].data_ptr(),
+                                             gathered[2].data_ptr(), total, 3)
+            state["appended_points"] += kept
+            state["appends"] += 1 if kept else 0
 
     def finish_exchange(buf):
         nonlocal pending, pending_n
+        if gathered is not None:
+            return finish_exchange_capi(buf)
         cnt = ctx.increment_wait()                    # blocks for the increment, not the next batch
         main = torch.cuda.current_stream()
         with torch.cuda.stream(side):
@@ -683,9 +728,10 @@ def main():
                 done.record(side)
                 allb.record_stream(main)
                 main.wait_event(done)
-                ctx.map_append_dev(allb[0].data_ptr(), allb[1].data_ptr(), allb[2].data_ptr(),
-                                   allb.shape[1])
-                state["appends"] += 1
+                kept = ctx.map_append_sparse_dev(allb[0].data_ptr(), allb[1].data_ptr(), allb[2].data_ptr(),
+                                                 allb.shape[1], 3)
+                state["appended_points"] += kept
+                state["appends"] += 1 if kept else 0
                 pending, pending_n = [], 0
 
     def step(timed):
@@ -718,7 +764,7 @@ def main():
     torch.cuda.synchronize()
     trace("warm-up done")
     ctx.pairs_total(reset=True)
-    state["exchanged_points"] = state["appends"] = 0
+    state["exchanged_points"] = state["appends"] = state["appended_points"] = 0
     if world > 1:
         dist.barrier()
     lin_ms, lin_n, lin_first, lin_min, n_samples = 0.0, 0, 0.0, 1e30, 0
@@ -785,9 +831,11 @@ def main():
             "worst_pose_error_m": worst,
         }
         if exchange:
-            out["exchange"] = {"increments": "every frame of every batch", "transport": "torch.distributed " +
-                               (dist.get_backend() if world > 1 else "(single rank)"),
+            out["exchange"] = {"increments": "every frame of every batch",
+                               "transport": transport + ((" " + dist.get_backend()) if world > 1 and gathered is None else ""),
                                "points_exchanged": state["exchanged_points"], "map_appends": state["appends"],
+                               "points_appended": state["appended_points"],
+                               "insertion": "voxel-downsampled (velo_map_append_sparse, min_count 3)",
                                "map_points_after": int(mi.n_points)}
         single = world == 1
         avg_s = (1e-3 * lin_ms / lin_n) if lin_n else None
@@ -821,7 +869,7 @@ def main():
                 out["stream"] = run_stream(args, dev, local, args.stream_steps, 10,
                                            args.stream_map_points, args.stream_frames,
                                            src=d["stream_src"] if rank == 0 and F >= 24 else None)
-        print(json.dumps(out))
+        emit(out)
         if rc:
             sys.stderr.write("bench: GPU pose differs from the CPU path beyond the north-star tolerance: %r\n"
                              % (out.get("parity"),))

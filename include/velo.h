@@ -150,6 +150,16 @@ int velo_map_reset_dev(velo_ctx*, const float* dx, const float* dy, const float*
  * and only normals within one voxel of a new point are re-estimated. */
 int velo_map_append(velo_ctx*, const float* x, const float* y, const float* z, size_t n);
 int velo_map_append_dev(velo_ctx*, const float* dx, const float* dy, const float* dz, size_t n);
+/* Voxel-downsampled insertion: of the n points, taken in order, one is appended iff
+ * its voxel (on the map's current grid, extended to any integer coordinate) holds fewer than
+ * min_count points counting the map's and the points accepted before it -- what integrating the
+ * frames one after another would leave.  F frames x W ranks that all see the same under-filled
+ * voxel then add min_count points to it, not F*W near-duplicates.  *n_accepted (may be NULL) gets
+ * the number appended; the rest is velo_map_append. */
+int velo_map_append_sparse(velo_ctx*, const float* x, const float* y, const float* z, size_t n,
+                           int min_count, size_t* n_accepted);
+int velo_map_append_sparse_dev(velo_ctx*, const float* dx, const float* dy, const float* dz, size_t n,
+                               int min_count, size_t* n_accepted);
 /* Rolling map (BASELINE configs[2]; the reference's patch eviction policy is unimplemented,
  * MapManager.h:43): drop every map point outside the closed box [lo, hi]; append order of the
  * survivors is kept.  Refused (VELO_E_INVALID, map unchanged) if nothing would remain.  The
@@ -299,6 +309,29 @@ int velo_increment_wait(velo_ctx*, size_t* n_out);
  * last reset, counted on the device (exact; lets a caller that never fetches per-batch results
  * -- the bench loop -- report pairs/s).  Synchronises the ctx stream. */
 int velo_pairs_total(velo_ctx*, uint64_t* out, int reset);
+
+/* ---- multi-GPU exchange step (no reference counterpart: the reference is one
+ * process, one CPU) ---------------------------------------------------------------------------
+ * One process per GPU, one ctx per process.  Rank 0 makes an id (velo_comm_unique_id), the host
+ * application carries its 128 bytes to the other ranks by whatever it has (MPI, a socket, a
+ * file, torch.distributed), every rank calls velo_comm_init: an RCCL communicator over xGMI,
+ * opened with dlopen at that moment -- the library does not link against RCCL. */
+#define VELO_COMM_ID_BYTES 128
+int velo_comm_unique_id(uint8_t id[VELO_COMM_ID_BYTES]);
+int velo_comm_init(velo_ctx*, const uint8_t id[VELO_COMM_ID_BYTES], int rank, int world);
+int velo_comm_destroy(velo_ctx*);
+int velo_comm_info(velo_ctx*, int32_t* rank, int32_t* world); /* world = 0: no communicator */
+/* All-gather of every rank's accepted increment (device SoA, n_local points; may be 0): counts
+ * first, then max-padded blocks, packed in RANK ORDER into the device arrays ox/oy/oz (capacity
+ * cap points) -- appending that list with velo_map_append_dev keeps every replica of the map
+ * bit-identical.  counts (host, world entries, may be NULL) and *n_total are valid on return; the
+ * blocks are complete for work enqueued on the ctx stream after the call.  The collectives run on
+ * the ctx's own communication stream: with after_async_increment != 0 they wait only for the
+ * last velo_increment_*_async, not for a batch enqueued behind it (overlap with the next batch);
+ * with 0 they wait for everything enqueued on the ctx stream so far. */
+int velo_exchange_increments(velo_ctx*, const float* dx, const float* dy, const float* dz, size_t n_local,
+                             int after_async_increment, float* ox, float* oy, float* oz, size_t cap,
+                             int32_t* counts, size_t* n_total);
 
 /* per-kernel device time of the last velo_icp_batch* call, HIP events on the ctx
  * stream: [0] linearise kernel total ms, [1] its launch count, [2] solve total ms,

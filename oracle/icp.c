@@ -528,6 +528,83 @@ int vo_roll_append(vo_roll* r, const float* x, const float* y, const float* z, s
     return below;
 }
 
+/* Voxel-downsampled insertion: of the m new points, taken IN ORDER, one is
+ * accepted iff its voxel (on the map's current grid, which extends to any integer coordinate)
+ * holds fewer than min_count points counting the map's and those accepted before it.  What a
+ * sequence of frames integrated one after another would leave behind; it keeps F frames x W
+ * ranks that all see the same under-filled voxel from piling near-duplicates into it. */
+static inline int sparse_coord(float p, float o, float inv_h)
+{
+    float f = floorf((p - o) * inv_h);
+    f = f < -1048576.0f ? -1048576.0f : (f > 1048575.0f ? 1048575.0f : f);
+    return (int)f;
+}
+
+size_t vo_roll_filter_sparse(const vo_roll* r, const float* x, const float* y, const float* z,
+                             size_t m, int min_count, unsigned char* accept)
+{
+    const vo_map* mp = r->map;
+    size_t cap = 16;
+    while (cap < 2 * m + 1) cap <<= 1;
+    uint64_t* keys = (uint64_t*)malloc(cap * sizeof(uint64_t));
+    int32_t* cnt = (int32_t*)calloc(cap, sizeof(int32_t));
+    memset(keys, 0xFF, cap * sizeof(uint64_t));
+    size_t n_acc = 0;
+    for (size_t i = 0; i < m; ++i) {
+        const int cx = sparse_coord(x[i], mp->o[0], mp->inv_h), cy = sparse_coord(y[i], mp->o[1], mp->inv_h),
+                  cz = sparse_coord(z[i], mp->o[2], mp->inv_h);
+        const uint64_t key = ((uint64_t)(cz + 1048576) << 42) | ((uint64_t)(cy + 1048576) << 21) |
+                             (uint64_t)(cx + 1048576);
+        size_t hsh = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+        while (keys[hsh] != key && keys[hsh] != UINT64_MAX) hsh = (hsh + 1) & (cap - 1);
+        if (keys[hsh] == UINT64_MAX) {  /* first new point of this voxel: start from the map's count */
+            keys[hsh] = key;
+            int occ = 0;
+            if (cx >= 0 && cx < mp->dims[0] && cy >= 0 && cy < mp->dims[1] && cz >= 0 && cz < mp->dims[2])
+                for (int fz = cz * mp->S; fz < (cz + 1) * mp->S; ++fz)
+                    for (int fy = cy * mp->S; fy < (cy + 1) * mp->S; ++fy) {
+                        size_t row = ((size_t)fz * mp->fd[1] + fy) * mp->fd[0];
+                        occ += mp->cell_start[row + (size_t)(cx + 1) * mp->S] -
+                               mp->cell_start[row + (size_t)cx * mp->S];
+                    }
+            cnt[hsh] = occ;
+        }
+        accept[i] = cnt[hsh] < min_count;
+        if (accept[i]) {
+            cnt[hsh]++;
+            ++n_acc;
+        }
+    }
+    free(keys);
+    free(cnt);
+    return n_acc;
+}
+
+/* filter, then vo_roll_append of the survivors; returns the number appended (-1 on failure) */
+long vo_roll_append_sparse(vo_roll* r, const float* x, const float* y, const float* z, size_t m,
+                           int min_count)
+{
+    if (m == 0) return 0;
+    unsigned char* acc = (unsigned char*)malloc(m);
+    const size_t k = vo_roll_filter_sparse(r, x, y, z, m, min_count, acc);
+    float *ax = (float*)malloc((k + 1) * sizeof(float)), *ay = (float*)malloc((k + 1) * sizeof(float)),
+          *az = (float*)malloc((k + 1) * sizeof(float));
+    size_t w = 0;
+    for (size_t i = 0; i < m; ++i)
+        if (acc[i]) {
+            ax[w] = x[i];
+            ay[w] = y[i];
+            az[w] = z[i];
+            ++w;
+        }
+    const int rc = k ? vo_roll_append(r, ax, ay, az, k) : 0;
+    free(acc);
+    free(ax);
+    free(ay);
+    free(az);
+    return rc < 0 ? -1 : (long)k;
+}
+
 /* keep region = closed box, optionally intersected with the vertical cylinder of radius `radius`
  * around (cx, cy) (radius < 0: box only).  The cylinder is the rolling-map policy behind
  * ROI_RANGE (MapManager.h:13: "sensor detecting range"): distance in the ground plane, z free. */

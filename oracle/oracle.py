@@ -122,6 +122,10 @@ def lib():
     L.vo_roll_size.restype = C.c_size_t
     L.vo_roll_append.argtypes = [C.c_void_p, fp, fp, fp, C.c_size_t]
     L.vo_roll_evict_outside.argtypes = [C.c_void_p, fp, fp]
+    L.vo_roll_filter_sparse.argtypes = [C.c_void_p, fp, fp, fp, C.c_size_t, C.c_int, C.c_void_p]
+    L.vo_roll_filter_sparse.restype = C.c_size_t
+    L.vo_roll_append_sparse.argtypes = [C.c_void_p, fp, fp, fp, C.c_size_t, C.c_int]
+    L.vo_roll_append_sparse.restype = C.c_long
     L.vo_roll_evict_region.argtypes = [C.c_void_p, fp, fp, C.c_float, C.c_float, C.c_float]
     L.vo_map_free.argtypes = [C.c_void_p]
     L.vo_map_size.argtypes = [C.c_void_p]
@@ -469,6 +473,22 @@ class RollingMap:
         lo = np.ascontiguousarray(lo, np.float32)
         hi = np.ascontiguousarray(hi, np.float32)
         return lib().vo_roll_evict_outside(self.r, _f(lo), _f(hi))
+
+
+def _filter_sparse(self, x, y, z, min_count):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    acc = np.zeros(x.size, np.uint8)
+    lib().vo_roll_filter_sparse(self.r, _f(x), _f(y), _f(z), x.size, int(min_count), acc.ctypes.data_as(C.c_void_p))
+    return acc.astype(bool)
+
+
+def _append_sparse(self, x, y, z, min_count):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    return lib().vo_roll_append_sparse(self.r, _f(x), _f(y), _f(z), x.size, int(min_count))
+
+
+RollingMap.filter_sparse = _filter_sparse
+RollingMap.append_sparse = _append_sparse
 
 
 def _evict_radius(self, cx, cy, radius):

@@ -145,6 +145,12 @@ const vo_map* vo_roll_map(const vo_roll*);
 size_t vo_roll_size(const vo_roll*);
 int vo_roll_append(vo_roll*, const float* x, const float* y, const float* z, size_t m);
 int vo_roll_evict_outside(vo_roll*, const float lo[3], const float hi[3]);
+/* voxel-downsampled insertion: accept[i] = 1 iff new point i's voxel (current grid) holds fewer
+ * than min_count points counting the map's and the new points accepted before it */
+size_t vo_roll_filter_sparse(const vo_roll* r, const float* x, const float* y, const float* z,
+                             size_t m, int min_count, unsigned char* accept);
+long vo_roll_append_sparse(vo_roll* r, const float* x, const float* y, const float* z, size_t m,
+                           int min_count);
 /* box intersected with the cylinder of `radius` around (cx, cy) in the ground plane (radius < 0:
  * box only): eviction by ROI_RANGE (MapManager.h:13) */
 int vo_roll_evict_region(vo_roll* r, const float lo[3], const float hi[3], float cx, float cy,

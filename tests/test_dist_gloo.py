@@ -60,6 +60,53 @@ def test_exchange_increments_world2():
             assert np.array_equal(b0[r], rng.uniform(-1, 1, (3, n)).astype(np.float32))
 
 
+def _replica_worker(rank, world, port, q):
+    """Every rank holds a replica of the map; each contributes a different increment; all append
+    the gathered blocks in rank order -> the replicas must stay IDENTICAL (sorted order, cell
+    table), which is what makes the frame-parallel results independent of the rank count."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as orc
+        base = np.random.default_rng(7).uniform(0, 12, (3, 4000)).astype(np.float32)
+        roll = orc.RollingMap(*base, 1.0, 8, 3, margin=2)
+        digests = []
+        for rnd in range(3):
+            rng = np.random.default_rng(1000 * rnd + rank)
+            n = [300, 0, 41][(rank + rnd) % 3]
+            mine = rng.uniform(1, 11, (3, n)).astype(np.float32)
+            buf = torch.zeros((3, 512), dtype=torch.float32)
+            buf[:, :n] = torch.from_numpy(mine)
+            blocks, counts = exchange_increments(buf, n)
+            for b in blocks:                      # rank order
+                if b.shape[1]:
+                    roll.append(*b.numpy())
+            m = roll.map
+            digests.append((roll.n, m.perm().tobytes(), m.cell_start().tobytes(),
+                            m.normals()[0].tobytes(), counts))
+        q.put((rank, digests))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_stay_identical_after_rank_order_append():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_replica_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rnd in range(3):
+        assert res[0][rnd] == res[1][rnd]       # size, permutation, cell table, normals, counts
+    assert res[0][2][0] == 4000 + sum(sum(res[0][r][4]) for r in range(3))
+
+
 def test_exchange_single_process_passthrough():
     buf = torch.arange(30, dtype=torch.float32).view(3, 10)
     blocks, counts = exchange_increments(buf, 4)

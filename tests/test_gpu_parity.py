@@ -293,6 +293,34 @@ def test_rolling_map_evict_radius_equals_fresh_build(oracle, margin):
         c.close()
 
 
+@pytest.mark.parametrize("min_count,margin", [(3, 2), (1, 0), (5, 4)])
+def test_sparse_insertion_equals_oracle(oracle, min_count, margin):
+    """f3 voxel-downsampled insertion (velo_map_append_sparse): a new point is taken iff its voxel
+    holds fewer than min_count points counting the map's and the new points accepted before it.
+    Device (stable sort + rank) == oracle (sequential loop): same survivors, same map."""
+    rng = np.random.default_rng(77 + min_count)
+    base = rng.uniform(0, 8, (3, 1500)).astype(np.float32)
+    base[2] *= 0.3
+    c = capi.Context(0, max_batch=2, map_margin=margin)
+    try:
+        c.map_reset(*base, 1.0, 8)
+        roll = oracle.RollingMap(*base, 1.0, 8, 3, margin=margin)
+        for rnd in range(3):
+            new = rng.uniform(-3, 11, (3, 4000)).astype(np.float32)   # inside, outside, below the origin
+            new[2] *= 0.3
+            new[:, 100:140] = new[:, 60:100]                          # exact duplicates
+            new[:, 500:900] = (new[:, 499:500] + rng.normal(0, 0.01, (3, 400))).astype(np.float32)  # a clump
+            want = roll.filter_sparse(*new, min_count)
+            k_o = roll.append_sparse(*new, min_count)
+            k_g = c.map_append_sparse(*new, min_count)
+            assert k_g == k_o == int(want.sum())
+            _assert_map_equal(c, roll.map)
+        assert c.map_append_sparse(*new, min_count) == roll.append_sparse(*new, min_count)  # saturated now
+        _assert_map_equal(c, roll.map)
+    finally:
+        c.close()
+
+
 def test_rolling_map_registration_after_updates(oracle, wl, comp):
     """ICP against a map that was appended to and evicted from incrementally gives the pose of
     the oracle's ICP on the fresh build (hints of the previous map are forgotten)."""

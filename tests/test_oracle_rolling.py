@@ -91,3 +91,34 @@ def test_roll_evict_radius_is_a_cylinder_in_the_ground_plane(oracle):
     n = roll.n
     assert roll.evict_radius(cx, cy, 1e4) == 0 and roll.n == n
     assert roll.evict_radius(500.0, 500.0, 1.0) == -1 and roll.n == n
+
+
+def test_sparse_insertion_is_sequential_voxel_downsampling(oracle):
+    """vo_roll_filter_sparse: in order, a point is accepted iff its voxel holds fewer than
+    min_count points counting the map's and the ones accepted before it."""
+    rng = np.random.default_rng(4)
+    base = rng.uniform(0, 5, (3, 200)).astype(np.float32)
+    roll = oracle.RollingMap(*base, 1.0, 0, 3, margin=1)
+    o, d, _ = roll.map.grid()
+    new = rng.uniform(-2, 7, (3, 3000)).astype(np.float32)
+    acc = roll.filter_sparse(*new, 3)
+    # brute force with a dictionary
+    cnt = {}
+    for p in base.T:
+        v = tuple(np.floor((p - o) * np.float32(1.0)).astype(int))
+        cnt[v] = cnt.get(v, 0) + 1
+    want = np.zeros(3000, bool)
+    for i, p in enumerate(new.T):
+        v = tuple(np.floor((p - o) * np.float32(1.0)).astype(int))
+        if cnt.get(v, 0) < 3:
+            want[i] = True
+            cnt[v] = cnt.get(v, 0) + 1
+    assert np.array_equal(acc, want)
+    n0 = roll.n
+    assert roll.append_sparse(*new, 3) == int(want.sum()) and roll.n == n0 + int(want.sum())
+    # (that append re-anchored the grid -- points below the origin -- so voxel membership moved;
+    # on a grid that keeps, a second pass of the same points finds every voxel full)
+    inside = rng.uniform(0.5, 4.5, (3, 2000)).astype(np.float32)
+    roll2 = oracle.RollingMap(*base, 1.0, 0, 3, margin=1)
+    k1 = roll2.append_sparse(*inside, 3)
+    assert k1 > 0 and roll2.append_sparse(*inside, 3) == 0

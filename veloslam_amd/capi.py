@@ -67,10 +67,11 @@ class MapInfo(C.Structure):
 EXPORTS = [
     "velo_create", "velo_destroy", "velo_last_error", "velo_abi_version", "velo_cfg_get", "velo_set_stream",
     "velo_synchronize", "velo_map_reset", "velo_map_reset_dev", "velo_map_append",
-    "velo_map_append_dev", "velo_map_evict_outside", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
+    "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
+    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
+    "velo_exchange_increments", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
     "velo_insmeta_write", "velo_insmeta_read", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
@@ -114,6 +115,8 @@ def lib():
     L.velo_map_reset_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_int]
     L.velo_map_append.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.velo_map_append_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.velo_map_append_sparse.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
+    L.velo_map_append_sparse_dev.argtypes = L.velo_map_append_sparse.argtypes
     L.velo_map_evict_outside.argtypes = [vp, vp, vp]
     L.velo_map_evict_radius.argtypes = [vp, vp, C.c_float]
     L.velo_map_set_margins.argtypes = [vp, vp]
@@ -147,6 +150,12 @@ def lib():
     L.velo_increment_registered_async.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.velo_increment_all_registered_async.argtypes = [vp, C.c_int, vp, vp, vp]
     L.velo_increment_wait.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.velo_comm_unique_id.argtypes = [vp]
+    L.velo_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.velo_comm_destroy.argtypes = [vp]
+    L.velo_comm_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.velo_exchange_increments.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, C.c_size_t, vp,
+                                           C.POINTER(C.c_size_t)]
     L.velo_last_timing.argtypes = [vp, dp]
     L.velo_set_timing.argtypes = [vp, C.c_int]
     L.velo_last_linearize_us.argtypes = [vp, vp, C.c_int]
@@ -185,6 +194,15 @@ def _f32(a):
 
 
 # --------------------------------------------------------------- host helpers
+def comm_unique_id():
+    """128 opaque bytes from rank 0, to be carried to the other ranks (velo_comm_init)."""
+    buf = np.zeros(128, np.uint8)
+    rc = lib().velo_comm_unique_id(_p(buf))
+    if rc:
+        raise VeloError(rc, lib().velo_last_error(None).decode())
+    return buf.tobytes()
+
+
 def matrix_from_pose(T, Rdeg):
     tr = np.array(list(T) + list(Rdeg), dtype=np.float64)
     M = np.zeros(12)
@@ -390,6 +408,17 @@ class Context:
     def map_append_dev(self, px, py, pz, n):
         self._chk(lib().velo_map_append_dev(self.h, px, py, pz, n))
 
+    def map_append_sparse(self, x, y, z, min_count):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        k = C.c_size_t()
+        self._chk(lib().velo_map_append_sparse(self.h, _p(x), _p(y), _p(z), x.size, min_count, C.byref(k)))
+        return k.value
+
+    def map_append_sparse_dev(self, px, py, pz, n, min_count):
+        k = C.c_size_t()
+        self._chk(lib().velo_map_append_sparse_dev(self.h, px, py, pz, n, min_count, C.byref(k)))
+        return k.value
+
     def map_set_margins(self, mx, my, mz):
         m = np.array([mx, my, mz], np.int32)
         self._chk(lib().velo_map_set_margins(self.h, _p(m)))
@@ -562,6 +591,26 @@ class Context:
 
     def increment_all_registered_async(self, min_count, pox, poy, poz):
         self._chk(lib().velo_increment_all_registered_async(self.h, min_count, pox, poy, poz))
+
+    # ---- multi-GPU exchange (RCCL behind the C ABI)
+    def comm_init(self, unique_id, rank, world):
+        buf = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        assert buf.size == 128
+        self._chk(lib().velo_comm_init(self.h, _p(buf), rank, world))
+
+    def comm_info(self):
+        r, w = C.c_int32(), C.c_int32()
+        self._chk(lib().velo_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def exchange_increments(self, px, py, pz, n_local, pox, poy, poz, cap, after_async_increment=True):
+        """-> (counts per rank, total); blocks land in rank order in the output device arrays"""
+        _, world = self.comm_info()
+        counts = np.zeros(max(world, 1), np.int32)
+        tot = C.c_size_t()
+        self._chk(lib().velo_exchange_increments(self.h, px, py, pz, n_local, int(bool(after_async_increment)),
+                                                 pox, poy, poz, cap, _p(counts), C.byref(tot)))
+        return counts.tolist(), tot.value
 
     def increment_wait(self):
         cnt = C.c_size_t()

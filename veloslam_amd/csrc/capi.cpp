@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstring>
 #include <memory>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is opened at run time (velo_comm_init)
 #include "velo_internal.hpp"
 #include "../../include/veloslam/TransformManager.hpp"
 
@@ -106,6 +108,9 @@ struct velo_ctx {
     DevBuf<float> d2;
     DevBuf<uint32_t> flags, offs;
     DevBuf<float> inc_x, inc_y, inc_z;
+    DevBuf<uint64_t> sp_keys, sp_keys2;   // sparse insertion: voxel keys of the new points
+    DevBuf<uint32_t> sp_idx, sp_idx2;
+    DevBuf<float> sp_x, sp_y, sp_z;
     DevBuf<double> inc_pose;
     uint32_t* h_inc_total = nullptr;  // pinned: count of the asynchronous increment
     hipEvent_t ev_inc = nullptr;
@@ -135,6 +140,15 @@ struct velo_ctx {
     int t0_next = 0;
     bool lin_hints = false;  // velo_linearize keeps/uses hints across calls (tests)
     bool stats_on = false;   // launch the counting instantiation of the linearise kernel
+
+    // ---- multi-GPU exchange: RCCL communicator + its own stream
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_comm = nullptr, ev_comm_in = nullptr;
+    DevBuf<int32_t> comm_counts;   // [world]
+    DevBuf<float> comm_send, comm_recv;
+    int32_t* h_comm_counts = nullptr;  // pinned [world]
 
     // ---- f1 decode
     DevBuf<uint8_t> dk_pkts, dk_perm, dk_tvalid, dk_invlut;
@@ -955,6 +969,7 @@ void velo_destroy(velo_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)velo_comm_destroy(c);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     for (int b = 0; b < 2; ++b) {
         if (c->h_T0[b]) (void)hipHostFree(c->h_T0[b]);
@@ -1124,6 +1139,66 @@ static int map_append_impl(velo_ctx* c, const float* x, const float* y, const fl
 int velo_map_append(velo_ctx* c, const float* x, const float* y, const float* z, size_t n)
 {
     return map_append_impl(c, x, y, z, n, false);
+}
+
+// voxel-downsampled insertion (oracle/icp.c vo_roll_filter_sparse + vo_roll_append)
+static int map_append_sparse_impl(velo_ctx* c, const float* x, const float* y, const float* z, size_t n,
+                                  int min_count, size_t* n_accepted, bool dev)
+{
+    if (!c) return VELO_E_INVALID;
+    if (n_accepted) *n_accepted = 0;
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "velo_map_append_sparse before velo_map_reset");
+    if (n == 0) return VELO_OK;
+    if (!x || !y || !z) return c->fail(VELO_E_INVALID, "null point array");
+    if (min_count < 1) return c->fail(VELO_E_INVALID, "min_count must be >= 1");
+    if (n >= (size_t)INT32_MAX) return c->fail(VELO_E_RANGE, "too many points");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, c->sp_x.reserve(2 * n));  // [0,n): staged input (host entry), [n,2n): survivors
+    HIP_TRY(c, c->sp_y.reserve(2 * n));
+    HIP_TRY(c, c->sp_z.reserve(2 * n));
+    const float *dx = x, *dy = y, *dz = z;
+    if (!dev) {
+        HIP_TRY(c, hipMemcpyAsync(c->sp_x.p, x, n * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->sp_y.p, y, n * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->sp_z.p, z, n * sizeof(float), hipMemcpyHostToDevice, s));
+        dx = c->sp_x.p;
+        dy = c->sp_y.p;
+        dz = c->sp_z.p;
+    }
+    HIP_TRY(c, c->sp_keys.reserve(n));
+    HIP_TRY(c, c->sp_keys2.reserve(n));
+    HIP_TRY(c, c->sp_idx.reserve(n));
+    HIP_TRY(c, c->sp_idx2.reserve(n));
+    HIP_TRY(c, c->flags.reserve(n + 1));
+    HIP_TRY(c, c->offs.reserve(n + 1));
+    HIP_TRY(c, launch_sparse_keys(dx, dy, dz, n, c->mv, c->sp_keys.p, c->sp_idx.p, s));
+    size_t tb = 0, tb2 = 0;
+    HIP_TRY(c, sort_pairs64(nullptr, tb, c->sp_keys.p, c->sp_keys2.p, c->sp_idx.p, c->sp_idx2.p, n, s));
+    HIP_TRY(c, exclusive_scan_u32(nullptr, tb2, c->flags.p, c->offs.p, n + 1, s));
+    if (int rc = ensure_temp(c, std::max(tb, tb2))) return rc;
+    HIP_TRY(c, sort_pairs64(c->temp.p, tb, c->sp_keys.p, c->sp_keys2.p, c->sp_idx.p, c->sp_idx2.p, n, s));
+    HIP_TRY(c, launch_sparse_accept(c->sp_keys2.p, c->sp_idx2.p, n, c->mv, min_count, c->flags.p, s));
+    HIP_TRY(c, hipMemsetAsync(c->flags.p + n, 0, sizeof(uint32_t), s));
+    HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb2, c->flags.p, c->offs.p, n + 1, s));
+    uint32_t kept = 0;
+    HIP_TRY(c, hipMemcpyAsync(&kept, c->offs.p + n, sizeof kept, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, launch_compact3(dx, dy, dz, n, c->flags.p, c->offs.p, c->sp_x.p + n, c->sp_y.p + n,
+                               c->sp_z.p + n, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (n_accepted) *n_accepted = kept;
+    if (kept == 0) return VELO_OK;
+    return map_append_impl(c, c->sp_x.p + n, c->sp_y.p + n, c->sp_z.p + n, kept, true);
+}
+int velo_map_append_sparse(velo_ctx* c, const float* x, const float* y, const float* z, size_t n,
+                           int min_count, size_t* n_accepted)
+{
+    return map_append_sparse_impl(c, x, y, z, n, min_count, n_accepted, false);
+}
+int velo_map_append_sparse_dev(velo_ctx* c, const float* dx, const float* dy, const float* dz, size_t n,
+                               int min_count, size_t* n_accepted)
+{
+    return map_append_sparse_impl(c, dx, dy, dz, n, min_count, n_accepted, true);
 }
 int velo_map_append_dev(velo_ctx* c, const float* x, const float* y, const float* z, size_t n)
 {
@@ -2049,6 +2124,183 @@ int velo_increment_dev(velo_ctx* c, int frame, const double T[12], int min_count
                        float* doy, float* doz, size_t* n_out)
 {
     return increment_impl(c, frame, T, min_count, dox, doy, doz, n_out, true);
+}
+
+// ------------------------------------------------------------- multi-GPU exchange
+// RCCL is opened at run time: the library has no link-time dependency on it (a single-GPU
+// consumer never needs it), and inside a process that already carries an RCCL -- torch ships
+// one under the same soname -- the loader hands back that copy.
+namespace {
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool load()
+    {
+        if (h) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) {
+            err = std::string("cannot open librccl: ") + (dlerror() ? dlerror() : "?");
+            return false;
+        }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
+        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) {
+            err = "librccl lacks an expected symbol";
+            h = nullptr;
+            return false;
+        }
+        return true;
+    }
+} g_rccl;
+
+#define RCCL_TRY(ctx, expr)                                                                    \
+    do {                                                                                       \
+        ncclResult_t r__ = (expr);                                                             \
+        if (r__ != ncclSuccess)                                                                \
+            return (ctx)->fail(VELO_E_DEVICE, "%s failed: %s", #expr, g_rccl.GetErrorString(r__)); \
+    } while (0)
+}  // namespace
+
+int velo_comm_unique_id(uint8_t id[VELO_COMM_ID_BYTES])
+{
+    if (!id) return VELO_E_INVALID;
+    if (!g_rccl.load()) {
+        g_create_error = g_rccl.err;
+        return VELO_E_DEVICE;
+    }
+    ncclUniqueId u;
+    static_assert(sizeof u == VELO_COMM_ID_BYTES, "ncclUniqueId size");
+    if (g_rccl.GetUniqueId(&u) != ncclSuccess) {
+        g_create_error = "ncclGetUniqueId failed";
+        return VELO_E_DEVICE;
+    }
+    std::memcpy(id, &u, sizeof u);
+    return VELO_OK;
+}
+
+int velo_comm_init(velo_ctx* c, const uint8_t id[VELO_COMM_ID_BYTES], int rank, int world)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!id || world < 1 || rank < 0 || rank >= world) return c->fail(VELO_E_INVALID, "bad rank / world / id");
+    if (c->comm) return c->fail(VELO_E_INVALID, "communicator already initialised");
+    if (!g_rccl.load()) return c->fail(VELO_E_DEVICE, "%s", g_rccl.err.c_str());
+    HIP_TRY(c, hipSetDevice(c->device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    RCCL_TRY(c, g_rccl.CommInitRank(&c->comm, world, u, rank));
+    c->comm_rank = rank;
+    c->comm_world = world;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_comm_in, hipEventDisableTiming));
+    HIP_TRY(c, c->comm_counts.reserve((size_t)world + 1));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_comm_counts, ((size_t)world + 1) * sizeof(int32_t), 0));
+    return VELO_OK;
+}
+
+int velo_comm_destroy(velo_ctx* c)
+{
+    if (!c) return VELO_E_INVALID;
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    c->comm_stream = nullptr;
+    if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+    if (c->ev_comm_in) (void)hipEventDestroy(c->ev_comm_in);
+    c->ev_comm = c->ev_comm_in = nullptr;
+    if (c->h_comm_counts) (void)hipHostFree(c->h_comm_counts);
+    c->h_comm_counts = nullptr;
+    c->comm_world = 1;
+    c->comm_rank = 0;
+    return VELO_OK;
+}
+
+// All-gather-v of the accepted map increments: counts first (one int per rank), then blocks
+// padded to the largest count (a few hundred KB at most: latency-bound on the direct xGMI
+// links, one padded all-gather beats world-1 ring steps of exact sizes), then the blocks are
+// packed in RANK ORDER into ox/oy/oz so that every replica appends the same list.
+int velo_exchange_increments(velo_ctx* c, const float* dx, const float* dy, const float* dz, size_t n_local,
+                             int after_async_increment, float* ox, float* oy, float* oz, size_t cap,
+                             int32_t* counts, size_t* n_total)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!c->comm) return c->fail(VELO_E_INVALID, "velo_comm_init has not been called");
+    if ((n_local && (!dx || !dy || !dz)) || !ox || !oy || !oz || !n_total)
+        return c->fail(VELO_E_INVALID, "null argument");
+    if (n_local >= (size_t)INT32_MAX) return c->fail(VELO_E_RANGE, "increment too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int W = c->comm_world;
+    hipStream_t cs = c->comm_stream;
+    // the inputs are ready once the producing work on the ctx stream is: either the last
+    // asynchronous increment (its event), or everything enqueued so far
+    if (after_async_increment && c->ev_inc) {
+        HIP_TRY(c, hipStreamWaitEvent(cs, c->ev_inc, 0));
+    } else {
+        HIP_TRY(c, hipEventRecord(c->ev_comm_in, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(cs, c->ev_comm_in, 0));
+    }
+    c->h_comm_counts[W] = (int32_t)n_local;
+    HIP_TRY(c, hipMemcpyAsync(c->comm_counts.p + W, c->h_comm_counts + W, sizeof(int32_t),
+                              hipMemcpyHostToDevice, cs));
+    RCCL_TRY(c, g_rccl.AllGather(c->comm_counts.p + W, c->comm_counts.p, 1, ncclInt32, c->comm, cs));
+    HIP_TRY(c, hipMemcpyAsync(c->h_comm_counts, c->comm_counts.p, (size_t)W * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, cs));
+    HIP_TRY(c, hipStreamSynchronize(cs));  // the counts size the second phase
+    size_t pad = 1, total = 0;
+    for (int r = 0; r < W; ++r) {
+        if (c->h_comm_counts[r] < 0) return c->fail(VELO_E_DEVICE, "negative count from rank %d", r);
+        pad = std::max(pad, (size_t)c->h_comm_counts[r]);
+        total += (size_t)c->h_comm_counts[r];
+        if (counts) counts[r] = c->h_comm_counts[r];
+    }
+    *n_total = total;
+    if (total > cap) return c->fail(VELO_E_RANGE, "exchange: %zu points exceed the output capacity %zu", total, cap);
+    if (total == 0) return VELO_OK;
+    HIP_TRY(c, c->comm_send.reserve(3 * pad));
+    HIP_TRY(c, c->comm_recv.reserve(3 * pad * (size_t)W));
+    const float* src[3] = {dx, dy, dz};
+    for (int a = 0; a < 3; ++a) {
+        if (n_local)
+            HIP_TRY(c, hipMemcpyAsync(c->comm_send.p + (size_t)a * pad, src[a], n_local * sizeof(float),
+                                      hipMemcpyDeviceToDevice, cs));
+        if (n_local < pad)
+            HIP_TRY(c, hipMemsetAsync(c->comm_send.p + (size_t)a * pad + n_local, 0,
+                                      (pad - n_local) * sizeof(float), cs));
+    }
+    RCCL_TRY(c, g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, 3 * pad, ncclFloat32, c->comm, cs));
+    float* dst[3] = {ox, oy, oz};
+    size_t off = 0;
+    for (int r = 0; r < W; ++r) {
+        const size_t n = (size_t)c->h_comm_counts[r];
+        for (int a = 0; a < 3 && n; ++a)
+            HIP_TRY(c, hipMemcpyAsync(dst[a] + off, c->comm_recv.p + ((size_t)r * 3 + a) * pad,
+                                      n * sizeof(float), hipMemcpyDeviceToDevice, cs));
+        off += n;
+    }
+    // work enqueued on the ctx stream from now on (velo_map_append_dev) sees the blocks
+    HIP_TRY(c, hipEventRecord(c->ev_comm, cs));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    return VELO_OK;
+}
+
+int velo_comm_info(velo_ctx* c, int32_t* rank, int32_t* world)
+{
+    if (!c) return VELO_E_INVALID;
+    if (rank) *rank = c->comm_rank;
+    if (world) *world = c->comm ? c->comm_world : 0;
+    return VELO_OK;
 }
 
 }  // extern "C"

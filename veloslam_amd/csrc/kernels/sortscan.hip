@@ -19,6 +19,13 @@ hipError_t sort_pairs(void* temp, size_t& temp_bytes, const uint32_t* k_in, uint
                                               end_bit, s);
 }
 
+// 64-bit keys (voxel coordinates on the unbounded grid: sparse insertion)
+hipError_t sort_pairs64(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out,
+                        const uint32_t* v_in, uint32_t* v_out, size_t n, hipStream_t s)
+{
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (int)n, 0, 63, s);
+}
+
 hipError_t exclusive_scan_u32(void* temp, size_t& temp_bytes, const uint32_t* in, uint32_t* out,
                               size_t n, hipStream_t s)
 {

@@ -65,6 +65,8 @@ hipError_t launch_keys(const float* x, const float* y, const float* z, size_t n,
                        hipStream_t s);
 hipError_t sort_pairs(void* temp, size_t& temp_bytes, const uint32_t* k_in, uint32_t* k_out,
                       const uint32_t* v_in, uint32_t* v_out, size_t n, int end_bit, hipStream_t s);
+hipError_t sort_pairs64(void* temp, size_t& temp_bytes, const uint64_t* k_in, uint64_t* k_out,
+                        const uint32_t* v_in, uint32_t* v_out, size_t n, hipStream_t s);
 hipError_t launch_gather(const float* x, const float* y, const float* z, const uint32_t* perm,
                          size_t n, float4* pts, hipStream_t s);
 hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell,
@@ -160,6 +162,14 @@ hipError_t launch_increment_scatter_items(const BlockItem* items, int n_items, c
                                           const double* poses, const uint32_t* flags,
                                           const uint32_t* offs, float* ox, float* oy, float* oz,
                                           hipStream_t s);
+
+// voxel-downsampled insertion (oracle/icp.c vo_roll_filter_sparse)
+hipError_t launch_sparse_keys(const float* x, const float* y, const float* z, size_t n, const MapView& mv,
+                              uint64_t* keys, uint32_t* idx, hipStream_t s);
+hipError_t launch_sparse_accept(const uint64_t* keys_sorted, const uint32_t* idx_sorted, size_t n,
+                                const MapView& mv, int min_count, uint32_t* accept, hipStream_t s);
+hipError_t launch_compact3(const float* x, const float* y, const float* z, size_t n, const uint32_t* flags,
+                           const uint32_t* offs, float* ox, float* oy, float* oz, hipStream_t s);
 
 // ---- f1: packet decode (kernels/decode.hip)
 struct DecodeView {
