@@ -225,6 +225,24 @@ int velo_decode_stream(velo_ctx*, const uint8_t* packets, const int64_t* pkt_t_u
                        size_t n_poses, int flush, const double* crop_region, int crop_inside,
                        int32_t* n_frames, size_t* n_points);
 int velo_decode_stream_reset(velo_ctx*);
+/* The parser's remaining knobs, sticky on the ctx like the reference's setters (defaults: every
+ * laser, no skipping, start at block 0):
+ *   laser_selection[i] != 0  laser i is kept -- setLaserSelection (HDLParser.h:106-110, consumed at
+ *                            HDLParser.cxx:964; i = the laser id inside the frame: 0..63, or 0..15
+ *                            for a 16-laser sensor);
+ *   points_skip = k          only firing blocks with block % (k+1) == 0 are decoded --
+ *                            setPointsSkip (HDLParser.h:119, HDLParser.cxx:1042); frame splitting
+ *                            still looks at every block;
+ *   initial_firing_skip      the first packet of a parse that starts from fresh state begins at this
+ *                            block -- the `skip` argument of the offline re-read HDLParser::getFrame
+ *                            (HDLParser.cxx:505-544, consumed at :1013). */
+typedef struct velo_decode_opts {
+    uint32_t struct_size; /* = sizeof(velo_decode_opts) */
+    int32_t points_skip;
+    int32_t initial_firing_skip;
+    uint8_t laser_selection[64];
+} velo_decode_opts;
+int velo_decode_set_options(velo_ctx*, const velo_decode_opts* opts); /* NULL = defaults */
 /* Copy the last decode back; any pointer may be NULL.  frame_start: n_frames+1; beam_start:
  * n_frames x 65 (absolute offsets); packet_index: index of the source packet of each point. */
 int velo_decode_fetch(velo_ctx*, float* x, float* y, float* z, float* intensity, uint16_t* azimuth,

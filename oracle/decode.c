@@ -134,6 +134,13 @@ void vo_decoder_set_crop(vo_decoder* d, int enable, int crop_inside, const doubl
     if (region) memcpy(d->region, region, sizeof d->region);
 }
 void vo_decoder_set_skip(vo_decoder* d, int s) { d->firing_skip = s; }
+/* setLaserSelection (HDLParser.h:106-110; consumed at HDLParser.cxx:964, indexed by laser id) */
+void vo_decoder_set_laser_selection(vo_decoder* d, const unsigned char sel[64])
+{
+    for (int i = 0; i < 64; ++i) d->laser_sel[i] = sel[i] ? 1 : 0;
+}
+/* setPointsSkip (HDLParser.h:119; consumed at HDLParser.cxx:1042) */
+void vo_decoder_set_points_skip(vo_decoder* d, int s) { d->points_skip = s < 0 ? 0 : s; }
 int vo_decoder_num_frames(const vo_decoder* d) { return (int)d->nframes; }
 
 /* HDLParser.cxx:867-897 */

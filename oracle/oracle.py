@@ -93,6 +93,8 @@ def lib():
     L.vo_decoder_free.argtypes = [C.c_void_p]
     L.vo_decoder_set_crop.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
     L.vo_decoder_set_skip.argtypes = [C.c_void_p, C.c_int]
+    L.vo_decoder_set_laser_selection.argtypes = [C.c_void_p, C.c_char_p]
+    L.vo_decoder_set_points_skip.argtypes = [C.c_void_p, C.c_int]
     L.vo_decoder_packet.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64]
     L.vo_decoder_flush.argtypes = [C.c_void_p]
     L.vo_decoder_num_frames.argtypes = [C.c_void_p]
@@ -290,6 +292,12 @@ class Decoder:
 
     def set_skip(self, s):
         lib().vo_decoder_set_skip(self.h, int(s))
+
+    def set_laser_selection(self, sel):
+        lib().vo_decoder_set_laser_selection(self.h, bytes(bytearray(int(bool(v)) for v in sel)))
+
+    def set_points_skip(self, s):
+        lib().vo_decoder_set_points_skip(self.h, int(s))
 
     def packet(self, data, t_us):
         return lib().vo_decoder_packet(self.h, bytes(data), len(data), int(t_us))

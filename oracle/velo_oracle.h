@@ -101,6 +101,8 @@ vo_decoder* vo_decoder_new(const vo_laser_corr corr[64], int n_lasers, const vo_
 void vo_decoder_free(vo_decoder*);
 void vo_decoder_set_crop(vo_decoder*, int enable, int crop_inside, const double region[6]);
 void vo_decoder_set_skip(vo_decoder*, int firing_skip);
+void vo_decoder_set_laser_selection(vo_decoder*, const unsigned char sel[64]);
+void vo_decoder_set_points_skip(vo_decoder*, int points_skip);
 /* HDLParser.cxx:980-1055.  Returns number of frames completed so far. */
 int vo_decoder_packet(vo_decoder*, const unsigned char* data, size_t len, int64_t t_us);
 int vo_decoder_flush(vo_decoder*); /* splitFrame(force) like getFrame's tail, :541 */

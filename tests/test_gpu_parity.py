@@ -687,6 +687,58 @@ def test_gpu_decode_matches_oracle_parser(ctx, oracle, az_start, azcorr, with_po
     assert g["n_points"] == sum(dec.beam(f, b)[0].size for f in range(dec.num_frames) for b in range(64))
 
 
+@pytest.mark.parametrize("skip,first_block,n_lasers", [(0, 0, 64), (1, 0, 64), (2, 5, 64), (0, 7, 64), (1, 3, 16)])
+def test_gpu_decode_options_match_oracle_parser(oracle, skip, first_block, n_lasers):
+    """The parser's remaining knobs (velo_decode_set_options): laser selection
+    (HDLParser.cxx:964), pointsSkip (:1042) and the initial firing skip of the offline re-read
+    (HDLParser::getFrame, :505-544 / :1013) -- one shot and as a chunked stream, bit for bit."""
+    pk, ts, cal, mo = _stream(3, 20000)
+    if n_lasers == 16:
+        pk = [bytes(bytearray(b"".join(bytes([0xFF, 0xEE]) + p[100 * k + 2:100 * (k + 1)] for k in range(12)) + p[1200:]))
+              for p in pk]
+    rng = np.random.default_rng(skip * 10 + first_block)
+    sel = (rng.uniform(0, 1, 64) < 0.7).astype(np.uint8)
+    sel[3] = 0
+    track = mo.ins_track(ts[0], ts[-1])
+    tl = oracle.Timeline()
+    for (T, R, V, t) in track:
+        tl.add(T, R, V, t)
+    dec = oracle.Decoder(cal, n_lasers, tl)
+    dec.set_laser_selection(sel)
+    dec.set_points_skip(skip)
+    dec.set_skip(first_block)
+    for p, t in zip(pk, ts):
+        dec.packet(p, t)
+    dec.flush()
+    poses, n = capi.make_poses(track)
+    c = capi.Context(0, max_batch=4)
+    try:
+        c.decode_set_options(sel, skip, first_block)
+        g = c.decode(pk, ts, cal, n_lasers, poses, n, flush=True)
+        _check_decode(oracle, g, dec, dec.num_frames)
+        assert 0 < g["n_points"] < 384 * len(pk)
+        # a de-selected laser contributes nothing: its output beam is empty in every frame
+        lut = [38, 39, 42, 43, 32, 33, 36, 37, 40, 41, 46, 47, 50, 51, 54, 55, 44, 45, 48, 49, 52, 53, 58, 59, 62, 63,
+               34, 35, 56, 57, 60, 61, 6, 7, 10, 11, 0, 1, 4, 5, 8, 9, 14, 15, 18, 19, 22, 23, 12, 13, 16, 17, 20, 21,
+               26, 27, 30, 31, 2, 3, 24, 25, 28, 29]
+        if n_lasers == 64:
+            b3 = lut.index(3)
+            assert all(g["beam_start"][f, b3] == g["beam_start"][f, b3 + 1] for f in range(g["n_frames"]))
+        # the same through the stateful stream, in uneven chunks; the initial skip applies once
+        c.decode_stream_reset()
+        got, cuts = [], [0, 7, 8, 300, 301, 555, len(pk)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            got.append(c.decode(pk[a:b], ts[a:b], cal, n_lasers, poses, n, flush=(b == len(pk)), stream=True))
+        assert sum(x["n_frames"] for x in got) == dec.num_frames
+        assert sum(x["n_points"] for x in got) == g["n_points"]
+        # defaults restore the full decode
+        c.decode_set_options()
+        full = c.decode(pk, ts, cal, n_lasers, poses, n, flush=True)
+        assert full["n_points"] > g["n_points"]
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("n_lasers", [32, 16])
 def test_gpu_decode_32_and_16_laser_timing(ctx, oracle, n_lasers):
     """HDL-32 / VLP-16 packets (every firing block carries the 0xeeff id): the per-laser

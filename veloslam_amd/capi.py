@@ -45,6 +45,11 @@ class InsPVA(C.Structure):
                 ("V", C.c_double * 3), ("Eulr", C.c_double * 3), ("ins_status", C.c_int32)]
 
 
+class DecodeOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("points_skip", C.c_int32), ("initial_firing_skip", C.c_int32),
+                ("laser_selection", C.c_uint8 * 64)]
+
+
 class IcpIter(C.Structure):
     _fields_ = [("n_pairs", C.c_uint32), ("solve_flag", C.c_uint32), ("rmse", C.c_double)]
 
@@ -70,7 +75,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
+    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
     "velo_exchange_increments", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
@@ -143,6 +148,7 @@ def lib():
                               vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
     L.velo_decode_stream.argtypes = L.velo_decode.argtypes
     L.velo_decode_stream_reset.argtypes = [vp]
+    L.velo_decode_set_options.argtypes = [vp, C.POINTER(DecodeOpts)]
     L.velo_decode_fetch.argtypes = [vp] * 13
     L.velo_decode_to_frames.argtypes = [vp]
     L.velo_increment.argtypes = [vp, C.c_int, dp, C.c_int, vp, vp, vp, C.POINTER(C.c_size_t)]
@@ -554,6 +560,15 @@ class Context:
             C.cast(car, C.c_void_p), _p(out["frame_t_us"]), _p(out["frame_packets"])))
         out["carposes"] = car
         return out
+
+    def decode_set_options(self, laser_selection=None, points_skip=0, initial_firing_skip=0):
+        o = DecodeOpts()
+        o.struct_size = C.sizeof(DecodeOpts)
+        o.points_skip = points_skip
+        o.initial_firing_skip = initial_firing_skip
+        for i in range(64):
+            o.laser_selection[i] = 1 if laser_selection is None else int(bool(laser_selection[i]))
+        self._chk(lib().velo_decode_set_options(self.h, C.byref(o)))
 
     def decode_stream_reset(self):
         self._chk(lib().velo_decode_stream_reset(self.h))

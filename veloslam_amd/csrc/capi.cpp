@@ -165,6 +165,7 @@ struct velo_ctx {
     std::vector<int32_t> dk_beam_start, dk_frame_packets;
     std::vector<velo_pose> dk_carposes;
 
+    velo_decode_opts dopts{};  // laser selection, points skip, initial firing skip (sticky)
     // parser state carried across velo_decode_stream calls (HDLParser is stateful across packets)
     struct DecodeStream {
         int last_az = -1, firing_skip = 0;
@@ -961,6 +962,8 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
         return nullptr;
     }
     c->stream = c->own_stream;
+    c->dopts.struct_size = sizeof c->dopts;
+    std::memset(c->dopts.laser_selection, 1, sizeof c->dopts.laser_selection);
     return c.release();
 }
 
@@ -1697,7 +1700,10 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     c->dk_carposes.clear();
     c->dk_frame_t.clear();
     c->dk_frame_packets.clear();
-    int last_az = st.last_az, firing_skip = st.firing_skip, cur = 0;
+    // a parse that starts from fresh state begins at the configured block (getFrame's `skip`)
+    const bool fresh = !st.inited && !st.open && st.t.empty() && st.last_az == -1;
+    int last_az = st.last_az, firing_skip = fresh ? c->dopts.initial_firing_skip : st.firing_skip, cur = 0;
+    const int pskip = c->dopts.points_skip;
     bool inited = st.inited, is_hdl64 = st.is_hdl64;
     veloslam::PoseTransform carpose = st.carpose;
     auto open_frame = [&]() {
@@ -1754,7 +1760,8 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
                 open_frame();
                 inited = false;
             }
-            blk[p * 12 + block] = (int16_t)cur;
+            // :1042 -- a skipped block still takes part in the split logic above
+            if (pskip == 0 || block % (pskip + 1) == 0) blk[p * 12 + block] = (int16_t)cur;
             last_az = rot;
         }
     }
@@ -1832,6 +1839,9 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     v.az_cos = c->dk_azc.p;
     v.az_sin = c->dk_azs.p;
     v.inv_lut = c->dk_invlut.p;
+    v.laser_mask = 0;
+    for (int i = 0; i < 64; ++i)
+        if (c->dopts.laser_selection[i]) v.laser_mask |= 1ull << i;
     v.n_pkt = (int)n_pkt;
     v.n_lasers = n_lasers;
     v.crop = crop_region != nullptr;
@@ -1904,6 +1914,23 @@ int velo_decode_stream(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t
     }
     return decode_impl(c, c->dstream, packets, pkt_t_us, n_pkt, corr, n_lasers, poses, n_poses, flush,
                        crop_region, crop_inside, true, n_frames, n_points);
+}
+
+int velo_decode_set_options(velo_ctx* c, const velo_decode_opts* o)
+{
+    if (!c) return VELO_E_INVALID;
+    velo_decode_opts d{};
+    d.struct_size = sizeof d;
+    std::memset(d.laser_selection, 1, sizeof d.laser_selection);
+    if (o) {
+        if (o->struct_size < sizeof d) return c->fail(VELO_E_INVALID, "velo_decode_opts.struct_size too small");
+        if (o->points_skip < 0 || o->initial_firing_skip < 0 || o->initial_firing_skip > 12)
+            return c->fail(VELO_E_INVALID, "points_skip must be >= 0, initial_firing_skip in [0,12]");
+        d = *o;
+        d.struct_size = sizeof d;
+    }
+    c->dopts = d;
+    return VELO_OK;
 }
 
 int velo_decode_stream_reset(velo_ctx* c)

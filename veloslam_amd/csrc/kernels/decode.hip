@@ -68,6 +68,7 @@ __device__ __forceinline__ Ret classify(const DecodeView& v, size_t r)
     o.intensity = lr[2];
     if (o.raw_dist == 0) return o;
     if (laser >= v.n_lasers && v.n_lasers < 64) return o;  // no such beam in the frame
+    if (!((v.laser_mask >> laser) & 1ull)) return o;       // de-selected laser (:964)
     o.laser = laser;
     o.azimuth = (unsigned short)((unsigned short)(rot + az_adj) % 36000);
     o.frame = fr;

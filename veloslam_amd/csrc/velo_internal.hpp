@@ -185,6 +185,7 @@ struct DecodeView {
     const double* az_cos;       // 64 * 36000 (rows of lasers with azimuthCorrection != 0)
     const double* az_sin;
     const uint8_t* inv_lut;     // 64
+    unsigned long long laser_mask;  // bit i: laser id i is selected (HDLParser.cxx:964)
     int n_pkt, n_lasers;
     int crop, crop_inside;
     double region[6];
