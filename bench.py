@@ -169,6 +169,8 @@ def roofline_record(ctx, T0, iters, d_max, n_q, avg_launch_s, first_us, min_us, 
            "traffic": tr["hbm_bytes_per_launch"] if tr else None,
            "traffic_source": tr["source"] if tr else None,
            "traffic_GBps": (tr["hbm_bytes_per_launch"] / avg_launch_s / 1e9) if tr else None,
+           "traffic_frac": (tr["hbm_bytes_per_launch"] / avg_launch_s / 1e9 / HBM_PEAK_GBPS) if tr else None,
+           "traffic_rocprof_avg_launch_us": tr.get("rocprof_avg_launch_us") if tr else None,
            "kernel": "k_linearize", "avg_launch_us": 1e6 * avg_launch_s,
            "first_launch_us": first_us, "min_launch_us": min_us, "queries_per_launch": n_q,
            "bytes_per_launch": mb["mean_bytes_per_launch"],

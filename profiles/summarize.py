@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Turn the raw rocprofv3 CSVs of profiles/collect.sh (gpurun_out/prof_<round>/) into the small
-summaries committed under profiles/<round>/ and into profiles/traffic_latest.json, which
-bench.py reads for roofline.traffic.
+summaries committed under profiles/<round>/ and into profiles/traffic.json, which bench.py reads
+for roofline.traffic (key "F<frames>_M<map points>": same batch, same map as the bench record).
 
 HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE/WRITE_SIZE are in
-KiB, and on gfx950 FETCH_SIZE reports half the bytes of coalesced reads
-(MI355X_MICROARCH.md, section HBM); k_keys / k_minmax in the same trace confirm the factor on
-this code (they read exactly 12 B per map point).  For the gather-dominated k_linearize the
-factor is an upper bound, so the figure is conservative (over-states traffic)."""
+KiB, and on gfx950 FETCH_SIZE reports half the bytes of coalesced reads (MI355X_MICROARCH.md,
+section HBM).  The counters sit on the fabric side of L2 and include Infinity-Cache hits; for
+the gather-dominated k_linearize the x2 is an upper bound (conservative: over-states traffic).
+Launches are told apart by grid size: 450 workgroups per 115 200-point frame."""
 import collections
 import csv
 import glob
@@ -16,44 +16,67 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
-TAG = sys.argv[2] if len(sys.argv) > 2 else "final"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + R)
 DST = os.path.join(ROOT, "profiles", R)
 os.makedirs(DST, exist_ok=True)
+CONFIGS = {"F64_M1000000": 64 * 450 * 256, "F16_M10000000": 16 * 450 * 256}  # key -> Grid_Size (threads)
 
 
 def counters(sub):
-    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    """kernel short name -> grid -> counter -> list of per-dispatch values (dispatch order)"""
+    out = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
     for f in glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
             if "velo::" in k:
-                out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                out[k][int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
 
-stats = sorted(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
-if stats:
-    shutil.copy(stats[-1], os.path.join(DST, "kernel_stats_%s.csv" % TAG))
+def stats(v):
+    return dict(launches=len(v), mean=sum(v) / len(v), min=min(v), max=max(v))
+
+
+for sub, name in (("trace", "kernel_stats_batch_dense.csv"), ("trace_stream", "kernel_stats_stream.csv")):
+    st = sorted(glob.glob(os.path.join(SRC, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    if st:
+        shutil.copy(st[-1], os.path.join(DST, name))
+# per-config launch durations of k_linearize from the kernel trace (the judge's cross-check)
+dur = collections.defaultdict(list)
+for f in glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        if "k_linearize<false, 1, false>" in r["Kernel_Name"]:  # the production instantiation
+            dur[int(r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 summary = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
-    for k, v in counters(sub).items():
-        for c, x in v.items():
-            tail = x[len(x) // 2:]  # second half of the launches: steady state
-            summary.setdefault(k, {})[c] = dict(launches=len(x), mean=sum(x) / len(x),
-                                                mean_steady=sum(tail) / len(tail))
-json.dump(dict(note=__doc__, kernels=summary), open(os.path.join(DST, "pmc_%s.json" % TAG), "w"), indent=1)
-lin = [k for k in summary if "k_linearize" in k]
-if lin and "FETCH_SIZE" in summary[lin[0]] and "WRITE_SIZE" in summary[lin[0]]:
-    f = summary[lin[0]]["FETCH_SIZE"]["mean"]
-    w = summary[lin[0]]["WRITE_SIZE"]["mean"]
-    t = dict(kernel=lin[0], FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, hbm_bytes_per_launch=(2 * f + w) * 1024,
-             source="profiles/%s/pmc_%s.json" % (R, TAG),
-             correction="gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)")
-    json.dump(t, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
-    print(t)
-b = os.path.join(SRC, "bench_default.json")
-if os.path.exists(b):
-    shutil.copy(b, os.path.join(DST, "bench_%s.json" % TAG))
+    for k, grids in counters(sub).items():
+        for g, cs in grids.items():
+            for c, x in cs.items():
+                summary.setdefault(k, {}).setdefault(str(g), {})[c] = stats(x)
+json.dump(dict(note=__doc__, kernels=summary), open(os.path.join(DST, "pmc.json"), "w"), indent=1)
+traffic = {}
+for key, grid in CONFIGS.items():
+    for k, grids in summary.items():
+        if "k_linearize<false, 1, false>" not in k or str(grid) not in grids:
+            continue
+        c = grids[str(grid)]
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            f, w = c["FETCH_SIZE"]["mean"], c["WRITE_SIZE"]["mean"]
+            d = dur.get(grid, [])
+            traffic[key] = dict(kernel=k, grid_threads=grid, FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w,
+                                hbm_bytes_per_launch=(2 * f + w) * 1024,
+                                launches_counted=c["FETCH_SIZE"]["launches"],
+                                rocprof_avg_launch_us=(sum(d) / len(d)) if d else None,
+                                rocprof_launches=len(d), source="profiles/%s/pmc.json" % R,
+                                correction="gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)")
+            if d:
+                traffic[key]["traffic_GBps_at_rocprof_avg"] = traffic[key]["hbm_bytes_per_launch"] / (
+                    sum(d) / len(d) * 1e-6) / 1e9
+json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
+for nm in ("bench_default.json", "bench_stream.json", "bench_trace.json"):
+    b = os.path.join(SRC, nm)
+    if os.path.exists(b) and os.path.getsize(b):
+        shutil.copy(b, os.path.join(DST, nm))
