@@ -45,7 +45,7 @@ enum {
     VELO_E_NOMAP = -2,    /* registration asked before velo_map_reset */
     VELO_E_DEVICE = -3,   /* HIP runtime error (see velo_last_error) */
     VELO_E_NOMEM = -4,
-    VELO_E_RANGE = -5,    /* grid too large / d_max > voxel / too many frames */
+    VELO_E_RANGE = -5,    /* grid beyond the 32-bit fine key / d_max > voxel / too many frames */
     VELO_E_NODATA = -6    /* empty pose store etc. */
 };
 
@@ -74,7 +74,11 @@ typedef struct velo_cfg {
                                slack update the sorted map incrementally (default 0 = tight) */
     int32_t map_full_rebuild; /* 1: every append/evict re-sorts and re-estimates the whole map
                                (same result; A/B switch for the incremental update) */
-    int32_t reserved[6];
+    int32_t map_hash_load;  /* fine-cell table.  0 (default): the dense prefix table while it has
+                               < 2^31 entries, an open-addressing hash over the occupied cells
+                               (load factor 0.5) beyond that; 5..90: always the hash, at that load
+                               factor in percent.  Same sorted order, same results either way. */
+    int32_t reserved[5];
 } velo_cfg;
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */
@@ -118,6 +122,10 @@ typedef struct velo_map_info {
     int32_t last_update;  /* how the last reset/append/evict was applied: 0 = full build on a
                              freshly anchored grid, 1 = incremental on the kept grid */
     uint64_t n_normals_recomputed; /* normals estimated by that update */
+    int32_t table_kind;   /* 0 = dense prefix table, 1 = hash over the occupied fine cells */
+    int32_t reserved;
+    uint64_t table_slots; /* entries of the dense table / slots of the hash */
+    uint64_t table_occupied; /* hash: occupied fine cells (load = occupied / slots); dense: 0 */
 } velo_map_info;
 
 /* ---- lifetime -------------------------------------------------------------- */

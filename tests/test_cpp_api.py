@@ -16,7 +16,10 @@ EXE = os.path.join(ROOT, "tests", "cpp", "api_smoke")
 def build_exe():
     src = os.path.join(ROOT, "tests", "cpp", "api_smoke.cpp")
     csrc = os.path.join(ROOT, "veloslam_amd", "csrc")
-    if (not os.path.exists(EXE)) or os.path.getmtime(EXE) < os.path.getmtime(src):
+    import glob
+    deps = [src, os.path.join(csrc, "libveloslam_amd.so")] + glob.glob(os.path.join(ROOT, "include", "*.h")) + \
+        glob.glob(os.path.join(ROOT, "include", "veloslam", "*.hpp"))
+    if (not os.path.exists(EXE)) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["hipcc", "-std=c++17", "-O2", "-x", "c++", src, "-I", os.path.join(ROOT, "include"),
                                "-L", csrc, "-lveloslam_amd", "-Wl,-rpath," + csrc, "-o", EXE])
     return EXE

@@ -973,9 +973,9 @@ def test_config4_size_100m_map_knn32_properties():
 
 
 def test_huge_extent_lowers_subdivision():
-    """A map whose dense fine-cell table would exceed 2^31 entries at the configured
-    sub-division is indexed at the largest sub-division that fits (reported in map_info);
-    registration queries still work."""
+    """A map whose fine grid would exceed the 32-bit fine key at the configured sub-division is
+    indexed at the largest sub-division that fits (reported in map_info) -- through the sparse
+    table, since even that grid has more than 2^31 cells; registration queries still work."""
     rng = np.random.default_rng(4)
     a = rng.uniform(0, 30, (3, 3000)).astype(np.float32)
     b = a.copy()
@@ -986,7 +986,9 @@ def test_huge_extent_lowers_subdivision():
     try:
         c.map_reset(m[0], m[1], m[2], 1.0, 8)
         mi = c.map_info()
-        assert mi.subdiv == 1 and mi.n_cells == int(mi.dims[0]) * int(mi.dims[1]) * int(mi.dims[2])
+        # 2.7e8 voxels: x27 = 7.4e9 cells do not fit a 32-bit key, x8 = 2.2e9 do (round 1: S = 1)
+        assert mi.subdiv == 2 and mi.n_cells == 8 * int(mi.dims[0]) * int(mi.dims[1]) * int(mi.dims[2])
+        assert mi.table_kind == 1 and mi.n_cells > 2 ** 31
         q = a[:, :500] + np.float32(0.01)
         c.frames_upload([tuple(q)])
         I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)

@@ -30,7 +30,7 @@ class Cfg(C.Structure):
                 ("linearize_variant", C.c_int32), ("sort_frames", C.c_int32),
                 ("use_graph", C.c_int32), ("map_subdiv", C.c_int32), ("use_hints", C.c_int32),
                 ("rounds_per_block", C.c_int32), ("map_margin", C.c_int32),
-                ("map_full_rebuild", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("map_full_rebuild", C.c_int32), ("map_hash_load", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class Pose(C.Structure):
@@ -65,7 +65,8 @@ class MapInfo(C.Structure):
                 ("voxel", C.c_float), ("inv_voxel", C.c_float), ("dims", C.c_int32 * 3),
                 ("k_normals", C.c_int32), ("n_invalid_normals", C.c_uint64),
                 ("subdiv", C.c_int32), ("last_update", C.c_int32),
-                ("n_normals_recomputed", C.c_uint64)]
+                ("n_normals_recomputed", C.c_uint64), ("table_kind", C.c_int32), ("reserved", C.c_int32),
+                ("table_slots", C.c_uint64), ("table_occupied", C.c_uint64)]
 
 
 # every symbol include/velo.h declares (tests check the library exports them all)
@@ -326,7 +327,8 @@ class Context:
     """One velo_ctx: one GPU, one stream, single-threaded."""
 
     def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=1, map_subdiv=3,
-                 use_hints=2, use_graph=1, rounds_per_block=0, map_margin=0, map_full_rebuild=0):
+                 use_hints=2, use_graph=1, rounds_per_block=0, map_margin=0, map_full_rebuild=0,
+                 map_hash_load=0):
         L = lib()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -339,6 +341,7 @@ class Context:
         cfg.rounds_per_block = rounds_per_block
         cfg.map_margin = map_margin
         cfg.map_full_rebuild = map_full_rebuild
+        cfg.map_hash_load = map_hash_load
         self.h = L.velo_create(device, C.byref(cfg))
         if not self.h:
             raise VeloError(-3, L.velo_last_error(None).decode())
@@ -453,6 +456,13 @@ class Context:
                                                     ("x", "y", "z", "nx", "ny", "nz", "perm",
                                                      "cell_start")]))
         return out
+
+    def map_download_perm(self):
+        """only the sort permutation (maps whose dense table is too large to copy back)"""
+        n = self.map_info().n_points
+        perm = np.empty(n, np.int32)
+        self._chk(lib().velo_map_download(self.h, None, None, None, None, None, None, _p(perm), None))
+        return perm
 
     # ---- K1
     def compensate(self, x, y, z, pkt, table):

@@ -65,6 +65,9 @@ struct velo_ctx {
     DevBuf<uint32_t> keys, keys_sorted, idx, perm;
     DevBuf<float4> pts, nrm;
     DevBuf<int32_t> cell_start;
+    DevBuf<int4> hash_tab;     // sparse fine-cell table (cfg.map_hash_load / extents beyond 2^31 cells)
+    DevBuf<unsigned long long> run_cnt;  // scratch: occupied fine cells
+    bool use_hash = false;
     DevBuf<unsigned> mm_scratch;
     DevBuf<unsigned long long> invalid_cnt;
     // incremental update (f3): second set of sorted arrays (swapped in), new-point keys,
@@ -279,6 +282,11 @@ int publish_map(velo_ctx* c, MapView mv, int k_normals, unsigned long long inval
     c->info.dims[2] = mv.nz;
     c->info.k_normals = k_normals;
     c->info.subdiv = mv.S;
+    c->info.table_kind = mv.cell_start ? 0 : 1;
+    if (mv.cell_start) {
+        c->info.table_slots = (uint64_t)mv.fx * mv.fy * mv.fz + 1;
+        c->info.table_occupied = 0;
+    }
     c->info.n_invalid_normals = invalid;
     c->info.last_update = last_update;
     c->info.n_normals_recomputed = n_recomputed;
@@ -293,6 +301,40 @@ int publish_map(velo_ctx* c, MapView mv, int k_normals, unsigned long long inval
 // without one).  A normal depends on the point list only, so they are permuted into the new
 // order and only the neighbourhoods of fresh points -- and of the removed points
 // old_pts[i] with removed_keep[i] == 0 -- are re-estimated.
+// Fine-cell table over the sorted keys: the dense prefix table, or -- when it would pass 2^31
+// entries, or when cfg.map_hash_load asks for it -- an open-addressing hash over the occupied
+// cells only (capacity = occupied / load factor, rounded up to a power of two).
+int build_table(velo_ctx* c, MapView& mv, const uint32_t* keys_sorted, size_t n, size_t ncell)
+{
+    hipStream_t s = c->stream;
+    if (!c->use_hash) {
+        if (ncell + 8 > c->cell_start.cap) HIP_TRY(c, hipStreamSynchronize(s));  // queued readers
+        HIP_TRY(c, c->cell_start.reserve(ncell + 8));  // +1 entry, padded: rows are read 4 entries at a time
+        HIP_TRY(c, launch_cell_start(keys_sorted, n, ncell, c->cell_start.p, s));
+        mv.cell_start = c->cell_start.p;
+        mv.hash = nullptr;
+        mv.hash_cap = 0;
+        return VELO_OK;
+    }
+    HIP_TRY(c, c->run_cnt.reserve(1));
+    HIP_TRY(c, launch_count_runs(keys_sorted, n, c->run_cnt.p, s));
+    unsigned long long occ = 0;
+    HIP_TRY(c, hipMemcpyAsync(&occ, c->run_cnt.p, sizeof occ, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const int pct = c->cfg.map_hash_load > 0 ? std::min(std::max(c->cfg.map_hash_load, 5), 90) : 50;
+    const double want = std::ceil((double)std::max<unsigned long long>(occ, 1) * 100.0 / (double)pct) + 1.0;
+    if (want >= 4294967295.0) return c->fail(VELO_E_RANGE, "hash table of %.3g slots", want);
+    const size_t cap = (size_t)std::max(want, 16.0);
+    HIP_TRY(c, c->hash_tab.reserve(cap));
+    HIP_TRY(c, launch_hash_build(keys_sorted, n, c->hash_tab.p, (uint32_t)cap, s));
+    mv.cell_start = nullptr;
+    mv.hash = c->hash_tab.p;
+    mv.hash_cap = (uint32_t)cap;
+    c->info.table_slots = cap;
+    c->info.table_occupied = occ;
+    return VELO_OK;
+}
+
 struct CarryNormals {
     const uint32_t* removed_keep = nullptr;  // flags over the OLD sorted order (0 = removed)
     uint32_t removed_n = 0;
@@ -331,12 +373,17 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     }
     // sub-division: as configured, lowered (never raised) until the dense fine-cell table fits
     // 2^31 entries; the value actually used is reported in velo_map_info.subdiv
+    // The dense table holds < 2^31 entries; past that (or on request) the table is a hash over
+    // the occupied cells and only the 32-bit fine KEY limits the grid: < 2^32 - 1 cells.  The
+    // sub-division is lowered (never raised) only when even that does not fit.
     int S = c->map_S;
-    while (S > 1 && ncell_d * (double)S * S * S >= 2147483648.0) --S;
+    const double key_limit = 4294967295.0;
+    while (S > 1 && ncell_d * (double)S * S * S >= key_limit) --S;
     ncell_d *= (double)S * S * S;
-    if (ncell_d >= 2147483648.0)
-        return c->fail(VELO_E_RANGE, "dense voxel grid of %.3g cells exceeds 2^31 even without "
-                       "sub-division (sparse/hashed grids are a later row)", ncell_d);
+    if (ncell_d >= key_limit)
+        return c->fail(VELO_E_RANGE, "voxel grid of %.3g cells exceeds the 32-bit fine key even "
+                       "without sub-division", ncell_d);
+    c->use_hash = c->cfg.map_hash_load > 0 || ncell_d >= 2147483648.0;
     const int fdims[3] = {dims[0] * S, dims[1] * S, dims[2] * S};
     const size_t ncell = (size_t)fdims[0] * fdims[1] * fdims[2];
     HIP_TRY(c, c->keys.reserve(n));
@@ -350,8 +397,6 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
         HIP_TRY(c, c->pts.reserve(n));
         HIP_TRY(c, c->nrm.reserve(n));
     }
-    if (ncell + 8 > c->cell_start.cap) HIP_TRY(c, hipStreamSynchronize(s));
-    HIP_TRY(c, c->cell_start.reserve(ncell + 8));  // +1 entry, padded: rows are read 4 entries at a time
     HIP_TRY(c, c->invalid_cnt.reserve(1));
     HIP_TRY(c, launch_keys(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, org[0], org[1], org[2],
                            inv_h, S, fdims[0], fdims[1], c->keys.p, c->idx.p, s));
@@ -372,11 +417,10 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     } else {
         HIP_TRY(c, launch_gather(c->raw_x.p, c->raw_y.p, c->raw_z.p, c->perm.p, n, c->pts.p, s));
     }
-    HIP_TRY(c, launch_cell_start(c->keys_sorted.p, n, ncell, c->cell_start.p, s));
     MapView mv{};
+    if (int rc = build_table(c, mv, c->keys_sorted.p, n, ncell)) return rc;
     mv.pts = c->pts.p;
     mv.nrm = c->nrm.p;
-    mv.cell_start = c->cell_start.p;
     mv.ox = org[0];
     mv.oy = org[1];
     mv.oz = org[2];
@@ -507,7 +551,8 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     }
     const int S = old.S;
     const double ncell_d = (double)dims[0] * dims[1] * dims[2] * (double)S * S * S;
-    if (ncell_d >= 2147483648.0) return VELO_OK;  // let the full path lower S or refuse
+    // past the table's limit: let the full path switch to the sparse table, lower S or refuse
+    if (ncell_d >= (c->use_hash ? 4294967295.0 : 2147483648.0)) return VELO_OK;
     MapView g = old;
     g.nx = dims[0];
     g.ny = dims[1];
@@ -544,7 +589,9 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
                             c->raw_x.p, c->raw_y.p, c->raw_z.p, (uint32_t)n_old, c->nk_sorted.p,
                             c->nidx_sorted.p, (uint32_t)m, c->pts_alt.p, c->nrm_alt.p,
                             c->perm_alt.p, c->keys_alt.p, s));
-    if (grew) {
+    if (c->use_hash) {  // sparse table: re-hashed from the merged keys (O(points), no table pass)
+        if (int rc = build_table(c, g, c->keys_alt.p, total, ncell)) return rc;
+    } else if (grew) {
         HIP_TRY(c, hipStreamSynchronize(s));  // the old table may still be read by queued work
         HIP_TRY(c, c->cell_start.reserve(ncell + 8));
         HIP_TRY(c, launch_cell_start(c->keys_alt.p, total, ncell, c->cell_start.p, s));
@@ -561,7 +608,7 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     std::swap(c->keys_sorted.cap, c->keys_alt.cap);
     g.pts = c->pts.p;
     g.nrm = c->nrm.p;
-    g.cell_start = c->cell_start.p;
+    if (!c->use_hash) g.cell_start = c->cell_start.p;
     g.n = (int)total;
     unsigned long long invalid = total;
     c->n_done_host = 0;
@@ -1324,7 +1371,12 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
                                      c->offs.p, c->roffs.p, c->pts_alt.p, c->nrm_alt.p,
                                      c->perm_alt.p, c->keys_alt.p, s));
     const size_t ncell = (size_t)old.fx * old.fy * old.fz;
-    HIP_TRY(c, launch_table_remap(c->cell_start.p, ncell + 1, c->offs.p, n, kept, s));
+    MapView g = old;
+    if (c->use_hash) {
+        if (int rc = build_table(c, g, c->keys_alt.p, kept, ncell)) return rc;
+    } else {
+        HIP_TRY(c, launch_table_remap(c->cell_start.p, ncell + 1, c->offs.p, n, kept, s));
+    }
     swap_raw();
     c->raw_n = kept;
     std::swap(c->pts.p, c->pts_alt.p);
@@ -1335,10 +1387,9 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     std::swap(c->perm.cap, c->perm_alt.cap);
     std::swap(c->keys_sorted.p, c->keys_alt.p);
     std::swap(c->keys_sorted.cap, c->keys_alt.cap);
-    MapView g = old;
     g.pts = c->pts.p;
     g.nrm = c->nrm.p;
-    g.cell_start = c->cell_start.p;
+    if (!c->use_hash) g.cell_start = c->cell_start.p;
     g.n = (int)kept;
     unsigned long long invalid = kept;
     c->n_done_host = 0;
@@ -1397,9 +1448,16 @@ int velo_map_download(velo_ctx* c, float* x, float* y, float* z, float* nx, floa
         }
     }
     if (perm) HIP_TRY(c, hipMemcpyAsync(perm, c->perm.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (cell_start)
+    if (cell_start) {
+        if (c->use_hash) {  // the dense prefix table the sparse one stands for, built for the copy
+            if (c->info.n_cells + 8 >= 2147483648ull)
+                return c->fail(VELO_E_RANGE, "the dense cell table of this map has more than 2^31 entries");
+            HIP_TRY(c, c->cell_start.reserve(c->info.n_cells + 8));
+            HIP_TRY(c, launch_cell_start(c->keys_sorted.p, n, c->info.n_cells, c->cell_start.p, c->stream));
+        }
         HIP_TRY(c, hipMemcpyAsync(cell_start, c->cell_start.p, (c->info.n_cells + 1) * sizeof(int32_t),
                                   hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VELO_OK;
 }

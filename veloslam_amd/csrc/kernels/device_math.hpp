@@ -33,6 +33,62 @@ __device__ __forceinline__ float dist2(float4 c, float qx, float qy, float qz)
     return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
 
+// ---- fine-cell lookups: dense prefix table or sparse hash (MapView) ----------------------
+__device__ __forceinline__ uint32_t cell_slot(const MapView& mv, uint32_t key)
+{
+    // multiplicative hash, then a multiply-shift range reduction: any capacity, no division
+    return (uint32_t)(((unsigned long long)(key * 0x9E3779B1u) * mv.hash_cap) >> 32);
+}
+
+// occupied fine cell `key` -> its index range; false = the cell is empty
+__device__ __forceinline__ bool cell_find(const MapView& mv, uint32_t key, int& start, int& end)
+{
+    uint32_t h = cell_slot(mv, key);
+    for (;;) {
+        const int4 e = mv.hash[h];
+        if ((uint32_t)e.x == key) {
+            start = e.y;
+            end = e.z;
+            return true;
+        }
+        if ((uint32_t)e.x == 0xffffffffu) return false;
+        h = h + 1 == mv.hash_cap ? 0u : h + 1;
+    }
+}
+
+// index range [jlo, jhi) of the fine cells x0..x1 (inclusive, x0 <= x1, both inside the row) of
+// the row whose first cell has key `row`.  Cells of a row are consecutive in the sorted order,
+// so in sparse mode the range runs from the first occupied cell's start to the last one's end.
+template <bool HASH>
+__device__ __forceinline__ bool row_range(const MapView& mv, size_t row, int x0, int x1, int& jlo,
+                                          int& jhi)
+{
+    if (!HASH) {
+        jlo = mv.cell_start[row + (size_t)x0];
+        jhi = mv.cell_start[row + (size_t)x1 + 1];
+        return jhi > jlo;
+    }
+    bool any = false;
+    for (int x = x0; x <= x1; ++x) {
+        int a, b;
+        if (cell_find(mv, (uint32_t)(row + (size_t)x), a, b)) {
+            if (!any) jlo = a;
+            jhi = b;
+            any = true;
+        }
+    }
+    if (!any) jlo = jhi = 0;
+    return any;
+}
+
+// run-time form for the kernels outside the iteration loop
+__device__ __forceinline__ bool row_range_rt(const MapView& mv, size_t row, int x0, int x1, int& jlo,
+                                             int& jhi)
+{
+    return mv.cell_start ? row_range<false>(mv, row, x0, x1, jlo, jhi)
+                         : row_range<true>(mv, row, x0, x1, jlo, jhi);
+}
+
 // order-preserving float <-> unsigned map (for atomic min/max on floats)
 __device__ __forceinline__ unsigned enc_f32(float f)
 {

@@ -206,8 +206,8 @@ __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float 
 #pragma unroll 1
         for (int fy = vy0 * S; fy < (vy1 + 1) * S; ++fy) {
             const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
-            const int j0 = mv.cell_start[row + (size_t)vx0 * S];
-            const int j1 = mv.cell_start[row + (size_t)(vx1 + 1) * S];
+            int j0, j1;
+            if (!row_range_rt(mv, row, vx0 * S, (vx1 + 1) * S - 1, j0, j1)) continue;
 #pragma unroll 4
             for (int j = j0; j < j1; ++j) {
                 const float d2 = dist2(mv.pts[j], qx, qy, qz);
@@ -329,7 +329,7 @@ __device__ __forceinline__ int finish_block(float bd, float sd, float gr, float&
     return final ? kFinal : kStraggler;
 }
 
-template <int ABL, bool STATS, int W>
+template <int ABL, bool STATS, int W, bool HASH>
 __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& g, float qx,
                                             float qy, float qz, float ub0, SearchLds& L,
                                             int tid, float& bd, int& bj, float& cert,
@@ -369,11 +369,17 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
                 x1 = min(x1, mv.fx - 1);
                 if (x0 > x1) continue;
                 const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
-                const Int4U e = *reinterpret_cast<const Int4U*>(mv.cell_start + row + xb);
-                tl.table(1, 16);
-                const int a = x0 - xb, b = x1 + 1 - xb;  // both in [0,3]
-                const int jlo = a == 0 ? e.v[0] : (a == 1 ? e.v[1] : (a == 2 ? e.v[2] : e.v[3]));
-                const int jhi = b == 1 ? e.v[1] : (b == 2 ? e.v[2] : (b == 3 ? e.v[3] : e.v[0]));
+                int jlo, jhi;
+                if constexpr (HASH) {
+                    tl.table((unsigned)(x1 - x0 + 1), 16);
+                    row_range<true>(mv, row, x0, x1, jlo, jhi);
+                } else {
+                    const Int4U e = *reinterpret_cast<const Int4U*>(mv.cell_start + row + xb);
+                    tl.table(1, 16);
+                    const int a = x0 - xb, b = x1 + 1 - xb;  // both in [0,3]
+                    jlo = a == 0 ? e.v[0] : (a == 1 ? e.v[1] : (a == 2 ? e.v[2] : e.v[3]));
+                    jhi = b == 1 ? e.v[1] : (b == 2 ? e.v[2] : (b == 3 ? e.v[3] : e.v[0]));
+                }
                 if (jhi > jlo) {
                     L.hi[nr][tid] = jhi;
                     L.lo[nr][tid] = jlo;
@@ -401,7 +407,7 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
 // descending order in chunks of kMaxRanges.  Per chunk the table entries of all its rows are
 // requested together, the surviving ranges staged in LDS and walked like stage A -- two
 // memory round trips per nine rows instead of two per row.
-template <bool STATS>
+template <bool STATS, bool HASH>
 __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, float ub,
                             SearchLds& L, int tid, float& bd, int& bj, Tally<STATS>& tl)
 {
@@ -433,7 +439,8 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
                     const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
                     if (x0 <= x1) {
                         const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
-                        const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
+                        int jlo, jhi;
+                        row_range<HASH>(mv, row, x0, x1, jlo, jhi);
                         tl.table(2, 4);
                         if (jhi > jlo) {
                             L.hi[nr][tid] = jhi;
@@ -460,7 +467,7 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
 // Every lane returns the same winner.  Rows are independent, so all their loads are in
 // flight together: a handful of stragglers no longer costs a serial chain of ~50 dependent
 // loads while the other wavefronts of the workgroup wait at the barrier.
-template <bool STATS>
+template <bool STATS, bool HASH>
 __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, float qy, float qz,
                                                  float ub, int lane, float& bd, int& bj, float& sd,
                                                  Tally<STATS>& tl)
@@ -488,7 +495,8 @@ __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, fl
         const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
         if (x0 > x1) continue;
         const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
-        const int jlo = mv.cell_start[row + x0], jhi = mv.cell_start[row + x1 + 1];
+        int jlo, jhi;
+        row_range<HASH>(mv, row, x0, x1, jlo, jhi);
         tl.table(2, 4);
         tl.candidates((unsigned)max(jhi - jlo, 0));
 #pragma unroll 4
@@ -531,7 +539,7 @@ __device__ __forceinline__ float axis_gap(int d, float t, float hf, float mg)
 
 // index range of fine row (Fz+dz, Fy+dy) inside the ball of squared radius `bound` around the
 // query (conservative: rounded outwards); clip1: only the cells Fx-1..Fx+1.  false = nothing.
-template <bool STATS>
+template <bool STATS, bool HASH>
 __device__ __forceinline__ bool ball_row(const MapView& mv, const QueryCell& g, int dz, int dy,
                                          float bound, float xf, float hf, float inv_hf, float mg,
                                          bool clip1, int& jlo, int& jhi, Tally<STATS>& tl)
@@ -550,10 +558,8 @@ __device__ __forceinline__ bool ball_row(const MapView& mv, const QueryCell& g, 
     }
     if (x0 > x1) return false;
     const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
-    jlo = mv.cell_start[row + x0];
-    jhi = mv.cell_start[row + x1 + 1];
     tl.table(2, 4);
-    return jhi > jlo;
+    return row_range<HASH>(mv, row, x0, x1, jlo, jhi);
 }
 
 // rows of the (2R+1)^2 window a ball of squared radius b can reach (R <= S since b <= h^2)
@@ -564,7 +570,7 @@ __device__ __forceinline__ int ball_window(float b, float inv_hf, int S)
 
 // per-lane form.  Called by every lane of the wavefront (`active` = this lane is a straggler):
 // the loops synchronise with __any.
-template <bool STATS>
+template <bool STATS, bool HASH>
 __device__ void search_ball_lat(const MapView& mv, float qx, float qy, float qz, float ub, bool active,
                                 bool probe, SearchLds& L, int tid, float& bd, int& bj, Tally<STATS>& tl)
 {
@@ -594,7 +600,7 @@ __device__ void search_ball_lat(const MapView& mv, float qx, float qy, float qz,
                 const int dz = side == 0 ? k : (side == 1 ? -k : 0);
                 const int dy = side == 2 ? k : (side == 3 ? -k : 0);
                 int jlo, jhi;
-                if (ball_row(mv, g, dz, dy, pb, xf, hf, inv_hf, mg, true, jlo, jhi, tl)) {
+                if (ball_row<STATS, HASH>(mv, g, dz, dy, pb, xf, hf, inv_hf, mg, true, jlo, jhi, tl)) {
                     L.hi[nr][tid] = jhi;
                     L.lo[nr][tid] = jlo;
                     ++nr;
@@ -621,7 +627,7 @@ __device__ void search_ball_lat(const MapView& mv, float qx, float qy, float qz,
         int nr = 0;
         while (nr < kMaxRanges && dz >= -R) {
             int jlo, jhi;
-            if (ball_row(mv, g, dz, dy, bd, xf, hf, inv_hf, mg, false, jlo, jhi, tl)) {
+            if (ball_row<STATS, HASH>(mv, g, dz, dy, bd, xf, hf, inv_hf, mg, false, jlo, jhi, tl)) {
                 L.hi[nr][tid] = jhi;
                 L.lo[nr][tid] = jlo;
                 ++nr;
@@ -638,7 +644,7 @@ __device__ void search_ball_lat(const MapView& mv, float qx, float qy, float qz,
 
 // cooperative form: as search_ball_wave, over the rows the ball can actually reach, a wide ball
 // bounded first by the axis probe (one probe row per lane)
-template <bool STATS>
+template <bool STATS, bool HASH>
 __device__ __forceinline__ void search_ball_wave_lat(const MapView& mv, float qx, float qy, float qz,
                                                      float ub, int lane, float& bd, int& bj, float& sd,
                                                      Tally<STATS>& tl)
@@ -657,7 +663,7 @@ __device__ __forceinline__ void search_ball_wave_lat(const MapView& mv, float qx
             const int dz = side == 0 ? k : (side == 1 ? -k : 0);
             const int dy = side == 2 ? k : (side == 3 ? -k : 0);
             int jlo, jhi;
-            if (ball_row(mv, g, dz, dy, ub, xf, hf, inv_hf, mg, true, jlo, jhi, tl)) {
+            if (ball_row<STATS, HASH>(mv, g, dz, dy, ub, xf, hf, inv_hf, mg, true, jlo, jhi, tl)) {
                 tl.candidates((unsigned)(jhi - jlo));
                 for (int j = jhi - 1; j >= jlo; --j) pb = fminf(pb, dist2(mv.pts[j], qx, qy, qz));
             }
@@ -677,7 +683,7 @@ __device__ __forceinline__ void search_ball_wave_lat(const MapView& mv, float qx
     for (int r = lane; r < nrows; r += 64) {
         const int dz = R - r / side, dy = R - r % side;
         int jlo, jhi;
-        if (!ball_row(mv, g, dz, dy, ub, xf, hf, inv_hf, mg, false, jlo, jhi, tl)) continue;
+        if (!ball_row<STATS, HASH>(mv, g, dz, dy, ub, xf, hf, inv_hf, mg, false, jlo, jhi, tl)) continue;
         tl.candidates((unsigned)(jhi - jlo));
 #pragma unroll 4
         for (int j = jhi - 1; j >= jlo; --j) {
@@ -728,7 +734,7 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 // issue and occupancy: 72 registers, 7 waves per SIMD).  LAT = true: the latency kernel (a
 // single frame: < 2 workgroups per CU, bound by dependent memory round trips: registers are
 // free, stage B is the packed / probed form above).  Same results bit for bit.
-template <bool WRITE_CORR, int VARIANT, bool STATS, bool LAT>
+template <bool WRITE_CORR, int VARIANT, bool STATS, bool LAT, bool HASH>
 __device__ __forceinline__ void linearize_body(
     const BlockItem* __restrict__ items, const FrameView& fv, const MapView& mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
@@ -825,7 +831,7 @@ __device__ __forceinline__ void linearize_body(
                         empty = mv.vox_near[((size_t)g.cz * mv.ny + g.cy) * mv.nx + g.cx] == 0;
                     tl.add(hj < 0 && mv.vox_near ? 1 : 0);
                     if (!empty)
-                        st = search_block<(VARIANT >= 11 ? VARIANT - 10 : 0), STATS, (LAT ? VELO_WALK_W_LAT : VELO_WALK_W)>(
+                        st = search_block<(VARIANT >= 11 ? VARIANT - 10 : 0), STATS, (LAT ? VELO_WALK_W_LAT : VELO_WALK_W), HASH>(
                             mv, g, qx, qy, qz, ub0, s_u.s, lane, bd, bj, rho_new_out, blk_gr, tl);
                     VELO_COUNT(3, empty);
                     VELO_COUNT(2, !empty);
@@ -842,15 +848,15 @@ __device__ __forceinline__ void linearize_body(
                 if constexpr (LAT) {
                     float rbd = bd;
                     int rbj = bj;
-                    search_ball_lat(mv, qx, qy, qz, queued ? bd : 0.0f, queued, queued && bj < 0, s_u.s, lane,
-                                    rbd, rbj, tl);
+                    search_ball_lat<STATS, HASH>(mv, qx, qy, qz, queued ? bd : 0.0f, queued, queued && bj < 0,
+                                                 s_u.s, lane, rbd, rbj, tl);
                     if (queued) {
                         bd = rbd;
                         bj = rbj;
                     }
                 } else if (queued) {
                     const float ub = bd;
-                    search_ball(mv, qx, qy, qz, ub, s_u.s, lane, bd, bj, tl);
+                    search_ball<STATS, HASH>(mv, qx, qy, qz, ub, s_u.s, lane, bd, bj, tl);
                 }
             } else {
                 while (need) {
@@ -866,9 +872,9 @@ __device__ __forceinline__ void linearize_body(
                     float rbd, rsd;
                     int rbj;
                     if constexpr (LAT)
-                        search_ball_wave_lat(mv, sx, sy, sz, sub, lane, rbd, rbj, rsd, tl);
+                        search_ball_wave_lat<STATS, HASH>(mv, sx, sy, sz, sub, lane, rbd, rbj, rsd, tl);
                     else
-                        search_ball_wave(mv, sx, sy, sz, sub, lane, rbd, rbj, rsd, tl);
+                        search_ball_wave<STATS, HASH>(mv, sx, sy, sz, sub, lane, rbd, rbj, rsd, tl);
                     if (lane == src) {
                         bd = rbd;
                         bj = rbj;
@@ -953,7 +959,7 @@ __device__ __forceinline__ void linearize_body(
     }
 }
 
-template <bool WRITE_CORR, int VARIANT, bool STATS>
+template <bool WRITE_CORR, int VARIANT, bool STATS, bool HASH = false>
 __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
     const BlockItem* __restrict__ items, FrameView fv, MapView mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
@@ -962,11 +968,11 @@ __global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
 {
     __shared__ LinLds s_uw[kLinThreads / 64];
     __shared__ double s_w[4][32];
-    linearize_body<WRITE_CORR, VARIANT, STATS, false>(items, fv, mv, poses, dmax2, partials, corr, d2out,
-                                                      hint, rho, poses_prev, s_uw, s_w);
+    linearize_body<WRITE_CORR, VARIANT, STATS, false, HASH>(items, fv, mv, poses, dmax2, partials, corr,
+                                                            d2out, hint, rho, poses_prev, s_uw, s_w);
 }
 
-template <bool WRITE_CORR, bool STATS>
+template <bool WRITE_CORR, bool STATS, bool HASH = false>
 __global__ __launch_bounds__(kLinThreads, 4) void k_linearize_lat(
     const BlockItem* __restrict__ items, FrameView fv, MapView mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
@@ -975,8 +981,8 @@ __global__ __launch_bounds__(kLinThreads, 4) void k_linearize_lat(
 {
     __shared__ LinLds s_uw[kLinThreads / 64];
     __shared__ double s_w[4][32];
-    linearize_body<WRITE_CORR, 1, STATS, true>(items, fv, mv, poses, dmax2, partials, corr, d2out, hint,
-                                               rho, poses_prev, s_uw, s_w);
+    linearize_body<WRITE_CORR, 1, STATS, true, HASH>(items, fv, mv, poses, dmax2, partials, corr, d2out,
+                                                     hint, rho, poses_prev, s_uw, s_w);
 }
 
 hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)
@@ -1002,6 +1008,29 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
     // a launch that leaves most of the chip idle is a latency problem: fewer than kLatItems
     // workgroups (~4 frames) go to the latency kernel
     const bool lat = variant == VELO_VARIANT_BALL && n_items < kLatItems;
+    if (!mv.cell_start) {
+        // sparse fine-cell table: the ball search in its two kernels (the validation scan and
+        // the counting instantiation read the table through the run-time form)
+        if (variant == VELO_VARIANT_SCAN) {
+            hipLaunchKernelGGL((k_linearize<true, 0, false>), dim3(n_items), dim3(kLinThreads), 0, s, items,
+                               fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+        } else if (lat) {
+            if (wc)
+                hipLaunchKernelGGL((k_linearize_lat<true, false, true>), dim3(n_items), dim3(kLinThreads), 0,
+                                   s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+            else
+                hipLaunchKernelGGL((k_linearize_lat<false, false, true>), dim3(n_items), dim3(kLinThreads), 0,
+                                   s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+        } else {
+            if (wc)
+                hipLaunchKernelGGL((k_linearize<true, 1, false, true>), dim3(n_items), dim3(kLinThreads), 0,
+                                   s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+            else
+                hipLaunchKernelGGL((k_linearize<false, 1, false, true>), dim3(n_items), dim3(kLinThreads), 0,
+                                   s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+        }
+        return hipGetLastError();
+    }
     if (stats && variant != VELO_VARIANT_SCAN && variant < 10) {  // counting instantiation
         if (lat)
             hipLaunchKernelGGL((k_linearize_lat<true, true>), dim3(n_items), dim3(kLinThreads), 0, s,
@@ -1272,7 +1301,8 @@ __device__ __forceinline__ int voxel_count(const MapView& mv, int cx, int cy, in
     for (int fz = cz * mv.S; fz < (cz + 1) * mv.S && occ < enough; ++fz)
         for (int fy = cy * mv.S; fy < (cy + 1) * mv.S && occ < enough; ++fy) {
             const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
-            occ += mv.cell_start[row + (size_t)(cx + 1) * mv.S] - mv.cell_start[row + (size_t)cx * mv.S];
+            int j0, j1;
+            if (row_range_rt(mv, row, cx * mv.S, (cx + 1) * mv.S - 1, j0, j1)) occ += j1 - j0;
         }
     return occ;
 }

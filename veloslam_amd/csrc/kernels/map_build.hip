@@ -154,6 +154,59 @@ __global__ __launch_bounds__(256) void k_cell_start(const uint32_t* __restrict__
     }
 }
 
+// ---- sparse table ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count_runs(const uint32_t* __restrict__ keys, size_t n,
+                                                    unsigned long long* __restrict__ total)
+{
+    unsigned c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, (unsigned long long)c);
+}
+// the first point of every run of equal keys inserts {key, start, end}: end by a binary search
+// for the first greater key; the slot is claimed with a compare-and-swap on the key word
+__global__ __launch_bounds__(256) void k_hash_build(const uint32_t* __restrict__ keys, size_t n,
+                                                    int4* __restrict__ hash, uint32_t cap)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t k = keys[i];
+        if (i != 0 && keys[i - 1] == k) continue;
+        size_t lo = i + 1, hi = n;  // first index whose key exceeds k
+        while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            if (keys[mid] > k) hi = mid; else lo = mid + 1;
+        }
+        uint32_t h = (uint32_t)(((unsigned long long)(k * 0x9E3779B1u) * cap) >> 32);
+        for (;;) {
+            const unsigned prev = atomicCAS(reinterpret_cast<unsigned*>(&hash[h].x), 0xffffffffu, k);
+            if (prev == 0xffffffffu) break;
+            h = h + 1 == cap ? 0u : h + 1;
+        }
+        hash[h].y = (int)i;
+        hash[h].z = (int)lo;
+        hash[h].w = 0;
+    }
+}
+hipError_t launch_count_runs(const uint32_t* sorted_keys, size_t n, unsigned long long* d_count, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess || n == 0) return e;
+    const size_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(k_count_runs, dim3((int)(g > 8192 ? 8192 : g)), dim3(256), 0, s, sorted_keys, n, d_count);
+    return hipGetLastError();
+}
+hipError_t launch_hash_build(const uint32_t* sorted_keys, size_t n, int4* hash, uint32_t cap, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(hash, 0xFF, (size_t)cap * sizeof(int4), s);
+    if (e != hipSuccess || n == 0) return e;
+    const size_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(k_hash_build, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, s, sorted_keys, n, hash,
+                       cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell,
                              int32_t* cell_start, hipStream_t s)
 {
@@ -259,8 +312,8 @@ __device__ __forceinline__ int collect_knn(const MapView& mv, const uint32_t* __
                     const int fb = min(x1, (int)floorf(fminf(ux + xr, 2.0e9f)));
                     if (fa > fb) continue;
                     const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
-                    const int j0 = mv.cell_start[row + (size_t)fa];
-                    const int j1 = mv.cell_start[row + (size_t)fb + 1];
+                    int j0, j1;
+                    if (!row_range_rt(mv, row, fa, fb, j0, j1)) continue;
                     // four candidate loads in flight per trip (the walk is a latency chain);
                     // a slot past the end repeats the last index and is masked
                     for (int jb = j0; jb < j1; jb += 4) {

@@ -16,7 +16,12 @@ namespace velo {
 struct MapView {
     const float4* pts;     // [n] sorted by FINE cell key (stable)
     const float4* nrm;     // [n]
-    const int32_t* cell_start;  // [fx*fy*fz + 1] fine-cell table: number of keys < k
+    const int32_t* cell_start;  // [fx*fy*fz + 1] fine-cell table: number of keys < k (dense mode)
+    // sparse mode (cell_start == nullptr): open-addressing hash over the OCCUPIED fine cells,
+    // entry = {fine key, first sorted index, one past the last, 0}; key 0xffffffff = empty slot.
+    // slot = ((key * 0x9E3779B1) * capacity) >> 32, linear probing.  Same sorted order, same answers.
+    const int4* hash;
+    uint32_t hash_cap;
     const uint8_t* vox_near;    // [nx*ny*nz] 0 = no map point in the 27 voxels around (or nullptr)
     float ox, oy, oz, inv_h, h;
     int nx, ny, nz;        // voxels per axis
@@ -71,6 +76,9 @@ hipError_t launch_gather(const float* x, const float* y, const float* z, const u
                          size_t n, float4* pts, hipStream_t s);
 hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell,
                              int32_t* cell_start, hipStream_t s);
+// sparse table: number of occupied fine cells, then the hash itself (cap slots)
+hipError_t launch_count_runs(const uint32_t* sorted_keys, size_t n, unsigned long long* d_count, hipStream_t s);
+hipError_t launch_hash_build(const uint32_t* sorted_keys, size_t n, int4* hash, uint32_t cap, hipStream_t s);
 hipError_t launch_normals(const MapView& mv, const uint32_t* perm, int k, float4* nrm,
                           unsigned long long* d_invalid, hipStream_t s);
 
