@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--stream-map-points", type=int, default=12_000_000,
                     help="points of the whole scene the rolling map is cut from")
     ap.add_argument("--stream-subdiv", type=int, default=0)
+    ap.add_argument("--stream-hash-load", type=int, default=0, help="stream map: 0 = dense fine table, else hash load (%)")
     ap.add_argument("--roi-range", type=float, default=ROI_RANGE, help="rolling map: kept radius around the pose (m)")
     ap.add_argument("--evict-every", type=int, default=5)
     ap.add_argument("--append-threshold", type=int, default=512,
@@ -226,6 +227,7 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct, src=No
 
     calc = np.ascontiguousarray(cal, dtype=np.float64).reshape(64, 9)
     ctx = capi.Context(local, max_batch=2, map_margin=args.map_margin, map_subdiv=args.stream_subdiv,
+                       map_hash_load=args.stream_hash_load,
                        map_full_rebuild=1 if args.full_rebuild else 0, sort_frames=args.sort_frames,
                        use_hints=0 if args.no_hints else args.hints,
                        use_graph=0 if args.no_graph else 1)
