@@ -78,7 +78,10 @@ typedef struct velo_cfg {
                                < 2^31 entries, an open-addressing hash over the occupied cells
                                (load factor 0.5) beyond that; 5..90: always the hash, at that load
                                factor in percent.  Same sorted order, same results either way. */
-    int32_t reserved[5];
+    int32_t force_kernel;   /* 0: the linearise kernel is chosen by launch size (latency kernel below
+                               2048 workgroups, throughput kernel above); 1: always the throughput
+                               kernel, 2: always the latency kernel (tests hold both to the oracle) */
+    int32_t reserved[4];
 } velo_cfg;
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */

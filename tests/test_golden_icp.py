@@ -107,11 +107,11 @@ def test_getmatrix_oracle_and_product_vs_scipy_fixture(oracle, gm):
 
 
 # ------------------------------------------------------------------------------ GPU
-@pytest.fixture(scope="module")
-def gctx(gold):
+@pytest.fixture(scope="module", params=[1, 2], ids=["throughput", "latency"])
+def gctx(gold, request):
     from veloslam_amd import capi
     p = gold["params"]
-    c = capi.Context(0, max_batch=2, map_subdiv=p["subdiv"])
+    c = capi.Context(0, max_batch=2, map_subdiv=p["subdiv"], force_kernel=request.param)
     c.map_reset(*gold["m"], p["voxel"], p["k_normals"])
     c.frames_upload([gold["s"]])
     yield c
@@ -133,11 +133,11 @@ def test_gpu_reproduces_frozen_map(gctx, gold):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 100], ids=["ball", "scan"])
-def test_gpu_reproduces_frozen_linearisation(gold, variant):
+@pytest.mark.parametrize("variant,kernel", [(1, 1), (1, 2), (100, 0)], ids=["ball-throughput", "ball-latency", "scan"])
+def test_gpu_reproduces_frozen_linearisation(gold, variant, kernel):
     from veloslam_amd import capi
     p, a0 = gold["params"], gold["at_T0"]
-    c = capi.Context(0, max_batch=2, map_subdiv=p["subdiv"], linearize_variant=variant)
+    c = capi.Context(0, max_batch=2, map_subdiv=p["subdiv"], linearize_variant=variant, force_kernel=kernel)
     try:
         c.map_reset(*gold["m"], p["voxel"], p["k_normals"])
         c.frames_upload([gold["s"]])

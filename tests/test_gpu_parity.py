@@ -17,11 +17,13 @@ ROT_TOL = 1e-5  # radians
 SCAN, BALL = 100, 1  # VELO_VARIANT_SCAN / VELO_VARIANT_BALL (include/velo.h)
 
 
-@pytest.fixture(scope="module", params=[SCAN, BALL], ids=["scan", "pruned"])
+@pytest.fixture(scope="module", params=[(SCAN, 0), (BALL, capi.KERNEL_THROUGHPUT), (BALL, capi.KERNEL_LATENCY)],
+                ids=["scan", "pruned-throughput", "pruned-latency"])
 def ctx(request):
     """Both linearise kernels are held to the same oracle: VELO_VARIANT_SCAN = exhaustive
-    27-cell scan, VELO_VARIANT_BALL = pruned exact search, the default."""
-    c = capi.Context(0, max_batch=16, linearize_variant=request.param)
+    27-cell scan, VELO_VARIANT_BALL = pruned exact search, the default -- the latter in both of its
+    kernels (throughput: batches; latency: single frames), whatever the size of the test."""
+    c = capi.Context(0, max_batch=16, linearize_variant=request.param[0], force_kernel=request.param[1])
     yield c
     c.close()
 

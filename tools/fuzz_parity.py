@@ -54,8 +54,17 @@ def check(cond, what, seed):
         raise AssertionError("MISMATCH seed %d: %s" % (seed, what))
 
 
-def one_case(seed):
+def one_case(seed, kernel=None, hash_load=None):
+    """kernel: None = from the seed (round-2 dimension: throughput / latency linearise kernel),
+    hash_load likewise (0 = dense table).  Drawn from a SECOND generator so that the case a seed
+    stood for in round 1 (map, queries, poses, operations) is unchanged."""
     rng = np.random.default_rng(seed)
+    rng2 = np.random.default_rng(seed + 7_000_003)
+    if kernel is None:
+        kernel = int(rng2.choice([capi.KERNEL_THROUGHPUT, capi.KERNEL_LATENCY]))
+    if hash_load is None:
+        hash_load = int(rng2.choice([0, 0, 0, 30, 60, 85]))
+    auto_s = rng2.random() < 0.25
     ext = float(rng.choice([4.0, 9.0, 17.0]))
     n = int(rng.integers(200, 6000))
     voxel = float(rng.choice([0.5, 1.0, 1.5]))
@@ -63,8 +72,11 @@ def one_case(seed):
     k = int(rng.choice([5, 8, 16, 32]))
     margin = int(rng.choice([0, 0, 2, 5]))
     m = make_map(rng, n, ext)
+    if auto_s:
+        S = 0  # chosen from the density, by the same rule on both sides
     roll = orc.RollingMap(*m, voxel, k, S, margin=margin)
-    c = capi.Context(0, max_batch=2, map_subdiv=S, map_margin=margin, linearize_variant=1)
+    c = capi.Context(0, max_batch=2, map_subdiv=S, map_margin=margin, linearize_variant=1,
+                     force_kernel=kernel, map_hash_load=hash_load)
     try:
         c.map_reset(*m, voxel, k)
 
@@ -78,6 +90,8 @@ def one_case(seed):
             return om
 
         om = same_map("build")
+        check(c.map_info().subdiv == om.subdiv and c.map_info().table_kind == (1 if hash_load else 0),
+              "sub-division / table kind", seed)
         nq = int(rng.integers(100, 3000))
         q = rng.uniform(-1.5, ext + 1.5, (3, nq)).astype(np.float32)
         if rng.random() < 0.5:   # queries on top of map points and on lattice positions
@@ -104,11 +118,25 @@ def one_case(seed):
         # rolling operations
         for op in range(int(rng.integers(1, 5))):
             r = rng.random()
+            r2 = rng2.random()
             if r < 0.6:
                 mnew = make_map(rng, int(rng.integers(1, 400)), ext)
                 mnew += np.float32(rng.choice([0.0, 0.0, 1.7, -1.3]))
-                c.map_append(*mnew)
-                roll.append(*mnew)
+                if r2 < 0.35:   # voxel-downsampled insertion
+                    mc = int(rng2.choice([1, 3, 6]))
+                    check(c.map_append_sparse(*mnew, mc) == roll.append_sparse(*mnew, mc), "sparse count", seed)
+                else:
+                    c.map_append(*mnew)
+                    roll.append(*mnew)
+            elif r2 < 0.4:      # eviction by radius around a pose
+                cx, cy = rng2.uniform(0, ext, 2)
+                rad = float(rng2.uniform(ext * 0.3, ext * 1.1))
+                rc = roll.evict_radius(cx, cy, rad)
+                try:
+                    c.map_evict_radius(cx, cy, rad)
+                    check(rc != -1, "radius evict should have been refused", seed)
+                except capi.VeloError:
+                    check(rc == -1, "radius evict refused unexpectedly", seed)
             else:
                 lo = rng.uniform(-2, ext * 0.4, 3).astype(np.float32)
                 hi = (lo + rng.uniform(ext * 0.5, ext * 1.2, 3)).astype(np.float32)

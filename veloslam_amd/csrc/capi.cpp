@@ -855,7 +855,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
                 e = launch_linearize(c->cfg.linearize_variant, c->items.p, ni, fv, c->mv, c->poses.p,
                                      dmax2, c->partials.p, nullptr, nullptr, hint, rho,
-                                     c->poses_prev.p, false, s);
+                                     c->poses_prev.p, false, c->cfg.force_kernel, s);
                 if (e == hipSuccess)
                     e = launch_reduce_solve(c->partials.p, c->fbs.p, c->n_frames, c->poses.p,
                                             c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
@@ -893,7 +893,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             HIP_TRY(c, launch_linearize(c->cfg.linearize_variant,
                                         (fv.order && c->cfg.sort_frames == 1) ? c->items_xcd.p : c->items.p, ni, fv, c->mv,
                                         c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, rho,
-                                        c->poses_prev.p, c->stats_on, s));
+                                        c->poses_prev.p, c->stats_on, c->cfg.force_kernel, s));
         }
         {
             Timed t(c, 1);
@@ -1613,7 +1613,7 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
                                 c->poses.p, d_max * d_max, c->partials.p, c->corr.p, c->d2.p,
                                 c->lin_hints ? c->hint.p : nullptr,
                                 (c->lin_hints && c->cfg.use_hints >= 2) ? c->rho.p : nullptr,
-                                c->poses_prev.p, c->stats_on, s));
+                                c->poses_prev.p, c->stats_on, c->cfg.force_kernel, s));
     HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p + frame, 1, c->poses.p, nullptr, 0, 1,
                                    c->acc.p, 0, nullptr, nullptr, s));
     if (corr)

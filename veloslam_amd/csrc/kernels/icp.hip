@@ -998,7 +998,7 @@ hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, int32_t* hint, float* rho,
-                            const double* poses_prev, bool stats, hipStream_t s)
+                            const double* poses_prev, bool stats, int force_kernel, hipStream_t s)
 {
     if (n_items == 0) return hipSuccess;
     const bool wc = corr || d2;
@@ -1007,7 +1007,8 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
                        items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev)
     // a launch that leaves most of the chip idle is a latency problem: fewer than kLatItems
     // workgroups (~4 frames) go to the latency kernel
-    const bool lat = variant == VELO_VARIANT_BALL && n_items < kLatItems;
+    const bool lat = variant == VELO_VARIANT_BALL &&
+                     (force_kernel == 2 || (force_kernel != 1 && n_items < kLatItems));
     if (!mv.cell_start) {
         // sparse fine-cell table: the ball search in its two kernels (the validation scan and
         // the counting instantiation read the table through the run-time form)

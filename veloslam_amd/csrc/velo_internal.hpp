@@ -142,7 +142,7 @@ hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const f
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, int32_t* hint, float* rho,
-                            const double* poses_prev, bool stats, hipStream_t s);
+                            const double* poses_prev, bool stats, int force_kernel, hipStream_t s);
 hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s);
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
