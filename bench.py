@@ -688,10 +688,17 @@ def main():
                 ctx.comm_init(box[0], rank, world)
             else:
                 ctx.comm_init(capi.comm_unique_id(), 0, 1)
+            ok = 1
+        except capi.VeloError as e:
+            ok = 0
+            sys.stderr.write("bench: C-ABI communicator unavailable (%s); using torch.distributed\n" % e)
+        if world > 1:   # every rank must take the same transport
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
             transport = "velo_exchange_increments (RCCL via the C ABI)"
             gathered = torch.empty((3, n_q * world), dtype=torch.float32, device=dev)
-        except capi.VeloError as e:
-            sys.stderr.write("bench: C-ABI communicator unavailable (%s); using torch.distributed\n" % e)
     side = torch.cuda.Stream() if exchange else None
     ev_inc = [torch.cuda.Event(), torch.cuda.Event()] if exchange else None
     ev_free = [None, None]  # side stream is done reading increment buffer b
