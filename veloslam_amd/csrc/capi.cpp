@@ -98,6 +98,11 @@ struct velo_ctx {
     std::vector<int32_t> fbs_h;
     DevBuf<BlockItem> items;
     DevBuf<BlockItem> items_xcd;      // same blocks, dealt so that XCD r works on spatial slab r
+    // second decomposition for the hinted iterations of a batch: three rounds of 256 queries per
+    // workgroup (plan_frames); ni_late == 0 = not in use
+    DevBuf<BlockItem> items_late;
+    DevBuf<int32_t> fbs_late;
+    int ni_late = 0;
     DevBuf<float> sx, sy, sz;         // cell-sorted copies of the frames (cfg.sort_frames)
     DevBuf<int32_t> fbs;
     DevBuf<double> poses, partials, acc;
@@ -661,6 +666,38 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     }
     c->fbs_h[n_frames] = (int32_t)c->items_h.size();
     const size_t ni = c->items_h.size();
+    // Iterations after the first of a BATCH run three rounds per workgroup: their work is even
+    // (hinted / certified queries), so a third of the workgroups -- a third of the item / pose
+    // loads, block reductions, partial rows for the solve to read -- is cheaper (64 frames:
+    // converged launch 84 -> 77 us, registration 2.67 -> 2.49 ms); the first, unhinted iteration
+    // is ragged and keeps one round (503 us with three against 488).  Small launches (single
+    // frames: the latency kernel) keep one round throughout: they have too few workgroups as it is.
+    c->ni_late = 0;
+    if (c->cfg.rounds_per_block <= 0 && ni >= 4096) {
+        std::vector<BlockItem> late;
+        std::vector<int32_t> fbl((size_t)n_frames + 1, 0);
+        const int per_late = kLinThreads * 3;
+        for (int f = 0; f < n_frames; ++f) {
+            fbl[f] = (int32_t)late.size();
+            for (int64_t q = frame_start[f]; q < frame_start[f + 1]; q += per_late) {
+                BlockItem it;
+                it.frame = f;
+                it.q0 = (int32_t)q;
+                it.q1 = (int32_t)std::min<int64_t>(q + per_late, frame_start[f + 1]);
+                it.slot = (int32_t)late.size();
+                late.push_back(it);
+            }
+        }
+        fbl[n_frames] = (int32_t)late.size();
+        HIP_TRY(c, c->items_late.reserve(late.size()));
+        HIP_TRY(c, c->fbs_late.reserve((size_t)n_frames + 1));
+        HIP_TRY(c, hipMemcpyAsync(c->items_late.p, late.data(), late.size() * sizeof(BlockItem),
+                                  hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->fbs_late.p, fbl.data(), fbl.size() * sizeof(int32_t),
+                                  hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors go out of scope
+        c->ni_late = (int)late.size();
+    }
     HIP_TRY(c, c->items.reserve(std::max<size_t>(ni, 1)));
     HIP_TRY(c, c->fbs.reserve((size_t)n_frames + 1));
     HIP_TRY(c, c->d_frame_start.reserve((size_t)n_frames + 1));
@@ -853,11 +890,13 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             if (e == hipSuccess && rho) e = hipMemsetAsync(rho, 0, n_all * sizeof(float), s);
             FrameView fv{c->ax, c->ay, c->az, nullptr};
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
-                e = launch_linearize(c->cfg.linearize_variant, c->items.p, ni, fv, c->mv, c->poses.p,
+                const bool late = it > 0 && c->ni_late > 0 && hint;
+                e = launch_linearize(c->cfg.linearize_variant, late ? c->items_late.p : c->items.p,
+                                     late ? c->ni_late : ni, fv, c->mv, c->poses.p,
                                      dmax2, c->partials.p, nullptr, nullptr, hint, rho,
                                      c->poses_prev.p, false, c->cfg.force_kernel, s);
                 if (e == hipSuccess)
-                    e = launch_reduce_solve(c->partials.p, c->fbs.p, c->n_frames, c->poses.p,
+                    e = launch_reduce_solve(c->partials.p, late ? c->fbs_late.p : c->fbs.p, c->n_frames, c->poses.p,
                                             c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
                                             c->pairs_total.p, s);
             }
@@ -888,16 +927,21 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     if (hint) HIP_TRY(c, hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s));
     if (rho) HIP_TRY(c, hipMemsetAsync(rho, 0, n_all * sizeof(float), s));
     for (int it = 0; it < iters; ++it) {
+        bool late_it = false;
         {
             Timed t(c, 0);
+            const bool late = it > 0 && c->ni_late > 0 && hint && !fv.order;
+            late_it = late;
             HIP_TRY(c, launch_linearize(c->cfg.linearize_variant,
-                                        (fv.order && c->cfg.sort_frames == 1) ? c->items_xcd.p : c->items.p, ni, fv, c->mv,
+                                        late ? c->items_late.p
+                                             : ((fv.order && c->cfg.sort_frames == 1) ? c->items_xcd.p : c->items.p),
+                                        late ? c->ni_late : ni, fv, c->mv,
                                         c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, rho,
                                         c->poses_prev.p, c->stats_on, c->cfg.force_kernel, s));
         }
         {
             Timed t(c, 1);
-            HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p, c->n_frames, c->poses.p,
+            HIP_TRY(c, launch_reduce_solve(c->partials.p, late_it ? c->fbs_late.p : c->fbs.p, c->n_frames, c->poses.p,
                                            c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
                                            c->pairs_total.p, s));
         }
