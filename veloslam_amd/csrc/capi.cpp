@@ -673,7 +673,7 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     // is ragged and keeps one round (503 us with three against 488).  Small launches (single
     // frames: the latency kernel) keep one round throughout: they have too few workgroups as it is.
     c->ni_late = 0;
-    if (c->cfg.rounds_per_block <= 0 && ni >= 4096) {
+    if (c->cfg.rounds_per_block <= 0 && ni >= 3 * 4096) {  // still >= 4096 workgroups (16 per CU) afterwards
         std::vector<BlockItem> late;
         std::vector<int32_t> fbl((size_t)n_frames + 1, 0);
         const int per_late = kLinThreads * 3;
