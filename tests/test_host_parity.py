@@ -280,3 +280,52 @@ def test_public_header_is_plain_c(tmp_path):
                         "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
 
+
+
+def test_geodesy_live_against_reference_object_code(oracle):
+    """Where the reference's own CoordiTran object code is at hand (oracle/_ref, built from
+    /root/reference/CoordiTran.cpp where it lies; it travels with the snapshot), oracle AND product
+    are run against it live on fresh random inputs -- not only on the committed vectors."""
+    import ctypes as C
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libcoorditran_ref.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built (no reference tree on this box)")
+    R = C.CDLL(ref)
+    dp = C.POINTER(C.c_double)
+    R.ref_MappingAngle.restype = C.c_double
+    R.ref_MappingAngle.argtypes = [C.c_double]
+
+    def r2(name, a):
+        a = np.array(a, np.float64); o = np.zeros(3)
+        getattr(R, name)(a.ctypes.data_as(dp), o.ctypes.data_as(dp))
+        return o
+
+    def r3(name, a, org):
+        a = np.array(a, np.float64); org = np.array(org, np.float64); o = np.zeros(3)
+        getattr(R, name)(a.ctypes.data_as(dp), org.ctypes.data_as(dp), o.ctypes.data_as(dp))
+        return o
+
+    def same(a, b):
+        return np.array_equal(np.asarray(a, np.float64).view(np.uint64), np.asarray(b, np.float64).view(np.uint64))
+
+    rng = np.random.default_rng(987654)
+    org = r2("ref_llh2xyz", [np.radians(39.8569901), np.radians(116.1736406), 89.09288895])
+    for _ in range(2000):
+        llh = np.array([np.radians(rng.uniform(-80, 80)), np.radians(rng.uniform(-179, 179)), rng.uniform(-100, 9000)])
+        xyz = r2("ref_llh2xyz", llh)
+        for impl in (oracle, capi):
+            assert same(impl.llh2xyz(llh), xyz)
+            assert same(impl.xyz2llh(xyz), r2("ref_xyz2llh", xyz))
+        near = np.array([np.radians(39.8569901 + rng.uniform(-0.2, 0.2)), np.radians(116.1736406 + rng.uniform(-0.2, 0.2)),
+                         rng.uniform(0, 300)])
+        enu = r3("ref_llh2enu", near, org)
+        for impl in (oracle, capi):
+            assert same(impl.llh2enu(near, org), enu)
+            assert same(impl.enu2xyz(enu, org), r3("ref_enu2xyz", enu, org))
+            assert same(impl.enu2llh(enu, org), r3("ref_enu2llh", enu, org))
+        e = rng.uniform(-3.2, 3.2, 3)
+        d = np.zeros(9)
+        R.ref_eulr2dcm(np.array(e).ctypes.data_as(dp), d.ctypes.data_as(dp))
+        assert same(oracle.eulr2dcm(e).ravel(), d) and same(capi.eulr2dcm(e).ravel(), d)
+        a = rng.uniform(-720, 720)
+        assert same([oracle.mapping_angle(a)], [R.ref_MappingAngle(a)]) and same([capi.mapping_angle(a)], [R.ref_MappingAngle(a)])
