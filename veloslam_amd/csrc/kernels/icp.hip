@@ -727,6 +727,10 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 #ifndef VELO_COOP_MAX
 #define VELO_COOP_MAX 16
 #endif
+#ifndef VELO_COOP_MAX_LAT
+#define VELO_COOP_MAX_LAT 4  // latency kernel: cooperative searches run one after the other (dense
+                             // single frame, second launch: 67 us at 16, 46-50 at 1-8)
+#endif
 #ifndef VELO_LIN_WAVES
 #define VELO_LIN_WAVES 7  // measured: 8 spills (64 VGPRs), 7 = 72 VGPRs no spill, fastest
 #endif
@@ -843,7 +847,7 @@ __device__ __forceinline__ void linearize_body(
             unsigned long long need = __ballot(queued);
             VELO_COUNT(0, live);
             VELO_COUNT(6, queued);
-            if (__popcll(need) > VELO_COOP_MAX) {
+            if (__popcll(need) > (LAT ? VELO_COOP_MAX_LAT : VELO_COOP_MAX)) {
                 VELO_COUNT(5, queued);
                 if constexpr (LAT) {
                     float rbd = bd;
