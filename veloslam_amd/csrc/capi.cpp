@@ -314,7 +314,9 @@ int build_table(velo_ctx* c, MapView& mv, const uint32_t* keys_sorted, size_t n,
     hipStream_t s = c->stream;
     if (!c->use_hash) {
         if (ncell + 8 > c->cell_start.cap) HIP_TRY(c, hipStreamSynchronize(s));  // queued readers
-        HIP_TRY(c, c->cell_start.reserve(ncell + 8));  // +1 entry, padded: rows are read 4 entries at a time
+        // +1 entry, padded: rows are read 4 entries at a time; with slack, because a rolling map's
+        // grid grows a margin at a time and a fresh 0.3-0.6 GB allocation costs milliseconds
+        HIP_TRY(c, reserve_slack(c->cell_start, ncell + 8));
         HIP_TRY(c, launch_cell_start(keys_sorted, n, ncell, c->cell_start.p, s));
         mv.cell_start = c->cell_start.p;
         mv.hash = nullptr;
@@ -466,7 +468,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
 
 // Sub-division of a freshly reset map: as configured, or (cfg.map_subdiv == 0) chosen from the
 // density exactly as oracle/icp.c vo_auto_subdiv does: rho = points per occupied voxel,
-// S = round(sqrt(rho / 2.8)) clamped to [2, 6].  Kept until the next velo_map_reset.
+// S = round(1.6 rho^0.2) clamped to [2, 8].  Kept until the next velo_map_reset.
 int resolve_subdiv(velo_ctx* c, float voxel)
 {
     if (c->cfg.map_subdiv > 0) {
@@ -502,8 +504,8 @@ int resolve_subdiv(velo_ctx* c, float voxel)
     HIP_TRY(c, hipStreamSynchronize(s));
     if (occ == 0) return VELO_OK;
     const double rho = (double)c->raw_n / (double)occ;
-    const int S = (int)std::floor(std::sqrt(rho / 2.8) + 0.5);
-    c->map_S = S < 2 ? 2 : (S > 6 ? 6 : S);
+    const int S = (int)std::floor(1.6 * std::pow(rho, 0.2) + 0.5);
+    c->map_S = S < 2 ? 2 : (S > 8 ? 8 : S);
     return VELO_OK;
 }
 
@@ -598,7 +600,7 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
         if (int rc = build_table(c, g, c->keys_alt.p, total, ncell)) return rc;
     } else if (grew) {
         HIP_TRY(c, hipStreamSynchronize(s));  // the old table may still be read by queued work
-        HIP_TRY(c, c->cell_start.reserve(ncell + 8));
+        HIP_TRY(c, reserve_slack(c->cell_start, ncell + 8));
         HIP_TRY(c, launch_cell_start(c->keys_alt.p, total, ncell, c->cell_start.p, s));
     } else {
         HIP_TRY(c, launch_table_shift(c->cell_start.p, ncell + 1, c->nk_sorted.p, (uint32_t)m, s));
