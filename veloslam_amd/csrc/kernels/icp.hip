@@ -728,8 +728,10 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 #define VELO_COOP_MAX 16
 #endif
 #ifndef VELO_COOP_MAX_LAT
-#define VELO_COOP_MAX_LAT 4  // latency kernel: cooperative searches run one after the other (dense
-                             // single frame, second launch: 67 us at 16, 46-50 at 1-8)
+#define VELO_COOP_MAX_LAT 16  // (4 takes 20 us off the second launch on a dense map, but only the
+                              // cooperative search leaves a certificate behind: stragglers sent to
+                              // the per-lane search come back at every iteration -- converged launch
+                              // of a 1 M-point single frame 9 -> 24 us)
 #endif
 #ifndef VELO_LIN_WAVES
 #define VELO_LIN_WAVES 7  // measured: 8 spills (64 VGPRs), 7 = 72 VGPRs no spill, fastest
