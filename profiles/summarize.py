@@ -21,7 +21,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + R)
 DST = os.path.join(ROOT, "profiles", R)
 os.makedirs(DST, exist_ok=True)
-CONFIGS = {"F64_M1000000": 64 * 450 * 256, "F16_M10000000": 16 * 450 * 256}  # key -> Grid_Size (threads)
+# key -> Grid_Size values (threads) of that configuration's linearise launches: a batch of >= 28
+# frames runs iteration 0 with one round of 256 queries per workgroup (450 workgroups per frame)
+# and the hinted iterations with three (150 per frame); smaller batches one round throughout
+CONFIGS = {"F64_M1000000": [64 * 450 * 256, 64 * 150 * 256], "F16_M10000000": [16 * 450 * 256]}
+PROD = "k_linearize<false, 1, false"  # the production instantiation (any table kind)
 
 
 def counters(sub):
@@ -47,7 +51,7 @@ for sub, name in (("trace", "kernel_stats_batch_dense.csv"), ("trace_stream", "k
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
-        if "k_linearize<false, 1, false>" in r["Kernel_Name"]:  # the production instantiation
+        if PROD in r["Kernel_Name"]:
             dur[int(r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 summary = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
@@ -57,23 +61,30 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
                 summary.setdefault(k, {}).setdefault(str(g), {})[c] = stats(x)
 json.dump(dict(note=__doc__, kernels=summary), open(os.path.join(DST, "pmc.json"), "w"), indent=1)
 traffic = {}
-for key, grid in CONFIGS.items():
-    for k, grids in summary.items():
-        if "k_linearize<false, 1, false>" not in k or str(grid) not in grids:
-            continue
-        c = grids[str(grid)]
-        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            f, w = c["FETCH_SIZE"]["mean"], c["WRITE_SIZE"]["mean"]
-            d = dur.get(grid, [])
-            traffic[key] = dict(kernel=k, grid_threads=grid, FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w,
-                                hbm_bytes_per_launch=(2 * f + w) * 1024,
-                                launches_counted=c["FETCH_SIZE"]["launches"],
-                                rocprof_avg_launch_us=(sum(d) / len(d)) if d else None,
-                                rocprof_launches=len(d), source="profiles/%s/pmc.json" % R,
-                                correction="gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)")
-            if d:
-                traffic[key]["traffic_GBps_at_rocprof_avg"] = traffic[key]["hbm_bytes_per_launch"] / (
-                    sum(d) / len(d) * 1e-6) / 1e9
+raw = {sub: counters(sub) for sub in ("pmc_fetch", "pmc_write")}
+for key, grids_of in CONFIGS.items():
+    vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+    kname = None
+    for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        for k, grids in raw[sub].items():
+            if PROD not in k:
+                continue
+            kname = k
+            for g in grids_of:
+                vals[cname] += grids.get(g, {}).get(cname, [])
+    if not vals["FETCH_SIZE"] or not vals["WRITE_SIZE"]:
+        continue
+    f = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])
+    w = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
+    d = [x for g in grids_of for x in dur.get(g, [])]
+    traffic[key] = dict(kernel=kname, grid_threads=grids_of, FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w,
+                        hbm_bytes_per_launch=(2 * f + w) * 1024, launches_counted=len(vals["FETCH_SIZE"]),
+                        rocprof_avg_launch_us=(sum(d) / len(d)) if d else None, rocprof_launches=len(d),
+                        source="profiles/%s/pmc.json" % R,
+                        correction="gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)")
+    if d:
+        traffic[key]["traffic_GBps_at_rocprof_avg"] = traffic[key]["hbm_bytes_per_launch"] / (
+            sum(d) / len(d) * 1e-6) / 1e9
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 for nm in ("bench_default.json", "bench_stream.json", "bench_trace.json"):
