@@ -34,7 +34,7 @@ for cfg in a.cfg or ["subdiv=3"]:
     kv = dict(x.split("=") for x in cfg.split(",") if x)
     ctx = capi.Context(0, max_batch=a.frames, map_subdiv=int(kv.get("subdiv", 3)), use_hints=int(kv.get("hints", 2)),
                        linearize_variant=int(kv.get("variant", 1)), use_graph=0,
-                       rounds_per_block=int(kv.get("rounds", 0)))
+                       rounds_per_block=int(kv.get("rounds", 0)), sort_frames=int(kv.get("sort", 0)))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if a.device_map:
         ctx.map_reset_dev(mx.data_ptr(), my.data_ptr(), mz.data_ptr(), a.map_points, 1.0, 16)
@@ -55,7 +55,7 @@ for cfg in a.cfg or ["subdiv=3"]:
     if a.stats:
         ctx.set_stats(1)
         prev = None
-        for k in range(1, min(a.iters, 8) + 1):
+        for k in range(1, min(a.iters, int(kv.get("stat_iters", 8))) + 1):
             ctx.search_stats(reset=True)
             ctx.icp_batch(d["T0"], k, 1.0)
             st = ctx.search_stats(reset=True)
@@ -67,5 +67,7 @@ for cfg in a.cfg or ["subdiv=3"]:
                   % (k - 1, 100.0 * q["searched"] / n_q, 100.0 * q["stage_b"] / n_q,
                      100.0 * q["stage_b_per_lane"] / n_q, q["candidates"] / n_q, q["table_requests"] / n_q,
                      q["bytes"] / 1e6))
+            if kv.get("raw"):
+                print("        raw:", " ".join("%s=%d" % (k_, v_) for k_, v_ in q.items() if k_ not in ("bytes",)))
         ctx.set_stats(0)
     ctx.close()

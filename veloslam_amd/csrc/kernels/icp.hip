@@ -407,18 +407,39 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
 // descending order in chunks of kMaxRanges.  Per chunk the table entries of all its rows are
 // requested together, the surviving ranges staged in LDS and walked like stage A -- two
 // memory round trips per nine rows instead of two per row.
+// squared radius actually searched around a query whose best distance so far is sqrt(b): a
+// little beyond it (so that the outcome certifies a radius, see linearize_body), never past one
+// voxel (the row window ends there)
+__device__ __forceinline__ float cover_of(float b, float h)
+{
+    const float r = sqrtf(b) * 1.000001f + 1e-7f + kCertSlack;
+    return fminf(r * r * 1.00001f, h * h);
+}
+
+// certified radius after a ball search: second-best examined / radius covered / one voxel
+__device__ __forceinline__ float ball_certificate(float sd, float cov, float h, float mg)
+{
+    return fmaxf(fminf(sqrtf(fminf(sd, cov)) * 0.999999f, h - 2.0f * mg) - 1e-6f, 0.0f);
+}
+
 template <bool STATS, bool HASH>
 __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, float ub,
-                            SearchLds& L, int tid, float& bd, int& bj, Tally<STATS>& tl)
+                            SearchLds& L, int tid, float& bd, int& bj, float& cert, Tally<STATS>& tl)
 {
     const QueryCell g = locate(mv, qx, qy, qz);
-    bd = ub;
-    bj = -1;
     const int S = mv.S;
     const float hf = mv.h / (float)S;
     const float inv_hf = (float)S * mv.inv_h;
     const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
     const float xf = (float)g.Fx + g.tx;  // fine coordinate of the query along x
+    // `cov` is the ball searched: it follows the best distance down, slack included, so every
+    // map point within sqrt(cov) at the end has been looked at and `sd` (second-smallest
+    // distance seen) bounds everything but the winner -- a certificate, as in the cooperative
+    // form.  (Without it a straggler of this path came back as a straggler at every iteration.)
+    float cov = cover_of(ub, mv.h);
+    float sd = cov;
+    bd = cov;
+    bj = -1;
     int dz = S, dy = S;
     const int nrows = (2 * S + 1) * (2 * S + 1);
 #pragma unroll 1
@@ -433,9 +454,9 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
                 const float by = dy == 0 ? 0.0f
                                          : fmaxf(((float)(abs(dy) - 1) + (dy > 0 ? 1.0f - g.ty : g.ty)) * hf - mg, 0.0f);
                 const float rb2 = (bz * bz + by * by) * 0.99999f;
-                if (zz >= 0 && zz < mv.fz && yy >= 0 && yy < mv.fy && !(rb2 > bd)) {
+                if (zz >= 0 && zz < mv.fz && yy >= 0 && yy < mv.fy && !(rb2 > cov)) {
                     // half-width of the ball in this row, in fine cells, rounded outwards
-                    const float w = (sqrtf(fmaxf(bd - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
+                    const float w = (sqrtf(fmaxf(cov - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
                     const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
                     if (x0 <= x1) {
                         const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
@@ -455,9 +476,10 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
                 }
             }
         }
-        float sd_unused = bd;
-        walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd_unused, tl);
+        walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd, tl);
+        cov = fminf(cov, cover_of(bd, mv.h));
     }
+    cert = bj >= 0 ? ball_certificate(sd, cov, mv.h, mg) : 0.0f;
 }
 
 // stage B, cooperative form: ONE straggler searched by a whole wavefront.  Lane l takes row
@@ -572,7 +594,8 @@ __device__ __forceinline__ int ball_window(float b, float inv_hf, int S)
 // the loops synchronise with __any.
 template <bool STATS, bool HASH>
 __device__ void search_ball_lat(const MapView& mv, float qx, float qy, float qz, float ub, bool active,
-                                bool probe, SearchLds& L, int tid, float& bd, int& bj, Tally<STATS>& tl)
+                                bool probe, SearchLds& L, int tid, float& bd, int& bj, float& cert,
+                                Tally<STATS>& tl)
 {
     const QueryCell g = locate(mv, qx, qy, qz);
     bd = ub;
@@ -620,14 +643,18 @@ __device__ void search_ball_lat(const MapView& mv, float qx, float qy, float qz,
     }
     // Phase 2: every row the ball can reach, descending (the tie rule), the surviving rows
     // packed nine to a trip: table entries requested together, ranges staged in LDS, one walk.
-    const int R = ball_window(bd, inv_hf, S);
+    // (`cov`, `sd`: the ball searched and the second-smallest distance seen, see search_ball)
+    float cov = cover_of(bd, mv.h);
+    float sd = cov;
+    bd = cov;
+    const int R = ball_window(cov, inv_hf, S);
     int dz = active ? R : -R - 1, dy = R;
 #pragma unroll 1
     do {
         int nr = 0;
         while (nr < kMaxRanges && dz >= -R) {
             int jlo, jhi;
-            if (ball_row<STATS, HASH>(mv, g, dz, dy, bd, xf, hf, inv_hf, mg, false, jlo, jhi, tl)) {
+            if (ball_row<STATS, HASH>(mv, g, dz, dy, cov, xf, hf, inv_hf, mg, false, jlo, jhi, tl)) {
                 L.hi[nr][tid] = jhi;
                 L.lo[nr][tid] = jlo;
                 ++nr;
@@ -637,9 +664,10 @@ __device__ void search_ball_lat(const MapView& mv, float qx, float qy, float qz,
                 --dz;
             }
         }
-        float sd_unused = bd;
-        walk_ranges<VELO_WALK_W_LAT>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd_unused, tl);
+        walk_ranges<VELO_WALK_W_LAT>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd, tl);
+        cov = fminf(cov, cover_of(bd, mv.h));
     } while (__any(dz >= -R));
+    cert = bj >= 0 ? ball_certificate(sd, cov, mv.h, mg) : 0.0f;
 }
 
 // cooperative form: as search_ball_wave, over the rows the ball can actually reach, a wide ball
@@ -852,17 +880,18 @@ __device__ __forceinline__ void linearize_body(
             if (__popcll(need) > (LAT ? VELO_COOP_MAX_LAT : VELO_COOP_MAX)) {
                 VELO_COUNT(5, queued);
                 if constexpr (LAT) {
-                    float rbd = bd;
+                    float rbd = bd, rcert = 0.0f;
                     int rbj = bj;
                     search_ball_lat<STATS, HASH>(mv, qx, qy, qz, queued ? bd : 0.0f, queued, queued && bj < 0,
-                                                 s_u.s, lane, rbd, rbj, tl);
+                                                 s_u.s, lane, rbd, rbj, rcert, tl);
                     if (queued) {
                         bd = rbd;
                         bj = rbj;
+                        rho_new_out = rcert;
                     }
                 } else if (queued) {
                     const float ub = bd;
-                    search_ball<STATS, HASH>(mv, qx, qy, qz, ub, s_u.s, lane, bd, bj, tl);
+                    search_ball<STATS, HASH>(mv, qx, qy, qz, ub, s_u.s, lane, bd, bj, rho_new_out, tl);
                 }
             } else {
                 while (need) {
