@@ -129,27 +129,44 @@ def want(args, name):
 
 # ------------------------------------------------------------------------- byte accounting
 def measured_bytes(ctx, T0, iters, d_max):
-    """Bytes k_linearize requests from memory, counted by its counting instantiation on the
-    resident frames: mean per launch over a whole registration, first launch, last launch."""
-    def run(k):
-        ctx.search_stats(reset=True)
-        ctx.icp_batch(T0, k, d_max)
-        return ctx.search_stats(reset=True)
+    """Byte accounting of k_linearize by its counting instantiation on the resident frames, per
+    launch (cumulative statistics of registrations of 1..iters iterations, differenced).
+
+    requested  every load and store the kernel issues (what L1/L2 see).
+    query side the per-query stream (12 B coordinates + 4 B hint + 4 B certificate in, 4 + 4 B
+               out when they change) and the per-workgroup item / pose / partial row: no cache
+               can save these.
+    map side   gathers from the map (16 B per candidate / hinted / matched point, 16 B per normal,
+               16 or 8 B per fine-table request).  No byte of the map has to cross the fabric
+               more than once per launch, so the ALGORITHMIC bytes of a launch are
+               query side + min(map side requested, bytes of the resident map: points + normals
+               + fine table)."""
+    mi = ctx.map_info()
+    resident = int(mi.n_points) * 32 + int(mi.table_slots) * (16 if mi.table_kind == 1 else 4)
     ctx.set_stats(1)
     try:
-        full = run(iters)
-        first = run(1)
-        prev = run(iters - 1) if iters > 1 else dict.fromkeys(full, 0)
+        cum = []
+        for k in range(1, iters + 1):
+            ctx.search_stats(reset=True)
+            ctx.icp_batch(T0, k, d_max)
+            cum.append(ctx.search_stats(reset=True))
     finally:
         ctx.set_stats(0)
-    last = {k: full[k] - prev[k] for k in full}
+    zero = dict.fromkeys(cum[0], 0)
+    per = [{k: c[k] - p[k] for k in c} for p, c in zip([zero] + cum[:-1], cum)]
+    alg = [l["query_bytes"] + min(l["bytes"] - l["query_bytes"], resident) for l in per]
+    full = cum[-1]
     return dict(mean_bytes_per_launch=full["bytes"] / max(full["launches"], 1),
-                first_launch_bytes=first["bytes"], last_launch_bytes=last["bytes"],
+                mean_algorithmic_bytes=sum(alg) / len(alg),
+                mean_query_bytes=full["query_bytes"] / max(full["launches"], 1),
+                map_resident_bytes=resident,
+                first_launch_bytes=per[0]["bytes"], last_launch_bytes=per[-1]["bytes"],
+                first_launch_algorithmic=alg[0], last_launch_algorithmic=alg[-1],
                 per_registration={k: full[k] for k in ("live", "certified", "searched", "stage_a_final",
                                                        "stage_b", "stage_b_per_lane", "candidates",
                                                        "table_requests", "valid_pairs", "launches")},
-                first_launch={k: first[k] for k in ("searched", "stage_b", "stage_b_per_lane", "candidates",
-                                                    "table_requests")})
+                first_launch={k: per[0][k] for k in ("searched", "stage_b", "stage_b_per_lane", "candidates",
+                                                     "table_requests")})
 
 
 def traffic_for(key):
@@ -164,7 +181,7 @@ def traffic_for(key):
 
 def roofline_record(ctx, T0, iters, d_max, n_q, avg_launch_s, first_us, min_us, key, cbar=None):
     mb = measured_bytes(ctx, T0, iters, d_max)
-    ach = mb["mean_bytes_per_launch"] / avg_launch_s / 1e9
+    ach = mb["mean_algorithmic_bytes"] / avg_launch_s / 1e9
     tr = traffic_for(key)
     rec = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "frac": ach / HBM_PEAK_GBPS,
@@ -175,18 +192,28 @@ def roofline_record(ctx, T0, iters, d_max, n_q, avg_launch_s, first_us, min_us, 
            "traffic_rocprof_avg_launch_us": tr.get("rocprof_avg_launch_us") if tr else None,
            "kernel": "k_linearize", "avg_launch_us": 1e6 * avg_launch_s,
            "first_launch_us": first_us, "min_launch_us": min_us, "queries_per_launch": n_q,
-           "bytes_per_launch": mb["mean_bytes_per_launch"],
-           "bytes_per_query": mb["mean_bytes_per_launch"] / max(n_q, 1),
-           "first_launch_bytes": mb["first_launch_bytes"],
-           "last_launch_bytes": mb["last_launch_bytes"],
-           "last_launch_GBps": (mb["last_launch_bytes"] / (1e-6 * min_us) / 1e9) if min_us > 0 else None,
+           "algorithmic_bytes_per_launch": mb["mean_algorithmic_bytes"],
+           "query_bytes_per_launch": mb["mean_query_bytes"],
+           "map_resident_bytes": mb["map_resident_bytes"],
+           "algorithmic_bytes_per_query": mb["mean_algorithmic_bytes"] / max(n_q, 1),
+           "first_launch_algorithmic_bytes": mb["first_launch_algorithmic"],
+           "last_launch_algorithmic_bytes": mb["last_launch_algorithmic"],
+           "last_launch_GBps": (mb["last_launch_algorithmic"] / (1e-6 * min_us) / 1e9) if min_us > 0 else None,
+           # what L1/L2 serve (not an HBM claim: above the HBM peak when the map is cache-resident)
+           "requested_bytes_per_launch": mb["mean_bytes_per_launch"],
+           "requested_GBps": mb["mean_bytes_per_launch"] / avg_launch_s / 1e9,
+           "first_launch_requested_bytes": mb["first_launch_bytes"],
+           "last_launch_requested_bytes": mb["last_launch_bytes"],
            "search": mb["per_registration"], "search_first_launch": mb["first_launch"],
-           "note": "achieved = bytes the kernel requested from memory (16 B per candidate / hinted / "
-                   "matched point and per normal, 16 or 8 B per fine-table request, 20 B query + hint "
-                   "+ certificate read, 8 B written back), counted by the kernel's counting "
-                   "instantiation in this run, / mean launch time of the timed steps (HIP events on "
-                   "the ctx stream) / 8 TB/s.  16-B gathers move whole 64/128-B lines: `traffic` "
-                   "(PMC, fabric side of L2, includes Infinity-Cache hits) is the physical figure"}
+           "note": "achieved = ALGORITHMIC bytes per launch / mean launch time of the timed steps (HIP "
+                   "events on the ctx stream).  Algorithmic bytes of a launch = the query side (20 B "
+                   "read + up to 8 B written per query, per-workgroup item / pose / partial row) + "
+                   "min(map-side bytes the search requested, bytes of the resident map: no map byte "
+                   "has to cross the fabric twice in a launch); both sides counted per launch by "
+                   "the kernel's counting instantiation in this run.  `requested_*` = every load / "
+                   "store issued (cache-level throughput).  `traffic` = PMC 2 x FETCH_SIZE + "
+                   "WRITE_SIZE per launch (profiles/, fabric side of L2, includes Infinity-Cache "
+                   "hits): the physical figure"}
     if cbar is not None:
         exh = (232.0 + 12.0 * cbar + 24.0) * n_q
         rec["exhaustive_equivalent_GBps"] = exh / avg_launch_s / 1e9

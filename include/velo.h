@@ -379,7 +379,9 @@ int velo_set_timing(velo_ctx*, int on);
  * [2] searched, [3] empty-neighbourhood skips, [4] stage-A final, [5] stragglers searched per
  * lane, [6] stage-B stragglers (all), [7] valid pairs, [8] BYTES the kernel requested from
  * memory (loads + stores: the roofline numerator bench.py uses), [9] candidate points examined,
- * [10] fine-table requests, [11] launches.  velo_debug_search_stats = the first 8. */
+ * [10] fine-table requests, [11] launches, [12] the query-side part of [8] (per-query stream and
+ * per-workgroup rows; the rest of [8] are gathers from the map: points, normals, fine table).
+ * velo_debug_search_stats = the first 8. */
 int velo_set_stats(velo_ctx*, int on);
 int velo_search_stats(velo_ctx*, uint64_t out[16], int reset);
 int velo_debug_search_stats(velo_ctx*, uint64_t out[8], int reset);

@@ -384,7 +384,7 @@ class Context:
         self._chk(lib().velo_search_stats(self.h, out, int(reset)))
         return dict(zip(("live", "certified", "searched", "empty_skips", "stage_a_final",
                          "stage_b_per_lane", "stage_b", "valid_pairs", "bytes", "candidates",
-                         "table_requests", "launches"), [int(v) for v in out[:12]]))
+                         "table_requests", "launches", "query_bytes"), [int(v) for v in out[:13]]))
 
     def synchronize(self):
         self._chk(lib().velo_synchronize(self.h))

@@ -12,6 +12,10 @@
 #include "velo_internal.hpp"
 #include "../../include/veloslam/TransformManager.hpp"
 
+#ifndef VELO_LATE_TAIL_PCT
+#define VELO_LATE_TAIL_PCT 10
+#endif
+
 using namespace velo;
 
 namespace {
@@ -676,21 +680,31 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     // frames: the latency kernel) keep one round throughout: they have too few workgroups as it is.
     c->ni_late = 0;
     if (c->cfg.rounds_per_block <= 0 && ni >= 3 * 4096) {  // still >= 4096 workgroups (16 per CU) afterwards
-        std::vector<BlockItem> late;
+        // The last VELO_LATE_TAIL_PCT % of every frame's queries are cut into one-round items and
+        // all of those are launched AFTER the three-round ones: the launch then drains in small
+        // pieces instead of ending on a row of 13-us workgroups.  (Rows of the partial-sum buffer
+        // -- `slot` -- stay frame-major whatever the launch order.)
+        std::vector<BlockItem> late, tail;
         std::vector<int32_t> fbl((size_t)n_frames + 1, 0);
         const int per_late = kLinThreads * 3;
+        int32_t slot = 0;
         for (int f = 0; f < n_frames; ++f) {
-            fbl[f] = (int32_t)late.size();
-            for (int64_t q = frame_start[f]; q < frame_start[f + 1]; q += per_late) {
+            fbl[f] = slot;
+            const int64_t nqf = frame_start[f + 1] - frame_start[f];
+            const int64_t big_end = frame_start[f] + (nqf * (100 - VELO_LATE_TAIL_PCT) / 100) / per_late * per_late;
+            for (int64_t q = frame_start[f]; q < frame_start[f + 1];) {
+                const int64_t step = q < big_end ? per_late : kLinThreads;
                 BlockItem it;
                 it.frame = f;
                 it.q0 = (int32_t)q;
-                it.q1 = (int32_t)std::min<int64_t>(q + per_late, frame_start[f + 1]);
-                it.slot = (int32_t)late.size();
-                late.push_back(it);
+                it.q1 = (int32_t)std::min<int64_t>(q + step, frame_start[f + 1]);
+                it.slot = slot++;
+                (q < big_end ? late : tail).push_back(it);
+                q += step;
             }
         }
-        fbl[n_frames] = (int32_t)late.size();
+        fbl[n_frames] = slot;
+        late.insert(late.end(), tail.begin(), tail.end());
         HIP_TRY(c, c->items_late.reserve(late.size()));
         HIP_TRY(c, c->fbs_late.reserve((size_t)n_frames + 1));
         HIP_TRY(c, hipMemcpyAsync(c->items_late.p, late.data(), late.size() * sizeof(BlockItem),

@@ -107,7 +107,8 @@ __constant__ unsigned char c_ib[32] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4,
 // [0] live queries, [1] certified (no search), [2] searched, [3] empty-neighbourhood skips,
 // [4] stage-A final, [5] stragglers searched per lane, [6] stage-B stragglers (all),
 // [7] valid pairs, [8] bytes requested from memory (loads + stores, see Tally),
-// [9] candidate points examined, [10] fine-table requests, [11] launches
+// [9] candidate points examined, [10] fine-table requests, [11] launches, [12] the query-side
+// part of [8] (per-query stream + per-workgroup rows: everything that is not a map-side gather)
 __device__ unsigned long long g_lin_stats[16];
 
 // Bytes this lane asked the memory system for: the roofline numerator of the pruned kernel
@@ -116,10 +117,19 @@ __device__ unsigned long long g_lin_stats[16];
 // 12 B query + 4 B hint + 4 B certificate read, 4 + 4 B written back, 1 B voxel flag.
 template <bool STATS>
 struct Tally {
-    unsigned bytes = 0, cand = 0, tab = 0;
+    unsigned bytes = 0, cand = 0, tab = 0, qbytes = 0;
     __device__ __forceinline__ void add(unsigned b)
     {
         if constexpr (STATS) bytes += b;
+    }
+    // query side: the per-query stream (coordinates, hint, certificate in; hint, certificate
+    // out) and the per-workgroup item / pose / partial row -- bytes no cache can save
+    __device__ __forceinline__ void addq(unsigned b)
+    {
+        if constexpr (STATS) {
+            bytes += b;
+            qbytes += b;
+        }
     }
     __device__ __forceinline__ void candidates(unsigned n)
     {
@@ -786,7 +796,7 @@ __device__ __forceinline__ void linearize_body(
     Tally<STATS> tl;
     if constexpr (STATS) {
         if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_lin_stats[11], 1ull);
-        if (tid == 0) tl.add(16 + 96 + kAccN * 8);  // work item, pose, partial sums
+        if (tid == 0) tl.addq(16 + 96 + kAccN * 8);  // work item, pose, partial sums
     }
 
     for (int base = it.q0; base < it.q1; base += kLinThreads) {
@@ -799,7 +809,7 @@ __device__ __forceinline__ void linearize_body(
             syq = fv.y[q];
             szq = fv.z[q];
             if (hint) hj = hint[q];
-            tl.add(hint ? 16 : 12);
+            tl.addq(hint ? 16 : 12);
         }
         double px = 0, py = 0, pz = 0;
         float bd = INFINITY;
@@ -828,7 +838,7 @@ __device__ __forceinline__ void linearize_body(
                 bool certified = false;
                 if (hj >= 0) {
                     tl.candidates(1);
-                    tl.add(rho ? 4 : 0);
+                    tl.addq(rho ? 4 : 0);
                     const float d1sq = dist2(mv.pts[hj], qx, qy, qz);
                     const float d1 = sqrtf(d1sq) * 1.000001f + 1e-7f;
                     if (rho) {
@@ -932,7 +942,7 @@ __device__ __forceinline__ void linearize_body(
             if (!(state_same && ok)) {
                 if (hint) hint[q] = ok ? bj : -1;
                 if (VARIANT >= 1 && rho) rho[q] = rho_new_out;
-                tl.add((hint ? 4 : 0) + ((VARIANT >= 1 && rho) ? 4 : 0));
+                tl.addq((hint ? 4 : 0) + ((VARIANT >= 1 && rho) ? 4 : 0));
             }
             if (WRITE_CORR) {
                 const int qi = fv.order ? fv.order[q] : q;
@@ -983,6 +993,7 @@ __device__ __forceinline__ void linearize_body(
         stat_add(8, tl.bytes);
         stat_add(9, tl.cand);
         stat_add(10, tl.tab);
+        stat_add(12, tl.qbytes);
     }
     // halves -> wave (shuffle), waves -> block (LDS), fixed order
     const double other = __shfl_down(colsum, 32, 64);
