@@ -22,6 +22,21 @@
 #ifndef VELO_ORDER_LATE
 #define VELO_ORDER_LATE 0
 #endif
+#ifndef VELO_LATE_ROUNDS
+#define VELO_LATE_ROUNDS 3
+#endif
+#ifndef VELO_FIRST_ROUNDS
+#define VELO_FIRST_ROUNDS 4
+#endif
+#ifndef VELO_MIN_SLOT_ROUNDS
+#define VELO_MIN_SLOT_ROUNDS 2.5
+#endif
+#ifndef VELO_CONV_ROUNDS
+#define VELO_CONV_ROUNDS 6
+#endif
+#ifndef VELO_CONV_FROM
+#define VELO_CONV_FROM 5
+#endif
 #ifndef VELO_LATE_TAIL_PCT
 #define VELO_LATE_TAIL_PCT 10
 #endif
@@ -118,6 +133,13 @@ struct velo_ctx {
     DevBuf<BlockItem> items_late;
     DevBuf<int32_t> fbs_late;
     int ni_late = 0;
+    // third decomposition, for the iterations from VELO_CONV_FROM on (hardly any query searches
+    // any more: coarser items)
+    bool plan_lat = false;            // the resident frames are cut for the latency kernel
+    int wave_slots = 256 * 28;        // wavefronts the device holds at 7 per SIMD (velo_create)
+    DevBuf<BlockItem> items_conv;
+    DevBuf<int32_t> fbs_conv;
+    int ni_conv = 0;
     DevBuf<float> sx, sy, sz;         // cell-sorted copies of the frames (cfg.sort_frames)
     DevBuf<int32_t> fbs;
     DevBuf<double> poses, partials, acc;
@@ -674,6 +696,75 @@ std::vector<BlockItem> launch_order(const std::vector<BlockItem>& items, int mod
     return out;
 }
 
+// A decomposition of the resident frames for the hinted iterations of a BATCH: `rounds` rounds of
+// a workgroup per item.  The last VELO_LATE_TAIL_PCT % of every frame's queries are cut into
+// one-round items and all of those are launched AFTER the big ones: the launch then drains in
+// small pieces instead of ending on a row of long workgroups.  (Rows of the partial-sum buffer --
+// `slot` -- stay frame-major whatever the launch order.)
+// rounds per wavefront of a decomposition: as many as `r_max`, as long as the launch keeps
+// VELO_MIN_SLOT_ROUNDS wavefronts per wavefront slot of the device (measured on 16 / 32 / 64
+// frames: a launch cut coarser than that loses more in its tail than it saves in fixed cost)
+int rounds_per_wave(const velo_ctx* c, int64_t n_queries, int r_max)
+{
+    const double wave_rounds = (double)n_queries / 64.0;
+    int r = r_max;
+    while (r > 1 && wave_rounds / r < VELO_MIN_SLOT_ROUNDS * (double)c->wave_slots) --r;
+    return r;
+}
+
+int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, int rounds,
+                       DevBuf<BlockItem>& d_items, DevBuf<int32_t>& d_fbs, int& n_out)
+{
+    std::vector<BlockItem> big, tail;
+    std::vector<int32_t> fbl((size_t)n_frames + 1, 0);
+    const int per_big = kLinNT * rounds;
+    int32_t slot = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        fbl[f] = slot;
+        const int64_t nqf = frame_start[f + 1] - frame_start[f];
+        const int64_t big_end = frame_start[f] + (nqf * (100 - VELO_LATE_TAIL_PCT) / 100) / per_big * per_big;
+        for (int64_t q = frame_start[f]; q < frame_start[f + 1];) {
+            const int64_t step = q < big_end ? per_big : kLinNT;
+            BlockItem it;
+            it.frame = f;
+            it.q0 = (int32_t)q;
+            it.q1 = (int32_t)std::min<int64_t>(q + step, frame_start[f + 1]);
+            it.slot = slot++;
+            (q < big_end ? big : tail).push_back(it);
+            q += step;
+        }
+    }
+    fbl[n_frames] = slot;
+    big = launch_order(big, VELO_ORDER_LATE);
+    tail = launch_order(tail, VELO_ORDER_LATE);
+    big.insert(big.end(), tail.begin(), tail.end());
+    HIP_TRY(c, d_items.reserve(big.size()));
+    HIP_TRY(c, d_fbs.reserve((size_t)n_frames + 1));
+    HIP_TRY(c, hipMemcpyAsync(d_items.p, big.data(), big.size() * sizeof(BlockItem), hipMemcpyHostToDevice,
+                              c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_fbs.p, fbl.data(), fbl.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors go out of scope
+    n_out = (int)big.size();
+    return VELO_OK;
+}
+
+// which work items iteration `it` of a registration runs on (plan_frames)
+struct Decomposition {
+    const BlockItem* items;
+    const int32_t* fbs;
+    int n;
+};
+
+Decomposition decomposition_for(velo_ctx* c, int it, bool hinted, bool sorted_queries)
+{
+    if (sorted_queries)
+        return {c->cfg.sort_frames == 1 ? c->items_xcd.p : c->items_first.p, c->fbs.p, (int)c->items_h.size()};
+    if (it >= VELO_CONV_FROM && c->ni_conv > 0 && hinted) return {c->items_conv.p, c->fbs_conv.p, c->ni_conv};
+    if (it > 0 && c->ni_late > 0 && hinted) return {c->items_late.p, c->fbs_late.p, c->ni_late};
+    return {c->items_first.p, c->fbs.p, (int)c->items_h.size()};
+}
+
 int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
 {
     if (n_frames < 1) return c->fail(VELO_E_INVALID, "n_frames must be >= 1");
@@ -693,7 +784,15 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     // start-up they cost, so the default is one round; cfg.rounds_per_block overrides.
     int rounds = 1;
     if (c->cfg.rounds_per_block > 0) rounds = std::min(c->cfg.rounds_per_block, 64);
-    const int per_block = kLinThreads * rounds;
+    int per_block = kLinThreads * rounds;
+    // Which kernel the registrations of these frames run on: fewer than kLatQueries queries (~4
+    // frames) leave most of the chip idle -- a latency problem, 256-query items for the latency
+    // kernel.  Otherwise the throughput kernel (workgroups of kLinNT threads), whose items are
+    // sized in rounds per wavefront (rounds_per_wave): up to 4 in the first, unhinted iteration.
+    const int64_t total_q = frame_start[n_frames];
+    c->plan_lat = c->cfg.force_kernel == 2 || (c->cfg.force_kernel != 1 && total_q < kLatQueries);
+    const bool planned = c->cfg.rounds_per_block <= 0 && !c->plan_lat;
+    if (planned) per_block = kLinNT * rounds_per_wave(c, total_q, VELO_FIRST_ROUNDS);
     for (int f = 0; f < n_frames; ++f) {
         c->fbs_h[f] = (int32_t)c->items_h.size();
         for (int64_t q = frame_start[f]; q < frame_start[f + 1]; q += per_block) {
@@ -707,54 +806,28 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     }
     c->fbs_h[n_frames] = (int32_t)c->items_h.size();
     const size_t ni = c->items_h.size();
-    // Iterations after the first of a BATCH run three rounds per workgroup: their work is even
-    // (hinted / certified queries), so a third of the workgroups -- a third of the item / pose
-    // loads, block reductions, partial rows for the solve to read -- is cheaper (64 frames:
-    // converged launch 84 -> 77 us, registration 2.67 -> 2.49 ms); the first, unhinted iteration
-    // is ragged and keeps one round (503 us with three against 488).  Small launches (single
-    // frames: the latency kernel) keep one round throughout: they have too few workgroups as it is.
+    // The hinted iterations of a batch run on coarser items: their work is even (hinted /
+    // certified queries), so fewer workgroups -- fewer item / pose loads, block reductions,
+    // partial rows for the solve to read -- are cheaper: up to VELO_LATE_ROUNDS rounds per
+    // wavefront while a good share of the queries still searches (iterations 1 .. VELO_CONV_FROM-1),
+    // up to VELO_CONV_ROUNDS afterwards (64 frames: converged launch 84 us on the first
+    // decomposition, 71 at three rounds, 68 at six, 76 at twelve).
     c->ni_late = 0;
-    if (c->cfg.rounds_per_block <= 0 && ni >= 3 * 4096) {  // still >= 4096 workgroups (16 per CU) afterwards
-        // The last VELO_LATE_TAIL_PCT % of every frame's queries are cut into one-round items and
-        // all of those are launched AFTER the three-round ones: the launch then drains in small
-        // pieces instead of ending on a row of 13-us workgroups.  (Rows of the partial-sum buffer
-        // -- `slot` -- stay frame-major whatever the launch order.)
-        std::vector<BlockItem> late, tail;
-        std::vector<int32_t> fbl((size_t)n_frames + 1, 0);
-        const int per_late = kLinThreads * 3;
-        int32_t slot = 0;
-        for (int f = 0; f < n_frames; ++f) {
-            fbl[f] = slot;
-            const int64_t nqf = frame_start[f + 1] - frame_start[f];
-            const int64_t big_end = frame_start[f] + (nqf * (100 - VELO_LATE_TAIL_PCT) / 100) / per_late * per_late;
-            for (int64_t q = frame_start[f]; q < frame_start[f + 1];) {
-                const int64_t step = q < big_end ? per_late : kLinThreads;
-                BlockItem it;
-                it.frame = f;
-                it.q0 = (int32_t)q;
-                it.q1 = (int32_t)std::min<int64_t>(q + step, frame_start[f + 1]);
-                it.slot = slot++;
-                (q < big_end ? late : tail).push_back(it);
-                q += step;
-            }
-        }
-        fbl[n_frames] = slot;
-        late = launch_order(late, VELO_ORDER_LATE);
-        tail = launch_order(tail, VELO_ORDER_LATE);
-        late.insert(late.end(), tail.begin(), tail.end());
-        HIP_TRY(c, c->items_late.reserve(late.size()));
-        HIP_TRY(c, c->fbs_late.reserve((size_t)n_frames + 1));
-        HIP_TRY(c, hipMemcpyAsync(c->items_late.p, late.data(), late.size() * sizeof(BlockItem),
-                                  hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->fbs_late.p, fbl.data(), fbl.size() * sizeof(int32_t),
-                                  hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors go out of scope
-        c->ni_late = (int)late.size();
+    c->ni_conv = 0;
+    size_t max_rows = std::max<size_t>(ni, 1);
+    if (planned) {
+        if (int rc = plan_decomposition(c, frame_start, n_frames, rounds_per_wave(c, total_q, VELO_LATE_ROUNDS),
+                                        c->items_late, c->fbs_late, c->ni_late))
+            return rc;
+        if (int rc = plan_decomposition(c, frame_start, n_frames, rounds_per_wave(c, total_q, VELO_CONV_ROUNDS),
+                                        c->items_conv, c->fbs_conv, c->ni_conv))
+            return rc;
+        max_rows = std::max(max_rows, (size_t)std::max(c->ni_late, c->ni_conv));
     }
     HIP_TRY(c, c->items.reserve(std::max<size_t>(ni, 1)));
     HIP_TRY(c, c->fbs.reserve((size_t)n_frames + 1));
     HIP_TRY(c, c->d_frame_start.reserve((size_t)n_frames + 1));
-    HIP_TRY(c, c->partials.reserve(std::max<size_t>(ni, 1) * kAccStride));
+    HIP_TRY(c, c->partials.reserve(max_rows * kAccStride));
     HIP_TRY(c, c->poses.reserve((size_t)maxb * 12));
     HIP_TRY(c, c->acc.reserve((size_t)maxb * kAccStride));
     HIP_TRY(c, c->stats.reserve((size_t)maxb * VELO_MAX_ITERS));
@@ -949,13 +1022,12 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             if (e == hipSuccess && rho) e = hipMemsetAsync(rho, 0, n_all * sizeof(float), s);
             FrameView fv{c->ax, c->ay, c->az, nullptr};
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
-                const bool late = it > 0 && c->ni_late > 0 && hint;
-                e = launch_linearize(c->cfg.linearize_variant, late ? c->items_late.p : c->items_first.p,
-                                     late ? c->ni_late : ni, fv, c->mv, c->poses.p,
+                const Decomposition dc = decomposition_for(c, it, hint != nullptr, false);
+                e = launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv, c->poses.p,
                                      dmax2, c->partials.p, nullptr, nullptr, hint, rho,
-                                     c->poses_prev.p, false, c->cfg.force_kernel, s);
+                                     c->poses_prev.p, false, c->plan_lat ? 2 : 1, s);
                 if (e == hipSuccess)
-                    e = launch_reduce_solve(c->partials.p, late ? c->fbs_late.p : c->fbs.p, c->n_frames, c->poses.p,
+                    e = launch_reduce_solve(c->partials.p, dc.fbs, c->n_frames, c->poses.p,
                                             c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
                                             c->pairs_total.p, s);
             }
@@ -986,21 +1058,16 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     if (hint) HIP_TRY(c, hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s));
     if (rho) HIP_TRY(c, hipMemsetAsync(rho, 0, n_all * sizeof(float), s));
     for (int it = 0; it < iters; ++it) {
-        bool late_it = false;
+        const Decomposition dc = decomposition_for(c, it, hint != nullptr, fv.order != nullptr);
         {
             Timed t(c, 0);
-            const bool late = it > 0 && c->ni_late > 0 && hint && !fv.order;
-            late_it = late;
-            HIP_TRY(c, launch_linearize(c->cfg.linearize_variant,
-                                        late ? c->items_late.p
-                                             : ((fv.order && c->cfg.sort_frames == 1) ? c->items_xcd.p : c->items_first.p),
-                                        late ? c->ni_late : ni, fv, c->mv,
+            HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv,
                                         c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, rho,
-                                        c->poses_prev.p, c->stats_on, c->cfg.force_kernel, s));
+                                        c->poses_prev.p, c->stats_on, c->plan_lat ? 2 : 1, s));
         }
         {
             Timed t(c, 1);
-            HIP_TRY(c, launch_reduce_solve(c->partials.p, late_it ? c->fbs_late.p : c->fbs.p, c->n_frames, c->poses.p,
+            HIP_TRY(c, launch_reduce_solve(c->partials.p, dc.fbs, c->n_frames, c->poses.p,
                                            c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
                                            c->pairs_total.p, s));
         }
@@ -1092,6 +1159,11 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     }
     std::unique_ptr<velo_ctx> c(new velo_ctx);
     c->device = device_id;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
+            c->wave_slots = cus * 4 * 7;
+    }
     std::memset(&c->cfg, 0, sizeof c->cfg);
     if (cfg) std::memcpy(&c->cfg, cfg, std::min<size_t>(cfg->struct_size, sizeof(velo_cfg)));
     c->cfg.struct_size = sizeof(velo_cfg);

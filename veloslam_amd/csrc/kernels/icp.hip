@@ -246,7 +246,8 @@ __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float 
 //            x-extent of each row cut to the ball, descending index, '<='.  Compaction keeps
 //            a handful of stragglers from stalling every wavefront of the workgroup.
 constexpr int kMaxRanges = 9;
-constexpr int kLatItems = 2048;  // launches below this many workgroups use the latency kernel
+constexpr int kLatItems = 2048;  // launches below this many workgroups use the latency kernel unless the
+                                 // caller says which (registrations do: kLatQueries, plan_frames)
 #ifndef VELO_CERT_SLACK
 #define VELO_CERT_SLACK 0.015f  // measured: 0.005-0.02 within 1%, 0.05 +3%, 0.10 +5% (batch); dense single frame 0.68 vs 0.73 ms
 #endif
@@ -778,7 +779,7 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 // issue and occupancy: 72 registers, 7 waves per SIMD).  LAT = true: the latency kernel (a
 // single frame: < 2 workgroups per CU, bound by dependent memory round trips: registers are
 // free, stage B is the packed / probed form above).  Same results bit for bit.
-template <bool WRITE_CORR, int VARIANT, bool STATS, bool LAT, bool HASH>
+template <bool WRITE_CORR, int VARIANT, bool STATS, bool LAT, bool HASH, int NT>
 __device__ __forceinline__ void linearize_body(
     const BlockItem* __restrict__ items, const FrameView& fv, const MapView& mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
@@ -799,7 +800,7 @@ __device__ __forceinline__ void linearize_body(
         if (tid == 0) tl.addq(16 + 96 + kAccN * 8);  // work item, pose, partial sums
     }
 
-    for (int base = it.q0; base < it.q1; base += kLinThreads) {
+    for (int base = it.q0; base < it.q1; base += NT) {
         const int q = base + tid;
         const bool live = q < it.q1;
         float sxq = 0.f, syq = 0.f, szq = 0.f;
@@ -1000,22 +1001,24 @@ __device__ __forceinline__ void linearize_body(
     if (half == 0) s_w[wave][col] = colsum + other;
     __syncthreads();
     if (tid < kAccN) {
-        const double t = ((s_w[0][tid] + s_w[1][tid]) + s_w[2][tid]) + s_w[3][tid];
+        double t = s_w[0][tid];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) t += s_w[w][tid];
         partials[(size_t)it.slot * kAccStride + tid] = t;
     }
 }
 
 template <bool WRITE_CORR, int VARIANT, bool STATS, bool HASH = false>
-__global__ __launch_bounds__(kLinThreads, VELO_LIN_WAVES) void k_linearize(
+__global__ __launch_bounds__(kLinNT, VELO_LIN_WAVES) void k_linearize(
     const BlockItem* __restrict__ items, FrameView fv, MapView mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
     int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint,
     float* __restrict__ rho, const double* __restrict__ poses_prev)
 {
-    __shared__ LinLds s_uw[kLinThreads / 64];
-    __shared__ double s_w[4][32];
-    linearize_body<WRITE_CORR, VARIANT, STATS, false, HASH>(items, fv, mv, poses, dmax2, partials, corr,
-                                                            d2out, hint, rho, poses_prev, s_uw, s_w);
+    __shared__ LinLds s_uw[kLinNT / 64];
+    __shared__ double s_w[kLinNT / 64][32];
+    linearize_body<WRITE_CORR, VARIANT, STATS, false, HASH, kLinNT>(items, fv, mv, poses, dmax2, partials, corr,
+                                                                    d2out, hint, rho, poses_prev, s_uw, s_w);
 }
 
 template <bool WRITE_CORR, bool STATS, bool HASH = false>
@@ -1027,8 +1030,8 @@ __global__ __launch_bounds__(kLinThreads, 4) void k_linearize_lat(
 {
     __shared__ LinLds s_uw[kLinThreads / 64];
     __shared__ double s_w[4][32];
-    linearize_body<WRITE_CORR, 1, STATS, true, HASH>(items, fv, mv, poses, dmax2, partials, corr, d2out,
-                                                     hint, rho, poses_prev, s_uw, s_w);
+    linearize_body<WRITE_CORR, 1, STATS, true, HASH, kLinThreads>(items, fv, mv, poses, dmax2, partials, corr,
+                                                                  d2out, hint, rho, poses_prev, s_uw, s_w);
 }
 
 hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)
@@ -1049,7 +1052,7 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
     if (n_items == 0) return hipSuccess;
     const bool wc = corr || d2;
 #define VELO_LAUNCH_LIN(WC, V)                                                                   \
-    hipLaunchKernelGGL((k_linearize<WC, V, false>), dim3(n_items), dim3(kLinThreads), 0, s,     \
+    hipLaunchKernelGGL((k_linearize<WC, V, false>), dim3(n_items), dim3(kLinNT), 0, s,     \
                        items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev)
     // a launch that leaves most of the chip idle is a latency problem: fewer than kLatItems
     // workgroups (~4 frames) go to the latency kernel
@@ -1059,7 +1062,7 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
         // sparse fine-cell table: the ball search in its two kernels (the validation scan and
         // the counting instantiation read the table through the run-time form)
         if (variant == VELO_VARIANT_SCAN) {
-            hipLaunchKernelGGL((k_linearize<true, 0, false>), dim3(n_items), dim3(kLinThreads), 0, s, items,
+            hipLaunchKernelGGL((k_linearize<true, 0, false>), dim3(n_items), dim3(kLinNT), 0, s, items,
                                fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
         } else if (lat) {
             if (wc)
@@ -1070,10 +1073,10 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
                                    s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
         } else {
             if (wc)
-                hipLaunchKernelGGL((k_linearize<true, 1, false, true>), dim3(n_items), dim3(kLinThreads), 0,
+                hipLaunchKernelGGL((k_linearize<true, 1, false, true>), dim3(n_items), dim3(kLinNT), 0,
                                    s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
             else
-                hipLaunchKernelGGL((k_linearize<false, 1, false, true>), dim3(n_items), dim3(kLinThreads), 0,
+                hipLaunchKernelGGL((k_linearize<false, 1, false, true>), dim3(n_items), dim3(kLinNT), 0,
                                    s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
         }
         return hipGetLastError();
@@ -1083,7 +1086,7 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
             hipLaunchKernelGGL((k_linearize_lat<true, true>), dim3(n_items), dim3(kLinThreads), 0, s,
                                items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
         else
-            hipLaunchKernelGGL((k_linearize<true, 1, true>), dim3(n_items), dim3(kLinThreads), 0, s,
+            hipLaunchKernelGGL((k_linearize<true, 1, true>), dim3(n_items), dim3(kLinNT), 0, s,
                                items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
     } else if (lat) {
         if (wc)

@@ -52,6 +52,14 @@ struct BlockItem {
 constexpr int kAccN = 29;      // 21 + 6 + 1 + 1
 constexpr int kAccStride = 32; // padded row of the partials buffer (doubles)
 constexpr int kLinThreads = 256;
+// threads per workgroup of the THROUGHPUT linearise kernel (the latency kernel and the first
+// decomposition's work items stay at kLinThreads: a smaller workgroup takes more rounds per item)
+#ifndef VELO_LIN_NT
+#define VELO_LIN_NT 128
+#endif
+constexpr int kLinNT = VELO_LIN_NT;
+// registrations of fewer queries than this (~4 frames) run on the latency kernel
+constexpr int64_t kLatQueries = 2048 * 256;
 
 // ---------------------------------------------------------------- launchers (kernels/*.hip)
 struct MapBuild;  // opaque scratch owned by the ctx
