@@ -1018,14 +1018,13 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             HIP_TRY(c, hipStreamSynchronize(s));
             HIP_TRY(c, hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
             hipError_t e = hipSuccess;  // (the pose upload stays outside the graph: its source alternates)
-            if (hint) e = hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s);
-            if (e == hipSuccess && rho) e = hipMemsetAsync(rho, 0, n_all * sizeof(float), s);
             FrameView fv{c->ax, c->ay, c->az, nullptr};
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
                 const Decomposition dc = decomposition_for(c, it, hint != nullptr, false);
                 e = launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv, c->poses.p,
                                      dmax2, c->partials.p, nullptr, nullptr, hint, rho,
-                                     c->poses_prev.p, false, c->plan_lat ? 2 : 1, s);
+                                     it == 0 ? nullptr : c->poses_prev.p,  // (first iteration: stale hints)
+                                     false, c->plan_lat ? 2 : 1, s);
                 if (e == hipSuccess)
                     e = launch_reduce_solve(c->partials.p, dc.fbs, c->n_frames, c->poses.p,
                                             c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
@@ -1055,15 +1054,14 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     FrameView fv{c->ax, c->ay, c->az, nullptr};
     if (int rc = maybe_sort_frames(c, fv)) return rc;
     // hints never outlive a registration: results do not depend on earlier calls
-    if (hint) HIP_TRY(c, hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s));
-    if (rho) HIP_TRY(c, hipMemsetAsync(rho, 0, n_all * sizeof(float), s));
     for (int it = 0; it < iters; ++it) {
         const Decomposition dc = decomposition_for(c, it, hint != nullptr, fv.order != nullptr);
         {
             Timed t(c, 0);
             HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv,
                                         c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, rho,
-                                        c->poses_prev.p, c->stats_on, c->plan_lat ? 2 : 1, s));
+                                        it == 0 ? nullptr : c->poses_prev.p,  // (first iteration: stale hints)
+                                        c->stats_on, c->plan_lat ? 2 : 1, s));
         }
         {
             Timed t(c, 1);

@@ -809,8 +809,10 @@ __device__ __forceinline__ void linearize_body(
             sxq = fv.x[q];
             syq = fv.y[q];
             szq = fv.z[q];
-            if (hint) hj = hint[q];
-            tl.addq(hint ? 16 : 12);
+            // poses_prev == nullptr marks the first iteration of a registration: whatever the
+            // hint / certificate arrays hold is stale (they are not cleared, just overwritten)
+            if (hint && poses_prev) hj = hint[q];
+            tl.addq(hint && poses_prev ? 16 : 12);
         }
         double px = 0, py = 0, pz = 0;
         float bd = INFINITY;
