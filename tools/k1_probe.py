@@ -25,3 +25,14 @@ torch.cuda.synchronize()
 t = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(40))
 us = 1e3 * t[len(t) // 2]
 print("K1: %d points, median %.1f us -> %.2f TB/s (26 B/point), min %.1f us" % (n_q, us, 26.0 * n_q / us / 1e6, 1e3 * t[0]))
+# copy ceiling at the same footprint: torch elementwise ops over the same arrays
+import time
+a_, b_, c_ = d["sx"], d["sy"], d["cx"]
+for _ in range(5): torch.add(a_, b_, out=c_)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+ev[0].record()
+for i in range(20):
+    torch.add(a_, b_, out=c_); ev[i + 1].record()
+torch.cuda.synchronize()
+t = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(20))
+print("torch add (2 reads + 1 write of %d floats): median %.1f us -> %.2f TB/s" % (n_q, 1e3 * t[10], 12.0 * n_q / (1e3 * t[10]) / 1e6))

@@ -20,6 +20,7 @@ ap.add_argument("--device-map", action="store_true", help="sample the map with t
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--cfg", action="append", default=[])
 ap.add_argument("--stats", action="store_true")
+ap.add_argument("--once", action="store_true", help="one registration only (for rocprofv3 --pmc)")
 a = ap.parse_args()
 sys.argv = [sys.argv[0], "--frames", str(a.frames), "--map-points", str(1000 if a.device_map else a.map_points)]
 args = bench.parse()
@@ -44,6 +45,9 @@ for cfg in a.cfg or ["subdiv=3"]:
                        d["tab"].data_ptr(), d["n_pkt"], d["cx"].data_ptr(), d["cy"].data_ptr(), d["cz"].data_ptr())
     ctx.frames_adopt_dev(d["cx"].data_ptr(), d["cy"].data_ptr(), d["cz"].data_ptr(), d["frame_start"])
     ctx.icp_batch(d["T0"], a.iters, 1.0)
+    if a.once:
+        ctx.close()
+        continue
     ctx.set_timing(1)
     us = []
     for _ in range(3):

@@ -57,6 +57,89 @@ __global__ __launch_bounds__(256) void k_compensate_v4(
     }
 }
 
+// The same with the table staged per WAVEFRONT: the 256 points of a wavefront are consecutive
+// returns of a beam, i.e. ~43 consecutive packets.  Fetched per lane, their 96-byte matrices are
+// six 16-byte loads at a 96-byte stride -- 48 cache lines per instruction, and the L1 data path,
+// not HBM, is what the kernel waits on (7.4 M points: 31 us without any table fetch, 48 with).
+// Here the wavefront finds its
+// packet range (two shuffled reductions), loads those matrices ONCE as contiguous 16-byte chunks
+// (8 lines per instruction) into its own LDS slice and every lane reads its matrix from there.
+// A wavefront that spans more than kK1Span packets (a beam boundary: 1 in 7) fetches per lane
+// as before.  No workgroup barrier: nothing is shared between wavefronts.
+constexpr int kK1Span = 64;
+struct __attribute__((aligned(16))) K1Lds {
+    double m[kK1Span * 12];
+};
+
+__global__ __launch_bounds__(256) void k_compensate_v4l(
+    const float4* __restrict__ x4, const float4* __restrict__ y4, const float4* __restrict__ z4,
+    const ushort4* __restrict__ p4, size_t n4, const double* __restrict__ tab, unsigned n_pkt,
+    float4* __restrict__ ox4, float4* __restrict__ oy4, float4* __restrict__ oz4)
+{
+    __shared__ K1Lds s_tab[4];
+    const int lane = threadIdx.x & 63;
+    K1Lds& L = s_tab[threadIdx.x >> 6];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n4;
+    const size_t ic = live ? i : n4 - 1;
+    const float4 x = x4[ic], y = y4[ic], z = z4[ic];
+    const ushort4 p = p4[ic];
+    const unsigned k[4] = {min((unsigned)p.x, n_pkt - 1), min((unsigned)p.y, n_pkt - 1),
+                           min((unsigned)p.z, n_pkt - 1), min((unsigned)p.w, n_pkt - 1)};
+    unsigned kmin = min(min(k[0], k[1]), min(k[2], k[3])), kmax = max(max(k[0], k[1]), max(k[2], k[3]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, off, 64));
+        kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, off, 64));
+    }
+    const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w}, zs[4] = {z.x, z.y, z.z, z.w};
+    float rx[4], ry[4], rz[4];
+    if (kmax - kmin < (unsigned)kK1Span) {  // (uniform)
+        const int chunks = (int)(kmax - kmin + 1) * 6;  // 16-byte pieces
+        const double2* src = reinterpret_cast<const double2*>(tab + 12 * (size_t)kmin);
+        double2* dst = reinterpret_cast<double2*>(L.m);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int c = lane + 64 * t;
+            if (c < chunks) dst[c] = src[c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (k[0] == k[3] && k[1] == k[2] && k[0] == k[1]) {
+            double M[12];
+            const double2* mp = reinterpret_cast<const double2*>(L.m + 12 * (k[0] - kmin));
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const double2 v = mp[e];
+                M[2 * e] = v.x;
+                M[2 * e + 1] = v.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) apply_affine(M, xs[j], ys[j], zs[j], rx[j], ry[j], rz[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                apply_affine(L.m + 12 * (k[j] - kmin), xs[j], ys[j], zs[j], rx[j], ry[j], rz[j]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else if (k[0] == k[3] && k[1] == k[2] && k[0] == k[1]) {
+        double M[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) M[e] = tab[12 * (size_t)k[0] + e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) apply_affine(M, xs[j], ys[j], zs[j], rx[j], ry[j], rz[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            apply_affine(tab + 12 * (size_t)k[j], xs[j], ys[j], zs[j], rx[j], ry[j], rz[j]);
+    }
+    if (live) {
+        ox4[i] = make_float4(rx[0], rx[1], rx[2], rx[3]);
+        oy4[i] = make_float4(ry[0], ry[1], ry[2], ry[3]);
+        oz4[i] = make_float4(rz[0], rz[1], rz[2], rz[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_compensate_v1(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
     const uint16_t* __restrict__ pkt, size_t i0, size_t n, const double* __restrict__ tab,
@@ -79,11 +162,18 @@ hipError_t launch_compensate(const float* x, const float* y, const float* z, con
     if (al16(x) && al16(y) && al16(z) && al16(ox) && al16(oy) && al16(oz) &&
         (reinterpret_cast<uintptr_t>(pkt) & 7u) == 0 && n >= 4) {
         const size_t n4 = n / 4;
-        size_t g = (n4 + 255) / 256;
-        const int grid = (int)(g > 16384 ? 16384 : g);
-        hipLaunchKernelGGL(k_compensate_v4, dim3(grid), dim3(256), 0, s, (const float4*)x,
-                           (const float4*)y, (const float4*)z, (const ushort4*)pkt, n4, T3x4,
-                           (unsigned)n_pkt, (float4*)ox, (float4*)oy, (float4*)oz);
+        if (al16(T3x4)) {
+            const size_t gl = (n4 + 255) / 256;
+            hipLaunchKernelGGL(k_compensate_v4l, dim3((unsigned)gl), dim3(256), 0, s, (const float4*)x,
+                               (const float4*)y, (const float4*)z, (const ushort4*)pkt, n4, T3x4,
+                               (unsigned)n_pkt, (float4*)ox, (float4*)oy, (float4*)oz);
+        } else {
+            size_t g = (n4 + 255) / 256;
+            const int grid = (int)(g > 16384 ? 16384 : g);
+            hipLaunchKernelGGL(k_compensate_v4, dim3(grid), dim3(256), 0, s, (const float4*)x,
+                               (const float4*)y, (const float4*)z, (const ushort4*)pkt, n4, T3x4,
+                               (unsigned)n_pkt, (float4*)ox, (float4*)oy, (float4*)oz);
+        }
         done = n4 * 4;
     }
     if (done < n) {
@@ -1193,7 +1283,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
 {
     __shared__ double s_g[kSolveGroups][32];
     __shared__ double s_acc[32];
+    __shared__ double s_pose[12];
     const int f = blockIdx.x, k = threadIdx.x & 31, g = threadIdx.x >> 5;
+    // the frame's pose travels with the partial sums (one memory round trip, not two in a row)
+    double pose_k = 0.0;
+    if (threadIdx.x < 12) pose_k = poses[12 * (size_t)f + threadIdx.x];
     {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         const int b0 = fbs[f], b1 = fbs[f + 1];
@@ -1209,6 +1303,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
         }
         s_g[g][k] = (a0 + a1) + (a2 + a3);
     }
+    if (threadIdx.x < 12) {
+        s_pose[threadIdx.x] = pose_k;
+        if (do_update && poses_prev) poses_prev[12 * (size_t)f + threadIdx.x] = pose_k;
+    }
     __syncthreads();
     if (threadIdx.x < kAccN) {
         double a = 0.0;
@@ -1219,10 +1317,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    // the pose this iteration was linearised at: the next k_linearize recomputes every
-    // query's previous position from it (uniqueness certificate)
-    if (do_update && poses_prev)
-        for (int i = 0; i < 12; ++i) poses_prev[12 * (size_t)f + i] = poses[12 * (size_t)f + i];
+    // (poses_prev, written above: the pose this iteration was linearised at -- the next
+    // k_linearize recomputes every query's previous position from it, uniqueness certificate)
     const double cnt = s_acc[28];
     velo_icp_iter st;
     st.n_pairs = (uint32_t)cnt;
@@ -1250,7 +1346,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
                 st.solve_flag = 2;
             } else {
                 double T[12];
-                for (int i = 0; i < 12; ++i) T[i] = poses[12 * (size_t)f + i];
+                for (int i = 0; i < 12; ++i) T[i] = s_pose[i];
                 se3_exp_apply(xi, T);
                 for (int i = 0; i < 12; ++i) poses[12 * (size_t)f + i] = T[i];
             }
