@@ -854,7 +854,7 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 };
 
 #ifndef VELO_COOP_MAX
-#define VELO_COOP_MAX 16
+#define VELO_COOP_MAX 8  // (both forms certify now; 64 frames: 16 -> 2.27 ms, 4..8 -> 2.22, 2 -> 2.26, 0 -> 2.38)
 #endif
 #ifndef VELO_COOP_MAX_LAT
 #define VELO_COOP_MAX_LAT 16  // (4 takes 20 us off the second launch on a dense map, but only the
