@@ -1289,17 +1289,26 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     double pose_k = 0.0;
     if (threadIdx.x < 12) pose_k = poses[12 * (size_t)f + threadIdx.x];
     {
+        // The kernel is a chain of memory round trips, not bandwidth: every group asks for ALL its
+        // rows of a pass at once (16 unconditional loads on clamped row numbers, masked after):
+        // a frame of up to 512 rows is one round trip (it was four loads in flight, i.e. four trips
+        // for a single frame's 450 rows).  Fixed order: run-to-run deterministic.
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         const int b0 = fbs[f], b1 = fbs[f + 1];
-        if (k < kAccN) {
-            int b = b0 + g;
-            for (; b + 3 * kSolveGroups < b1; b += 4 * kSolveGroups) {  // four loads in flight
-                a0 += partials[(size_t)b * kAccStride + k];
-                a1 += partials[(size_t)(b + kSolveGroups) * kAccStride + k];
-                a2 += partials[(size_t)(b + 2 * kSolveGroups) * kAccStride + k];
-                a3 += partials[(size_t)(b + 3 * kSolveGroups) * kAccStride + k];
+        if (k < kAccN && b1 > b0) {
+            for (int b = b0 + g; b < b1; b += 16 * kSolveGroups) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    v[u] = partials[(size_t)min(b + u * kSolveGroups, b1 - 1) * kAccStride + k];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (b + u * kSolveGroups >= b1) v[u] = 0.0;
+                a0 += (v[0] + v[4]) + (v[8] + v[12]);
+                a1 += (v[1] + v[5]) + (v[9] + v[13]);
+                a2 += (v[2] + v[6]) + (v[10] + v[14]);
+                a3 += (v[3] + v[7]) + (v[11] + v[15]);
             }
-            for (; b < b1; b += kSolveGroups) a0 += partials[(size_t)b * kAccStride + k];
         }
         s_g[g][k] = (a0 + a1) + (a2 + a3);
     }
