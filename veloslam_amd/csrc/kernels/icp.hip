@@ -1203,31 +1203,48 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
 }
 
 // ============================================================= reduce + solve
+// One lane runs this after the block reduction, so the kernel's duration is the length of the
+// dependent instruction chain: one reciprocal per pivot instead of a division per entry (27
+// fp64 divisions -> 6), and the rotation coefficients from their series for the small steps ICP
+// takes (no sin / cos / sqrt / division below 0.1 rad).  Agrees with oracle/icp.c
+// (vo_solve_update, plain divisions and libm) to a few ulp.
 __device__ int ldlt6(const double* H, const double* b, double* xs)
 {
-    double L[36], D[6];
+    double L[36], D[6], Di[6];
+#pragma unroll
     for (int i = 0; i < 36; ++i) L[i] = 0.0;
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = H[6 * j + j];
+#pragma unroll
         for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k] * D[k];
         if (!(d > 0.0)) return 1;
         D[j] = d;
+        const double inv = 1.0 / d;
+        Di[j] = inv;
         L[6 * j + j] = 1.0;
+#pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double v = H[6 * i + j];
+#pragma unroll
             for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k] * D[k];
-            L[6 * i + j] = v / d;
+            L[6 * i + j] = v * inv;
         }
     }
     double yv[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         double v = b[i];
+#pragma unroll
         for (int k = 0; k < i; ++k) v -= L[6 * i + k] * yv[k];
         yv[i] = v;
     }
-    for (int i = 0; i < 6; ++i) yv[i] /= D[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) yv[i] *= Di[i];
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double v = yv[i];
+#pragma unroll
         for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * xs[k];
         xs[i] = v;
     }
@@ -1238,11 +1255,14 @@ __device__ void se3_exp_apply(const double* xi, double* T)
 {
     const double wx = xi[0], wy = xi[1], wz = xi[2];
     const double th2 = wx * wx + wy * wy + wz * wz;
-    double A, B, C;
-    if (th2 < 1e-16) {
-        A = 1.0 - th2 / 6.0;
-        B = 0.5 - th2 / 24.0;
-        C = 1.0 / 6.0 - th2 / 120.0;
+    double A, B, C;  // sin(t)/t, (1-cos t)/t^2, (t - sin t)/t^3
+    if (th2 < 1e-2) {
+        // alternating series in t^2, eight terms: the first omitted term is < 1e-31 relative
+        // (reciprocal constants: no division in the chain)
+        const double x = th2;
+        A = 1.0 - x * (1.0 / 6.0) * (1.0 - x * (1.0 / 20.0) * (1.0 - x * (1.0 / 42.0) * (1.0 - x * (1.0 / 72.0) * (1.0 - x * (1.0 / 110.0) * (1.0 - x * (1.0 / 156.0) * (1.0 - x * (1.0 / 210.0)))))));
+        B = 0.5 * (1.0 - x * (1.0 / 12.0) * (1.0 - x * (1.0 / 30.0) * (1.0 - x * (1.0 / 56.0) * (1.0 - x * (1.0 / 90.0) * (1.0 - x * (1.0 / 132.0) * (1.0 - x * (1.0 / 182.0) * (1.0 - x * (1.0 / 240.0))))))));
+        C = (1.0 / 6.0) * (1.0 - x * (1.0 / 20.0) * (1.0 - x * (1.0 / 42.0) * (1.0 - x * (1.0 / 72.0) * (1.0 - x * (1.0 / 110.0) * (1.0 - x * (1.0 / 156.0) * (1.0 - x * (1.0 / 210.0) * (1.0 - x * (1.0 / 272.0))))))));
     } else {
         const double th = sqrt(th2);
         A = sin(th) / th;
