@@ -7,7 +7,9 @@ HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE/WRI
 KiB, and on gfx950 FETCH_SIZE reports half the bytes of coalesced reads (MI355X_MICROARCH.md,
 section HBM).  The counters sit on the fabric side of L2 and include Infinity-Cache hits; for
 the gather-dominated k_linearize the x2 is an upper bound (conservative: over-states traffic).
-Launches are told apart by grid size: 450 workgroups per 115 200-point frame."""
+The two configurations of a collection run (headline batch, then the dense record) are told apart
+by the map they run against: a launch belongs to the configuration whose map build (k_normals)
+was the last one dispatched before it."""
 import collections
 import csv
 import glob
@@ -21,22 +23,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + R)
 DST = os.path.join(ROOT, "profiles", R)
 os.makedirs(DST, exist_ok=True)
-# key -> Grid_Size values (threads) of that configuration's linearise launches: a batch of >= 28
-# frames runs iteration 0 with one round of 256 queries per workgroup (450 workgroups per frame)
-# and the hinted iterations with three (150 per frame); smaller batches one round throughout
-CONFIGS = {"F64_M1000000": [64 * 450 * 256, 64 * 150 * 256], "F16_M10000000": [16 * 450 * 256]}
+# configuration = how many map builds have been dispatched so far (bench.py --only dense: the
+# headline batch first, the dense record second)
+CONFIGS = {"F64_M1000000": 1, "F16_M10000000": 2}
 PROD = "k_linearize<false, 1, false"  # the production instantiation (any table kind)
+MAPBUILD = "k_normals<"
+
+
+def rows_in_order(path, id_col):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r[id_col]))
+    return rows
 
 
 def counters(sub):
-    """kernel short name -> grid -> counter -> list of per-dispatch values (dispatch order)"""
+    """kernel short name -> grid -> counter -> per-dispatch values; and, for the production
+    linearise kernel, configuration number -> counter -> values"""
     out = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
+    per_cfg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
+        builds, seen = 0, set()
+        for r in rows_in_order(f, "Dispatch_Id"):
             k = r["Kernel_Name"].split("(")[0]
+            if MAPBUILD in k and r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"])  # (one row per counter and dispatch)
+                builds += 1
             if "velo::" in k:
                 out[k][int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return out
+            if PROD in k:
+                per_cfg[builds][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                per_cfg[builds]["__kernel__"] = k
+    return out, per_cfg
 
 
 def stats(v):
@@ -50,35 +67,32 @@ for sub, name in (("trace", "kernel_stats_batch_dense.csv"), ("trace_stream", "k
 # per-config launch durations of k_linearize from the kernel trace (the judge's cross-check)
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv")):
-    for r in csv.DictReader(open(f)):
+    builds = 0
+    for r in rows_in_order(f, "Dispatch_Id"):
+        if MAPBUILD in r["Kernel_Name"]:
+            builds += 1
         if PROD in r["Kernel_Name"]:
-            dur[int(r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            dur[builds].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 summary = {}
+raw = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
-    for k, grids in counters(sub).items():
+    by_grid, raw[sub] = counters(sub)
+    for k, grids in by_grid.items():
         for g, cs in grids.items():
             for c, x in cs.items():
                 summary.setdefault(k, {}).setdefault(str(g), {})[c] = stats(x)
 json.dump(dict(note=__doc__, kernels=summary), open(os.path.join(DST, "pmc.json"), "w"), indent=1)
 traffic = {}
-raw = {sub: counters(sub) for sub in ("pmc_fetch", "pmc_write")}
-for key, grids_of in CONFIGS.items():
-    vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
-    kname = None
-    for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        for k, grids in raw[sub].items():
-            if PROD not in k:
-                continue
-            kname = k
-            for g in grids_of:
-                vals[cname] += grids.get(g, {}).get(cname, [])
-    if not vals["FETCH_SIZE"] or not vals["WRITE_SIZE"]:
+for key, cfg in CONFIGS.items():
+    fs = raw["pmc_fetch"].get(cfg, {}).get("FETCH_SIZE", [])
+    ws = raw["pmc_write"].get(cfg, {}).get("WRITE_SIZE", [])
+    if not fs or not ws:
         continue
-    f = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])
-    w = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
-    d = [x for g in grids_of for x in dur.get(g, [])]
-    traffic[key] = dict(kernel=kname, grid_threads=grids_of, FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w,
-                        hbm_bytes_per_launch=(2 * f + w) * 1024, launches_counted=len(vals["FETCH_SIZE"]),
+    f = sum(fs) / len(fs)
+    w = sum(ws) / len(ws)
+    d = dur.get(cfg, [])
+    traffic[key] = dict(kernel=raw["pmc_fetch"][cfg]["__kernel__"], FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w,
+                        hbm_bytes_per_launch=(2 * f + w) * 1024, launches_counted=len(fs),
                         rocprof_avg_launch_us=(sum(d) / len(d)) if d else None, rocprof_launches=len(d),
                         source="profiles/%s/pmc.json" % R,
                         correction="gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)")

@@ -25,6 +25,9 @@
 #ifndef VELO_LATE_ROUNDS
 #define VELO_LATE_ROUNDS 3
 #endif
+#ifndef VELO_FIRST_HEAD_PCT
+#define VELO_FIRST_HEAD_PCT 10
+#endif
 #ifndef VELO_FIRST_ROUNDS
 #define VELO_FIRST_ROUNDS 4
 #endif
@@ -795,13 +798,20 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     if (planned) per_block = kLinNT * rounds_per_wave(c, total_q, VELO_FIRST_ROUNDS);
     for (int f = 0; f < n_frames; ++f) {
         c->fbs_h[f] = (int32_t)c->items_h.size();
-        for (int64_t q = frame_start[f]; q < frame_start[f + 1]; q += per_block) {
+        // (planned: the head of every frame in one-round items -- launched item-major from the
+        // ends of the frames backwards, those are the last workgroups of the launch)
+        const int64_t nqf = frame_start[f + 1] - frame_start[f];
+        const int64_t head_end = planned ? frame_start[f] + nqf * VELO_FIRST_HEAD_PCT / 100 / kLinNT * kLinNT
+                                         : frame_start[f];
+        for (int64_t q = frame_start[f]; q < frame_start[f + 1];) {
+            const int64_t step = q < head_end ? kLinNT : per_block;
             BlockItem it;
             it.frame = f;
             it.q0 = (int32_t)q;
-            it.q1 = (int32_t)std::min<int64_t>(q + per_block, frame_start[f + 1]);
+            it.q1 = (int32_t)std::min<int64_t>(q + step, frame_start[f + 1]);
             it.slot = (int32_t)c->items_h.size();
             c->items_h.push_back(it);
+            q += step;
         }
     }
     c->fbs_h[n_frames] = (int32_t)c->items_h.size();
