@@ -387,7 +387,7 @@ __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float q
             if (live[u]) tl.candidates(1);
             if (live[u]) last = --j;
             jj[u] = last;
-            c[u] = mv.pts[last];
+            c[u] = mv.pts[(unsigned)last];  // (never negative: no sign extension)
         }
 #pragma unroll
         for (int u = 0; u < W; ++u) {
@@ -901,15 +901,16 @@ __device__ __forceinline__ void linearize_body(
     for (int base = it.q0; base < it.q1; base += NT) {
         const int q = base + tid;
         const bool live = q < it.q1;
+        const unsigned uq = (unsigned)q;  // (never negative: no sign extension in the addressing)
         float sxq = 0.f, syq = 0.f, szq = 0.f;
         int hj = -1;
         if (live) {
-            sxq = fv.x[q];
-            syq = fv.y[q];
-            szq = fv.z[q];
+            sxq = fv.x[uq];
+            syq = fv.y[uq];
+            szq = fv.z[uq];
             // poses_prev == nullptr marks the first iteration of a registration: whatever the
             // hint / certificate arrays hold is stale (they are not cleared, just overwritten)
-            if (hint && poses_prev) hj = hint[q];
+            if (hint && poses_prev) hj = hint[uq];
             tl.addq(hint && poses_prev ? 16 : 12);
         }
         double px = 0, py = 0, pz = 0;
@@ -940,13 +941,13 @@ __device__ __forceinline__ void linearize_body(
                 if (hj >= 0) {
                     tl.candidates(1);
                     tl.addq(rho ? 4 : 0);
-                    const float d1sq = dist2(mv.pts[hj], qx, qy, qz);
+                    const float d1sq = dist2(mv.pts[(unsigned)hj], qx, qy, qz);
                     const float d1 = sqrtf(d1sq) * 1.000001f + 1e-7f;
                     if (rho) {
                         double cx, cy, cz;
                         xform(poses_prev + 12 * (size_t)it.frame, sxq, syq, szq, cx, cy, cz);
                         const float ex = qx - (float)cx, ey = qy - (float)cy, ez = qz - (float)cz;
-                        const float rho_in = rho[q];
+                        const float rho_in = rho[uq];
                         // a query that has not moved at all (converged pose: bit-identical q)
                         // sees exactly last iteration's distances: the certificate holds verbatim
                         const bool still = (ex == 0.0f) && (ey == 0.0f) && (ez == 0.0f);
@@ -1041,8 +1042,8 @@ __device__ __forceinline__ void linearize_body(
             const bool ok = (bj >= 0) && (bd <= dmax2);
             // (a certified, unmoved query with a still-valid match keeps its state: no stores)
             if (!(state_same && ok)) {
-                if (hint) hint[q] = ok ? bj : -1;
-                if (VARIANT >= 1 && rho) rho[q] = rho_new_out;
+                if (hint) hint[uq] = ok ? bj : -1;
+                if (VARIANT >= 1 && rho) rho[uq] = rho_new_out;
                 tl.addq((hint ? 4 : 0) + ((VARIANT >= 1 && rho) ? 4 : 0));
             }
             if (WRITE_CORR) {
@@ -1053,8 +1054,8 @@ __device__ __forceinline__ void linearize_body(
             VELO_COUNT(7, ok);
             if (ok) {
                 tl.add(32);
-                const float4 nf = mv.nrm[bj];
-                const float4 mf = mv.pts[bj];  // issued with the normal: one round trip, not two
+                const float4 nf = mv.nrm[(unsigned)bj];
+                const float4 mf = mv.pts[(unsigned)bj];  // issued with the normal: one round trip, not two
                 if (!(nf.x == 0.0f && nf.y == 0.0f && nf.z == 0.0f)) {
                     const double nx = nf.x, ny = nf.y, nz = nf.z;
                     const double dx = px - (double)mf.x, dy = py - (double)mf.y,
