@@ -800,9 +800,9 @@ def main():
     trace("map + frames resident")
     # settle: the first process on a freshly leased box showed one-off 40 ms host stalls inside the
     # first ~100 launches (runtime pools growing); a quarter of a second of the same untimed steps
-    # absorbs them before the W warm-up steps the contract asks for
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle_s:
+    # (--settle-s / 2.5 ms steps) absorbs them before the W warm-up steps the contract asks for
+    # (a FIXED number of steps, the same on every rank: with N > 1 every step carries a collective)
+    for _ in range(int(round(args.settle_s / 0.0025))):
         step(False)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
