@@ -68,7 +68,8 @@ typedef struct velo_cfg {
                                its previous correspondence; 2: also skip the search when last
                                iteration certified that correspondence as the unique nearest
                                point within a radius the query has not left (cfg == NULL: 2) */
-    int32_t rounds_per_block; /* tuning: rounds of 256 queries per workgroup (0 = automatic) */
+    int32_t rounds_per_block; /* tuning: rounds of 256 queries per work item, in every iteration
+                               (0 = planned per iteration, see plan_wave_slots) */
     int32_t map_margin;     /* rolling map: the grid is anchored this many voxels below the lowest
                                point and padded as many above, so appends/evictions inside the
                                slack update the sorted map incrementally (default 0 = tight) */
@@ -78,10 +79,16 @@ typedef struct velo_cfg {
                                < 2^31 entries, an open-addressing hash over the occupied cells
                                (load factor 0.5) beyond that; 5..90: always the hash, at that load
                                factor in percent.  Same sorted order, same results either way. */
-    int32_t force_kernel;   /* 0: the linearise kernel is chosen by launch size (latency kernel below
-                               2048 workgroups, throughput kernel above); 1: always the throughput
-                               kernel, 2: always the latency kernel (tests hold both to the oracle) */
-    int32_t reserved[4];
+    int32_t force_kernel;   /* 0: the linearise kernel is chosen by the size of the registration
+                               (latency kernel below 2048 x 256 queries, ~4 frames; throughput kernel
+                               above); 1: always the throughput kernel, 2: always the latency kernel
+                               (tests hold both to the oracle) */
+    int32_t plan_wave_slots; /* tuning / tests: wavefront slots the work-item planner assumes
+                               (0 = the device's: CUs x 4 SIMDs x 7).  A batch is cut as coarse as
+                               4 / 3 / 6 rounds per wavefront (first / searching / converged
+                               iterations) while it keeps 2.5 wavefronts per slot; a small value
+                               makes a small batch take the decompositions of a large one */
+    int32_t reserved[3];
 } velo_cfg;
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */

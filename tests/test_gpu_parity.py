@@ -576,11 +576,18 @@ def test_sorted_query_order_gives_same_pose(omap, wl, comp, variant):
 # ------------------------------------------------------------- increment (8e)
 @pytest.mark.parametrize("kw", [dict(use_graph=0), dict(use_hints=0), dict(use_hints=1),
                                 dict(rounds_per_block=3), dict(rounds_per_block=64, use_graph=0),
-                                dict(sort_frames=2), dict(use_hints=0, use_graph=0, rounds_per_block=2)])
+                                dict(sort_frames=2), dict(use_hints=0, use_graph=0, rounds_per_block=2),
+                                # the planner of a LARGE batch on a small one: throughput kernel, work
+                                # items of 4 / 3 / 6 rounds per wavefront in the first / searching /
+                                # converged iterations, one-round head and tail items, item-major order
+                                dict(force_kernel=1, plan_wave_slots=8),
+                                dict(force_kernel=1, plan_wave_slots=8, use_graph=0, use_hints=1),
+                                dict(force_kernel=1, plan_wave_slots=40)])
 def test_cfg_switches_do_not_change_the_registration(omap, wl, comp, kw):
     """Every tuning switch of velo_cfg is performance-only: with hipGraph replay off, hints or
-    certificates off, several rounds per workgroup or cell-sorted queries, the registration has
-    the same per-iteration pair counts and the same pose (summation order may differ)."""
+    certificates off, several rounds per workgroup, cell-sorted queries or the work-item plan of
+    a large batch, the registration has the same per-iteration pair counts and the same pose
+    (summation order may differ)."""
     ref = capi.Context(0, max_batch=4)
     alt = capi.Context(0, max_batch=4, **kw)
     try:

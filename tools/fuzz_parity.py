@@ -65,6 +65,9 @@ def one_case(seed, kernel=None, hash_load=None):
     if hash_load is None:
         hash_load = int(rng2.choice([0, 0, 0, 30, 60, 85]))
     auto_s = rng2.random() < 0.25
+    # (a third stream, so that the cases of the first two keep their seeds: the work-item plan of
+    # a large batch -- several rounds per wavefront, one-round head items)
+    plan_slots = int(np.random.default_rng(seed + 11_000_003).choice([0, 0, 2, 16]))
     ext = float(rng.choice([4.0, 9.0, 17.0]))
     n = int(rng.integers(200, 6000))
     voxel = float(rng.choice([0.5, 1.0, 1.5]))
@@ -76,7 +79,7 @@ def one_case(seed, kernel=None, hash_load=None):
         S = 0  # chosen from the density, by the same rule on both sides
     roll = orc.RollingMap(*m, voxel, k, S, margin=margin)
     c = capi.Context(0, max_batch=2, map_subdiv=S, map_margin=margin, linearize_variant=1,
-                     force_kernel=kernel, map_hash_load=hash_load)
+                     force_kernel=kernel, map_hash_load=hash_load, plan_wave_slots=plan_slots)
     try:
         c.map_reset(*m, voxel, k)
 

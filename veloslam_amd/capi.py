@@ -31,7 +31,7 @@ class Cfg(C.Structure):
                 ("linearize_variant", C.c_int32), ("sort_frames", C.c_int32),
                 ("use_graph", C.c_int32), ("map_subdiv", C.c_int32), ("use_hints", C.c_int32),
                 ("rounds_per_block", C.c_int32), ("map_margin", C.c_int32),
-                ("map_full_rebuild", C.c_int32), ("map_hash_load", C.c_int32), ("force_kernel", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("map_full_rebuild", C.c_int32), ("map_hash_load", C.c_int32), ("force_kernel", C.c_int32), ("plan_wave_slots", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Pose(C.Structure):
@@ -329,7 +329,7 @@ class Context:
 
     def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=1, map_subdiv=3,
                  use_hints=2, use_graph=1, rounds_per_block=0, map_margin=0, map_full_rebuild=0,
-                 map_hash_load=0, force_kernel=0):
+                 map_hash_load=0, force_kernel=0, plan_wave_slots=0):
         L = lib()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -344,6 +344,7 @@ class Context:
         cfg.map_full_rebuild = map_full_rebuild
         cfg.map_hash_load = map_hash_load
         cfg.force_kernel = force_kernel
+        cfg.plan_wave_slots = plan_wave_slots
         self.h = L.velo_create(device, C.byref(cfg))
         if not self.h:
             raise VeloError(-3, L.velo_last_error(None).decode())

@@ -1176,6 +1176,7 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     if (cfg) std::memcpy(&c->cfg, cfg, std::min<size_t>(cfg->struct_size, sizeof(velo_cfg)));
     c->cfg.struct_size = sizeof(velo_cfg);
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 64;
+    if (c->cfg.plan_wave_slots > 0) c->wave_slots = c->cfg.plan_wave_slots;
     // 0 = the default (fast, pruned) kernel for every consumer -- C, C++ MapManager and Python
     // alike; the exhaustive validation kernel has to be asked for by name
     if (c->cfg.linearize_variant == 0) c->cfg.linearize_variant = VELO_VARIANT_BALL;
