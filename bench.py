@@ -214,6 +214,17 @@ def roofline_record(ctx, T0, iters, d_max, n_q, avg_launch_s, first_us, min_us, 
                    "store issued (cache-level throughput).  `traffic` = PMC 2 x FETCH_SIZE + "
                    "WRITE_SIZE per launch (profiles/, fabric side of L2, includes Infinity-Cache "
                    "hits): the physical figure"}
+    if tr and tr.get("converged_launch"):
+        # the last launch of a registration (every query certified: a stream of gathers, the regime
+        # in which the kernel is bound by memory): PMC bytes of that launch / its duration, rocprofv3
+        # on both sides; this run's own shortest launch beside it
+        cl = tr["converged_launch"]
+        rec["converged_launch"] = {"traffic": cl["hbm_bytes"], "rocprof_us": cl["rocprof_us"],
+                                   "traffic_GBps": cl["GBps"], "traffic_frac": cl["GBps"] / HBM_PEAK_GBPS,
+                                   "this_run_min_launch_us": min_us,
+                                   "algorithmic_bytes": mb["last_launch_algorithmic"],
+                                   "algorithmic_GBps": (mb["last_launch_algorithmic"] / (1e-6 * min_us) / 1e9)
+                                   if min_us > 0 else None}
     if cbar is not None:
         exh = (232.0 + 12.0 * cbar + 24.0) * n_q
         rec["exhaustive_equivalent_GBps"] = exh / avg_launch_s / 1e9

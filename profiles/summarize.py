@@ -28,6 +28,7 @@ os.makedirs(DST, exist_ok=True)
 CONFIGS = {"F64_M1000000": 1, "F16_M10000000": 2}
 PROD = "k_linearize<false, 1, false"  # the production instantiation (any table kind)
 MAPBUILD = "k_normals<"
+ITERS = 20  # linearise launches per registration in the collection runs (bench.py --iters default)
 
 
 def rows_in_order(path, id_col):
@@ -99,6 +100,19 @@ for key, cfg in CONFIGS.items():
     if d:
         traffic[key]["traffic_GBps_at_rocprof_avg"] = traffic[key]["hbm_bytes_per_launch"] / (
             sum(d) / len(d) * 1e-6) / 1e9
+    # the same per iteration of a registration (launch i, ITERS + i, ... of the configuration): the
+    # first launches search (VALU-bound), the converged ones stream -- launch 19 is the HBM regime
+    if len(fs) % ITERS == 0 and len(ws) % ITERS == 0 and d and len(d) % ITERS == 0:
+        by_it = []
+        for i in range(ITERS):
+            fi = fs[i::ITERS]
+            wi = ws[i::ITERS]
+            di = d[i::ITERS]
+            nbytes = (2 * sum(fi) / len(fi) + sum(wi) / len(wi)) * 1024
+            us = sum(di) / len(di)
+            by_it.append(dict(iteration=i, hbm_bytes=nbytes, rocprof_us=us, GBps=nbytes / (us * 1e-6) / 1e9))
+        traffic[key]["by_iteration"] = by_it
+        traffic[key]["converged_launch"] = by_it[-1]
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 for nm in ("bench_default.json", "bench_stream.json", "bench_trace.json"):

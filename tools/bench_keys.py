@@ -11,6 +11,11 @@ if d.get("dense"):
     x = d["dense"]
     print("dense  %.4e pairs/s  first %.0f avg %.1f min %.1f us  frac %.3f traffic_frac %s" % (
         x["pairs_per_s"], x["first_launch_us"], x["avg_launch_us"], x["min_launch_us"], x["frac"], x.get("traffic_frac")))
+for nm, x in (("", r), ("dense ", d.get("dense") or {})):
+    c = x.get("converged_launch")
+    if c:
+        print("%sconverged launch: PMC %.0f MB in %.1f us = %.2f TB/s (%.2f of peak); this run %.1f us" % (
+            nm, c["traffic"] / 1e6, c["rocprof_us"], c["traffic_GBps"] / 1e3, c["traffic_frac"], c["this_run_min_launch_us"]))
 if d.get("single_frame"):
     x = d["single_frame"]
     print("single %.3f ms  first %.0f min %.1f us" % (x["ms_per_registration"], x["linearize_first_launch_us"], x["linearize_min_launch_us"]))
