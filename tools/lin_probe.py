@@ -35,7 +35,8 @@ for cfg in a.cfg or ["subdiv=3"]:
     kv = dict(x.split("=") for x in cfg.split(",") if x)
     ctx = capi.Context(0, max_batch=a.frames, map_subdiv=int(kv.get("subdiv", 3)), use_hints=int(kv.get("hints", 2)),
                        linearize_variant=int(kv.get("variant", 1)), use_graph=0,
-                       rounds_per_block=int(kv.get("rounds", 0)), sort_frames=int(kv.get("sort", 0)))
+                       rounds_per_block=int(kv.get("rounds", 0)), sort_frames=int(kv.get("sort", 0)),
+                       map_hash_load=int(kv.get("hash", 0)))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if a.device_map:
         ctx.map_reset_dev(mx.data_ptr(), my.data_ptr(), mz.data_ptr(), a.map_points, 1.0, 16)

@@ -1109,8 +1109,9 @@ __device__ __forceinline__ void linearize_body(
     }
 }
 
+// (the hash-table instantiation needs 80 registers: 6 waves per SIMD without spills beat 7 with)
 template <bool WRITE_CORR, int VARIANT, bool STATS, bool HASH = false>
-__global__ __launch_bounds__(kLinNT, VELO_LIN_WAVES) void k_linearize(
+__global__ __launch_bounds__(kLinNT, (HASH ? VELO_LIN_WAVES - 1 : VELO_LIN_WAVES)) void k_linearize(
     const BlockItem* __restrict__ items, FrameView fv, MapView mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
     int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint,
