@@ -957,6 +957,15 @@ int upload_T0(velo_ctx* c, const double* T0, size_t pose_bytes)
     return VELO_OK;
 }
 
+// A registration leaves its last iteration's hints and certificates in the arrays (the next one
+// ignores them).  velo_linearize in hinted mode (velo_linearize_hints, a test hook) would read them
+// against a different "previous pose": in that mode they are dropped instead.
+int forget_hints_for_linearize(velo_ctx* c, int32_t* hint, size_t n_all, hipStream_t s)
+{
+    if (c->lin_hints && hint) HIP_TRY(c, hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s));
+    return VELO_OK;
+}
+
 int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
 {
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map: call velo_map_reset first");
@@ -1058,7 +1067,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         if (int rc = upload_T0(c, T0, pose_bytes)) return rc;
         HIP_TRY(c, hipGraphLaunch(c->graph_exec, s));
         c->last_iters = iters;
-        return VELO_OK;
+        return forget_hints_for_linearize(c, hint, n_all, s);
     }
     if (int rc = upload_T0(c, T0, pose_bytes)) return rc;
     FrameView fv{c->ax, c->ay, c->az, nullptr};
@@ -1082,7 +1091,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev_call1, s));
     c->last_iters = iters;
-    return VELO_OK;
+    return forget_hints_for_linearize(c, hint, n_all, s);
 }
 
 int fetch_icp(velo_ctx* c, velo_icp_result* out)
