@@ -40,6 +40,9 @@
 #ifndef VELO_CONV_FROM
 #define VELO_CONV_FROM 5
 #endif
+#ifndef VELO_CONV_TAIL_PCT
+#define VELO_CONV_TAIL_PCT 10
+#endif
 #ifndef VELO_LATE_TAIL_PCT
 #define VELO_LATE_TAIL_PCT 10
 #endif
@@ -715,7 +718,7 @@ int rounds_per_wave(const velo_ctx* c, int64_t n_queries, int r_max)
     return r;
 }
 
-int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, int rounds,
+int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, int rounds, int tail_pct,
                        DevBuf<BlockItem>& d_items, DevBuf<int32_t>& d_fbs, int& n_out)
 {
     std::vector<BlockItem> big, tail;
@@ -725,7 +728,7 @@ int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, in
     for (int f = 0; f < n_frames; ++f) {
         fbl[f] = slot;
         const int64_t nqf = frame_start[f + 1] - frame_start[f];
-        const int64_t big_end = frame_start[f] + (nqf * (100 - VELO_LATE_TAIL_PCT) / 100) / per_big * per_big;
+        const int64_t big_end = frame_start[f] + (nqf * (100 - tail_pct) / 100) / per_big * per_big;
         for (int64_t q = frame_start[f]; q < frame_start[f + 1];) {
             const int64_t step = q < big_end ? per_big : kLinNT;
             BlockItem it;
@@ -827,10 +830,10 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     size_t max_rows = std::max<size_t>(ni, 1);
     if (planned) {
         if (int rc = plan_decomposition(c, frame_start, n_frames, rounds_per_wave(c, total_q, VELO_LATE_ROUNDS),
-                                        c->items_late, c->fbs_late, c->ni_late))
+                                        VELO_LATE_TAIL_PCT, c->items_late, c->fbs_late, c->ni_late))
             return rc;
         if (int rc = plan_decomposition(c, frame_start, n_frames, rounds_per_wave(c, total_q, VELO_CONV_ROUNDS),
-                                        c->items_conv, c->fbs_conv, c->ni_conv))
+                                        VELO_CONV_TAIL_PCT, c->items_conv, c->fbs_conv, c->ni_conv))
             return rc;
         max_rows = std::max(max_rows, (size_t)std::max(c->ni_late, c->ni_conv));
     }
