@@ -411,6 +411,56 @@ def test_hinted_search_is_exact(ctx, omap, wl, comp):
         ctx.linearize_hints(0)
 
 
+@pytest.mark.parametrize("kernel", [capi.KERNEL_THROUGHPUT, capi.KERNEL_LATENCY], ids=["throughput", "latency"])
+def test_every_straggler_search_leaves_a_certificate(oracle, kernel):
+    """A frame hanging 0.6 m over a plane: every nearest neighbour lies beyond the 3x3x3 fine block
+    (guaranteed radius <= 0.5 m at S = 3), so every query is a stage-B straggler, and with 64 of
+    them per wavefront they all take the PER-LANE ball search.  That search certifies too since
+    round 2 (the ball follows the best distance plus a slack, the second-best is tracked): asked
+    again at the same pose, and at a pose 2 mm away, (next to) no query searches -- and the answers
+    are the oracle's throughout.  (Before, such a wavefront repeated its 49-row search in every
+    iteration of a registration.)"""
+    g = np.arange(0.0, 12.0, 0.125, dtype=np.float32)
+    mx, my = [a.ravel().copy() for a in np.meshgrid(g, g)]
+    rng = np.random.default_rng(5)
+    mx += rng.uniform(-0.02, 0.02, mx.size).astype(np.float32)
+    my += rng.uniform(-0.02, 0.02, my.size).astype(np.float32)
+    mz = rng.uniform(-0.01, 0.01, mx.size).astype(np.float32)
+    n = 4096
+    qx = rng.uniform(2.0, 10.0, n).astype(np.float32)
+    qy = rng.uniform(2.0, 10.0, n).astype(np.float32)
+    qz = np.full(n, 0.6, np.float32)
+    om = oracle.Map(mx, my, mz, 1.0, 8, 3)
+    c = capi.Context(0, max_batch=2, map_subdiv=3, force_kernel=kernel)
+    try:
+        c.map_reset(mx, my, mz, 1.0, 8)
+        c.frames_upload([(qx, qy, qz)])
+        c.linearize_hints(1)
+        c.set_stats(1)
+        T = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+        T2 = T.copy()
+        T2[3] += 0.002
+        seen = []
+        for pose in (T, T, T2):
+            c.search_stats(reset=True)
+            corr, d2, _ = c.linearize(0, pose, 1.0, n)
+            seen.append(c.search_stats(reset=True))
+            oc, od2, _ = om.correspond(qx, qy, qz, pose, 1.0)
+            assert np.array_equal(corr, oc) and (oc >= 0).all()
+            assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+        assert seen[0]["stage_b"] == n and seen[0]["stage_b_per_lane"] == n      # all per lane
+        # ... and certified (all but the odd query whose two nearest points are equidistant to
+        # within the rounding margins: nothing can certify a tie)
+        assert seen[1]["certified"] >= n - 8 and seen[1]["searched"] <= 8
+        # 2 mm further most certificates still hold (over a dense plane the second-nearest point is
+        # only millimetres further than the nearest: the radius certified is that thin)
+        assert seen[2]["certified"] >= n // 2
+    finally:
+        c.set_stats(0)
+        c.linearize_hints(0)
+        c.close()
+
+
 def test_queries_outside_grid_and_dmax(ctx, oracle):
     rng = np.random.default_rng(11)
     m = rng.uniform(0, 8, (3, 4000)).astype(np.float32)
