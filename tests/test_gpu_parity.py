@@ -608,6 +608,29 @@ def test_icp_ragged_batch_with_empty_frame(ctx, omap, wl, comp):
     assert r[2].iter[4].n_pairs == st[4]["n_pairs"]
 
 
+def test_icp_ragged_batch_with_empty_frame_planned_items(omap, wl, comp):
+    """The same ragged batch (a full frame, an empty one, 777 points) under the work-item plan of
+    a large batch: several rounds per wavefront, one-round head and tail items, item-major launch
+    order, the third decomposition from iteration 5 on."""
+    c = capi.Context(0, max_batch=4, force_kernel=capi.KERNEL_THROUGHPUT, plan_wave_slots=4)
+    try:
+        c.map_reset(*wl["map"], 1.0, 16)
+        e = np.zeros(0, np.float32)
+        part = tuple(a[:777].copy() for a in comp[1])
+        T0 = np.stack([wl["frames"][0]["T0"], wl["frames"][0]["T0"], wl["frames"][1]["T0"]])
+        c.frames_upload([comp[0], (e, e, e), part])
+        r = c.icp_batch(T0, 8, 1.0)
+        assert r[1].iter[0].n_pairs == 0 and r[1].iter[7].solve_flag == 2
+        assert list(r[1].T) == list(T0[1])  # untouched pose
+        for fi, (pts, t0) in ((0, (comp[0], T0[0])), (2, (part, T0[2]))):
+            T_o, st, _ = omap.icp(*pts, t0, 8, 1.0)
+            dpos, drot = pose_delta(r[fi].T, T_o)
+            assert dpos <= POS_TOL and drot <= ROT_TOL
+            assert [r[fi].iter[i].n_pairs for i in range(8)] == [q["n_pairs"] for q in st]
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("variant", [SCAN, BALL])
 def test_sorted_query_order_gives_same_pose(omap, wl, comp, variant):
     c2 = capi.Context(0, max_batch=4, sort_frames=1, linearize_variant=variant)
