@@ -23,6 +23,12 @@
 #ifndef VELO_ORDER_LATE
 #define VELO_ORDER_LATE 0
 #endif
+// (order 5, eighth x of every frame on XCD x, takes the converged launch from 69 to 67 us but
+// costs as much in iterations 5-6, which still search a little; in the searching iterations it
+// piles the expensive ends of the frames on one XCD: iteration 1 260 -> 388 us.  Not used.)
+#ifndef VELO_ORDER_CONV
+#define VELO_ORDER_CONV 0
+#endif
 #ifndef VELO_LATE_ROUNDS
 #define VELO_LATE_ROUNDS 3
 #endif
@@ -695,6 +701,18 @@ std::vector<BlockItem> launch_order(const std::vector<BlockItem>& items, int mod
     for (auto& f : per_frame) longest = std::max(longest, f.size());
     std::vector<BlockItem> out;
     out.reserve(items.size());
+    if (mode == 5) {
+        // frame-major inside each XCD, eighth x of every frame on XCD x (slabs)
+        std::vector<std::vector<BlockItem>> q(8);
+        for (auto& f : per_frame)
+            for (size_t i = 0; i < f.size(); ++i) q[i * 8 / f.size()].push_back(f[i]);
+        size_t most = 0;
+        for (auto& v : q) most = std::max(most, v.size());
+        for (size_t t = 0; t < most; ++t)
+            for (int x = 0; x < 8; ++x)
+                if (t < q[(size_t)x].size()) out.push_back(q[(size_t)x][t]);
+        return out;
+    }
     if (mode == 3 || mode == 4) {
         // item-major, the item indices dealt over the 8 XCDs (workgroup b runs on XCD b % 8, each
         // with its own L2): XCD x gets the items i with i % 8 == x of every frame, so its L2 holds
@@ -737,7 +755,7 @@ int rounds_per_wave(const velo_ctx* c, int64_t n_queries, int r_max)
 }
 
 int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, int rounds, int tail_pct,
-                       DevBuf<BlockItem>& d_items, DevBuf<int32_t>& d_fbs, int& n_out)
+                       int order, DevBuf<BlockItem>& d_items, DevBuf<int32_t>& d_fbs, int& n_out)
 {
     std::vector<BlockItem> big, tail;
     std::vector<int32_t> fbl((size_t)n_frames + 1, 0);
@@ -759,8 +777,8 @@ int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, in
         }
     }
     fbl[n_frames] = slot;
-    big = launch_order(big, VELO_ORDER_LATE);
-    tail = launch_order(tail, VELO_ORDER_LATE);
+    big = launch_order(big, order);
+    tail = launch_order(tail, order);
     big.insert(big.end(), tail.begin(), tail.end());
     HIP_TRY(c, d_items.reserve(big.size()));
     HIP_TRY(c, d_fbs.reserve((size_t)n_frames + 1));
@@ -848,10 +866,10 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     size_t max_rows = std::max<size_t>(ni, 1);
     if (planned) {
         if (int rc = plan_decomposition(c, frame_start, n_frames, rounds_per_wave(c, total_q, VELO_LATE_ROUNDS),
-                                        VELO_LATE_TAIL_PCT, c->items_late, c->fbs_late, c->ni_late))
+                                        VELO_LATE_TAIL_PCT, VELO_ORDER_LATE, c->items_late, c->fbs_late, c->ni_late))
             return rc;
         if (int rc = plan_decomposition(c, frame_start, n_frames, rounds_per_wave(c, total_q, VELO_CONV_ROUNDS),
-                                        VELO_CONV_TAIL_PCT, c->items_conv, c->fbs_conv, c->ni_conv))
+                                        VELO_CONV_TAIL_PCT, VELO_ORDER_CONV, c->items_conv, c->fbs_conv, c->ni_conv))
             return rc;
         max_rows = std::max(max_rows, (size_t)std::max(c->ni_late, c->ni_conv));
     }
