@@ -411,11 +411,15 @@ def test_hinted_search_is_exact(ctx, omap, wl, comp):
         ctx.linearize_hints(0)
 
 
-@pytest.mark.parametrize("kernel", [capi.KERNEL_THROUGHPUT, capi.KERNEL_LATENCY], ids=["throughput", "latency"])
-def test_every_straggler_search_leaves_a_certificate(oracle, kernel):
+@pytest.mark.parametrize("kernel,rounds,per_lane", [(capi.KERNEL_THROUGHPUT, 0, True), (capi.KERNEL_LATENCY, 1, True),
+                                                     (capi.KERNEL_LATENCY, 0, False)],
+                         ids=["throughput", "latency-64-lanes", "latency-8-lanes"])
+def test_every_straggler_search_leaves_a_certificate(oracle, kernel, rounds, per_lane):
     """A frame hanging 0.6 m over a plane: every nearest neighbour lies beyond the 3x3x3 fine block
     (guaranteed radius <= 0.5 m at S = 3), so every query is a stage-B straggler, and with 64 of
-    them per wavefront they all take the PER-LANE ball search.  That search certifies too since
+    them per wavefront they all take the PER-LANE ball search (the latency kernel cuts an unhinted
+    frame to 8 queries per wavefront, which sends them to the cooperative search instead:
+    rounds_per_block = 1 keeps its 64-lane items).  That search certifies too since
     round 2 (the ball follows the best distance plus a slack, the second-best is tracked): asked
     again at the same pose, and at a pose 2 mm away, (next to) no query searches -- and the answers
     are the oracle's throughout.  (Before, such a wavefront repeated its 49-row search in every
@@ -431,7 +435,7 @@ def test_every_straggler_search_leaves_a_certificate(oracle, kernel):
     qy = rng.uniform(2.0, 10.0, n).astype(np.float32)
     qz = np.full(n, 0.6, np.float32)
     om = oracle.Map(mx, my, mz, 1.0, 8, 3)
-    c = capi.Context(0, max_batch=2, map_subdiv=3, force_kernel=kernel)
+    c = capi.Context(0, max_batch=2, map_subdiv=3, force_kernel=kernel, rounds_per_block=rounds)
     try:
         c.map_reset(mx, my, mz, 1.0, 8)
         c.frames_upload([(qx, qy, qz)])
@@ -448,7 +452,7 @@ def test_every_straggler_search_leaves_a_certificate(oracle, kernel):
             oc, od2, _ = om.correspond(qx, qy, qz, pose, 1.0)
             assert np.array_equal(corr, oc) and (oc >= 0).all()
             assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
-        assert seen[0]["stage_b"] == n and seen[0]["stage_b_per_lane"] == n      # all per lane
+        assert seen[0]["stage_b"] == n and seen[0]["stage_b_per_lane"] == (n if per_lane else 0)
         # ... and certified (all but the odd query whose two nearest points are equidistant to
         # within the rounding margins: nothing can certify a tie)
         assert seen[1]["certified"] >= n - 8 and seen[1]["searched"] <= 8

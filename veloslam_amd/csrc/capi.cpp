@@ -149,6 +149,7 @@ struct velo_ctx {
     // third decomposition, for the iterations from VELO_CONV_FROM on (hardly any query searches
     // any more: coarser items)
     bool plan_lat = false;            // the resident frames are cut for the latency kernel
+    int lat_first_lanes = 64;         // ... with this many queries per wavefront in the first decomposition
     int wave_slots = 256 * 28;        // wavefronts the device holds at 7 per SIMD (velo_create)
     DevBuf<BlockItem> items_conv;
     DevBuf<int32_t> fbs_conv;
@@ -796,15 +797,17 @@ struct Decomposition {
     const BlockItem* items;
     const int32_t* fbs;
     int n;
+    int lat_lanes;  // latency kernel: queries per wavefront the items are cut for
 };
 
 Decomposition decomposition_for(velo_ctx* c, int it, bool hinted, bool sorted_queries)
 {
     if (sorted_queries)
-        return {c->cfg.sort_frames == 1 ? c->items_xcd.p : c->items_first.p, c->fbs.p, (int)c->items_h.size()};
-    if (it >= VELO_CONV_FROM && c->ni_conv > 0 && hinted) return {c->items_conv.p, c->fbs_conv.p, c->ni_conv};
-    if (it > 0 && c->ni_late > 0 && hinted) return {c->items_late.p, c->fbs_late.p, c->ni_late};
-    return {c->items_first.p, c->fbs.p, (int)c->items_h.size()};
+        return {c->cfg.sort_frames == 1 ? c->items_xcd.p : c->items_first.p, c->fbs.p, (int)c->items_h.size(),
+                c->lat_first_lanes};
+    if (it >= VELO_CONV_FROM && c->ni_conv > 0 && hinted) return {c->items_conv.p, c->fbs_conv.p, c->ni_conv, 64};
+    if (it > 0 && c->ni_late > 0 && hinted) return {c->items_late.p, c->fbs_late.p, c->ni_late, 64};
+    return {c->items_first.p, c->fbs.p, (int)c->items_h.size(), c->lat_first_lanes};
 }
 
 int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
@@ -835,6 +838,11 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     c->plan_lat = c->cfg.force_kernel == 2 || (c->cfg.force_kernel != 1 && total_q < kLatQueries);
     const bool planned = c->cfg.rounds_per_block <= 0 && !c->plan_lat;
     if (planned) per_block = kLinNT * rounds_per_wave(c, total_q, VELO_FIRST_ROUNDS);
+    // latency kernel: the first iteration runs kLatFirstLanes queries per wavefront (one round per
+    // item), the hinted ones all 64 -- a second, 256-query decomposition below
+    const bool lat_sparse = c->plan_lat && c->cfg.rounds_per_block <= 0 && kLatFirstLanes < 64;
+    c->lat_first_lanes = lat_sparse ? kLatFirstLanes : 64;
+    if (lat_sparse) per_block = (kLinThreads / 64) * kLatFirstLanes;
     for (int f = 0; f < n_frames; ++f) {
         c->fbs_h[f] = (int32_t)c->items_h.size();
         // (planned: the head of every frame in one-round items -- launched item-major from the
@@ -872,6 +880,32 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
                                         VELO_CONV_TAIL_PCT, VELO_ORDER_CONV, c->items_conv, c->fbs_conv, c->ni_conv))
             return rc;
         max_rows = std::max(max_rows, (size_t)std::max(c->ni_late, c->ni_conv));
+    }
+    if (lat_sparse) {  // plain 256-query items, frame-major, for the hinted iterations
+        std::vector<BlockItem> late;
+        std::vector<int32_t> fbl((size_t)n_frames + 1, 0);
+        for (int f = 0; f < n_frames; ++f) {
+            fbl[f] = (int32_t)late.size();
+            for (int64_t q = frame_start[f]; q < frame_start[f + 1]; q += kLinThreads) {
+                BlockItem it;
+                it.frame = f;
+                it.q0 = (int32_t)q;
+                it.q1 = (int32_t)std::min<int64_t>(q + kLinThreads, frame_start[f + 1]);
+                it.slot = (int32_t)late.size();
+                late.push_back(it);
+            }
+        }
+        fbl[n_frames] = (int32_t)late.size();
+        if (!late.empty()) {
+            HIP_TRY(c, c->items_late.reserve(late.size()));
+            HIP_TRY(c, c->fbs_late.reserve((size_t)n_frames + 1));
+            HIP_TRY(c, hipMemcpyAsync(c->items_late.p, late.data(), late.size() * sizeof(BlockItem),
+                                      hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->fbs_late.p, fbl.data(), fbl.size() * sizeof(int32_t),
+                                      hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors go out of scope
+            c->ni_late = (int)late.size();
+        }
     }
     HIP_TRY(c, c->items.reserve(std::max<size_t>(ni, 1)));
     HIP_TRY(c, c->fbs.reserve((size_t)n_frames + 1));
@@ -1082,7 +1116,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
                 e = launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv, c->poses.p,
                                      dmax2, c->partials.p, nullptr, nullptr, hint, rho,
                                      it == 0 ? nullptr : c->poses_prev.p,  // (first iteration: stale hints)
-                                     false, c->plan_lat ? 2 : 1, s);
+                                     false, c->plan_lat ? 2 : 1, s, dc.lat_lanes);
                 if (e == hipSuccess)
                     e = launch_reduce_solve(c->partials.p, dc.fbs, c->n_frames, c->poses.p,
                                             c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
@@ -1119,7 +1153,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv,
                                         c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, rho,
                                         it == 0 ? nullptr : c->poses_prev.p,  // (first iteration: stale hints)
-                                        c->stats_on, c->plan_lat ? 2 : 1, s));
+                                        c->stats_on, c->plan_lat ? 2 : 1, s, dc.lat_lanes));
         }
         {
             Timed t(c, 1);
@@ -1845,7 +1879,10 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
                                 c->poses.p, d_max * d_max, c->partials.p, c->corr.p, c->d2.p,
                                 c->lin_hints ? c->hint.p : nullptr,
                                 (c->lin_hints && c->cfg.use_hints >= 2) ? c->rho.p : nullptr,
-                                c->poses_prev.p, c->stats_on, c->cfg.force_kernel, s));
+                                c->poses_prev.p, c->stats_on,
+                                // (the frames are cut for one kernel: say which, item counts no longer do)
+                                c->cfg.linearize_variant == VELO_VARIANT_BALL ? (c->plan_lat ? 2 : 1) : c->cfg.force_kernel,
+                                s, c->lat_first_lanes));
     HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p + frame, 1, c->poses.p, nullptr, 0, 1,
                                    c->acc.p, 0, nullptr, nullptr, s));
     if (corr)

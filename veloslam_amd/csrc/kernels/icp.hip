@@ -882,7 +882,8 @@ __device__ __forceinline__ void linearize_body(
     const BlockItem* __restrict__ items, const FrameView& fv, const MapView& mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
     int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint,
-    float* __restrict__ rho, const double* __restrict__ poses_prev, LinLds* s_uw, double (*s_w)[32])
+    float* __restrict__ rho, const double* __restrict__ poses_prev, LinLds* s_uw, double (*s_w)[32],
+    int lat_lanes = 64)
 {
     const BlockItem it = items[blockIdx.x];
     const double* __restrict__ T = poses + 12 * (size_t)it.frame;
@@ -898,9 +899,15 @@ __device__ __forceinline__ void linearize_body(
         if (tid == 0) tl.addq(16 + 96 + kAccN * 8);  // work item, pose, partial sums
     }
 
-    for (int base = it.q0; base < it.q1; base += NT) {
-        const int q = base + tid;
-        const bool live = q < it.q1;
+    // LAT: only the first `lat_lanes` lanes of a wavefront carry a query.  At this launch size the
+    // machine is mostly idle, and a wavefront's stragglers are searched one after the other or in
+    // lock-step: in the first iteration (a fifth of the queries are stragglers on a dense map) 8
+    // queries per wavefront put eight times as many searches in flight -- first launch 304 -> 132 us
+    // on a 9 M-point map, 80 -> 62 on 1 M; later iterations use all 64 lanes (9 us against 15).
+    const int qpr = LAT ? (NT / 64) * lat_lanes : NT;  // queries per round of the workgroup
+    for (int base = it.q0; base < it.q1; base += qpr) {
+        const int q = LAT ? base + wave * lat_lanes + lane : base + tid;
+        const bool live = q < it.q1 && (!LAT || lane < lat_lanes);
         const unsigned uq = (unsigned)q;  // (never negative: no sign extension in the addressing)
         float sxq = 0.f, syq = 0.f, szq = 0.f;
         int hj = -1;
@@ -1128,12 +1135,12 @@ __global__ __launch_bounds__(kLinThreads, 4) void k_linearize_lat(
     const BlockItem* __restrict__ items, FrameView fv, MapView mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
     int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint,
-    float* __restrict__ rho, const double* __restrict__ poses_prev)
+    float* __restrict__ rho, const double* __restrict__ poses_prev, int lat_lanes)
 {
     __shared__ LinLds s_uw[kLinThreads / 64];
     __shared__ double s_w[4][32];
     linearize_body<WRITE_CORR, 1, STATS, true, HASH, kLinThreads>(items, fv, mv, poses, dmax2, partials, corr,
-                                                                  d2out, hint, rho, poses_prev, s_uw, s_w);
+                                                                  d2out, hint, rho, poses_prev, s_uw, s_w, lat_lanes);
 }
 
 hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)
@@ -1149,9 +1156,10 @@ hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, int32_t* hint, float* rho,
-                            const double* poses_prev, bool stats, int force_kernel, hipStream_t s)
+                            const double* poses_prev, bool stats, int force_kernel, hipStream_t s, int lat_lanes)
 {
     if (n_items == 0) return hipSuccess;
+    if (lat_lanes < 1 || lat_lanes > 64) lat_lanes = 64;
     const bool wc = corr || d2;
 #define VELO_LAUNCH_LIN(WC, V)                                                                   \
     hipLaunchKernelGGL((k_linearize<WC, V, false>), dim3(n_items), dim3(kLinNT), 0, s,     \
@@ -1169,10 +1177,10 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
         } else if (lat) {
             if (wc)
                 hipLaunchKernelGGL((k_linearize_lat<true, false, true>), dim3(n_items), dim3(kLinThreads), 0,
-                                   s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+                                   s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev, lat_lanes);
             else
                 hipLaunchKernelGGL((k_linearize_lat<false, false, true>), dim3(n_items), dim3(kLinThreads), 0,
-                                   s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+                                   s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev, lat_lanes);
         } else {
             if (wc)
                 hipLaunchKernelGGL((k_linearize<true, 1, false, true>), dim3(n_items), dim3(kLinNT), 0,
@@ -1186,17 +1194,17 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
     if (stats && variant != VELO_VARIANT_SCAN && variant < 10) {  // counting instantiation
         if (lat)
             hipLaunchKernelGGL((k_linearize_lat<true, true>), dim3(n_items), dim3(kLinThreads), 0, s,
-                               items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+                               items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev, lat_lanes);
         else
             hipLaunchKernelGGL((k_linearize<true, 1, true>), dim3(n_items), dim3(kLinNT), 0, s,
                                items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
     } else if (lat) {
         if (wc)
             hipLaunchKernelGGL((k_linearize_lat<true, false>), dim3(n_items), dim3(kLinThreads), 0, s,
-                               items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+                               items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev, lat_lanes);
         else
             hipLaunchKernelGGL((k_linearize_lat<false, false>), dim3(n_items), dim3(kLinThreads), 0, s,
-                               items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+                               items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev, lat_lanes);
     } else if (variant == VELO_VARIANT_SCAN) {
         if (wc) VELO_LAUNCH_LIN(true, 0); else VELO_LAUNCH_LIN(false, 0);
     } else if (variant == 11) {  // timing ablations (wrong results by design)

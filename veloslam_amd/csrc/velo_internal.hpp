@@ -60,6 +60,11 @@ constexpr int kLinThreads = 256;
 constexpr int kLinNT = VELO_LIN_NT;
 // registrations of fewer queries than this (~4 frames) run on the latency kernel
 constexpr int64_t kLatQueries = 2048 * 256;
+// queries per wavefront of the latency kernel in the first (unhinted) iteration of a registration
+#ifndef VELO_LAT_FIRST_LANES
+#define VELO_LAT_FIRST_LANES 8
+#endif
+constexpr int kLatFirstLanes = VELO_LAT_FIRST_LANES;
 
 // ---------------------------------------------------------------- launchers (kernels/*.hip)
 struct MapBuild;  // opaque scratch owned by the ctx
@@ -150,7 +155,7 @@ hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const f
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, int32_t* hint, float* rho,
-                            const double* poses_prev, bool stats, int force_kernel, hipStream_t s);
+                            const double* poses_prev, bool stats, int force_kernel, hipStream_t s, int lat_lanes = 64);
 hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s);
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
