@@ -32,6 +32,9 @@
 #ifndef VELO_LATE_ROUNDS
 #define VELO_LATE_ROUNDS 3
 #endif
+#ifndef VELO_LAT_SPARSE_MIN_S
+#define VELO_LAT_SPARSE_MIN_S 4
+#endif
 #ifndef VELO_FIRST_HEAD_PCT
 #define VELO_FIRST_HEAD_PCT 10
 #endif
@@ -807,6 +810,12 @@ Decomposition decomposition_for(velo_ctx* c, int it, bool hinted, bool sorted_qu
                 c->lat_first_lanes};
     if (it >= VELO_CONV_FROM && c->ni_conv > 0 && hinted) return {c->items_conv.p, c->fbs_conv.p, c->ni_conv, 64};
     if (it > 0 && c->ni_late > 0 && hinted) return {c->items_late.p, c->fbs_late.p, c->ni_late, 64};
+    // latency kernel, sparse first iteration: it pays where stragglers are expensive -- fine cells
+    // full of points (S >= 4: first launch 304 -> 132 us on a 9 M-point map); on a light map (S = 3,
+    // 1 M points) the 13 us it saves are less than the eight times as many partial rows cost the
+    // solve: there the 256-query items serve every iteration
+    if (c->plan_lat && c->lat_first_lanes < 64 && c->ni_late > 0 && c->mv.S < VELO_LAT_SPARSE_MIN_S)
+        return {c->items_late.p, c->fbs_late.p, c->ni_late, 64};
     return {c->items_first.p, c->fbs.p, (int)c->items_h.size(), c->lat_first_lanes};
 }
 
