@@ -258,6 +258,14 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct, src=No
         frames.append(dict(buf=np.frombuffer(b"".join(f["packets"]), dtype=np.uint8).copy(),
                            ts=np.ascontiguousarray(f["ts"], dtype=np.int64), poses=f["poses"], n=f["n"], Tt=Tt,
                            T0=synth.perturbed_guess(Tt, dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))))
+    # the packets of a frame wait in pinned host memory, as a capture thread's ring buffer would
+    # hold them (a pageable source costs the upload a staging copy)
+    pinned = []
+    for fr in frames:
+        tb = torch.from_numpy(fr["buf"]).pin_memory()
+        tt = torch.from_numpy(fr["ts"]).pin_memory()
+        pinned.append((tb, tt))
+        fr["buf"], fr["ts"] = tb.numpy(), tt.numpy()
     nfr = len(frames)
     period = max(2 * nfr - 2, 1)
 
