@@ -2184,10 +2184,15 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     v.crop_inside = crop_inside;
     for (int i = 0; i < 6; ++i) v.region[i] = crop_region ? crop_region[i] : 0.0;
     HIP_TRY(c, launch_decode_keys(v, n_ret, c->dk_keys.p, c->dk_idx.p, s));
+    // valid keys are < n_keys, the key of a dropped return is all ones: the low bits that cover
+    // n_keys order both (one radix pass for a frame or two instead of four over 32 bits)
+    int key_bits = 1;
+    while (key_bits < 32 && (1u << key_bits) <= n_keys) ++key_bits;
     size_t tb = 0;
-    HIP_TRY(c, sort_pairs(nullptr, tb, c->dk_keys.p, c->dk_keys2.p, c->dk_idx.p, c->dk_order.p, n_ret, 32, s));
+    HIP_TRY(c, sort_pairs(nullptr, tb, c->dk_keys.p, c->dk_keys2.p, c->dk_idx.p, c->dk_order.p, n_ret, key_bits, s));
     if (int rc = ensure_temp(c, tb)) return rc;
-    HIP_TRY(c, sort_pairs(c->temp.p, tb, c->dk_keys.p, c->dk_keys2.p, c->dk_idx.p, c->dk_order.p, n_ret, 32, s));
+    HIP_TRY(c, sort_pairs(c->temp.p, tb, c->dk_keys.p, c->dk_keys2.p, c->dk_idx.p, c->dk_order.p, n_ret, key_bits,
+                          s));
     HIP_TRY(c, launch_key_starts(c->dk_keys2.p, n_ret, n_keys, c->dk_starts.p, s));
     std::vector<int32_t> starts((size_t)n_keys + 1);
     HIP_TRY(c, hipMemcpyAsync(starts.data(), c->dk_starts.p, starts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -2202,7 +2207,8 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     HIP_TRY(c, c->dk_pidx.reserve(std::max<size_t>(n_valid, 1)));
     HIP_TRY(c, launch_decode_emit(v, c->dk_order.p, n_valid, c->dk_x.p, c->dk_y.p, c->dk_z.p, c->dk_i.p,
                                   c->dk_az.p, c->dk_dist.p, c->dk_pidx.p, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    // (no wait for the emit: whoever reads the frames -- velo_decode_fetch, the registration -- is
+    // ordered behind it on the ctx stream)
     c->dk_frames = nfr;
     c->dk_points = n_valid;
     c->dk_frame_start.assign((size_t)nfr + 1, 0);
