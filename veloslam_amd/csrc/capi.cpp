@@ -175,6 +175,9 @@ struct velo_ctx {
     DevBuf<float> sp_x, sp_y, sp_z;
     DevBuf<double> inc_pose;
     uint32_t* h_inc_total = nullptr;  // pinned: count of the asynchronous increment
+    uint8_t* h_dec_stage = nullptr;   // pinned: packets + per-packet plan of one decode call
+    size_t h_dec_cap = 0;
+    DevBuf<uint8_t> dk_stage;         // ... and their one device-side copy
     hipEvent_t ev_inc = nullptr;
     bool inc_pending = false;
     int last_iters = 0;
@@ -213,10 +216,9 @@ struct velo_ctx {
     int32_t* h_comm_counts = nullptr;  // pinned [world]
 
     // ---- f1 decode
-    DevBuf<uint8_t> dk_pkts, dk_perm, dk_tvalid, dk_invlut;
-    DevBuf<int16_t> dk_blk;
-    DevBuf<double> dk_table, dk_corr, dk_lutc, dk_luts, dk_azc, dk_azs;
-    DevBuf<int32_t> dk_azdiff, dk_starts;
+    DevBuf<uint8_t> dk_invlut;
+    DevBuf<double> dk_corr, dk_lutc, dk_luts, dk_azc, dk_azs;
+    DevBuf<int32_t> dk_starts;
     DevBuf<uint32_t> dk_keys, dk_keys2, dk_idx, dk_order;
     DevBuf<float> dk_x, dk_y, dk_z, dk_i, dk_dist;
     DevBuf<uint16_t> dk_az, dk_pidx;
@@ -1301,6 +1303,7 @@ void velo_destroy(velo_ctx* c)
         if (c->ev_T0[b]) (void)hipEventDestroy(c->ev_T0[b]);
     }
     if (c->h_inc_total) (void)hipHostFree(c->h_inc_total);
+    if (c->h_dec_stage) (void)hipHostFree(c->h_dec_stage);
     if (c->ev_inc) (void)hipEventDestroy(c->ev_inc);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_call0) (void)hipEventDestroy(c->ev_call0);
@@ -2144,31 +2147,41 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     const uint8_t* packets_all = bytes.data();
     // ---- device side
     const size_t n_ret = n_pkt * 384;
-    HIP_TRY(c, c->dk_pkts.reserve(n_pkt * 1206));
-    HIP_TRY(c, c->dk_blk.reserve(blk.size()));
-    HIP_TRY(c, c->dk_perm.reserve(perm.size()));
-    HIP_TRY(c, c->dk_table.reserve(table.size()));
-    HIP_TRY(c, c->dk_tvalid.reserve(n_pkt));
-    HIP_TRY(c, c->dk_azdiff.reserve(n_pkt));
     HIP_TRY(c, c->dk_keys.reserve(n_ret));
     HIP_TRY(c, c->dk_keys2.reserve(n_ret));
     HIP_TRY(c, c->dk_idx.reserve(n_ret));
     HIP_TRY(c, c->dk_order.reserve(n_ret));
     const uint32_t n_keys = (uint32_t)std::max(nfr, 1) * 64u;
     HIP_TRY(c, c->dk_starts.reserve((size_t)n_keys + 1));
-    HIP_TRY(c, hipMemcpyAsync(c->dk_pkts.p, packets_all, n_pkt * 1206, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->dk_blk.p, blk.data(), blk.size() * sizeof(int16_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->dk_perm.p, perm.data(), perm.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->dk_table.p, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->dk_tvalid.p, tvalid.data(), n_pkt, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->dk_azdiff.p, azdiff.data(), n_pkt * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    // Packets and per-packet plan go up in ONE copy from a pinned staging buffer (six copies from
+    // pageable vectors each blocked the host for their staging).  The buffer is free again at the
+    // synchronisation below, well before the next call.
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_pk = 0, o_blk = al(o_pk + n_pkt * 1206), o_perm = al(o_blk + blk.size() * sizeof(int16_t)),
+                 o_tab = al(o_perm + perm.size()), o_tv = al(o_tab + table.size() * sizeof(double)),
+                 o_az = al(o_tv + n_pkt), stage_bytes = al(o_az + n_pkt * sizeof(int32_t));
+    if (c->h_dec_cap < stage_bytes) {
+        if (c->h_dec_stage) (void)hipHostFree(c->h_dec_stage);
+        c->h_dec_stage = nullptr;
+        c->h_dec_cap = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_dec_stage, stage_bytes + stage_bytes / 2, 0));
+        c->h_dec_cap = stage_bytes + stage_bytes / 2;
+    }
+    HIP_TRY(c, c->dk_stage.reserve(stage_bytes));
+    std::memcpy(c->h_dec_stage + o_pk, packets_all, n_pkt * 1206);
+    std::memcpy(c->h_dec_stage + o_blk, blk.data(), blk.size() * sizeof(int16_t));
+    std::memcpy(c->h_dec_stage + o_perm, perm.data(), perm.size());
+    std::memcpy(c->h_dec_stage + o_tab, table.data(), table.size() * sizeof(double));
+    std::memcpy(c->h_dec_stage + o_tv, tvalid.data(), n_pkt);
+    std::memcpy(c->h_dec_stage + o_az, azdiff.data(), n_pkt * sizeof(int32_t));
+    HIP_TRY(c, hipMemcpyAsync(c->dk_stage.p, c->h_dec_stage, stage_bytes, hipMemcpyHostToDevice, s));
     DecodeView v;
-    v.pkts = c->dk_pkts.p;
-    v.blk_frame = c->dk_blk.p;
-    v.frame_perm = c->dk_perm.p;
-    v.table = c->dk_table.p;
-    v.tvalid = c->dk_tvalid.p;
-    v.az_diff = c->dk_azdiff.p;
+    v.pkts = c->dk_stage.p + o_pk;
+    v.blk_frame = reinterpret_cast<const int16_t*>(c->dk_stage.p + o_blk);
+    v.frame_perm = c->dk_stage.p + o_perm;
+    v.table = reinterpret_cast<const double*>(c->dk_stage.p + o_tab);
+    v.tvalid = c->dk_stage.p + o_tv;
+    v.az_diff = reinterpret_cast<const int32_t*>(c->dk_stage.p + o_az);
     v.corr = c->dk_corr.p;
     v.lut_cos = c->dk_lutc.p;
     v.lut_sin = c->dk_luts.p;
