@@ -658,8 +658,52 @@ def incl_h2d_record(args, d, dev, ctx, steps):
 
 
 # ------------------------------------------------------------------------- main
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process becomes the parent of N fresh
+    rank processes (python -m torch.distributed.run, one per GPU) BEFORE anything here touches the
+    GPU -- a process that has initialised HIP must never be re-exec'ed, so nothing is: the ranks
+    are children, their rank 0's JSON line is relayed and their return code propagated."""
+    import socket
+    import subprocess
+    n_vis = torch.cuda.device_count()       # counts devices without initialising the runtime
+    # (VELO_BENCH_ONE_DEVICE=1: functional check of the N > 1 code path with every rank on GPU 0
+    # and gloo as the transport -- not a measurement, and the line says so)
+    if n_vis < args.gpus and not (os.environ.get("VELO_BENCH_ONE_DEVICE") == "1" and n_vis >= 1):
+        sys.stderr.write("bench: --gpus %d but only %d GPU(s) are visible; refusing to run fewer ranks than asked\n"
+                         % (args.gpus, n_vis))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it here
+    sys.stderr.write("bench: starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for raw in p.stdout:                     # rank 0 prints the one JSON line; relay it as ours
+        txt = raw.decode(errors="replace")
+        if txt.lstrip().startswith("{") and '"metric"' in txt:
+            line = txt
+        else:
+            sys.stderr.write(txt)
+    rc = p.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench: the ranks exited 0 without a JSON line\n")
+        rc = 4
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     # stdout carries exactly one JSON line: anything else that writes to fd 1 (RCCL prints a
     # version banner there when its first communicator comes up) goes to stderr instead
     sys.stdout.flush()
@@ -672,6 +716,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench: launched with WORLD_SIZE=%d but --gpus %d: the line's n_gpus must be what ran"
+                         % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     # (functional check of the N > 1 path on a one-GPU box: VELO_BENCH_ONE_DEVICE=1 puts every
@@ -679,6 +726,8 @@ def main():
     one_dev = os.environ.get("VELO_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         local = 0
+    elif torch.cuda.device_count() <= local:
+        raise SystemExit("bench: rank %d has no GPU %d (%d visible)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # One explicit stream carries torch's work AND the ctx's kernels (velo_set_stream): torch's
@@ -735,14 +784,23 @@ def main():
     transport = "torch.distributed"
     gathered = None
     if exchange and not one_dev and args.exchange == "capi":
+        # Every rank takes part in every collective of the negotiation whatever fails locally: rank 0
+        # broadcasts the id or None, then all ranks agree on `ok` (a rank that skipped the broadcast
+        # would leave the others blocked in it).
+        uid, ok = None, 1
+        if rank == 0:
+            try:
+                uid = capi.comm_unique_id()
+            except (capi.VeloError, RuntimeError) as e:
+                sys.stderr.write("bench: velo_comm_unique_id failed (%s)\n" % e)
+        if world > 1:
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
         try:
-            if world > 1:
-                box = [capi.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                ctx.comm_init(box[0], rank, world)
-            else:
-                ctx.comm_init(capi.comm_unique_id(), 0, 1)
-            ok = 1
+            if uid is None:
+                raise capi.VeloError(-3, "no communicator id")
+            ctx.comm_init(uid, rank, world)
         except capi.VeloError as e:
             ok = 0
             sys.stderr.write("bench: C-ABI communicator unavailable (%s); using torch.distributed\n" % e)
@@ -906,13 +964,18 @@ def main():
                                                                  args.d_max, args.voxel, F),
                        "frames_per_step_per_gpu": F, "points_per_frame": n_q // F,
                        "map_points": args.map_points, "iters": args.iters, "map_subdiv": int(mi.subdiv),
-                       "parallelism": "frame-parallel x%d" % world},
+                       "parallelism": "frame-parallel x%d" % world + (" (FUNCTIONAL CHECK: all ranks on one device, gloo)" if one_dev else "")},
             "frames_per_s": world * F * args.steps / elapsed,
             "total_pairs": total_pairs,
             "worst_pose_error_m": worst,
         }
         if exchange:
-            out["exchange"] = {"increments": "every frame of every batch",
+            c_rank, c_world = ctx.comm_info()
+            out["exchange"] = {"ranks": c_world if gathered is not None else world,   # velo_comm_info: what the communicator really spans
+                               "verified": ("rank-order pack kernel vs numpy for W = 1..64 (tests/test_gpu_comm.py); "
+                                            "RCCL transport at world > 1 first exercised by this run"
+                                            if world > 1 else "single rank: the collectives are degenerate"),
+                               "increments": "every frame of every batch",
                                "transport": transport + ((" " + dist.get_backend()) if world > 1 and gathered is None else ""),
                                "points_exchanged": state["exchanged_points"], "map_appends": state["appends"],
                                "points_appended": state["appended_points"],

@@ -33,8 +33,11 @@
 extern "C" {
 #endif
 
-#define VELO_ABI_VERSION 1
+/* 2: velo_map_info carries a caller-filled struct_size (and grew); velo_cfg carries abi_version,
+ *    checked by velo_create; cfg zero values map_subdiv = automatic, linearize_variant = ball */
+#define VELO_ABI_VERSION 2
 #define VELO_MAX_ITERS 64
+#define VELO_MAX_RANKS 64   /* ranks of one exchange communicator */
 #define VELO_MAX_KNORMALS 32
 #define VELO_VARIANT_BALL 1
 #define VELO_VARIANT_SCAN 100
@@ -52,11 +55,13 @@ enum {
 typedef struct velo_ctx velo_ctx;
 
 typedef struct velo_cfg {
-    uint32_t struct_size;   /* = sizeof(velo_cfg) */
+    uint32_t struct_size;   /* = sizeof(velo_cfg); velo_create refuses a cfg whose abi_version (below)
+                               is not VELO_ABI_VERSION: a consumer compiled against another header
+                               fails loudly instead of being misread */
     int32_t max_batch;      /* frames registered per launch (default 64) */
     int32_t linearize_variant; /* 0 = default = VELO_VARIANT_BALL (exact pruned ball search);
                                VELO_VARIANT_SCAN = the exhaustive 27-voxel validation kernel
-                               (same results, ~10x slower); 11..13 timing ablations */
+                               (same results, ~10x slower) */
     int32_t sort_frames;    /* 1: order each frame's queries by map cell once per registration */
     int32_t use_graph;      /* 1: replay a registration's launch sequence as one hipGraph
                                (cfg == NULL enables it) */
@@ -88,7 +93,8 @@ typedef struct velo_cfg {
                                4 / 3 / 6 rounds per wavefront (first / searching / converged
                                iterations) while it keeps 2.5 wavefronts per slot; a small value
                                makes a small batch take the decompositions of a large one */
-    int32_t reserved[3];
+    uint32_t abi_version;   /* = VELO_ABI_VERSION (the header the caller was compiled against) */
+    int32_t reserved[2];
 } velo_cfg;
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */
@@ -120,6 +126,9 @@ typedef struct velo_icp_result {
 } velo_icp_result;
 
 typedef struct velo_map_info {
+    uint32_t struct_size; /* IN: = sizeof(velo_map_info) of the caller's header; velo_map_info_get
+                             writes at most that many bytes (0 is refused) */
+    uint32_t reserved0;
     uint64_t n_points;
     uint64_t n_cells;     /* fine cells; cell_start has n_cells + 1 entries */
     float origin[3];
@@ -357,10 +366,25 @@ int velo_comm_unique_id(uint8_t id[VELO_COMM_ID_BYTES]);
 int velo_comm_init(velo_ctx*, const uint8_t id[VELO_COMM_ID_BYTES], int rank, int world);
 int velo_comm_destroy(velo_ctx*);
 int velo_comm_info(velo_ctx*, int32_t* rank, int32_t* world); /* world = 0: no communicator */
+/* The host-side half of the exchange, on its own (no ctx, no GPU): the per-rank counts the first
+ * all-gather returned -> offsets[r] = first output index of rank r's block (offsets has world + 1
+ * entries, offsets[world] = total), *pad = floats per axis of every padded block (the largest
+ * count, at least 1), *total = points of all ranks.  VELO_E_INVALID: world outside
+ * 1..VELO_MAX_RANKS or a negative count; VELO_E_RANGE: total beyond 2^32 - 1. */
+int velo_exchange_plan(const int32_t* counts, int world, uint32_t* offsets, size_t* pad, size_t* total);
+/* The device-side half on its own: `recv` (device) laid out as the padded all-gather leaves it --
+ * rank r's block at recv + r*3*pad floats, [x | y | z] each padded to pad -- is packed in RANK
+ * ORDER into ox/oy/oz (one kernel, stream-ordered on the ctx stream).  This is the step
+ * velo_exchange_increments runs after its second all-gather; exported so that it can be held to a
+ * reference for any world size on one GPU. */
+int velo_exchange_pack_dev(velo_ctx*, const float* recv, const int32_t* counts, int world, size_t pad,
+                           float* ox, float* oy, float* oz, size_t cap, size_t* n_total);
 /* All-gather of every rank's accepted increment (device SoA, n_local points; may be 0): counts
  * first, then max-padded blocks, packed in RANK ORDER into the device arrays ox/oy/oz (capacity
  * cap points) -- appending that list with velo_map_append_dev keeps every replica of the map
- * bit-identical.  counts (host, world entries, may be NULL) and *n_total are valid on return; the
+ * bit-identical.  Every rank must pass the same cap (a rank that returned early would leave the
+ * others inside the second collective: the capacity is checked after it, VELO_E_RANGE on every
+ * rank alike).  counts (host, world entries, may be NULL) and *n_total are valid on return; the
  * blocks are complete for work enqueued on the ctx stream after the call.  The collectives run on
  * the ctx's own communication stream: with after_async_increment != 0 they wait only for the
  * last velo_increment_*_async, not for a batch enqueued behind it (overlap with the next batch);

@@ -126,6 +126,7 @@ int main(int argc, char** argv)
     // integrate: the accepted increment goes into the host tiles AND is merged into the device
     // map in place; the next registration must not re-upload the ROI
     velo_map_info mi0, mi1, mi2;
+    mi0.struct_size = mi1.struct_size = mi2.struct_size = sizeof(velo_map_info);
     velo_map_info_get(mgr.context(), &mi0);
     opt.integrate = true;
     PoseTransform out2, out3;

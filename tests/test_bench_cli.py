@@ -1,0 +1,48 @@
+"""bench.py's --gpus contract: the flag decides how many ranks run, and a
+box that cannot give that many GPUs makes the run fail loudly instead of printing n_gpus: 1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=e, timeout=timeout)
+
+
+def test_more_ranks_than_gpus_is_refused_before_anything_runs():
+    import torch
+    n = torch.cuda.device_count()
+    r = _run(["--gpus", str(n + 1) if n else "2"])
+    assert r.returncode == 2 and r.stdout.strip() == ""
+    assert "refusing" in r.stderr
+
+
+def test_launcher_world_must_match_the_flag():
+    r = _run(["--gpus", "1"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.gpu
+def test_gpus_flag_starts_that_many_ranks_and_relays_one_line():
+    """The launcher path end to end on a one-GPU box: two rank processes (both on GPU 0, gloo:
+    a functional check, RCCL refuses two ranks on one device), one JSON line with n_gpus = 2."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "4", "--settle-s", "0.01",
+              "--map-points", "200000", "--no-cpu-baseline", "--no-subrecords"],
+             env={"VELO_BENCH_ONE_DEVICE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["exchange"]["ranks"] == 2
+    assert out["frames_per_s"] > 0 and "FUNCTIONAL" in out["config"]["parallelism"]

@@ -1,4 +1,8 @@
-"""world_size-2 gloo test of the multi-GPU exchange step (runs on CPU)."""
+"""world_size-2 gloo tests (CPU) of the all-torch exchange path (veloslam_amd/dist.py: bench.py
+--exchange torch, and the recorded fallback), and of the C library's host-side plan
+(velo_exchange_plan) on counts that really came out of a two-process all-gather.  The default
+transport of bench.py --gpus N -- RCCL behind velo_exchange_increments -- is a different
+implementation: its pack kernel is held to numpy in tests/test_gpu_comm.py."""
 import os
 import socket
 
@@ -30,6 +34,13 @@ def _worker(rank, world, port, q):
             buf = torch.zeros((3, 64), dtype=torch.float32)
             buf[:, :n] = torch.from_numpy(rng.uniform(-1, 1, (3, n)).astype(np.float32))
             blocks, counts = exchange_increments(buf, n)
+            # the C library's plan for the same gathered counts places the same blocks
+            from veloslam_amd import capi
+            offs, pad, total = capi.exchange_plan(counts)
+            cat = np.concatenate([b.numpy() for b in blocks], axis=1)
+            assert cat.shape[1] == total and pad == max(max(counts), 1)
+            for r, b in enumerate(blocks):
+                assert np.array_equal(cat[:, offs[r]:offs[r + 1]], b.numpy())
             out.append(([b.numpy().copy() for b in blocks], counts))
         q.put((rank, out))
     finally:

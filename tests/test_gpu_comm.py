@@ -1,7 +1,11 @@
 """The exchange step behind the C ABI (velo_comm_*, velo_exchange_increments): RCCL opened at
 run time, counts + max-padded blocks, rank-order packing.  One GPU here, so the communicator has
-one rank (RCCL refuses two ranks on one device); the N > 1 packing logic is the same code path
-with W > 1 and is covered on CPU tensors by tests/test_dist_gloo.py."""
+one rank (RCCL refuses two ranks on one device).  What W > 1 adds on top of that -- the counts ->
+offsets plan and the rank-order pack kernel -- is the library's own code and is held to numpy here
+for W = 1..64 (velo_exchange_pack_dev; plan on CPU: tests/test_exchange_plan.py).  The transport
+itself with world > 1 needs a multi-GPU node: bench.py --gpus N records what ran there
+(exchange.ranks, exchange.transport).  tests/test_dist_gloo.py covers the all-torch fallback
+(veloslam_amd/dist.py), a different implementation."""
 import numpy as np
 import pytest
 import torch
@@ -58,5 +62,66 @@ def test_single_rank_exchange_roundtrip_and_append(oracle):
             c.exchange_increments(src[0].data_ptr(), src[1].data_ptr(), src[2].data_ptr(), 700,
                                   dst[0].data_ptr(), dst[1].data_ptr(), dst[2].data_ptr(), 100,
                                   after_async_increment=False)
+    finally:
+        c.close()
+
+
+def _numpy_pack(recv, counts, pad):
+    """reference of the rank-order pack: rank r's block is [x | y | z], each `pad` floats"""
+    W = len(counts)
+    blocks = recv.reshape(W, 3, pad)
+    return np.concatenate([blocks[r, :, :counts[r]] for r in range(W)], axis=1)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 8, 16, 64])
+def test_rank_order_pack_matches_numpy_for_any_world(world):
+    """velo_exchange_pack_dev is the step velo_exchange_increments runs after its second all-gather
+    (one kernel): held to numpy for W = 1..64 on one GPU, with empty ranks, equal counts, one rank
+    holding everything, and counts that straddle wavefront boundaries."""
+    rng = np.random.default_rng(100 + world)
+    c = capi.Context(0, max_batch=2)
+    try:
+        cases = [rng.integers(0, 3000, world), np.full(world, 257), np.zeros(world, np.int64)]
+        one = np.zeros(world, np.int64)
+        one[world // 2] = 5000
+        cases.append(one)
+        sparse = rng.integers(0, 130, world) * (rng.random(world) < 0.5)
+        cases.append(sparse)
+        for counts in cases:
+            counts = [int(v) for v in counts]
+            offs, pad, total = capi.exchange_plan(counts)
+            assert pad == max(max(counts), 1) and total == sum(counts)
+            pad_used = pad + int(rng.integers(0, 5))          # a block may be wider than the plan needs
+            recv = rng.standard_normal(world * 3 * pad_used).astype(np.float32)
+            d_recv = torch.from_numpy(recv).cuda()
+            cap = total + 7
+            out = torch.full((3, cap), -7.0, dtype=torch.float32, device="cuda")
+            got = c.exchange_pack_dev(d_recv.data_ptr(), counts, pad_used, out[0].data_ptr(), out[1].data_ptr(),
+                                      out[2].data_ptr(), cap)
+            c.synchronize()
+            assert got == total
+            h = out.cpu().numpy()
+            assert np.array_equal(h[:, :total], _numpy_pack(recv, counts, pad_used))
+            assert np.all(h[:, total:] == -7.0)               # nothing written past the total
+    finally:
+        c.close()
+
+
+def test_rank_order_pack_refuses_bad_plans():
+    c = capi.Context(0, max_batch=2)
+    try:
+        buf = torch.zeros(3 * 4 * 16, dtype=torch.float32, device="cuda")
+        out = torch.zeros((3, 64), dtype=torch.float32, device="cuda")
+        args = (out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+        with pytest.raises(capi.VeloError) as e:            # capacity
+            c.exchange_pack_dev(buf.data_ptr(), [16, 16, 16, 16], 16, *args, 63)
+        assert e.value.code == -5
+        with pytest.raises(capi.VeloError):                 # a count wider than the blocks
+            c.exchange_pack_dev(buf.data_ptr(), [17, 1, 1, 1], 16, *args, 64)
+        with pytest.raises(capi.VeloError):                 # negative count
+            c.exchange_pack_dev(buf.data_ptr(), [4, -1, 1, 1], 16, *args, 64)
+        with pytest.raises(capi.VeloError):                 # world beyond VELO_MAX_RANKS
+            c.exchange_pack_dev(buf.data_ptr(), [0] * 65, 16, *args, 64)
+        assert c.exchange_pack_dev(buf.data_ptr(), [16, 16, 16, 16], 16, *args, 64) == 64
     finally:
         c.close()

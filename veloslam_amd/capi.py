@@ -15,6 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("VELO_LIB") or os.path.join(CSRC, "libveloslam_amd.so")  # VELO_LIB: A/B builds
 
 VELO_MAX_ITERS = 64
+VELO_ABI_VERSION = 2   # include/velo.h; lib() refuses a library that reports another
+VELO_MAX_RANKS = 64
 VARIANT_BALL, VARIANT_SCAN = 1, 100  # velo_cfg.linearize_variant (0 = default = BALL)
 KERNEL_AUTO, KERNEL_THROUGHPUT, KERNEL_LATENCY = 0, 1, 2  # velo_cfg.force_kernel
 VELO_TIME_INVALID = -(2 ** 63)
@@ -31,7 +33,8 @@ class Cfg(C.Structure):
                 ("linearize_variant", C.c_int32), ("sort_frames", C.c_int32),
                 ("use_graph", C.c_int32), ("map_subdiv", C.c_int32), ("use_hints", C.c_int32),
                 ("rounds_per_block", C.c_int32), ("map_margin", C.c_int32),
-                ("map_full_rebuild", C.c_int32), ("map_hash_load", C.c_int32), ("force_kernel", C.c_int32), ("plan_wave_slots", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("map_full_rebuild", C.c_int32), ("map_hash_load", C.c_int32), ("force_kernel", C.c_int32), ("plan_wave_slots", C.c_int32), ("abi_version", C.c_uint32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class Pose(C.Structure):
@@ -62,7 +65,8 @@ class IcpResult(C.Structure):
 
 
 class MapInfo(C.Structure):
-    _fields_ = [("n_points", C.c_uint64), ("n_cells", C.c_uint64), ("origin", C.c_float * 3),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+                ("n_points", C.c_uint64), ("n_cells", C.c_uint64), ("origin", C.c_float * 3),
                 ("voxel", C.c_float), ("inv_voxel", C.c_float), ("dims", C.c_int32 * 3),
                 ("k_normals", C.c_int32), ("n_invalid_normals", C.c_uint64),
                 ("subdiv", C.c_int32), ("last_update", C.c_int32),
@@ -78,7 +82,7 @@ EXPORTS = [
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
     "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
-    "velo_exchange_increments", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
+    "velo_exchange_increments", "velo_exchange_plan", "velo_exchange_pack_dev", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
     "velo_insmeta_write", "velo_insmeta_read", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
@@ -108,6 +112,9 @@ def lib():
             "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback."
             % LIB_PATH)
     L = C.CDLL(LIB_PATH)
+    if L.velo_abi_version() != VELO_ABI_VERSION:
+        raise RuntimeError("%s implements VELO_ABI_VERSION %d, this binding was written for %d: rebuild it "
+                           "(make -C veloslam_amd/csrc)" % (LIB_PATH, L.velo_abi_version(), VELO_ABI_VERSION))
     fp, dp, ip = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)
     vp = C.c_void_p
     L.velo_create.restype = vp
@@ -164,6 +171,9 @@ def lib():
     L.velo_comm_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.velo_exchange_increments.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, C.c_size_t, vp,
                                            C.POINTER(C.c_size_t)]
+    L.velo_exchange_plan.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.velo_exchange_pack_dev.argtypes = [vp, vp, vp, C.c_int, C.c_size_t, vp, vp, vp, C.c_size_t,
+                                         C.POINTER(C.c_size_t)]
     L.velo_last_timing.argtypes = [vp, dp]
     L.velo_set_timing.argtypes = [vp, C.c_int]
     L.velo_last_linearize_us.argtypes = [vp, vp, C.c_int]
@@ -209,6 +219,17 @@ def comm_unique_id():
     if rc:
         raise VeloError(rc, lib().velo_last_error(None).decode())
     return buf.tobytes()
+
+
+def exchange_plan(counts):
+    """velo_exchange_plan (host only, no GPU): per-rank counts -> (offsets[world+1], pad, total)"""
+    cnt = np.ascontiguousarray(counts, np.int32)
+    offs = np.zeros(cnt.size + 1, np.uint32)
+    pad, tot = C.c_size_t(), C.c_size_t()
+    rc = lib().velo_exchange_plan(_p(cnt), cnt.size, _p(offs), C.byref(pad), C.byref(tot))
+    if rc:
+        raise VeloError(rc, "velo_exchange_plan")
+    return offs, pad.value, tot.value
 
 
 def matrix_from_pose(T, Rdeg):
@@ -333,6 +354,7 @@ class Context:
         L = lib()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
+        cfg.abi_version = VELO_ABI_VERSION
         cfg.max_batch = max_batch
         cfg.sort_frames = sort_frames
         cfg.linearize_variant = linearize_variant
@@ -446,6 +468,7 @@ class Context:
 
     def map_info(self):
         mi = MapInfo()
+        mi.struct_size = C.sizeof(MapInfo)
         self._chk(lib().velo_map_info_get(self.h, C.byref(mi)))
         return mi
 
@@ -639,6 +662,14 @@ class Context:
         self._chk(lib().velo_exchange_increments(self.h, px, py, pz, n_local, int(bool(after_async_increment)),
                                                  pox, poy, poz, cap, _p(counts), C.byref(tot)))
         return counts.tolist(), tot.value
+
+    def exchange_pack_dev(self, precv, counts, pad, pox, poy, poz, cap):
+        """the rank-order pack of velo_exchange_increments alone (any world size on one GPU)"""
+        cnt = np.ascontiguousarray(counts, np.int32)
+        tot = C.c_size_t()
+        self._chk(lib().velo_exchange_pack_dev(self.h, precv, _p(cnt), cnt.size, pad, pox, poy, poz, cap,
+                                               C.byref(tot)))
+        return tot.value
 
     def increment_wait(self):
         cnt = C.c_size_t()

@@ -8,9 +8,18 @@
 #include <cstring>
 #include <memory>
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types only: the library is opened at run time (velo_comm_init)
 #include "velo_internal.hpp"
 #include "../../include/veloslam/TransformManager.hpp"
+
+// The handful of RCCL declarations the exchange needs, stated here so that the library builds
+// without the RCCL headers too (values as in rccl.h of ROCm 7.x == nccl.h: the C ABI of the
+// collectives library is stable across releases).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[VELO_COMM_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt32 = 2, ncclFloat32 = 7 } ncclDataType_t;
+}
 
 // launch order of the work items (launch_order below): measured on 64 frames, first iteration
 // 486 us frame-major, 465 item-major, 448 item-major backwards (the ends of the frames hold the
@@ -1266,13 +1275,38 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
             c->wave_slots = cus * 4 * 7;
     }
     std::memset(&c->cfg, 0, sizeof c->cfg);
-    if (cfg) std::memcpy(&c->cfg, cfg, std::min<size_t>(cfg->struct_size, sizeof(velo_cfg)));
+    if (cfg) {
+        // the meaning of fields (and of their zero values) changes with VELO_ABI_VERSION: a cfg
+        // filled in against another header is refused, not reinterpreted
+        const bool has_abi = cfg->struct_size >= offsetof(velo_cfg, abi_version) + sizeof(uint32_t);
+        if (!has_abi || cfg->abi_version != VELO_ABI_VERSION) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "velo_cfg.abi_version is %u, this library implements VELO_ABI_VERSION %d "
+                     "(set cfg.struct_size and cfg.abi_version from the header you compile against)",
+                     has_abi ? cfg->abi_version : 0u, VELO_ABI_VERSION);
+            g_create_error = buf;
+            return nullptr;
+        }
+        std::memcpy(&c->cfg, cfg, std::min<size_t>(cfg->struct_size, sizeof(velo_cfg)));
+    }
+    c->cfg.abi_version = VELO_ABI_VERSION;
     c->cfg.struct_size = sizeof(velo_cfg);
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 64;
     if (c->cfg.plan_wave_slots > 0) c->wave_slots = c->cfg.plan_wave_slots;
     // 0 = the default (fast, pruned) kernel for every consumer -- C, C++ MapManager and Python
     // alike; the exhaustive validation kernel has to be asked for by name
     if (c->cfg.linearize_variant == 0) c->cfg.linearize_variant = VELO_VARIANT_BALL;
+    {
+        const int v = c->cfg.linearize_variant;
+        bool known = v == VELO_VARIANT_BALL || v == VELO_VARIANT_SCAN;
+#ifdef VELO_ABLATIONS  // private timing builds (tools/build_variant.sh -DVELO_ABLATIONS): wrong results by design
+        known = known || (v >= 11 && v <= 13);
+#endif
+        if (!known) {
+            g_create_error = "velo_cfg.linearize_variant: unknown value (0 / VELO_VARIANT_BALL / VELO_VARIANT_SCAN)";
+            return nullptr;
+        }
+    }
     if (!cfg) {
         c->cfg.use_hints = 2;
         c->cfg.use_graph = 1;
@@ -1694,7 +1728,15 @@ int velo_map_info_get(velo_ctx* c, velo_map_info* out)
 {
     if (!c || !out) return VELO_E_INVALID;
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
-    *out = c->info;
+    // the caller says how large ITS velo_map_info is; never write past that (the struct has grown
+    // before and will again)
+    const uint32_t have = out->struct_size;
+    if (have < offsetof(velo_map_info, n_points) + sizeof(uint64_t))
+        return c->fail(VELO_E_INVALID, "velo_map_info.struct_size must be set to sizeof(velo_map_info) by the caller");
+    velo_map_info full = c->info;
+    full.struct_size = (uint32_t)std::min<size_t>(have, sizeof full);
+    full.reserved0 = 0;
+    std::memcpy(out, &full, full.struct_size);
     return VELO_OK;
 }
 
@@ -2574,7 +2616,8 @@ int velo_comm_unique_id(uint8_t id[VELO_COMM_ID_BYTES])
 int velo_comm_init(velo_ctx* c, const uint8_t id[VELO_COMM_ID_BYTES], int rank, int world)
 {
     if (!c) return VELO_E_INVALID;
-    if (!id || world < 1 || rank < 0 || rank >= world) return c->fail(VELO_E_INVALID, "bad rank / world / id");
+    if (!id || world < 1 || world > VELO_MAX_RANKS || rank < 0 || rank >= world)
+        return c->fail(VELO_E_INVALID, "bad rank / world (1..%d) / id", VELO_MAX_RANKS);
     if (c->comm) return c->fail(VELO_E_INVALID, "communicator already initialised");
     if (!g_rccl.load()) return c->fail(VELO_E_DEVICE, "%s", g_rccl.err.c_str());
     HIP_TRY(c, hipSetDevice(c->device));
@@ -2609,10 +2652,61 @@ int velo_comm_destroy(velo_ctx* c)
     return VELO_OK;
 }
 
+// Host half of the exchange: counts -> offsets / pad / total (pure, no ctx: CPU-testable).
+int velo_exchange_plan(const int32_t* counts, int world, uint32_t* offsets, size_t* pad, size_t* total)
+{
+    if (!counts || !offsets || world < 1 || world > VELO_MAX_RANKS) return VELO_E_INVALID;
+    uint64_t run = 0;
+    size_t widest = 1;  // a zero-length all-gather is not a collective every RCCL accepts
+    for (int r = 0; r < world; ++r) {
+        if (counts[r] < 0) return VELO_E_INVALID;
+        offsets[r] = (uint32_t)run;
+        run += (uint64_t)counts[r];
+        if (run > 0xFFFFFFFFull) return VELO_E_RANGE;
+        widest = std::max(widest, (size_t)counts[r]);
+    }
+    offsets[world] = (uint32_t)run;
+    if (pad) *pad = widest;
+    if (total) *total = (size_t)run;
+    return VELO_OK;
+}
+
+namespace {
+// device half: the W padded blocks -> ox/oy/oz in rank order, one launch on stream s
+int pack_rank_blocks(velo_ctx* c, const float* recv, const int32_t* counts, int world, size_t pad,
+                     float* ox, float* oy, float* oz, size_t cap, size_t* n_total, hipStream_t s)
+{
+    RankOffsets ro{};
+    size_t need_pad = 0, total = 0;
+    const int rc = velo_exchange_plan(counts, world, ro.off, &need_pad, &total);
+    if (rc == VELO_E_RANGE) return c->fail(rc, "exchange: more than 2^32 - 1 points in one round");
+    if (rc) return c->fail(rc, "exchange: bad counts / world (1..%d ranks, counts >= 0)", VELO_MAX_RANKS);
+    ro.world = world;
+    if (n_total) *n_total = total;
+    if (pad < need_pad) return c->fail(VELO_E_INVALID, "exchange: blocks of %zu floats cannot hold a count of %zu", pad, need_pad);
+    if (pad > 0xFFFFFFFFull / 3) return c->fail(VELO_E_RANGE, "exchange: block too large");
+    if (total > cap) return c->fail(VELO_E_RANGE, "exchange: %zu points exceed the output capacity %zu", total, cap);
+    if (total == 0) return VELO_OK;
+    if (!recv || !ox || !oy || !oz) return c->fail(VELO_E_INVALID, "null argument");
+    HIP_TRY(c, launch_pack_rank_blocks(recv, ro, (uint32_t)pad, ox, oy, oz, s));
+    return VELO_OK;
+}
+}  // namespace
+
+int velo_exchange_pack_dev(velo_ctx* c, const float* recv, const int32_t* counts, int world, size_t pad,
+                           float* ox, float* oy, float* oz, size_t cap, size_t* n_total)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!counts) return c->fail(VELO_E_INVALID, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return pack_rank_blocks(c, recv, counts, world, pad, ox, oy, oz, cap, n_total, c->stream);
+}
+
 // All-gather-v of the accepted map increments: counts first (one int per rank), then blocks
 // padded to the largest count (a few hundred KB at most: latency-bound on the direct xGMI
 // links, one padded all-gather beats world-1 ring steps of exact sizes), then the blocks are
-// packed in RANK ORDER into ox/oy/oz so that every replica appends the same list.
+// packed in RANK ORDER into ox/oy/oz so that every replica appends the same list.  Device work
+// per call: one pack kernel before the second collective, one after it.
 int velo_exchange_increments(velo_ctx* c, const float* dx, const float* dy, const float* dz, size_t n_local,
                              int after_async_increment, float* ox, float* oy, float* oz, size_t cap,
                              int32_t* counts, size_t* n_total)
@@ -2640,37 +2734,22 @@ int velo_exchange_increments(velo_ctx* c, const float* dx, const float* dy, cons
     HIP_TRY(c, hipMemcpyAsync(c->h_comm_counts, c->comm_counts.p, (size_t)W * sizeof(int32_t),
                               hipMemcpyDeviceToHost, cs));
     HIP_TRY(c, hipStreamSynchronize(cs));  // the counts size the second phase
+    uint32_t offs[VELO_MAX_RANKS + 1];
     size_t pad = 1, total = 0;
-    for (int r = 0; r < W; ++r) {
-        if (c->h_comm_counts[r] < 0) return c->fail(VELO_E_DEVICE, "negative count from rank %d", r);
-        pad = std::max(pad, (size_t)c->h_comm_counts[r]);
-        total += (size_t)c->h_comm_counts[r];
-        if (counts) counts[r] = c->h_comm_counts[r];
-    }
+    if (int rc = velo_exchange_plan(c->h_comm_counts, W, offs, &pad, &total))
+        return c->fail(rc == VELO_E_RANGE ? VELO_E_RANGE : VELO_E_DEVICE,
+                       "exchange: the gathered counts are not a valid plan (negative, or beyond 2^32 - 1 points)");
+    for (int r = 0; r < W && counts; ++r) counts[r] = c->h_comm_counts[r];
     *n_total = total;
-    if (total > cap) return c->fail(VELO_E_RANGE, "exchange: %zu points exceed the output capacity %zu", total, cap);
-    if (total == 0) return VELO_OK;
+    if (total == 0) return VELO_OK;  // the same decision on every rank: the counts are identical
+    // From here to the second collective nothing may depend on rank-local state (cap, the
+    // output pointers): a rank that returned early would leave the others inside the all-gather.
     HIP_TRY(c, c->comm_send.reserve(3 * pad));
     HIP_TRY(c, c->comm_recv.reserve(3 * pad * (size_t)W));
-    const float* src[3] = {dx, dy, dz};
-    for (int a = 0; a < 3; ++a) {
-        if (n_local)
-            HIP_TRY(c, hipMemcpyAsync(c->comm_send.p + (size_t)a * pad, src[a], n_local * sizeof(float),
-                                      hipMemcpyDeviceToDevice, cs));
-        if (n_local < pad)
-            HIP_TRY(c, hipMemsetAsync(c->comm_send.p + (size_t)a * pad + n_local, 0,
-                                      (pad - n_local) * sizeof(float), cs));
-    }
+    HIP_TRY(c, launch_pack_send(dx, dy, dz, (uint32_t)n_local, (uint32_t)pad, c->comm_send.p, cs));
     RCCL_TRY(c, g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, 3 * pad, ncclFloat32, c->comm, cs));
-    float* dst[3] = {ox, oy, oz};
-    size_t off = 0;
-    for (int r = 0; r < W; ++r) {
-        const size_t n = (size_t)c->h_comm_counts[r];
-        for (int a = 0; a < 3 && n; ++a)
-            HIP_TRY(c, hipMemcpyAsync(dst[a] + off, c->comm_recv.p + ((size_t)r * 3 + a) * pad,
-                                      n * sizeof(float), hipMemcpyDeviceToDevice, cs));
-        off += n;
-    }
+    if (int rc = pack_rank_blocks(c, c->comm_recv.p, c->h_comm_counts, W, pad, ox, oy, oz, cap, nullptr, cs))
+        return rc;
     // work enqueued on the ctx stream from now on (velo_map_append_dev) sees the blocks
     HIP_TRY(c, hipEventRecord(c->ev_comm, cs));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_comm, 0));

@@ -5,10 +5,13 @@
 // against this library unchanged.  Host-only, fp64: ~15 transcendental calls
 // per 100 Hz INS sample is not GPU work.
 //
-// Written from the formulas, not from the reference text, but every expression
-// keeps the reference's evaluation order (cited per function) because the
-// parity test is bit-exact against vectors cut from the reference's own object
-// code (tests/golden/coorditran.json).  Built with -ffp-contract=off.
+// The parity bar is bit-exact against vectors cut from the reference's own object
+// code (tests/golden/coorditran.json, and live against oracle/_ref), and a closed
+// form held to the last bit leaves no freedom: every expression keeps the
+// reference's evaluation order, cited per function.  xyz2llh in particular follows
+// CoordiTran.cpp:82-150 expression for expression (renamed variables); what is
+// this file's own is the structure around the formulas (Ellipsoid, EnuBasis, mul3).
+// Built with g++ -O2 -ffp-contract=off, the reference's compiler (csrc/Makefile).
 #include <cmath>
 #include "../../../include/velo.h"
 

@@ -1169,11 +1169,18 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
     const bool lat = variant == VELO_VARIANT_BALL &&
                      (force_kernel == 2 || (force_kernel != 1 && n_items < kLatItems));
     if (!mv.cell_start) {
-        // sparse fine-cell table: the ball search in its two kernels (the validation scan and
-        // the counting instantiation read the table through the run-time form)
+        // sparse fine-cell table: the ball search in its two kernels and their counting
+        // instantiations (the validation scan reads the table through the run-time form)
         if (variant == VELO_VARIANT_SCAN) {
             hipLaunchKernelGGL((k_linearize<true, 0, false>), dim3(n_items), dim3(kLinNT), 0, s, items,
                                fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
+        } else if (stats) {
+            if (lat)
+                hipLaunchKernelGGL((k_linearize_lat<true, true, true>), dim3(n_items), dim3(kLinThreads), 0,
+                                   s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev, lat_lanes);
+            else
+                hipLaunchKernelGGL((k_linearize<true, 1, true, true>), dim3(n_items), dim3(kLinNT), 0,
+                                   s, items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev);
         } else if (lat) {
             if (wc)
                 hipLaunchKernelGGL((k_linearize_lat<true, false, true>), dim3(n_items), dim3(kLinThreads), 0,
@@ -1207,12 +1214,14 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
                                items, fv, mv, poses, dmax2, partials, corr, d2, hint, rho, poses_prev, lat_lanes);
     } else if (variant == VELO_VARIANT_SCAN) {
         if (wc) VELO_LAUNCH_LIN(true, 0); else VELO_LAUNCH_LIN(false, 0);
-    } else if (variant == 11) {  // timing ablations (wrong results by design)
+#ifdef VELO_ABLATIONS  // timing ablations (wrong results by design): private builds only
+    } else if (variant == 11) {
         VELO_LAUNCH_LIN(false, 11);
     } else if (variant == 12) {
         VELO_LAUNCH_LIN(false, 12);
     } else if (variant == 13) {
         VELO_LAUNCH_LIN(false, 13);
+#endif
     } else {  // VELO_VARIANT_BALL and anything unknown: the default kernel
         if (wc) VELO_LAUNCH_LIN(true, 1); else VELO_LAUNCH_LIN(false, 1);
     }

@@ -192,6 +192,16 @@ hipError_t launch_sparse_accept(const uint64_t* keys_sorted, const uint32_t* idx
 hipError_t launch_compact3(const float* x, const float* y, const float* z, size_t n, const uint32_t* flags,
                            const uint32_t* offs, float* ox, float* oy, float* oz, hipStream_t s);
 
+// ---- multi-GPU exchange step: pack kernels either side of the all-gather (kernels/exchange.hip)
+struct RankOffsets {
+    uint32_t off[VELO_MAX_RANKS + 1];  // off[r] = first output index of rank r's block, off[world] = total
+    int32_t world;
+};
+hipError_t launch_pack_send(const float* x, const float* y, const float* z, uint32_t n, uint32_t pad,
+                            float* send, hipStream_t s);
+hipError_t launch_pack_rank_blocks(const float* recv, const RankOffsets& ro, uint32_t pad, float* ox,
+                                   float* oy, float* oz, hipStream_t s);
+
 // ---- f1: packet decode (kernels/decode.hip)
 struct DecodeView {
     const uint8_t* pkts;        // n_pkt * 1206
