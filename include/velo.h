@@ -443,6 +443,25 @@ int velo_packet_transforms(const velo_pose* sorted, size_t n, const int64_t* pkt
  * *n_out = cap) when the file holds more than cap packets. */
 int velo_pcap_write(const char* path, const uint8_t* packets, const int64_t* t_us, size_t n_pkt);
 int velo_pcap_read(const char* path, uint8_t* packets, int64_t* t_us, size_t cap, size_t* n_out);
+/* Frame index of a capture -- HDLParser::readFrameInformation (HDLParser.cxx:1065-1160), consumed
+ * by HDLManager::loadOffline (HDLManager.cxx:103-117: fileStartPos / skips / timestamp per frame)
+ * and by the offline re-read HDLParser::getFrame (HDLParser.cxx:505-544).  One pass over the file
+ * that looks only at the rotational position of every firing block: frame 0 starts at the first
+ * record (position 24, skip 0, time of the first lidar packet; present even for an empty capture,
+ * with t_us = VELO_TIME_INVALID, as the reference pushes it before reading); every block whose
+ * raw azimuth is below the previous block's opens a frame at { position of the record holding it,
+ * block index, that packet's time }.  first_packet (not in the reference) = ordinal of that packet
+ * among the 1206-byte packets, i.e. the index into what velo_pcap_read returns: decoding
+ * packets [first_packet, ...) with velo_decode_opts.initial_firing_skip = firing_skip reproduces
+ * the frame.  frames may be NULL to count; VELO_E_RANGE (with *n_out = frames found) beyond cap. */
+typedef struct velo_frame_index {
+    int64_t file_pos;       /* HDLFrame::fileStartPos */
+    int32_t firing_skip;    /* HDLFrame::skips */
+    int32_t reserved;
+    int64_t first_packet;
+    int64_t t_us;           /* HDLFrame::timestamp */
+} velo_frame_index;
+int velo_pcap_index(const char* path, velo_frame_index* frames, size_t cap, size_t* n_out);
 /* InsPVA wire struct (type_defs.h:39-58, natural alignment: 104 bytes) */
 typedef struct velo_inspva {
     uint16_t message_id;

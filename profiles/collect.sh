@@ -1,19 +1,21 @@
 #!/bin/bash
 # How the files under profiles/rNN/ are produced (run on the GPU box through gpurun):
-#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r02'
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r03'
 # Raw rocprofv3 output goes to gpurun_out/prof_<round>/ (scratch); profiles/summarize.py turns
 # it into the small committed summaries and profiles/traffic.json (what bench.py's
 # roofline.traffic reads, keyed by batch size and map size).  Counter passes are separate runs
 # with --kernel-trace only (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md,
 # rocprofv3 PMC slots); the program itself follows `--`.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
 B="--no-cpu-baseline --only dense"        # main batch (F=64, 1 M) + the dense record (F=16, 10 M)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 $B > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 $B > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
+# exact fabric-side read bytes: requests by size class (tools/pmc_calib: FETCH_SIZE tallies a 128-byte request as 64)
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/pmc_rdreq -- python3 bench.py --steps 2 --warmup 1 $B > $OUT/bench_rdreq.json 2> $OUT/bench_rdreq.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 $B > $OUT/bench_write.json 2> $OUT/bench_write.err
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 2 --warmup 1 $B > $OUT/bench_sq.json 2> $OUT/bench_sq.err
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_tcc -- python3 bench.py --steps 2 --warmup 1 $B > $OUT/bench_tcc.json 2> $OUT/bench_tcc.err

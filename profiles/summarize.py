@@ -3,10 +3,14 @@
 summaries committed under profiles/<round>/ and into profiles/traffic.json, which bench.py reads
 for roofline.traffic (key "F<frames>_M<map points>": same batch, same map as the bench record).
 
-HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE/WRITE_SIZE are in
-KiB, and on gfx950 FETCH_SIZE reports half the bytes of coalesced reads (MI355X_MICROARCH.md,
-section HBM).  The counters sit on the fabric side of L2 and include Infinity-Cache hits; for
-the gather-dominated k_linearize the x2 is an upper bound (conservative: over-states traffic).
+Fabric-side bytes per launch = 32 x TCC_EA0_RDREQ_32B + 64 x TCC_EA0_RDREQ_64B + 128 x
+TCC_EA0_RDREQ_128B (reads, by request size) + WRITE_SIZE x 1024 (writes).  Calibrated on
+micro-kernels of known bytes (tools/pmc_calib.*, profiles/r03/pmc_calib.json): FETCH_SIZE tallies
+every request at 64 B, so it reports exactly half of a coalesced 8/16-byte-per-lane stream (128-byte
+requests) and exactly the bytes of scattered 64-byte requests -- round 2's blanket x2 was right for
+K1 and up to 2x too high for the gather-dominated k_linearize.  The size-class counters are exact for
+both (within 0.2 % of the known bytes in every class); WRITE_SIZE is exact as it is.  The counters sit
+on the fabric side of L2 and include Infinity-Cache hits (MI355X_MICROARCH.md, HBM).
 The two configurations of a collection run (headline batch, then the dense record) are told apart
 by the map they run against: a launch belongs to the configuration whose map build (k_normals)
 was the last one dispatched before it."""
@@ -18,7 +22,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + R)
 DST = os.path.join(ROOT, "profiles", R)
@@ -76,7 +80,7 @@ for f in glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv")):
             dur[builds].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 summary = {}
 raw = {}
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
+for sub in ("pmc_fetch", "pmc_rdreq", "pmc_write", "pmc_sq", "pmc_tcc"):
     by_grid, raw[sub] = counters(sub)
     for k, grids in by_grid.items():
         for g, cs in grids.items():
@@ -85,18 +89,24 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
 json.dump(dict(note=__doc__, kernels=summary), open(os.path.join(DST, "pmc.json"), "w"), indent=1)
 traffic = {}
 for key, cfg in CONFIGS.items():
-    fs = raw["pmc_fetch"].get(cfg, {}).get("FETCH_SIZE", [])
+    rq = raw["pmc_rdreq"].get(cfg, {})
+    r32, r64, r128 = (rq.get("TCC_EA0_RDREQ_%s_sum" % k, []) for k in ("32B", "64B", "128B"))
     ws = raw["pmc_write"].get(cfg, {}).get("WRITE_SIZE", [])
-    if not fs or not ws:
+    if not r64 or not ws or not (len(r32) == len(r64) == len(r128)):
         continue
+    fs = [(32 * a + 64 * b + 128 * c) / 1024.0 for a, b, c in zip(r32, r64, r128)]   # exact read KiB per launch
+    fraw = raw["pmc_fetch"].get(cfg, {}).get("FETCH_SIZE", [])
     f = sum(fs) / len(fs)
     w = sum(ws) / len(ws)
     d = dur.get(cfg, [])
-    traffic[key] = dict(kernel=raw["pmc_fetch"][cfg]["__kernel__"], FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w,
-                        hbm_bytes_per_launch=(2 * f + w) * 1024, launches_counted=len(fs),
+    traffic[key] = dict(kernel=rq["__kernel__"], read_KiB=f, WRITE_SIZE_KiB=w,
+                        FETCH_SIZE_KiB_raw=(sum(fraw) / len(fraw)) if fraw else None,
+                        read_requests_32_64_128B=[sum(v) / len(v) for v in (r32, r64, r128)],
+                        hbm_bytes_per_launch=(f + w) * 1024, launches_counted=len(fs),
                         rocprof_avg_launch_us=(sum(d) / len(d)) if d else None, rocprof_launches=len(d),
                         source="profiles/%s/pmc.json" % R,
-                        correction="gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)")
+                        correction="reads = 32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B (calibrated: "
+                                   "profiles/%s/pmc_calib.json); writes = WRITE_SIZE" % R)
     if d:
         traffic[key]["traffic_GBps_at_rocprof_avg"] = traffic[key]["hbm_bytes_per_launch"] / (
             sum(d) / len(d) * 1e-6) / 1e9
@@ -108,11 +118,25 @@ for key, cfg in CONFIGS.items():
             fi = fs[i::ITERS]
             wi = ws[i::ITERS]
             di = d[i::ITERS]
-            nbytes = (2 * sum(fi) / len(fi) + sum(wi) / len(wi)) * 1024
+            nbytes = (sum(fi) / len(fi) + sum(wi) / len(wi)) * 1024
             us = sum(di) / len(di)
             by_it.append(dict(iteration=i, hbm_bytes=nbytes, rocprof_us=us, GBps=nbytes / (us * 1e-6) / 1e9))
         traffic[key]["by_iteration"] = by_it
         traffic[key]["converged_launch"] = by_it[-1]
+# K1 (known bytes: 26 B per point): the check that the byte formula is calibrated on this library's
+# own streaming kernel too
+for k, grids in summary.items():
+    if "k_compensate" not in k:
+        continue
+    for g, cs in grids.items():
+        if all(("TCC_EA0_RDREQ_%s_sum" % c) in cs for c in ("32B", "64B", "128B")) and "WRITE_SIZE" in cs:
+            rd = sum(m * cs["TCC_EA0_RDREQ_%s_sum" % c]["mean"] for c, m in (("32B", 32), ("64B", 64), ("128B", 128)))
+            wr = cs["WRITE_SIZE"]["mean"] * 1024
+            # 4 points per lane (k_compensate_v4l): grid threads x 4 >= n; the headline batch has 64 x 115 200 points
+            n_pts = 64 * 115200 if int(g) * 4 >= 64 * 115200 > (int(g) - 256) * 4 else None
+            traffic["K1_grid%s" % g] = dict(kernel=k, read_bytes=rd, write_bytes=wr, pmc_bytes=rd + wr,
+                                            points=n_pts, algorithmic_bytes=(26 * n_pts) if n_pts else None,
+                                            pmc_over_algorithmic=((rd + wr) / (26 * n_pts)) if n_pts else None)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 for nm in ("bench_default.json", "bench_stream.json", "bench_trace.json"):

@@ -54,6 +54,11 @@ class DecodeOpts(C.Structure):
                 ("laser_selection", C.c_uint8 * 64)]
 
 
+class FrameIndex(C.Structure):
+    _fields_ = [("file_pos", C.c_int64), ("firing_skip", C.c_int32), ("reserved", C.c_int32),
+                ("first_packet", C.c_int64), ("t_us", C.c_int64)]
+
+
 class IcpIter(C.Structure):
     _fields_ = [("n_pairs", C.c_uint32), ("solve_flag", C.c_uint32), ("rmse", C.c_double)]
 
@@ -84,7 +89,7 @@ EXPORTS = [
     "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
     "velo_exchange_increments", "velo_exchange_plan", "velo_exchange_pack_dev", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
-    "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_ins_to_pose",
+    "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_pcap_index", "velo_ins_to_pose",
     "velo_insmeta_write", "velo_insmeta_read", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
     "llh2enu", "MappingAngle",
 ]
@@ -308,6 +313,21 @@ def pcap_read(path):
     if rc:
         raise VeloError(rc, "velo_pcap_read")
     return [bytes(buf[i * 1206:(i + 1) * 1206]) for i in range(n.value)], t
+
+
+def pcap_index(path):
+    """velo_pcap_index -> list of FrameIndex (file_pos, firing_skip, first_packet, t_us)"""
+    L = lib()
+    L.velo_pcap_index.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    n = C.c_size_t()
+    rc = L.velo_pcap_index(path.encode(), None, 0, C.byref(n))
+    if rc:
+        raise VeloError(rc, "velo_pcap_index")
+    arr = (FrameIndex * max(n.value, 1))()
+    rc = L.velo_pcap_index(path.encode(), arr, n.value, C.byref(n))
+    if rc:
+        raise VeloError(rc, "velo_pcap_index")
+    return list(arr[:n.value])
 
 
 def _geo2(name, a):

@@ -187,6 +187,85 @@ int velo_pcap_read(const char* path, uint8_t* packets, int64_t* t_us, size_t cap
     return VELO_OK;
 }
 
+// HDLParser::readFrameInformation (HDLParser.cxx:1065-1160): one pass over the capture that
+// looks at nothing but the rotational position of every firing block.  The first frame starts at
+// the first record (file position right after the 24-byte global header, skip 0, time of the first
+// lidar packet); a frame boundary is a block whose RAW azimuth (no modulo, HDLParser.cxx:1126) is
+// below the previous block's, and the new frame is { position of the record that holds that
+// block, index of the block, time of that packet } -- exactly what HDLManager::loadOffline
+// (HDLManager.cxx:103-117) stores per frame and HDLParser::getFrame (HDLParser.cxx:505-544) seeks
+// to.  Like the reference, the position remembered is the one after the last 1206-byte packet,
+// so foreign records in between are skipped again on re-read.
+int velo_pcap_index(const char* path, velo_frame_index* frames, size_t cap, size_t* n_out)
+{
+    if (!path || !n_out) return VELO_E_INVALID;
+    *n_out = 0;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return VELO_E_NODATA;
+    uint8_t gh[24];
+    if (std::fread(gh, 1, 24, f) != 24) {
+        std::fclose(f);
+        return VELO_E_INVALID;
+    }
+    const uint32_t magic = get32(gh, false);
+    bool swap = false, nano = false;
+    if (magic == 0xa1b2c3d4u) {
+    } else if (magic == 0xa1b23c4du) {
+        nano = true;
+    } else if (magic == 0xd4c3b2a1u) {
+        swap = true;
+    } else if (magic == 0x4d3cb2a1u) {
+        swap = nano = true;
+    } else {
+        std::fclose(f);
+        return VELO_E_INVALID;
+    }
+    size_t n = 0;
+    bool overflow = false;
+    auto push = [&](int64_t pos, int32_t skip, int64_t pkt, int64_t t) {
+        if (frames && n >= cap) overflow = true;  // keep counting: *n_out = frames found
+        if (frames && n < cap) {
+            frames[n].file_pos = pos;
+            frames[n].firing_skip = skip;
+            frames[n].reserved = 0;
+            frames[n].first_packet = pkt;
+            frames[n].t_us = t;
+        }
+        ++n;
+    };
+    int64_t last_pos = 24, n_pkt = 0;
+    unsigned last_az = 0;
+    bool have_first = false;
+    push(last_pos, 0, 0, VELO_TIME_INVALID);
+    std::vector<uint8_t> rec;
+    for (;;) {
+        uint8_t rh[16];
+        if (std::fread(rh, 1, 16, f) != 16) break;
+        const uint32_t sec = get32(rh, swap), frac = get32(rh + 4, swap), incl = get32(rh + 8, swap);
+        if (incl > (1u << 20)) break;
+        rec.resize(incl);
+        if (incl && std::fread(rec.data(), 1, incl, f) != incl) break;
+        if (incl != 1248 || rec[12] != 0x08 || rec[13] != 0x00 || (rec[14] & 0x0f) != 5 || rec[23] != 17)
+            continue;  // not a 1206-byte lidar datagram: position NOT remembered, as in the reference
+        const int64_t t = (int64_t)sec * 1000000 + (nano ? frac / 1000 : frac);
+        if (!have_first) {
+            have_first = true;
+            if (frames && cap) frames[0].t_us = t;
+        }
+        const uint8_t* pk = rec.data() + 42;
+        for (int b = 0; b < 12; ++b) {
+            const unsigned az = (unsigned)pk[b * 100 + 2] | ((unsigned)pk[b * 100 + 3] << 8);
+            if (az < last_az) push(last_pos, b, n_pkt, t);
+            last_az = az;
+        }
+        ++n_pkt;
+        last_pos = (int64_t)std::ftell(f);
+    }
+    std::fclose(f);
+    *n_out = n;
+    return overflow ? VELO_E_RANGE : VELO_OK;
+}
+
 // INSSource::calcTransform (INSSource.cxx:305-326): LLH degrees -> radians -> ENU about
 // orig_xyz (the reference's default is {-2781621.9891904, 4672106.75052387, 18.8910392},
 // INSSource.cxx:334 -- passed in, never "fixed"); Euler angles and velocity copied.  The
