@@ -49,4 +49,22 @@ private:
     double originLLH_[3], originXYZ_[3];
 };
 
+// A time-sorted velo_pose array read in place with the same bracket / interpolation rules: what the
+// C entry points (velo_interp_pose, velo_packet_transforms, velo_decode*) are handed.  O(log n) per
+// query, nothing copied; const and stateless, so one view may serve several threads.
+class SortedPoseView {
+public:
+    SortedPoseView(const velo_pose* sorted, size_t n);
+    bool interpolate(int64_t t_us, PoseTransform* xform) const;
+    bool packetTransforms(const int64_t* pkt_t_us, size_t n_pkt, double* T3x4, uint8_t* valid,
+                          PoseTransform* carpose) const;
+
+private:
+    int bucket(size_t i) const { return (int)((double)(p_[i].t_us - p_[0].t_us) / interval_); }
+    const velo_pose* p_;
+    size_t n_;
+    double interval_ = 0;
+    bool strict_ = true;
+};
+
 }  // namespace veloslam

@@ -29,6 +29,7 @@ DST = os.path.join(ROOT, "profiles", R)
 os.makedirs(DST, exist_ok=True)
 # configuration = how many map builds have been dispatched so far (bench.py --only dense: the
 # headline batch first, the dense record second)
+R_SRC = R
 CONFIGS = {"F64_M1000000": 1, "F16_M10000000": 2}
 PROD = "k_linearize<false, 1, false"  # the production instantiation (any table kind)
 MAPBUILD = "k_normals<"

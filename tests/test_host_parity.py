@@ -115,6 +115,38 @@ def test_interp_pose_matches_oracle_timeline(oracle, n):
             assert _same_pose(po, pp), "query %d of %d samples" % (q, n)
 
 
+def test_interp_pose_reads_the_array_in_place_and_survives_equal_stamps(oracle):
+    """velo_interp_pose no longer rebuilds a pose store per call (SortedPoseView, O(log n)): a
+    20 000-sample store answers in microseconds, and an array with EQUAL time stamps -- which the
+    reference's store would have merged (later sample wins, TimeLine.h:197-200) -- still gives
+    what the literal store gives (the slow path)."""
+    import time
+    rng = np.random.default_rng(77)
+    n = 20_000
+    t0 = 1_467_590_400_000_000
+    times = t0 + np.cumsum(np.maximum(1, (10000 + rng.normal(0, 1000, n)).astype(np.int64)))
+    tl, poses, cnt = _timeline_pair(oracle, times, rng)
+    qs = [int(q) for q in rng.integers(times[0] - 2000, times[-1] + 2000, 300)] + [int(t) for t in times[::97]]
+    a = time.perf_counter()
+    got = [capi.interp_pose(poses, cnt, q) for q in qs]
+    per_call = (time.perf_counter() - a) / len(qs)
+    assert per_call < 2e-3          # the rebuild took ~4 ms per call at this size (ctypes overhead included here)
+    for q, (ok_p, pp) in zip(qs, got):
+        ok_o, po = tl.interpolate(q)
+        assert ok_o == ok_p and _same_pose(po, pp)
+    # equal stamps: at the front, next to a bracket, and at the back
+    for dup_at in (3, 200, 395):
+        m = 400
+        times = t0 + np.cumsum(np.maximum(1, (10000 + rng.normal(0, 1000, m)).astype(np.int64)))
+        times[dup_at + 1] = times[dup_at]
+        tl, poses, cnt = _timeline_pair(oracle, times, rng)
+        for q in [int(times[dup_at]) - 3000, int(times[dup_at]), int(times[dup_at]) + 3000, int(times[dup_at + 2]),
+                  int(times[50]), int(times[-1]) + 5]:
+            ok_o, po = tl.interpolate(q)
+            ok_p, pp = capi.interp_pose(poses, cnt, q)
+            assert ok_o == ok_p and _same_pose(po, pp), (dup_at, q)
+
+
 def test_single_sample_extrapolates_and_stays_invalid(oracle):
     poses, n = capi.make_poses([((1, 2, 3), (4, 5, 6), (10, 0, -1), 1_000_000)])
     ok, p = capi.interp_pose(poses, n, 1_123_456)

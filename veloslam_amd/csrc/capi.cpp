@@ -2063,8 +2063,7 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     if (int rc = upload_calibration(c, corr)) return rc;
     hipStream_t s = c->stream;
 
-    veloslam::TransformManager tm;
-    for (size_t i = 0; i < n_poses; ++i) tm.addTransform(veloslam::PoseTransform::fromC(poses[i]));
+    const veloslam::SortedPoseView tm(poses, n_poses);  // the caller's store, read in place: O(log n) per packet
     // working set = what the unfinished frame still needs + the new packets
     std::vector<uint8_t> bytes(st.bytes);
     bytes.insert(bytes.end(), packets, packets + n_new * 1206);
@@ -2102,7 +2101,7 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     for (size_t p = n_pend; p < n_pkt; ++p) {
         const uint8_t* d = bytes.data() + p * 1206;
         veloslam::PoseTransform tr;
-        tm.interpolateTransform(times[p], &tr);
+        tm.interpolate(times[p], &tr);
         if (!inited) {  // :992-1001
             carpose = tr;
             c->dk_carposes[cur] = tr.toC();

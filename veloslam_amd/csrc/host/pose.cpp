@@ -433,18 +433,126 @@ int velo_pose_from_matrix(const double T[12], double TRdeg[6])
     return VELO_OK;
 }
 
-static void fill(veloslam::TransformManager& tm, const velo_pose* sorted, size_t n)
+}  // extern "C" (reopened below)
+
+namespace veloslam {
+
+// A caller-held array sorted by time, read in place: what the C entry points get.  Same bracket
+// rules as TransformManager (TimeLine::getBoundaryData, TimeLine.h:384-468) in O(log n) per query
+// and without copying the store -- the first version of these entry points rebuilt a
+// TransformManager from the array on EVERY call, 100 MB of copies per frame on a 1e6-pose drive
+// (found by tools/interp_bench).  The reference's bucket grid is a function of the first samples
+// only when the samples arrive in time order (interval fixed when the 11th sample is added,
+// TimeLine.h:166,536-552), which a sorted array is; equal time stamps (a later sample overwrites an
+// earlier one, TimeLine.h:197-200) shift indices, so an array that shows one where it matters --
+// the first 11 samples, the last 6, the neighbours of the bracket -- takes the slow path through a
+// real TransformManager instead.
+SortedPoseView::SortedPoseView(const velo_pose* sorted, size_t n) : p_(sorted), n_(n)
 {
-    for (size_t i = 0; i < n; ++i) tm.addTransform(PoseTransform::fromC(sorted[i]));
+    strict_ = true;
+    for (size_t i = 1; i < n_ && i < 11; ++i) strict_ = strict_ && p_[i - 1].t_us < p_[i].t_us;
+    for (size_t i = n_ > 6 ? n_ - 6 : 1; i < n_; ++i) strict_ = strict_ && p_[i - 1].t_us < p_[i].t_us;
+    if (n_ >= 11)
+        interval_ = (double)((uint64_t)(p_[9].t_us - p_[0].t_us) / (uint64_t)10);
+    else if (n_ >= 2)
+        interval_ = (double)(p_[1].t_us - p_[0].t_us) * 0.95;
+    if (n_ >= 2 && !(interval_ > 0)) strict_ = false;
 }
+
+bool SortedPoseView::interpolate(int64_t t, PoseTransform* out) const
+{
+    const size_t n = n_;
+    if (n == 0) {
+        out->timestamp = t;
+        return false;
+    }
+    size_t fi = 0, bi = 0;
+    bool two = n >= 2, slow = !strict_;
+    if (two && !slow) {
+        if (t <= p_[0].t_us) {
+            fi = 0, bi = 1;
+        } else if (t >= p_[n - 1].t_us) {
+            fi = n - 2, bi = n - 1;
+        } else {
+            size_t lo = 0, hi = n;  // first index with t_us >= t
+            while (lo < hi) {
+                const size_t mid = lo + (hi - lo) / 2;
+                if (p_[mid].t_us < t) lo = mid + 1; else hi = mid;
+            }
+            // equal stamps next to the bracket would have been merged by the store
+            for (size_t i = lo >= 2 ? lo - 2 : 0; i + 1 < n && i <= lo + 1; ++i)
+                slow = slow || !(p_[i].t_us < p_[i + 1].t_us);
+            fi = lo - 1, bi = lo;
+            if (!slow && p_[lo].t_us == t) {  // exact knot: see TransformManager::Impl::boundary
+                const size_t ring0 = n >= 5 ? n - 5 : 0;
+                const bool in_ring = t > p_[ring0].t_us;
+                if (!in_ring && bucket(lo) != bucket(lo - 1) && lo + 1 < n) {
+                    const int64_t gap_next = p_[lo + 1].t_us - t, gap_prev = t - p_[lo - 1].t_us;
+                    if (!(gap_next < gap_prev)) fi = lo, bi = lo + 1;
+                }
+            }
+        }
+    }
+    if (slow) {
+        TransformManager tm;
+        for (size_t i = 0; i < n; ++i) tm.addTransform(PoseTransform::fromC(p_[i]));
+        return tm.interpolateTransform(t, out);
+    }
+    out->timestamp = t;  // TransformManager.cxx:151
+    const PoseTransform fore = PoseTransform::fromC(p_[fi]);
+    if (!two) {
+        const double sec = (double)((float)(t - fore.timestamp) / 1e6f);  // TransformManager.cxx:161
+        for (int i = 0; i < 3; ++i) {
+            out->V[i] = fore.V[i];
+            out->R[i] = fore.R[i];
+            out->T[i] = fore.T[i] + fore.V[i] * sec;
+        }
+        return true;
+    }
+    const PoseTransform back = PoseTransform::fromC(p_[bi]);
+    const double ratio = double(t - fore.timestamp) / double(back.timestamp - fore.timestamp);
+    *out = fore + ((back - fore) * ratio);
+    out->seconds_pos = 0;  // TransformManager.cxx:174
+    return true;
+}
+
+bool SortedPoseView::packetTransforms(const int64_t* pkt_t, size_t n_pkt, double* T3x4, uint8_t* valid,
+                                      PoseTransform* carpose_out) const
+{
+    PoseTransform car;
+    for (size_t i = 0; i < n_pkt; ++i) {
+        PoseTransform tr;
+        const bool got = interpolate(pkt_t[i], &tr);
+        if (i == 0) {
+            car = tr;  // HDLParser.cxx:993-1001
+            if (carpose_out) *carpose_out = car;
+        }
+        tr.timestamp = pkt_t[i];
+        double* M = T3x4 + 12 * i;
+        if (got && tr.seconds_pos != -1) {  // HDLParser.cxx:1004
+            for (int a = 0; a < 3; ++a) tr.T[a] -= car.T[a];  // :1057-1062
+            const Affine3x4 A = tr.getMatrix();
+            std::memcpy(M, A.data(), sizeof(double) * 12);
+            if (valid) valid[i] = 1;
+        } else {
+            static const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            std::memcpy(M, I, sizeof I);
+            if (valid) valid[i] = 0;
+        }
+    }
+    return n_pkt > 0;
+}
+
+}  // namespace veloslam
+
+extern "C" {
 
 int velo_interp_pose(const velo_pose* sorted, size_t n, int64_t t_us, velo_pose* out)
 {
     if (!out || (n && !sorted)) return VELO_E_INVALID;
-    veloslam::TransformManager tm;
-    fill(tm, sorted, n);
+    const veloslam::SortedPoseView view(sorted, n);
     PoseTransform p;  // fresh: seconds_pos = -1 unless a two-sample bracket sets it to 0
-    if (!tm.interpolateTransform(t_us, &p)) return VELO_E_NODATA;
+    if (!view.interpolate(t_us, &p)) return VELO_E_NODATA;
     *out = p.toC();
     return VELO_OK;
 }
@@ -453,10 +561,9 @@ int velo_packet_transforms(const velo_pose* sorted, size_t n, const int64_t* pkt
                            double* T3x4, uint8_t* valid, velo_pose* carpose)
 {
     if (!pkt_t_us || !T3x4 || (n && !sorted)) return VELO_E_INVALID;
-    veloslam::TransformManager tm;
-    fill(tm, sorted, n);
+    const veloslam::SortedPoseView view(sorted, n);
     PoseTransform car;
-    tm.packetTransforms(pkt_t_us, n_pkt, T3x4, valid, &car);
+    view.packetTransforms(pkt_t_us, n_pkt, T3x4, valid, &car);
     if (carpose) *carpose = car.toC();
     return VELO_OK;
 }

@@ -81,6 +81,21 @@ __device__ __forceinline__ bool row_range(const MapView& mv, size_t row, int x0,
     return any;
 }
 
+// the same with the row given as a 32-bit fine key (keys are < 2^32 by construction; modular
+// arithmetic on the caller's side): one 64-bit address computation per lookup instead of the
+// 64-bit multiplies a size_t row costs
+template <bool HASH>
+__device__ __forceinline__ bool row_range32(const MapView& mv, uint32_t row, int x0, int x1, int& jlo,
+                                            int& jhi)
+{
+    if (!HASH) {
+        jlo = mv.cell_start[row + (uint32_t)x0];
+        jhi = mv.cell_start[row + (uint32_t)x1 + 1u];
+        return jhi > jlo;
+    }
+    return row_range<true>(mv, (size_t)row, x0, x1, jlo, jhi);
+}
+
 // run-time form for the kernels outside the iteration loop
 __device__ __forceinline__ bool row_range_rt(const MapView& mv, size_t row, int x0, int x1, int& jlo,
                                              int& jhi)

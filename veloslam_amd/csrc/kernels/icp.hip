@@ -342,6 +342,12 @@ constexpr int kLatItems = 2048;  // launches below this many workgroups use the 
 #define VELO_CERT_SLACK 0.015f  // measured: 0.005-0.02 within 1%, 0.05 +3%, 0.10 +5% (batch); dense single frame 0.68 vs 0.73 ms
 #endif
 constexpr float kCertSlack = VELO_CERT_SLACK;  // metres searched beyond the hinted point (tuning only)
+#ifndef VELO_UBM
+#define VELO_UBM 0
+#endif
+#ifndef VELO_REXFORM
+#define VELO_REXFORM 1  // 0: keep p' live across the search (spills 20 B at 72 registers: converged launch 68 -> 78 us)
+#endif
 #ifndef VELO_WALK_W
 #define VELO_WALK_W 4
 #endif
@@ -438,6 +444,14 @@ __device__ __forceinline__ int finish_block(float bd, float sd, float gr, float&
     return final ? kFinal : kStraggler;
 }
 
+// Round 3: the row loop below used to cost ~60 VALU instructions per row, a third of them
+// quarter-rate 64-bit multiplies of the row address ((zz * fy + yy) * fx per row) -- with nine rows
+// unpruned that was the largest single item of an unhinted launch.  Now: one 32-bit row index per
+// query (fine keys are < 2^32 by construction, so modular uint32 arithmetic is exact, also for a
+// query one cell outside the grid), +-fx / +-fx*fy per row from scalar registers, squared face
+// distances per axis computed once, and the pruning thresholds folded into one compare per test
+// (`x > ub0 * 1.00002f` prunes a subset of what `x * 0.99999f > ub0` pruned: still conservative,
+// the results -- not the pruning decisions -- are what is exact).
 template <int ABL, bool STATS, int W, bool HASH>
 __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& g, float qx,
                                             float qy, float qz, float ub0, SearchLds& L,
@@ -451,43 +465,58 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
     if (!g.near) return kFinal;  // no voxel of the 27 exists: no candidates at all
     const float hf = mv.h / (float)mv.S;
     const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
-    // conservative distances from the query to the faces of its own fine cell
+    // conservative distances from the query to the faces of its own fine cell, squared;
+    // index 0 / 1 / 2 = offset -1 / 0 / +1 along the axis
     const float lox = fmaxf(g.tx * hf - mg, 0.0f), hix = fmaxf((1.0f - g.tx) * hf - mg, 0.0f);
     const float loy = fmaxf(g.ty * hf - mg, 0.0f), hiy = fmaxf((1.0f - g.ty) * hf - mg, 0.0f);
     const float loz = fmaxf(g.tz * hf - mg, 0.0f), hiz = fmaxf((1.0f - g.tz) * hf - mg, 0.0f);
     const float lox2 = lox * lox, hix2 = hix * hix;
+    const float by2[3] = {loy * loy, 0.0f, hiy * hiy};
+    const float bz2[3] = {loz * loz, 0.0f, hiz * hiz};
+    // guaranteed radius of the 3x3x3 block: one fine cell plus the distance to the nearer
+    // face of the query's own fine cell, per axis; shrunk for rounding.  Whatever was pruned
+    // inside the block is further than sqrt(ub0) >= sqrt(bd).  (Computed before the row loop: the
+    // fractional coordinates need not stay live across it.)
+    const float tmin = fminf(fminf(fminf(g.tx, 1.0f - g.tx), fminf(g.ty, 1.0f - g.ty)),
+                             fminf(g.tz, 1.0f - g.tz));
+    const float gr = fmaxf(hf * (1.0f + tmin) - mg, 0.0f);
+    gr_out = gr;
+#if VELO_UBM
+    const float ubm = ub0 * 1.00002f;  // x > ubm  =>  x * 0.99999f > ub0 (the bound, with its margin)
+#define VELO_PRUNED(x) ((x) > ubm)
+#else
+#define VELO_PRUNED(x) ((x) * 0.99999f > ub0)
+#endif
     const int xb = max(g.Fx - 1, 0);  // first table entry fetched for a row
+    // 32-bit row arithmetic (mod 2^32): key of cell (Fx = 0, Fy + dy, Fz + dz)
+    const uint32_t sy = (uint32_t)mv.fx, sz = (uint32_t)mv.fx * (uint32_t)mv.fy;
+    const uint32_t rowc = ((uint32_t)g.Fz * (uint32_t)mv.fy + (uint32_t)g.Fy) * (uint32_t)mv.fx;
     int nr = 0;
     if (g.Fx + 1 >= 0 && g.Fx - 1 < mv.fx && ABL < 3) {
 #pragma unroll
         for (int dz = 1; dz >= -1; --dz) {
-            const int zz = g.Fz + dz;
-            const float bz = dz == 0 ? 0.0f : (dz > 0 ? hiz : loz);
+            const bool zok = (unsigned)(g.Fz + dz) < (unsigned)mv.fz;
 #pragma unroll
             for (int dy = 1; dy >= -1; --dy) {
-                const int yy = g.Fy + dy;
-                const float by = dy == 0 ? 0.0f : (dy > 0 ? hiy : loy);
-                const float rb2 = bz * bz + by * by;
-                if (zz < 0 || zz >= mv.fz || yy < 0 || yy >= mv.fy || rb2 * 0.99999f > ub0)
-                    continue;
+                const float rb2 = bz2[dz + 1] + by2[dy + 1];
+                if (!zok || (unsigned)(g.Fy + dy) >= (unsigned)mv.fy || VELO_PRUNED(rb2)) continue;
                 // cells of this row inside the ball: own cell always, neighbours by their bound
-                int x0 = g.Fx, x1 = g.Fx;
-                if (!((lox2 + rb2) * 0.99999f > ub0)) x0 = g.Fx - 1;
-                if (!((hix2 + rb2) * 0.99999f > ub0)) x1 = g.Fx + 1;
+                int x0 = g.Fx - (VELO_PRUNED(lox2 + rb2) ? 0 : 1);
+                int x1 = g.Fx + (VELO_PRUNED(hix2 + rb2) ? 0 : 1);
                 x0 = max(x0, 0);
                 x1 = min(x1, mv.fx - 1);
                 if (x0 > x1) continue;
-                const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
+                const uint32_t row = rowc + (uint32_t)dz * sz + (uint32_t)dy * sy;
                 int jlo, jhi;
                 if constexpr (HASH) {
                     tl.table((unsigned)(x1 - x0 + 1), 16);
-                    row_range<true>(mv, row, x0, x1, jlo, jhi);
+                    row_range<true>(mv, (size_t)row, x0, x1, jlo, jhi);
                 } else {
-                    const Int4U e = *reinterpret_cast<const Int4U*>(mv.cell_start + row + xb);
+                    const Int4U e = *reinterpret_cast<const Int4U*>(mv.cell_start + (row + (uint32_t)xb));
                     tl.table(1, 16);
-                    const int a = x0 - xb, b = x1 + 1 - xb;  // both in [0,3]
-                    jlo = a == 0 ? e.v[0] : (a == 1 ? e.v[1] : (a == 2 ? e.v[2] : e.v[3]));
-                    jhi = b == 1 ? e.v[1] : (b == 2 ? e.v[2] : (b == 3 ? e.v[3] : e.v[0]));
+                    const int a = x0 - xb, b = x1 + 1 - xb;  // a in {0,1}, b in {1,2,3}
+                    jlo = a == 0 ? e.v[0] : e.v[1];
+                    jhi = b == 3 ? e.v[3] : (b == 2 ? e.v[2] : e.v[1]);
                 }
                 if (jhi > jlo) {
                     L.hi[nr][tid] = jhi;
@@ -497,14 +526,8 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
             }
         }
     }
+#undef VELO_PRUNED
     if (ABL >= 2) nr = min(nr, 0);
-    // guaranteed radius of the 3x3x3 block: one fine cell plus the distance to the nearer
-    // face of the query's own fine cell, per axis; shrunk for rounding.  Whatever was pruned
-    // inside the block is further than sqrt(ub0) >= sqrt(bd).
-    const float tmin = fminf(fminf(fminf(g.tx, 1.0f - g.tx), fminf(g.ty, 1.0f - g.ty)),
-                             fminf(g.tz, 1.0f - g.tz));
-    const float gr = fmaxf(hf * (1.0f + tmin) - mg, 0.0f);
-    gr_out = gr;
     float sd = ub0;  // everything not scanned inside the block is further than sqrt(ub0)
     walk_ranges<W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd, tl);
     if (ABL >= 1) return kFinal;
@@ -531,6 +554,18 @@ __device__ __forceinline__ float ball_certificate(float sd, float cov, float h, 
     return fmaxf(fminf(sqrtf(fminf(sd, cov)) * 0.999999f, h - 2.0f * mg) - 1e-6f, 0.0f);
 }
 
+// lower bound (rounded down) of the distance from the query to fine row offset d along one axis
+__device__ __forceinline__ float axis_gap(int d, float t, float hf, float mg)
+{
+    return d == 0 ? 0.0f : fmaxf(((float)(abs(d) - 1) + (d > 0 ? 1.0f - t : t)) * hf - mg, 0.0f);
+}
+
+// rows of the (2R+1)^2 window a ball of squared radius b can reach (R <= S since b <= h^2)
+__device__ __forceinline__ int ball_window(float b, float inv_hf, int S)
+{
+    return min(S, (int)floorf(sqrtf(b) * 1.00001f * inv_hf + 1.001f));
+}
+
 template <bool STATS, bool HASH>
 __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, float ub,
                             SearchLds& L, int tid, float& bd, int& bj, float& cert, Tally<STATS>& tl)
@@ -549,28 +584,30 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
     float sd = cov;
     bd = cov;
     bj = -1;
-    int dz = S, dy = S;
-    const int nrows = (2 * S + 1) * (2 * S + 1);
+    // Only the (2R+1)^2 rows the ball can reach (R <= S; a straggler with a candidate half a metre
+    // away needs 25 rows at S = 3, not 49), in descending order; the row key is carried along in
+    // 32-bit arithmetic (see search_block) instead of being multiplied out per row.
+    const int R = ball_window(cov, inv_hf, S);
+    const uint32_t sy = (uint32_t)mv.fx, sz = (uint32_t)mv.fx * (uint32_t)mv.fy;
+    uint32_t rowz = ((uint32_t)(g.Fz + R) * (uint32_t)mv.fy + (uint32_t)g.Fy) * (uint32_t)mv.fx;
+    int dz = R, dy = R;
+    const int nrows = (2 * R + 1) * (2 * R + 1);
 #pragma unroll 1
     for (int r0 = 0; r0 < nrows; r0 += kMaxRanges) {
         int nr = 0;
 #pragma unroll
         for (int t = 0; t < kMaxRanges; ++t) {
             if (r0 + t < nrows) {
-                const int zz = g.Fz + dz, yy = g.Fy + dy;
-                const float bz = dz == 0 ? 0.0f
-                                         : fmaxf(((float)(abs(dz) - 1) + (dz > 0 ? 1.0f - g.tz : g.tz)) * hf - mg, 0.0f);
-                const float by = dy == 0 ? 0.0f
-                                         : fmaxf(((float)(abs(dy) - 1) + (dy > 0 ? 1.0f - g.ty : g.ty)) * hf - mg, 0.0f);
+                const float bz = axis_gap(dz, g.tz, hf, mg), by = axis_gap(dy, g.ty, hf, mg);
                 const float rb2 = (bz * bz + by * by) * 0.99999f;
-                if (zz >= 0 && zz < mv.fz && yy >= 0 && yy < mv.fy && !(rb2 > cov)) {
+                if ((unsigned)(g.Fz + dz) < (unsigned)mv.fz && (unsigned)(g.Fy + dy) < (unsigned)mv.fy &&
+                    !(rb2 > cov)) {
                     // half-width of the ball in this row, in fine cells, rounded outwards
                     const float w = (sqrtf(fmaxf(cov - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
                     const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
                     if (x0 <= x1) {
-                        const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
                         int jlo, jhi;
-                        row_range<HASH>(mv, row, x0, x1, jlo, jhi);
+                        row_range32<HASH>(mv, rowz + (uint32_t)dy * sy, x0, x1, jlo, jhi);
                         tl.table(2, 4);
                         if (jhi > jlo) {
                             L.hi[nr][tid] = jhi;
@@ -579,9 +616,10 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
                         }
                     }
                 }
-                if (--dy < -S) {
-                    dy = S;
+                if (--dy < -R) {
+                    dy = R;
                     --dz;
+                    rowz -= sz;
                 }
             }
         }
@@ -625,9 +663,9 @@ __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, fl
         const float w = (sqrtf(fmaxf(ub - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
         const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
         if (x0 > x1) continue;
-        const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
+        const uint32_t row = ((uint32_t)zz * (uint32_t)mv.fy + (uint32_t)yy) * (uint32_t)mv.fx;
         int jlo, jhi;
-        row_range<HASH>(mv, row, x0, x1, jlo, jhi);
+        row_range32<HASH>(mv, row, x0, x1, jlo, jhi);
         tl.table(2, 4);
         tl.candidates((unsigned)max(jhi - jlo, 0));
 #pragma unroll 4
@@ -662,12 +700,6 @@ __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, fl
 
 // ---- stage B for the LATENCY kernel (k_linearize_lat: a single frame, a few hundred
 // workgroups -- nothing hides a memory round trip, and registers are plentiful) -------------
-// lower bound (rounded down) of the distance from the query to fine row offset d along one axis
-__device__ __forceinline__ float axis_gap(int d, float t, float hf, float mg)
-{
-    return d == 0 ? 0.0f : fmaxf(((float)(abs(d) - 1) + (d > 0 ? 1.0f - t : t)) * hf - mg, 0.0f);
-}
-
 // index range of fine row (Fz+dz, Fy+dy) inside the ball of squared radius `bound` around the
 // query (conservative: rounded outwards); clip1: only the cells Fx-1..Fx+1.  false = nothing.
 template <bool STATS, bool HASH>
@@ -688,15 +720,9 @@ __device__ __forceinline__ bool ball_row(const MapView& mv, const QueryCell& g, 
         x1 = min(x1, g.Fx + 1);
     }
     if (x0 > x1) return false;
-    const size_t row = ((size_t)zz * mv.fy + yy) * mv.fx;
+    const uint32_t row = ((uint32_t)zz * (uint32_t)mv.fy + (uint32_t)yy) * (uint32_t)mv.fx;
     tl.table(2, 4);
-    return row_range<HASH>(mv, row, x0, x1, jlo, jhi);
-}
-
-// rows of the (2R+1)^2 window a ball of squared radius b can reach (R <= S since b <= h^2)
-__device__ __forceinline__ int ball_window(float b, float inv_hf, int S)
-{
-    return min(S, (int)floorf(sqrtf(b) * 1.00001f * inv_hf + 1.001f));
+    return row_range32<HASH>(mv, row, x0, x1, jlo, jhi);
 }
 
 // per-lane form.  Called by every lane of the wavefront (`active` = this lane is a straggler):
@@ -1063,6 +1089,14 @@ __device__ __forceinline__ void linearize_body(
                 tl.add(32);
                 const float4 nf = mv.nrm[(unsigned)bj];
                 const float4 mf = mv.pts[(unsigned)bj];  // issued with the normal: one round trip, not two
+#if VELO_REXFORM
+                // the unrounded transformed point is needed again only here: recomputing it (9 fp64
+                // FMAs, same expression, same bits) keeps six registers free across the whole search
+                if (VARIANT >= 1) {
+                    asm volatile("" : "+v"(sxq), "+v"(syq), "+v"(szq));
+                    xform(T, sxq, syq, szq, px, py, pz);
+                }
+#endif
                 if (!(nf.x == 0.0f && nf.y == 0.0f && nf.z == 0.0f)) {
                     const double nx = nf.x, ny = nf.y, nz = nf.z;
                     const double dx = px - (double)mf.x, dy = py - (double)mf.y,
