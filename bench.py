@@ -93,6 +93,11 @@ def parse():
                     help="batch = BASELINE configs[1] (the headline line); stream = configs[2]: "
                          "packets -> decode -> register -> increment -> rolling-map update, "
                          "frame after frame")
+    ap.add_argument("--drive", default="", help="stream workload: replay this recorded drive (veloslam_amd/drive.py layout: "
+                    "drive.pcap, carposes.txt, db.xml, world.map) instead of the synthetic generator")
+    ap.add_argument("--export-drive", default="", help="write the synthetic drive of the stream workload to this directory "
+                    "(--stream-frames frames, --stream-map-points world points, --tile metres per tile) and exit")
+    ap.add_argument("--tile", type=float, default=10.0, help="--export-drive: tile edge of world.map (m)")
     ap.add_argument("--stream-frames", type=int, default=64, help="distinct synthetic frames (played forwards and backwards)")
     ap.add_argument("--stream-steps", type=int, default=100, help="stream sub-record: timed frames")
     ap.add_argument("--stream-map-points", type=int, default=12_000_000,
@@ -399,6 +404,155 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct, src=No
             "map_updates": counts["updates"], "map_updates_incremental": counts["incremental"],
             "normals_recomputed_per_update": counts["recomputed"] / max(counts["updates"], 1),
             "worst_pose_error_m": counts["worst"]}
+
+
+def run_replay(args, dev, local, steps, warmup):
+    """`--workload stream --drive DIR`: a recorded drive (veloslam_amd/drive.py layout: pcap +
+    carposes.txt + db.xml + world.map) replayed against a rolling map, the same loop
+    tools/stream_driver.cpp runs from C++ through veloslam::MapManager -- here through the C ABI:
+    per frame velo_decode of the packets the frame index names (readFrameInformation's position /
+    skip per frame) -> velo_decode_to_frames -> roll the device map to the tiles in range of the prior
+    (velo_map_evict_outside of the tile rectangle + velo_map_append of the entering tiles, host
+    tiles as MapManager holds them) -> 20 ICP iterations -> accepted increment to the device-side
+    pending list (merged once --append-threshold points are pending)."""
+    from veloslam_amd import drive
+    d = drive.load(args.drive)
+    meta = d["meta"]
+    pr, tiles = drive.read_map_file(os.path.join(args.drive, "world.map"))
+    tile_of = {}
+    for cx, cy, tx, ty, tz in tiles:
+        tile_of[(int(round(cx / pr)), int(round(cy / pr)))] = [tx, ty, tz]
+    ctx = capi.Context(local, max_batch=4, map_margin=args.map_margin, use_hints=0 if args.no_hints else args.hints,
+                       use_graph=0 if args.no_graph else 1, map_subdiv=args.stream_subdiv)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.map_set_margins(args.map_margin, args.map_margin, args.map_margin_z)
+    R = float(args.roi_range)
+    idx, times, pk = d["index"], d["times"], d["packets"]
+    nfr = len(idx)
+    truth = meta.get("true_positions")
+    period = max(2 * nfr - 2, 1)
+    state = dict(res=None, z=float(meta.get("z0", 0.0)), worst=0.0, pairs=0, rolls=0, full=0, up=0, ev=0, flush=0)
+    stage = dict(decode=0.0, roll=0.0, icp=0.0, increment=0.0)
+    big = 3.0e38
+
+    def tile_range(x, y):
+        f = lambda v: int(np.floor((v + pr / 2) / pr))  # noqa: E731  (MapManager::getPatchIdx)
+        return f(x - R), f(x + R), f(y - R), f(y + R)
+
+    def gather(rng, skip=None):
+        i0, i1, j0, j1 = rng
+        xs, ys, zs = [], [], []
+        for j in range(j0, j1 + 1):
+            for i in range(i0, i1 + 1):
+                if skip and skip[0] <= i <= skip[1] and skip[2] <= j <= skip[3]:
+                    continue
+                t = tile_of.get((i, j))
+                if t is not None and t[0].size:
+                    xs.append(t[0]); ys.append(t[1]); zs.append(t[2])
+        if not xs:
+            return (np.empty(0, np.float32),) * 3
+        return np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)
+
+    def flush():
+        n = ctx.pending_count(True)
+        if not n:
+            return
+        x, y, z = ctx.pending_fetch()
+        ctx.map_append_pending()
+        ti, tj = drive.tile_index(x, y, pr)
+        for k in range(n):   # (a few hundred points per flush)
+            t = tile_of.setdefault((int(ti[k]), int(tj[k])), [np.empty(0, np.float32)] * 3)
+            t[0], t[1], t[2] = np.append(t[0], x[k]), np.append(t[1], y[k]), np.append(t[2], z[k])
+        state["flush"] += 1
+
+    def roll_to(x, y, timed):
+        rng = tile_range(x, y)
+        cur = state["res"]
+        if cur == rng:
+            return
+        if cur is not None and rng[0] <= cur[1] and rng[1] >= cur[0] and rng[2] <= cur[3] and rng[3] >= cur[2]:
+            flush()
+            n0 = ctx.map_info().n_points
+            lo = np.array([rng[0] * pr - pr / 2, rng[2] * pr - pr / 2, -big], np.float32)
+            hi = np.array([np.nextafter(np.float32(rng[1] * pr + pr / 2), np.float32(-big)),
+                           np.nextafter(np.float32(rng[3] * pr + pr / 2), np.float32(-big)), big], np.float32)
+            if rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]:
+                ctx.map_evict_outside(lo, hi)
+            ex, ey, ez = gather(rng, skip=cur)
+            if ex.size:
+                ctx.map_append(ex, ey, ez)
+            if timed:
+                state["rolls"] += 1
+                state["up"] += int(ex.size)
+                state["ev"] += int(n0 - (ctx.map_info().n_points - ex.size))
+        else:
+            ex, ey, ez = gather(rng)
+            ctx.map_reset(ex, ey, ez, args.voxel, args.k_normals)
+            if timed:
+                state["full"] += 1
+        state["res"] = rng
+
+    def one(f, timed):
+        e = idx[f]
+        last = f + 1 >= nfr
+        p0 = int(e.first_packet)
+        p1 = len(times) if last else int(idx[f + 1].first_packet) + 1
+        t = [time.perf_counter()]
+        ctx.decode_set_options(initial_firing_skip=int(e.firing_skip))
+        nf, _ = ctx.decode_resident(pk[p0 * 1206:p1 * 1206], times[p0:p1], d["calib"], d["poses"], d["n_poses"],
+                                    flush=last)
+        assert nf >= 1
+        ctx.decode_to_frames()
+        t.append(time.perf_counter())
+        ok, car = capi.interp_pose(d["poses"], d["n_poses"], int(times[p0]))
+        Tt = np.array([1, 0, 0, car.T[0], 0, 1, 0, car.T[1], 0, 0, 1, state["z"]], np.float64)
+        T0 = synth.perturbed_guess(Tt, dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))
+        roll_to(float(T0[3]), float(T0[7]), timed)
+        t.append(time.perf_counter())
+        res = ctx.icp_batch(np.tile(T0, (ctx.n_frames, 1)), args.iters, args.d_max)[0]
+        t.append(time.perf_counter())
+        ctx.increment_pending(0, None, 3)
+        if ctx.pending_count(False) >= max(args.append_threshold, 1):
+            flush()
+        t.append(time.perf_counter())
+        state["z"] = float(res.T[11])
+        if timed:
+            for name, a, b in zip(stage, t[:-1], t[1:]):
+                stage[name] += b - a
+            state["pairs"] += int(res.total_pairs)
+            if truth:
+                err = float(np.linalg.norm(np.array([res.T[3], res.T[7], res.T[11]]) - np.array(truth[f])))
+                state["worst"] = max(state["worst"], err)
+
+    frame_at = lambda k: (k % period) if (k % period) < nfr else period - (k % period)  # noqa: E731
+    for k in range(warmup):
+        one(frame_at(k), False)
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one(frame_at(warmup + k), True)
+    flush()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    mi = ctx.map_info()
+    ctx.close()
+    if state["worst"] > 0.05:
+        raise SystemExit("bench replay: registration diverged (%.3f m)" % state["worst"])
+    return {"frames_per_s": steps / elapsed, "ms_per_frame": 1e3 * elapsed / steps, "frames": steps,
+            "host": "Python (C ABI through ctypes)",
+            "workload": "recorded drive %s: %d frames (pcap + carposes.txt + db.xml), world.map of %d tiles of %.0f m; "
+                        "per frame decode of the indexed packets + roll to the tiles within ROI_RANGE of the prior + "
+                        "%d ICP iters + increment (merged once %d points are pending)"
+                        % (os.path.basename(os.path.normpath(args.drive)), nfr, len(tiles), pr, args.iters,
+                           args.append_threshold),
+            "map_points_mean": int(mi.n_points), "map_subdiv": int(mi.subdiv), "map_update": "incremental",
+            "pairs_per_s": state["pairs"] / elapsed, "stage_ms_per_frame": {k: 1e3 * v / steps for k, v in stage.items()},
+            "map": dict(full_builds=state["full"], rolls=state["rolls"], points_uploaded=state["up"],
+                        points_evicted=state["ev"], increment_flushes=state["flush"]),
+            "last_update": int(mi.last_update), "worst_pose_error_m": state["worst"]}
 
 
 # ------------------------------------------------------------------------- inputs
@@ -741,10 +895,20 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.export_drive:
+        from veloslam_amd import drive
+        sc = synth.Scene()
+        wx, wy, wz = sc.sample_map_device(args.stream_map_points, dev)
+        meta = drive.export_synthetic(args.export_drive, n_frames=args.stream_frames, patch_range=args.tile,
+                                      world_xyz=(wx.cpu().numpy(), wy.cpu().numpy(), wz.cpu().numpy()),
+                                      voxel=args.voxel, k_normals=args.k_normals)
+        emit({"exported": args.export_drive, "frames": meta["n_frames"], "world_points": meta["world_points"],
+              "tiles": meta["tiles"]})
+        return
     if args.workload == "stream":
         if world > 1:
             raise SystemExit("the stream workload is one sequence on one GPU (run N replicas for N GPUs)")
-        rec = run_stream(args, dev, local, args.steps, args.warmup, args.stream_map_points, args.stream_frames)
+        rec = run_replay(args, dev, local, args.steps, args.warmup) if args.drive else run_stream(args, dev, local, args.steps, args.warmup, args.stream_map_points, args.stream_frames)
         out = {"metric": "rolling-map registered frames/s", "value": rec["frames_per_s"],
                "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": rec["ms_per_frame"], "higher_is_better": True, "scaling": "weak",

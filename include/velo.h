@@ -350,6 +350,23 @@ int velo_increment_registered_async(velo_ctx*, int frame, int min_count, float* 
 int velo_increment_all_registered_async(velo_ctx*, int min_count, float* dox, float* doy, float* doz);
 int velo_increment_wait(velo_ctx*, size_t* n_out);
 
+/* Pending increments: the accepted points of registered frames, collected in a device-side list
+ * inside the ctx until they are worth a map update -- what MapManager::registerFrame's integrate
+ * step and a streaming host use.  Nothing is fetched and nothing blocks per frame:
+ *   velo_increment_pending    the increment of resident frame `frame` (pose T, or NULL = the pose
+ *                             the last registration left on the device) is appended to the list;
+ *                             returns as soon as the work is enqueued;
+ *   velo_pending_count        points in the list; wait != 0 waits for the increment in flight and
+ *                             counts it, wait = 0 never blocks and never counts it (deterministic:
+ *                             the answer does not depend on how far the GPU has got);
+ *   velo_pending_fetch        host copy of the list (for a host-side tile store); VELO_E_RANGE with
+ *                             *n_out = the size needed beyond cap;
+ *   velo_map_append_pending   merges the list into the map (velo_map_append_dev) and empties it. */
+int velo_increment_pending(velo_ctx*, int frame, const double* T, int min_count);
+int velo_pending_count(velo_ctx*, size_t* n, int wait);
+int velo_pending_fetch(velo_ctx*, float* x, float* y, float* z, size_t cap, size_t* n_out);
+int velo_map_append_pending(velo_ctx*, size_t* n_appended);
+
 /* Valid correspondence pairs processed by every registration iteration of this ctx since the
  * last reset, counted on the device (exact; lets a caller that never fetches per-batch results
  * -- the bench loop -- report pairs/s).  Synchronises the ctx stream. */
@@ -479,6 +496,13 @@ int velo_ins_to_pose(const velo_inspva* ins, const double orig_xyz[3], int64_t t
 /* pose-store persistence: the record layout of type_defs.cxx:4-33 (ptime -> int64 us) */
 int velo_insmeta_write(const char* path, const velo_pose* poses, size_t n);
 int velo_insmeta_read(const char* path, velo_pose* poses, size_t cap, size_t* n_out);
+/* carposes.txt of an offline drive -- TransformManager::loadFromTxtFile (TransformManager.cxx:95-125),
+ * consumed by HDLManager::loadOffline (HDLManager.cxx:103-117): rows "x y yaw roll pitch v sec usec",
+ * angles in radians (converted to degrees, yaw sign flipped), no z and no velocity vector (both 0),
+ * time = sec * 1e6 + usec + 8 h (the reference's timevalToPtime, type_defs.cxx:69-72, adds the 8 h to
+ * pose AND packet stamps; a replay adds them to the packet stamps of velo_pcap_read, which does not).
+ * Poses come back sorted by time; poses may be NULL to count; VELO_E_RANGE beyond cap. */
+int velo_carposes_read(const char* path, velo_pose* poses, size_t cap, size_t* n_out);
 /* Velodyne calibration file (db.xml) -> the 64 laser corrections velo_decode takes.  Replaces
  * HDLParser::vsInternal::loadCorrectionsFile (HDLParser.cxx:771-858): same element names, same
  * units (centimetres in the file, metres afterwards) and derived sin/cos fields; n_enabled

@@ -25,7 +25,19 @@ struct RegisterOptions {
     float voxel = 1.0f;
     int k_normals = 16;
     int increment_min_count = 3;  // cells with fewer points accept new points
-    bool integrate = false;       // append the accepted increment to the map afterwards
+    bool integrate = false;       // collect the accepted increment (device-side pending list) and
+                                  // merge it into the map once append_threshold points are pending
+    int append_threshold = 512;   // (1 = after every frame)
+};
+
+// what the device map has been through (rolling-map bookkeeping; diagnostic)
+struct MapStats {
+    uint64_t full_builds = 0;        // velo_map_reset: first ROI, or voxel / k changed, or nothing could be kept
+    uint64_t rolls = 0;              // ROI changes applied incrementally (evict + append entering tiles)
+    uint64_t tiles_entered = 0, tiles_left = 0;
+    uint64_t points_uploaded = 0;    // host tile points sent to the device by rolls
+    uint64_t points_evicted = 0;
+    uint64_t increment_flushes = 0, increment_points = 0;
 };
 
 class MapManager {
@@ -36,6 +48,10 @@ public:
     std::shared_ptr<MapPatch> getPatch(double x, double y);   // creates if missing
     std::shared_ptr<MapPatch> findPatch(double x, double y);  // null if missing
     std::set<std::shared_ptr<MapPatch>> getROI(double x, double y);  // 4-corner lookup
+    // Every tile that overlaps the square of +-ROI_RANGE around (x, y), in (row, column) order: the
+    // same region getROI's four corners name when patchRange >= 2 * ROI_RANGE, and the rule that
+    // keeps covering "the current detecting range" (MapManager.h:22-25) when tiles are smaller.
+    std::vector<std::shared_ptr<MapPatch>> tilesInRange(double x, double y);
     // insert map-frame points into their tiles
     void addPoints(const float* x, const float* y, const float* z, size_t n);
     // Motion-compensated frame (frame-start origin, ENU axes) -> pose in the map.
@@ -43,6 +59,19 @@ public:
     // on error; lastError() says why.  result (optional) gets per-iteration stats.
     bool registerFrame(const HDLFrame& frame, const PoseTransform& init, const RegisterOptions& opts,
                        PoseTransform* out, velo_icp_result* result = nullptr);
+    // The same for the frame a velo_decode* + velo_decode_to_frames on context() left resident in
+    // HBM (frame index `frame` of that decode): packets in, pose out, the points never visit the host.
+    bool registerResident(int frame, int64_t timestamp, const PoseTransform& init, const RegisterOptions& opts,
+                          PoseTransform* out, velo_icp_result* result = nullptr);
+    // Rolling map (BASELINE configs[2]; the reference's eviction policy is a stub, MapManager.h:43):
+    // bring the DEVICE map to the tiles in range of (x, y).  The first call builds it; afterwards a
+    // changed tile set is applied in place -- velo_map_evict_outside for the tiles that left (the
+    // tile range is a box), one velo_map_append of the tiles that entered -- never a re-upload.
+    // registerFrame / registerResident call it with the prior's position.
+    bool rollTo(double x, double y, const RegisterOptions& opts);
+    // merge the pending increments into the device map and into the host tiles now
+    bool flushIncrements();
+    const MapStats& stats() const { return stats_; }
     // f3: drop every tile whose centre is further than `radius` (+ half a tile diagonal) from
     // (x, y) -- the rolling-map policy behind ROI_RANGE; returns the number of points dropped
     size_t evictOutside(double x, double y, double radius);
@@ -59,14 +88,19 @@ public:
 
 private:
     std::pair<int, int> getPatchIdx(double x, double y) const;
-    bool syncDeviceMap(double x, double y, const RegisterOptions& opts);
+    bool registerCore(int frame, int64_t timestamp, const PoseTransform& init, const RegisterOptions& opts,
+                      PoseTransform* out, velo_icp_result* result);
+    void tileRange(double x, double y, int& i0, int& i1, int& j0, int& j1) const;
     float patchRange_;
     std::map<std::pair<int, int>, std::shared_ptr<MapPatch>> patches_;
     velo_ctx* ctx_;
-    bool dirty_;
-    std::set<std::shared_ptr<MapPatch>> resident_;
+    bool dirty_;                   // host tiles changed behind the device map's back: rebuild
+    bool haveDevice_;
+    int res_i0_, res_i1_, res_j0_, res_j1_;  // resident tile index range (inclusive)
     float residentVoxel_;
     int residentK_;
+    MapStats stats_;
+    std::vector<float> stage_x_, stage_y_, stage_z_;
     mutable std::string err_;
 };
 

@@ -52,10 +52,30 @@ static int tiles_mode(const std::string& dir)
     return 0;
 }
 
+// a world.map written elsewhere (veloslam_amd/drive.py) read by MapManager::load: tiles, points,
+// tilesInRange around a query, and the size of the tile a given point falls into
+static int load_mode(const std::string& path, double qx, double qy)
+{
+    using namespace veloslam;
+    MapManager mgr(1.0f, 0);
+    if (!mgr.load(path)) {
+        std::cerr << mgr.lastError() << std::endl;
+        return 7;
+    }
+    size_t in_range = 0;
+    const auto tiles = mgr.tilesInRange(qx, qy);
+    for (const auto& t : tiles) in_range += t->size();
+    auto p = mgr.findPatch(qx, qy);
+    std::printf("loaded %zu %zu\ninrange %zu %zu\ntile %d %.17g %.17g\n", mgr.numPatches(), mgr.numPoints(),
+                tiles.size(), in_range, p ? (int)p->size() : -1, p ? p->centerX : 0.0, p ? p->centerY : 0.0);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
     if (std::string(argv[1]) == "--tiles") return argc < 3 ? 2 : tiles_mode(argv[2]);
+    if (std::string(argv[1]) == "--load") return argc < 5 ? 2 : load_mode(argv[2], std::atof(argv[3]), std::atof(argv[4]));
     const std::string dir = argv[1];
     using namespace veloslam;
     // pose store: rows of 10 doubles (T, Rdeg, V, t_us)
@@ -129,6 +149,7 @@ int main(int argc, char** argv)
     mi0.struct_size = mi1.struct_size = mi2.struct_size = sizeof(velo_map_info);
     velo_map_info_get(mgr.context(), &mi0);
     opt.integrate = true;
+    opt.append_threshold = 1;  // merge after every frame (the default collects 512 points first)
     PoseTransform out2, out3;
     if (!mgr.registerFrame(frame, prior, opt, &out2)) return 6;
     velo_map_info_get(mgr.context(), &mi1);

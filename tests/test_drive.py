@@ -1,0 +1,137 @@
+"""A recorded drive on disk (veloslam_amd/drive.py): the reference's file formats either side of
+the path -- pcap + frame index, carposes.txt, db.xml, MapManager's tile file -- written by the
+exporter, read back through the C ABI / the C++ classes; and (GPU) the replay of such a drive
+against a rolling device map from C++ (tools/stream_driver.cpp -> veloslam::MapManager) and from
+Python (bench.py --workload stream --drive), which must agree."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from veloslam_amd import capi, drive, synth
+from tests.test_cpp_api import build_exe
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tools", "stream_driver")
+
+
+def build_driver():
+    src = os.path.join(ROOT, "tools", "stream_driver.cpp")
+    csrc = os.path.join(ROOT, "veloslam_amd", "csrc")
+    import glob
+    deps = [src, os.path.join(csrc, "libveloslam_amd.so")] + glob.glob(os.path.join(ROOT, "include", "*.h")) + \
+        glob.glob(os.path.join(ROOT, "include", "veloslam", "*.hpp"))
+    if (not os.path.exists(DRIVER)) or os.path.getmtime(DRIVER) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["hipcc", "-std=c++17", "-O2", "-x", "c++", src, "-I", os.path.join(ROOT, "include"),
+                               "-L", csrc, "-lveloslam_amd", "-Wl,-rpath," + csrc, "-o", DRIVER])
+    return DRIVER
+
+
+def test_map_file_written_by_python_is_what_mapmanager_loads(tmp_path):
+    """world.map: veloslam::MapManager::load reads the exporter's file -- same tile count, same
+    points, the same tile for a given position (getPatchIdx on both sides), tilesInRange = the
+    tiles overlapping the +-ROI_RANGE square."""
+    rng = np.random.default_rng(4)
+    n = 30_000
+    x = rng.uniform(-260, 240, n).astype(np.float32)
+    y = rng.uniform(-130, 170, n).astype(np.float32)
+    z = rng.normal(0, 1, n).astype(np.float32)
+    x[:4] = [-5.0, 5.0, 4.9999995, -15.0]          # on and next to tile edges (10 m tiles: edges at +-5, +-15 ...)
+    path = str(tmp_path / "world.map")
+    n_tiles = drive.write_map_file(path, x, y, z, 10.0)
+    pr, tiles = drive.read_map_file(path)
+    assert pr == 10.0 and len(tiles) == n_tiles and sum(t[2].size for t in tiles) == n
+    ti, tj = drive.tile_index(x, y, 10.0)
+    for cx, cy, tx, ty, tz in tiles[::37]:
+        i, j = int(round(cx / 10)), int(round(cy / 10))
+        sel = (ti == i) & (tj == j)
+        assert np.array_equal(tx, x[sel]) and np.array_equal(tz, z[sel])     # input order inside a tile
+    exe = build_exe()
+    qx, qy = 12.3, -41.0
+    out = subprocess.run([exe, "--load", path, str(qx), str(qy)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    assert lines["loaded"] == "%d %d" % (n_tiles, n)
+    i0, j0 = drive.tile_index(qx - 100, qy - 100, 10.0)
+    i1, j1 = drive.tile_index(qx + 100, qy + 100, 10.0)
+    inside = (ti >= i0) & (ti <= i1) & (tj >= j0) & (tj <= j1)
+    n_in_tiles = len({(a, b) for a, b in zip(ti[inside], tj[inside])})
+    assert lines["inrange"] == "%d %d" % (n_in_tiles, int(inside.sum()))
+    qi, qj = drive.tile_index(qx, qy, 10.0)
+    cnt, cx, cy = lines["tile"].split()
+    assert int(cnt) == int(((ti == qi) & (tj == qj)).sum()) and float(cx) == qi * 10.0 and float(cy) == qj * 10.0
+
+
+def test_carposes_roundtrip_through_the_reference_format(tmp_path):
+    """carposes.txt (TransformManager.cxx:95-125): x, y and the angles survive (radians in the
+    file, yaw sign flipped, 8 h added to the stamp); z and the velocity vector do not exist in
+    the format."""
+    import ctypes as C
+    mo = synth.Motion()
+    samples = mo.ins_track(mo.t0_us, mo.t0_us + 300_000)
+    samples = [(T, np.array([1.5, -0.7, R[2]]), V, t) for T, R, V, t in samples]
+    path = str(tmp_path / "carposes.txt")
+    drive.write_carposes(path, samples)
+    n = C.c_size_t()
+    L = capi.lib()
+    L.velo_carposes_read.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    assert L.velo_carposes_read(path.encode(), None, 0, C.byref(n)) == 0 and n.value == len(samples)
+    poses = (capi.Pose * n.value)()
+    assert L.velo_carposes_read(path.encode(), poses, n.value, C.byref(n)) == 0
+    for p, (T, R, V, t) in zip(poses, samples):
+        assert p.T[0] == T[0] and p.T[1] == T[1] and p.T[2] == 0.0
+        assert abs(p.R[0] - R[0]) < 1e-12 and abs(p.R[1] - R[1]) < 1e-12 and abs(p.R[2] - R[2]) < 1e-12
+        assert p.t_us == t + drive.EIGHT_H_US and list(p.V) == [0.0, 0.0, 0.0]
+    small = (capi.Pose * 2)()
+    assert L.velo_carposes_read(path.encode(), small, 2, C.byref(n)) == -5
+    assert L.velo_carposes_read(str(tmp_path / "none.txt").encode(), None, 0, C.byref(n)) == -6
+
+
+def test_export_and_load_a_small_drive(tmp_path):
+    rng = np.random.default_rng(1)
+    world = tuple(rng.uniform(-50, 50, 5000).astype(np.float32) for _ in range(3))
+    meta = drive.export_synthetic(str(tmp_path), n_frames=2, patch_range=25.0, world_xyz=world)
+    d = drive.load(str(tmp_path))
+    assert meta["n_frames"] == 2 and len(d["index"]) == 2 and d["packets"].size == 600 * 1206
+    assert [e.first_packet for e in d["index"]] == [0, 300] and d["index"][1].firing_skip == 0
+    assert d["n_poses"] > 10 and d["calib"].shape == (64, 9)
+    # packet stamps and pose stamps share a clock: every packet has a pose bracket
+    assert d["poses"][0].t_us <= d["times"][0] and d["times"][-1] <= d["poses"][d["n_poses"] - 1].t_us
+    cal = synth.hdl64_calibration()
+    assert np.allclose(d["calib"][:, :5], np.asarray(cal)[:, :5], rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_cpp_stream_driver_rolls_the_device_map_and_matches_python(tmp_path):
+    """MapManager::registerResident on the rolling device map.  A drive whose ROI
+    rectangle loses a tile column on the way: the C++ driver (include/veloslam/*.hpp) must apply it
+    incrementally -- no full build after the first, last_update == 1 -- and register every frame
+    where the Python replay (same C ABI calls) does."""
+    sc = synth.Scene()
+    world = sc.sample_map(400_000)
+    # frames 70..77: the car passes x = 45 m, where the tile column [-65, -55) leaves the +-100 m square
+    drive.export_synthetic(str(tmp_path), n_frames=8, patch_range=10.0, first_frame=70, world_xyz=world)
+    exe = build_driver()
+    out = subprocess.run([exe, str(tmp_path), "--steps", "12", "--warmup", "1", "--threshold", "64"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cpp = json.loads(out.stdout.strip().splitlines()[-1])
+    assert cpp["worst_pose_error_m"] < 0.02
+    assert cpp["map"]["full_builds"] == 0 and cpp["map"]["rolls"] >= 1 and cpp["map"]["points_evicted"] > 0
+    assert cpp["last_update"] == 1 and cpp["map"]["increment_flushes"] >= 1
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    py = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stream", "--drive", str(tmp_path),
+                         "--steps", "12", "--warmup", "1", "--append-threshold", "64"],
+                        capture_output=True, text=True, timeout=600, env=env)
+    assert py.returncode == 0, py.stderr[-2000:]
+    rec = json.loads(py.stdout.strip().splitlines()[-1])
+    assert rec["worst_pose_error_m"] < 0.02 and rec["map"]["full_builds"] == 0 and rec["map"]["rolls"] == cpp["map"]["rolls"]
+    assert rec["map"]["points_evicted"] == cpp["map"]["points_evicted"]
+    assert rec["map_points_mean"] == cpp["map_points"]            # the two hosts left the same map behind
+    assert abs(rec["worst_pose_error_m"] - cpp["worst_pose_error_m"]) < 1e-9

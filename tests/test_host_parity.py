@@ -240,46 +240,7 @@ def test_ins_to_pose_and_insmeta(tmp_path, oracle):
         assert bytes(a)[:72] == bytes(b)[:72] and a.t_us == b.t_us and a.seconds_pos == b.seconds_pos
 
 
-def _write_db_xml(path, cal, enabled=64, shuffle=False):
-    """A calibration file in Velodyne's boost-serialisation layout (the element names are all
-    HDLParser::loadCorrectionsFile looks at, HDLParser.cxx:771-858); distances in centimetres."""
-    ids = list(range(64))
-    if shuffle:
-        ids = ids[::-1]
-    px = []
-    for i in ids:
-        r = cal[i]
-        px.append("""\t\t<item class_id="2" tracking_level="0" version="1">
-\t\t\t<px class_id="3" tracking_level="1" version="1" object_id="_%d">
-\t\t\t\t<id_>%d</id_>
-\t\t\t\t<rotCorrection_>%r</rotCorrection_>
-\t\t\t\t<vertCorrection_>%r</vertCorrection_>
-\t\t\t\t<distCorrection_>%r</distCorrection_>
-\t\t\t\t<distCorrectionX_>0</distCorrectionX_>
-\t\t\t\t<vertOffsetCorrection_>%r</vertOffsetCorrection_>
-\t\t\t\t<horizOffsetCorrection_>%r</horizOffsetCorrection_>
-\t\t\t\t<focalDistance_>0</focalDistance_>
-\t\t\t</px>
-\t\t</item>""" % (i, i, float(r[0]), float(r[1]), float(r[2]) * 100.0, float(r[3]) * 100.0, float(r[4]) * 100.0))
-    en = "\n".join("\t\t<item>%d</item>" % (1 if i < enabled else 0) for i in range(64))
-    with open(path, "w") as f:
-        f.write("""<?xml version="1.0" encoding="UTF-8" standalone="yes" ?>
-<!DOCTYPE boost_serialization>
-<boost_serialization signature="serialization::archive" version="4">
-<DB class_id="0" tracking_level="1" version="0" object_id="_0">
-\t<distLSB_>0.2</distLSB_>
-\t<enabled_ class_id="4" tracking_level="0" version="0">
-\t\t<count>64</count>
-%s
-\t</enabled_>
-\t<points_ class_id="1" tracking_level="0" version="0">
-\t\t<count>64</count>
-\t\t<item_version>1</item_version>
-%s
-\t</points_>
-</DB>
-</boost_serialization>
-""" % (en, "\n".join(px)))
+from veloslam_amd.drive import write_db_xml as _write_db_xml  # noqa: E402  (the generator lives with the drive exporter)
 
 
 @pytest.mark.parametrize("azcorr,enabled,shuffle", [(False, 64, False), (True, 32, True)])

@@ -86,11 +86,11 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
+    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_increment_pending", "velo_pending_count", "velo_pending_fetch", "velo_map_append_pending", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
     "velo_exchange_increments", "velo_exchange_plan", "velo_exchange_pack_dev", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_pcap_index", "velo_ins_to_pose",
-    "velo_insmeta_write", "velo_insmeta_read", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
+    "velo_insmeta_write", "velo_insmeta_read", "velo_carposes_read", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
     "llh2enu", "MappingAngle",
 ]
 
@@ -176,6 +176,10 @@ def lib():
     L.velo_comm_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.velo_exchange_increments.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, C.c_size_t, vp,
                                            C.POINTER(C.c_size_t)]
+    L.velo_increment_pending.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.velo_pending_count.argtypes = [vp, C.POINTER(C.c_size_t), C.c_int]
+    L.velo_pending_fetch.argtypes = [vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.velo_map_append_pending.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.velo_exchange_plan.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.velo_exchange_pack_dev.argtypes = [vp, vp, vp, C.c_int, C.c_size_t, vp, vp, vp, C.c_size_t,
                                          C.POINTER(C.c_size_t)]
@@ -690,6 +694,28 @@ class Context:
         self._chk(lib().velo_exchange_pack_dev(self.h, precv, _p(cnt), cnt.size, pad, pox, poy, poz, cap,
                                                C.byref(tot)))
         return tot.value
+
+    # ---- pending increments (device-side list inside the ctx)
+    def increment_pending(self, frame, T=None, min_count=3):
+        Tp = None if T is None else _d(np.ascontiguousarray(T, dtype=np.float64).reshape(12))
+        self._chk(lib().velo_increment_pending(self.h, frame, Tp, min_count))
+
+    def pending_count(self, wait=True):
+        n = C.c_size_t()
+        self._chk(lib().velo_pending_count(self.h, C.byref(n), int(bool(wait))))
+        return n.value
+
+    def pending_fetch(self):
+        n = self.pending_count(True)
+        x, y, z = (np.empty(n, np.float32) for _ in range(3))
+        k = C.c_size_t()
+        self._chk(lib().velo_pending_fetch(self.h, _p(x), _p(y), _p(z), n, C.byref(k)))
+        return x, y, z
+
+    def map_append_pending(self):
+        n = C.c_size_t()
+        self._chk(lib().velo_map_append_pending(self.h, C.byref(n)))
+        return n.value
 
     def increment_wait(self):
         cnt = C.c_size_t()

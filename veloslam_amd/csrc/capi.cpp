@@ -183,6 +183,12 @@ struct velo_ctx {
     DevBuf<uint32_t> sp_idx, sp_idx2;
     DevBuf<float> sp_x, sp_y, sp_z;
     DevBuf<double> inc_pose;
+    // device-side list of accepted increments not yet merged into the map (velo_increment_pending)
+    DevBuf<float> pend_x, pend_y, pend_z;
+    size_t pend_n = 0;                 // points in the list whose count has reached the host
+    uint32_t* h_pend_total = nullptr;  // pinned: count of the increment in flight
+    hipEvent_t ev_pend = nullptr;
+    bool pend_outstanding = false;
     uint32_t* h_inc_total = nullptr;  // pinned: count of the asynchronous increment
     uint8_t* h_dec_stage = nullptr;   // pinned: packets + per-packet plan of one decode call
     size_t h_dec_cap = 0;
@@ -1337,6 +1343,8 @@ void velo_destroy(velo_ctx* c)
         if (c->ev_T0[b]) (void)hipEventDestroy(c->ev_T0[b]);
     }
     if (c->h_inc_total) (void)hipHostFree(c->h_inc_total);
+    if (c->h_pend_total) (void)hipHostFree(c->h_pend_total);
+    if (c->ev_pend) (void)hipEventDestroy(c->ev_pend);
     if (c->h_dec_stage) (void)hipHostFree(c->h_dec_stage);
     if (c->ev_inc) (void)hipEventDestroy(c->ev_inc);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -2462,6 +2470,92 @@ static int increment_impl(velo_ctx* c, int frame, const double T[12], int min_co
     }
     *n_out = total;
     return VELO_OK;
+}
+
+// ---- pending increments: the accepted points of registered frames collected ON THE DEVICE until
+// they are worth a map update (what MapManager::registerFrame's integrate step and a streaming
+// host use: no host round trip per frame, no synchronisation per frame)
+static int pending_resolve(velo_ctx* c, bool wait)
+{
+    if (!c->pend_outstanding) return VELO_OK;
+    // wait == false never looks at the event: whether the increment in flight has landed yet must
+    // not change what a caller does next (a flush decided by timing would make the map, and with
+    // it every later registration, depend on the host's speed)
+    if (!wait) return VELO_OK;
+    HIP_TRY(c, hipEventSynchronize(c->ev_pend));
+    c->pend_n += *c->h_pend_total;
+    c->pend_outstanding = false;
+    return VELO_OK;
+}
+
+int velo_increment_pending(velo_ctx* c, int frame, const double* T, int min_count)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
+    if (frame < 0 || frame >= c->n_frames) return c->fail(VELO_E_INVALID, "frame index out of range");
+    if (!T && c->last_iters <= 0) return c->fail(VELO_E_INVALID, "no registration has run on the resident frames");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (int rc = pending_resolve(c, true)) return rc;  // the list's length decides where this one lands
+    const size_t n = (size_t)(c->frame_start[frame + 1] - c->frame_start[frame]);
+    if (n == 0) return VELO_OK;
+    if (!c->h_pend_total) HIP_TRY(c, hipHostMalloc((void**)&c->h_pend_total, sizeof(uint32_t), 0));
+    if (!c->ev_pend) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pend, hipEventDisableTiming));
+    HIP_TRY(c, c->pend_x.reserve(c->pend_n + n, true, s));
+    HIP_TRY(c, c->pend_y.reserve(c->pend_n + n, true, s));
+    HIP_TRY(c, c->pend_z.reserve(c->pend_n + n, true, s));
+    const double* d_pose = c->poses.p + 12 * (size_t)frame;  // where the last registration left it
+    if (T) {
+        HIP_TRY(c, c->inc_pose.reserve(12));
+        // (pageable source: the copy is staged before the call returns)
+        HIP_TRY(c, hipMemcpyAsync(c->inc_pose.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
+        d_pose = c->inc_pose.p;
+    }
+    *c->h_pend_total = 0;
+    if (int rc = enqueue_increment(c, frame, d_pose, min_count, c->pend_x.p + c->pend_n, c->pend_y.p + c->pend_n,
+                                   c->pend_z.p + c->pend_n, c->h_pend_total))
+        return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_pend, s));
+    c->pend_outstanding = true;
+    return VELO_OK;
+}
+
+int velo_pending_count(velo_ctx* c, size_t* n, int wait)
+{
+    if (!c || !n) return VELO_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = pending_resolve(c, wait != 0)) return rc;
+    *n = c->pend_n;
+    return VELO_OK;
+}
+
+int velo_pending_fetch(velo_ctx* c, float* x, float* y, float* z, size_t cap, size_t* n_out)
+{
+    if (!c || !n_out) return VELO_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = pending_resolve(c, true)) return rc;
+    *n_out = c->pend_n;
+    if (c->pend_n > cap) return c->fail(VELO_E_RANGE, "%zu pending points exceed the capacity %zu", c->pend_n, cap);
+    if (c->pend_n == 0) return VELO_OK;
+    if (!x || !y || !z) return c->fail(VELO_E_INVALID, "null output array");
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(x, c->pend_x.p, c->pend_n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(y, c->pend_y.p, c->pend_n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(z, c->pend_z.p, c->pend_n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return VELO_OK;
+}
+
+int velo_map_append_pending(velo_ctx* c, size_t* n_appended)
+{
+    if (!c) return VELO_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = pending_resolve(c, true)) return rc;
+    if (n_appended) *n_appended = c->pend_n;
+    if (c->pend_n == 0) return VELO_OK;
+    const size_t n = c->pend_n;
+    c->pend_n = 0;  // consumed either way: a failed append leaves the map as it was, the list is dropped
+    return velo_map_append_dev(c, c->pend_x.p, c->pend_y.p, c->pend_z.p, n);
 }
 
 int velo_increment_registered_async(velo_ctx* c, int frame, int min_count, float* dox, float* doy,

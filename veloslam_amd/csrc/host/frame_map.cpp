@@ -70,10 +70,27 @@ void intrusive_ptr_release(HDLFrame* p)
 
 // ---------------------------------------------------------------- MapManager
 MapManager::MapManager(float patchRange, int device_id)
-    : patchRange_(patchRange), ctx_(nullptr), dirty_(true), residentVoxel_(0), residentK_(0)
+    : patchRange_(patchRange), ctx_(nullptr), dirty_(true), haveDevice_(false), res_i0_(0), res_i1_(-1),
+      res_j0_(0), res_j1_(-1), residentVoxel_(0), residentK_(0)
 {
-    ctx_ = velo_create(device_id, nullptr);
-    if (!ctx_) err_ = velo_last_error(nullptr);
+    // the defaults of cfg == NULL (fast kernel, hints + certificates, graph replay) plus what a
+    // rolling map needs: slack around the grid so that rolls and increments update the sorted map
+    // in place (tens of voxels in x / y, two in z: the dense table grows with the product)
+    velo_cfg cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.abi_version = VELO_ABI_VERSION;
+    cfg.max_batch = 4;
+    cfg.use_hints = 2;
+    cfg.use_graph = 1;
+    cfg.map_margin = 16;
+    ctx_ = velo_create(device_id, &cfg);
+    if (!ctx_) {
+        err_ = velo_last_error(nullptr);
+        return;
+    }
+    const int32_t margins[3] = {16, 16, 2};
+    velo_map_set_margins(ctx_, margins);
 }
 MapManager::~MapManager()
 {
@@ -117,6 +134,25 @@ std::set<std::shared_ptr<MapPatch>> MapManager::getROI(double x, double y)
     return result;
 }
 
+void MapManager::tileRange(double x, double y, int& i0, int& i1, int& j0, int& j1) const
+{
+    const auto lo = getPatchIdx(x - ROI_RANGE, y - ROI_RANGE), hi = getPatchIdx(x + ROI_RANGE, y + ROI_RANGE);
+    i0 = lo.first, i1 = hi.first, j0 = lo.second, j1 = hi.second;
+}
+
+std::vector<std::shared_ptr<MapPatch>> MapManager::tilesInRange(double x, double y)
+{
+    int i0, i1, j0, j1;
+    tileRange(x, y, i0, i1, j0, j1);
+    std::vector<std::shared_ptr<MapPatch>> out;
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            auto it = patches_.find({i, j});
+            if (it != patches_.end()) out.push_back(it->second);
+        }
+    return out;
+}
+
 void MapManager::addPoints(const float* x, const float* y, const float* z, size_t n)
 {
     for (size_t i = 0; i < n; ++i) getPatch(x[i], y[i])->append(x + i, y + i, z + i, 1);
@@ -138,9 +174,11 @@ size_t MapManager::evictOutside(double x, double y, double radius)
         const double dx = it->second->centerX - x, dy = it->second->centerY - y;
         if (dx * dx + dy * dy > reach * reach) {
             dropped += it->second->size();
-            resident_.erase(it->second);
+            // a tile the device map holds is gone from the host store: the next roll rebuilds
+            if (haveDevice_ && it->first.first >= res_i0_ && it->first.first <= res_i1_ &&
+                it->first.second >= res_j0_ && it->first.second <= res_j1_)
+                dirty_ = true;
             it = patches_.erase(it);
-            dirty_ = true;
         } else {
             ++it;
         }
@@ -216,7 +254,6 @@ bool MapManager::load(const std::string& filename)
         return false;
     }
     patches_.clear();
-    resident_.clear();
     patchRange_ = pr;
     for (unsigned short i = 0; i < sz; ++i) {
         auto p = std::make_shared<MapPatch>();
@@ -247,41 +284,180 @@ bool MapManager::load(const std::string& filename)
     return true;
 }
 
-bool MapManager::syncDeviceMap(double x, double y, const RegisterOptions& o)
+// Rolling device map.  The resident set is a rectangle of tile indices, so "what stays" is a box
+// and the C ABI's box eviction applies it exactly; entering tiles go up in ONE append (row-major
+// tile order, each tile's points in their stored order): the device map then equals a fresh build of
+// [survivors in their old order, entering points] on the kept grid, by velo_map_append's definition.
+bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
 {
-    auto roi = getROI(x, y);
-    if (roi.empty()) {
-        err_ = "no map patch within ROI_RANGE of the prior";
-        return false;
-    }
-    if (!dirty_ && roi == resident_ && o.voxel == residentVoxel_ && o.k_normals == residentK_)
+    if (!ctx_) return false;
+    int i0, i1, j0, j1;
+    tileRange(x, y, i0, i1, j0, j1);
+    const bool same_cfg = o.voxel == residentVoxel_ && o.k_normals == residentK_;
+    if (haveDevice_ && !dirty_ && same_cfg && i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_)
         return true;
-    std::vector<float> mx, my, mz;
-    for (const auto& p : roi) {  // std::set iterates in pointer order; make it positional
-        (void)p;
+    auto gather = [&](int a0, int a1, int b0, int b1, bool only_new, size_t* tiles) {
+        stage_x_.clear(), stage_y_.clear(), stage_z_.clear();
+        for (int j = b0; j <= b1; ++j)
+            for (int i = a0; i <= a1; ++i) {
+                if (only_new && i >= res_i0_ && i <= res_i1_ && j >= res_j0_ && j <= res_j1_) continue;
+                auto it = patches_.find({i, j});
+                if (it == patches_.end() || it->second->size() == 0) continue;
+                const MapPatch& p = *it->second;
+                stage_x_.insert(stage_x_.end(), p.x.begin(), p.x.end());
+                stage_y_.insert(stage_y_.end(), p.y.begin(), p.y.end());
+                stage_z_.insert(stage_z_.end(), p.z.begin(), p.z.end());
+                if (tiles) ++*tiles;
+            }
+    };
+    const bool overlap = haveDevice_ && !dirty_ && same_cfg && i0 <= res_i1_ && i1 >= res_i0_ && j0 <= res_j1_ &&
+                         j1 >= res_j0_;
+    if (overlap) {
+        // increments accepted so far belong to the map before it rolls (and to the host tiles)
+        if (!flushIncrements()) return false;
+        velo_map_info mi;
+        mi.struct_size = sizeof mi;
+        velo_map_info_get(ctx_, &mi);
+        const uint64_t n_before = mi.n_points;
+        // keep region: the new tile rectangle (closed box on float coordinates; a tile covers
+        // [c - r/2, c + r/2), so the upper edge is the largest float below it)
+        const float big = 3.0e38f;
+        const float lo[3] = {(float)(i0 * (double)patchRange_ - patchRange_ / 2.0),
+                             (float)(j0 * (double)patchRange_ - patchRange_ / 2.0), -big};
+        const float hi[3] = {std::nextafter((float)(i1 * (double)patchRange_ + patchRange_ / 2.0), -big),
+                             std::nextafter((float)(j1 * (double)patchRange_ + patchRange_ / 2.0), -big), big};
+        bool kept_something = true;
+        if (i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_) {
+            const int rc = velo_map_evict_outside(ctx_, lo, hi);
+            if (rc == VELO_E_INVALID) {
+                kept_something = false;  // nothing of the device map lies in the new rectangle: rebuild
+            } else if (rc) {
+                err_ = velo_last_error(ctx_);
+                return false;
+            }
+        }
+        if (kept_something) {
+            velo_map_info_get(ctx_, &mi);
+            stats_.points_evicted += n_before - mi.n_points;
+            size_t tiles = 0;
+            gather(i0, i1, j0, j1, true, &tiles);
+            if (!stage_x_.empty() &&
+                velo_map_append(ctx_, stage_x_.data(), stage_y_.data(), stage_z_.data(), stage_x_.size())) {
+                err_ = velo_last_error(ctx_);
+                return false;
+            }
+            stats_.points_uploaded += stage_x_.size();
+            stats_.tiles_entered += tiles;
+            stats_.tiles_left += (uint64_t)std::max(0, (res_i1_ - res_i0_ + 1) * (res_j1_ - res_j0_ + 1) -
+                                                           (std::min(i1, res_i1_) - std::max(i0, res_i0_) + 1) *
+                                                               (std::min(j1, res_j1_) - std::max(j0, res_j0_) + 1));
+            ++stats_.rolls;
+            res_i0_ = i0, res_i1_ = i1, res_j0_ = j0, res_j1_ = j1;
+            return true;
+        }
     }
-    std::vector<std::shared_ptr<MapPatch>> ordered(roi.begin(), roi.end());
-    std::sort(ordered.begin(), ordered.end(), [](const auto& a, const auto& b) {
-        return a->centerY != b->centerY ? a->centerY < b->centerY : a->centerX < b->centerX;
-    });
-    for (const auto& p : ordered) {
-        mx.insert(mx.end(), p->x.begin(), p->x.end());
-        my.insert(my.end(), p->y.begin(), p->y.end());
-        mz.insert(mz.end(), p->z.begin(), p->z.end());
-    }
-    if (mx.empty()) {
-        err_ = "map patches in the ROI hold no points";
+    // first ROI, a jump with no overlap, other map parameters, or host tiles edited behind the
+    // device map's back (addPoints / load / evictOutside): build from the tiles
+    size_t tiles = 0;
+    gather(i0, i1, j0, j1, false, &tiles);
+    if (stage_x_.empty()) {
+        err_ = "no map points within ROI_RANGE of the prior";
         return false;
     }
-    if (velo_map_reset(ctx_, mx.data(), my.data(), mz.data(), mx.size(), o.voxel, o.k_normals)) {
+    if (velo_map_reset(ctx_, stage_x_.data(), stage_y_.data(), stage_z_.data(), stage_x_.size(), o.voxel,
+                       o.k_normals)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
-    resident_ = roi;
+    ++stats_.full_builds;
+    stats_.points_uploaded += stage_x_.size();
+    haveDevice_ = true;
+    dirty_ = false;
     residentVoxel_ = o.voxel;
     residentK_ = o.k_normals;
-    dirty_ = false;
+    res_i0_ = i0, res_i1_ = i1, res_j0_ = j0, res_j1_ = j1;
     return true;
+}
+
+bool MapManager::flushIncrements()
+{
+    if (!ctx_) return false;
+    size_t n = 0;
+    if (velo_pending_count(ctx_, &n, 1)) {
+        err_ = velo_last_error(ctx_);
+        return false;
+    }
+    if (n == 0) return true;
+    stage_x_.resize(n), stage_y_.resize(n), stage_z_.resize(n);
+    if (velo_pending_fetch(ctx_, stage_x_.data(), stage_y_.data(), stage_z_.data(), n, &n) ||
+        velo_map_append_pending(ctx_, nullptr)) {
+        err_ = velo_last_error(ctx_);
+        return false;
+    }
+    // the host tiles follow the device map (not the other way round: dirty_ stays as it was)
+    const bool was_dirty = dirty_;
+    addPoints(stage_x_.data(), stage_y_.data(), stage_z_.data(), n);
+    dirty_ = was_dirty;
+    ++stats_.increment_flushes;
+    stats_.increment_points += n;
+    return true;
+}
+
+bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform& init, const RegisterOptions& o,
+                              PoseTransform* out, velo_icp_result* result)
+{
+    if (!rollTo(init.T[0], init.T[1], o)) return false;
+    const Affine3x4 T0 = init.getMatrix();
+    // one registration of the resident frames; the other frames of a multi-frame decode keep the
+    // prior they are given here only if they are registered by their own call
+    velo_icp_result local[4];
+    velo_cfg eff;
+    velo_cfg_get(ctx_, &eff);
+    if (frame < 0 || frame >= 4) {
+        err_ = "frame index out of range (the context holds up to 4 resident frames)";
+        return false;
+    }
+    double T0s[4 * 12];
+    for (int f = 0; f < 4; ++f) std::memcpy(T0s + 12 * f, T0.data(), sizeof(double) * 12);
+    if (velo_icp_batch(ctx_, T0s, o.iters, o.d_max, local)) {
+        err_ = velo_last_error(ctx_);
+        return false;
+    }
+    const velo_icp_result& r = local[frame];
+    if (result) *result = r;
+    Affine3x4 M;
+    std::memcpy(M.data(), r.T, sizeof(double) * 12);
+    PoseTransform p = PoseTransform::fromMatrix(M);
+    p.timestamp = timestamp;
+    for (int i = 0; i < 3; ++i) p.V[i] = init.V[i];
+    *out = p;
+    if (o.integrate) {
+        // the accepted increment joins the device-side pending list at the pose the registration
+        // left on the device: nothing is fetched, nothing blocks
+        if (velo_increment_pending(ctx_, frame, nullptr, o.increment_min_count)) {
+            err_ = velo_last_error(ctx_);
+            return false;
+        }
+        if (o.append_threshold <= 1) {  // "after every frame": wait for this one
+            if (!flushIncrements()) return false;
+        } else {
+            size_t pending = 0;
+            velo_pending_count(ctx_, &pending, 0);  // without waiting: the frame in flight counts next time
+            if (pending >= (size_t)o.append_threshold && !flushIncrements()) return false;
+        }
+    }
+    return true;
+}
+
+bool MapManager::registerResident(int frame, int64_t timestamp, const PoseTransform& init, const RegisterOptions& o,
+                                  PoseTransform* out, velo_icp_result* result)
+{
+    if (!ctx_) return false;
+    if (!out) {
+        err_ = "null output";
+        return false;
+    }
+    return registerCore(frame, timestamp, init, o, out, result);
 }
 
 bool MapManager::registerFrame(const HDLFrame& frame, const PoseTransform& init,
@@ -293,37 +469,13 @@ bool MapManager::registerFrame(const HDLFrame& frame, const PoseTransform& init,
         err_ = "empty frame or null output";
         return false;
     }
-    if (!syncDeviceMap(init.T[0], init.T[1], o)) return false;
-    const Affine3x4 T0 = init.getMatrix();
-    velo_icp_result local;
-    velo_icp_result* r = result ? result : &local;
     const CloudView c = frame.getPointsAsOneCloud(0, frame.numBeams());
-    if (velo_icp(ctx_, c.x, c.y, c.z, c.size, T0.data(), o.iters, o.d_max, 1, r)) {
+    const int64_t fs[2] = {0, (int64_t)c.size};
+    if (velo_frames_upload(ctx_, 1, c.x, c.y, c.z, fs)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
-    Affine3x4 M;
-    std::memcpy(M.data(), r->T, sizeof(double) * 12);
-    PoseTransform p = PoseTransform::fromMatrix(M);
-    p.timestamp = frame.timestamp;
-    for (int i = 0; i < 3; ++i) p.V[i] = init.V[i];
-    *out = p;
-    if (o.integrate) {
-        std::vector<float> ix(c.size), iy(c.size), iz(c.size);
-        size_t n_inc = 0;
-        if (velo_increment(ctx_, 0, r->T, o.increment_min_count, ix.data(), iy.data(), iz.data(),
-                           &n_inc)) {
-            err_ = velo_last_error(ctx_);
-            return false;
-        }
-        addPoints(ix.data(), iy.data(), iz.data(), n_inc);
-        // keep the device map in step instead of re-uploading the ROI at the next frame: the
-        // increment is merged into the sorted map in place (velo_map_append is incremental).  If
-        // the ROI's tile set changes, syncDeviceMap rebuilds from the tiles as before.
-        if (n_inc == 0 || velo_map_append(ctx_, ix.data(), iy.data(), iz.data(), n_inc) == VELO_OK)
-            dirty_ = false;
-    }
-    return true;
+    return registerCore(0, frame.timestamp, init, o, out, result);
 }
 
 }  // namespace veloslam

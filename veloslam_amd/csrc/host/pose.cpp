@@ -557,6 +557,19 @@ int velo_interp_pose(const velo_pose* sorted, size_t n, int64_t t_us, velo_pose*
     return VELO_OK;
 }
 
+int velo_carposes_read(const char* path, velo_pose* poses, size_t cap, size_t* n_out)
+{
+    if (!path || !n_out) return VELO_E_INVALID;
+    veloslam::TransformManager tm;
+    if (!tm.loadFromTxtFile(path, true)) return VELO_E_NODATA;
+    const std::vector<velo_pose> v = tm.snapshot();
+    *n_out = v.size();
+    if (!poses) return VELO_OK;
+    if (v.size() > cap) return VELO_E_RANGE;
+    std::memcpy(poses, v.data(), v.size() * sizeof(velo_pose));
+    return VELO_OK;
+}
+
 int velo_packet_transforms(const velo_pose* sorted, size_t n, const int64_t* pkt_t_us, size_t n_pkt,
                            double* T3x4, uint8_t* valid, velo_pose* carpose)
 {
