@@ -1130,3 +1130,92 @@ def test_config2_full_size_properties(oracle):
         assert res.total_pairs == sum(s_["n_pairs"] for s_ in st)
     finally:
         c.close()
+
+
+def test_rolling_a_5m_point_map_incremental_equals_full_rebuild():
+    """BASELINE configs[2] at size: a 5.5 M-point device map rolled three times
+    -- evict everything beyond a radius of the moving pose, append the world points that came into
+    range, one of the rolls re-anchoring the grid (points below the origin).  Too large for the CPU
+    oracle in seconds, so the incremental update is held to the library's own full rebuild of the
+    same list on the same grid rules (cfg.map_full_rebuild = 1, which the small tests hold to the
+    oracle): sorted order, cell table, points and normals bit for bit after every operation; and the
+    exact ball search == the literal exhaustive scan on the rolled map."""
+    import torch
+    from veloslam_amd import synth
+    dev = torch.device("cuda", 0)
+    sc = synth.Scene()
+    wx, wy, wz = sc.sample_map_device(12_000_000, dev)
+    wl = make_workload(map_points=1000, n_frames=1)
+    f = wl["frames"][0]
+    s = f["sensor"]
+    inc = capi.Context(0, max_batch=2, map_margin=8)
+    ful = capi.Context(0, max_batch=2, map_margin=8, map_full_rebuild=1, linearize_variant=SCAN)
+    try:
+        for c in (inc, ful):
+            c.map_set_margins(8, 8, 2)
+        cx, cy, cz = inc.compensate(s["x"], s["y"], s["z"], s["pkt"], f["table"])
+        q = tuple(a[::3].copy() for a in (cx, cy, cz))
+        px, py = float(f["T_true"][3]), float(f["T_true"][7])
+
+        def d2(x0, y0):
+            return (wx - x0) ** 2 + (wy - y0) ** 2
+
+        R = 78.0
+        resident = d2(px, py) <= R * R
+        kx, ky, kz = (a[resident].contiguous() for a in (wx, wy, wz))
+        n0 = int(kx.numel())
+        assert n0 >= 5_000_000
+        torch.cuda.synchronize()
+        for c in (inc, ful):
+            c.map_reset_dev(kx.data_ptr(), ky.data_ptr(), kz.data_ptr(), n0, 1.0, 16)
+
+        def same_maps(expect_incremental):
+            a, b = inc.map_download(), ful.map_download()
+            ia, ib = inc.map_info(), ful.map_info()
+            assert ia.n_points == ib.n_points and list(ia.dims) == list(ib.dims) and list(ia.origin) == list(ib.origin)
+            assert ia.subdiv == ib.subdiv and ia.n_invalid_normals == ib.n_invalid_normals
+            for k in ("cell_start", "perm", "x", "y", "z"):
+                assert np.array_equal(a[k], b[k]), k
+            for k in ("nx", "ny", "nz"):
+                assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+            assert ib.last_update == 0
+            if expect_incremental is not None:
+                assert ia.last_update == (1 if expect_incremental else 0)
+            if ia.last_update:
+                assert ia.n_normals_recomputed < ia.n_points // 4
+            seen.append(int(ia.last_update))
+            for c in (inc, ful):
+                c.frames_upload([q])
+            for T in (f["T0"], f["T_true"]):
+                ca, da, _ = inc.linearize(0, T, 1.0, q[0].size)      # exact ball search, incremental map
+                cb, db, _ = ful.linearize(0, T, 1.0, q[0].size)      # exhaustive scan, rebuilt map
+                assert np.array_equal(ca, cb) and np.array_equal(da.view(np.uint32), db.view(np.uint32))
+                assert (ca >= 0).sum() > q[0].size // 2
+            return ia
+
+        seen = []
+        same_maps(False)
+        steps = [(4.0, 0.0, False), (9.0, 1.5, False), (15.0, -2.0, True)]
+        for dx, dy, reanchor in steps:
+            x1, y1 = px + dx, py + dy
+            for c in (inc, ful):
+                c.map_evict_radius(x1, y1, R)
+            mi = same_maps(None)   # (in place while the low side stays within the slack, re-anchored beyond)
+            dd = d2(x1, y1)
+            entering = (dd <= (R - 0.5) ** 2) & ~resident
+            resident = (resident & (dd <= R * R)) | entering
+            ex, ey, ez = (a[entering].contiguous() for a in (wx, wy, wz))
+            if reanchor:   # a few points far below the grid's origin (beyond the 8-voxel slack)
+                low = torch.tensor([[mi.origin[0] - 30.0], [mi.origin[1] - 25.0], [0.2]], device=dev).repeat(1, 40)
+                low = low + torch.rand_like(low)
+                ex, ey, ez = (torch.cat([e, l.to(torch.float32)]).contiguous() for e, l in zip((ex, ey, ez), low))
+            assert ex.numel() > 10_000
+            torch.cuda.synchronize()   # (the tensors were made on torch's stream, the ctx has its own)
+            for c in (inc, ful):
+                c.map_append_dev(ex.data_ptr(), ey.data_ptr(), ez.data_ptr(), ex.numel())
+            mi = same_maps(False if reanchor else None)
+            assert mi.n_points >= 5_000_000
+        assert seen.count(1) >= 3 and seen.count(0) >= 2      # most updates in place, the anchored ones not
+    finally:
+        inc.close()
+        ful.close()
