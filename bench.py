@@ -97,7 +97,12 @@ def parse():
                     "drive.pcap, carposes.txt, db.xml, world.map) instead of the synthetic generator")
     ap.add_argument("--export-drive", default="", help="write the synthetic drive of the stream workload to this directory "
                     "(--stream-frames frames, --stream-map-points world points, --tile metres per tile) and exit")
-    ap.add_argument("--tile", type=float, default=10.0, help="--export-drive: tile edge of world.map (m)")
+    ap.add_argument("--tile", type=float, default=10.0, help="tile edge of the world map (m): --export-drive, stream record")
+    ap.add_argument("--stream-policy", choices=["tiles", "radius"], default="tiles",
+                    help="stream record: how the map rolls.  tiles (default) = what veloslam::MapManager does: the "
+                         "resident set is the rectangle of tiles overlapping the +-ROI_RANGE square of the prior, rolled "
+                         "when it changes (host tiles); radius = round 2's loop: every --evict-every frames evict "
+                         "beyond ROI_RANGE of the pose and append the world points that came within range (device-resident world)")
     ap.add_argument("--stream-frames", type=int, default=64, help="distinct synthetic frames (played forwards and backwards)")
     ap.add_argument("--stream-steps", type=int, default=100, help="stream sub-record: timed frames")
     ap.add_argument("--stream-map-points", type=int, default=12_000_000,
@@ -406,7 +411,47 @@ def run_stream(args, dev, local, steps, warmup, scene_points, n_distinct, src=No
             "worst_pose_error_m": counts["worst"]}
 
 
-def run_replay(args, dev, local, steps, warmup):
+def synthetic_drive(args, dev, src):
+    """The stream record's inputs in the shape drive.load() gives a recorded drive: the synthetic
+    frames' packets written as a pcap and read back with the frame index through the C ABI
+    (velo_pcap_write / _read / _index), the full synthetic INS track as the pose store, and the
+    pre-mapped world binned into MapManager tiles held on the host (veloslam::MapPatch's role)."""
+    import tempfile
+    from veloslam_amd import drive
+    sc, mo, cal = synth.Scene(), synth.Motion(), synth.hdl64_calibration()
+    if src is None:
+        src = []
+        for k in range(args.stream_frames):
+            pk, ts, _ = synth.make_frame_packets(sc, mo, 3 + k, cal, seed=42)
+            src.append(dict(fi=3 + k, packets=pk, ts=ts))
+    src = sorted(src, key=lambda f: f["fi"])
+    assert all(b["fi"] == a["fi"] + 1 for a, b in zip(src[:-1], src[1:])), "the drive's frames must be consecutive"
+    packets = [p for f in src for p in f["packets"]]
+    times = [t for f in src for t in f["ts"]]
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "drive.pcap")
+        capi.pcap_write(path, packets, times)
+        pk, t = capi.pcap_read(path)
+        idx = capi.pcap_index(path)
+    poses, n = capi.make_poses(mo.ins_track(times[0], times[-1]))
+    wx, wy, wz = (a.cpu().numpy() for a in sc.sample_map_device(args.stream_map_points, dev))
+    pr = float(args.tile)
+    ti, tj = drive.tile_index(wx, wy, pr)
+    order = np.lexsort((tj, ti))
+    ti, tj = ti[order], tj[order]
+    cut = np.flatnonzero(np.r_[True, (ti[1:] != ti[:-1]) | (tj[1:] != tj[:-1]), True])
+    tile_of = {}
+    for a, b in zip(cut[:-1], cut[1:]):
+        sel = np.sort(order[a:b])
+        tile_of[(int(ti[a]), int(tj[a]))] = [wx[sel], wy[sel], wz[sel]]
+    truth = [[float(v) for v in mo.pose(f["ts"][0])[0]] for f in src]
+    return dict(packets=np.frombuffer(b"".join(pk), np.uint8).copy(), times=np.asarray(t, np.int64), index=idx,
+                poses=poses, n_poses=n, calib=np.ascontiguousarray(cal, np.float64).reshape(64, 9),
+                meta=dict(z0=truth[0][2], true_positions=truth), dir="synthetic (in memory)",
+                patch_range=pr, tile_of=tile_of, n_tiles=len(tile_of))
+
+
+def run_replay(args, dev, local, steps, warmup, d=None):
     """`--workload stream --drive DIR`: a recorded drive (veloslam_amd/drive.py layout: pcap +
     carposes.txt + db.xml + world.map) replayed against a rolling map, the same loop
     tools/stream_driver.cpp runs from C++ through veloslam::MapManager -- here through the C ABI:
@@ -416,12 +461,18 @@ def run_replay(args, dev, local, steps, warmup):
     tiles as MapManager holds them) -> 20 ICP iterations -> accepted increment to the device-side
     pending list (merged once --append-threshold points are pending)."""
     from veloslam_amd import drive
-    d = drive.load(args.drive)
+    if d is None:
+        d = drive.load(args.drive)
+        pr, tiles = drive.read_map_file(os.path.join(args.drive, "world.map"))
+        tile_of = {}
+        for cx, cy, tx, ty, tz in tiles:
+            tile_of[(int(round(cx / pr)), int(round(cy / pr)))] = [tx, ty, tz]
+        n_tiles = len(tiles)
+        name = "recorded drive " + os.path.basename(os.path.normpath(args.drive))
+    else:
+        pr, tile_of, n_tiles = d["patch_range"], d["tile_of"], d["n_tiles"]
+        name = "synthetic drive"
     meta = d["meta"]
-    pr, tiles = drive.read_map_file(os.path.join(args.drive, "world.map"))
-    tile_of = {}
-    for cx, cy, tx, ty, tz in tiles:
-        tile_of[(int(round(cx / pr)), int(round(cy / pr)))] = [tx, ty, tz]
     ctx = capi.Context(local, max_batch=4, map_margin=args.map_margin, use_hints=0 if args.no_hints else args.hints,
                        use_graph=0 if args.no_graph else 1, map_subdiv=args.stream_subdiv)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -543,11 +594,13 @@ def run_replay(args, dev, local, steps, warmup):
         raise SystemExit("bench replay: registration diverged (%.3f m)" % state["worst"])
     return {"frames_per_s": steps / elapsed, "ms_per_frame": 1e3 * elapsed / steps, "frames": steps,
             "host": "Python (C ABI through ctypes)",
-            "workload": "recorded drive %s: %d frames (pcap + carposes.txt + db.xml), world.map of %d tiles of %.0f m; "
-                        "per frame decode of the indexed packets + roll to the tiles within ROI_RANGE of the prior + "
-                        "%d ICP iters + increment (merged once %d points are pending)"
-                        % (os.path.basename(os.path.normpath(args.drive)), nfr, len(tiles), pr, args.iters,
-                           args.append_threshold),
+            "workload": "BASELINE configs[2], %s: %d frames 1 m apart (pcap + frame index + pose track), played "
+                        "forwards and backwards, through a pre-mapped world of %d tiles of %.0f m; per frame: decode of "
+                        "the indexed packets (H2D + decode + compensate) + roll of the device map to the tiles within "
+                        "ROI_RANGE %.0f m of the prior (MapManager.h:13: evict the tile rectangle's complement, append "
+                        "the entering tiles from host memory) + %d ICP iters + accepted increment (device-side pending "
+                        "list, merged once %d points are pending)"
+                        % (name, nfr, n_tiles, pr, R, args.iters, args.append_threshold),
             "map_points_mean": int(mi.n_points), "map_subdiv": int(mi.subdiv), "map_update": "incremental",
             "pairs_per_s": state["pairs"] / elapsed, "stage_ms_per_frame": {k: 1e3 * v / steps for k, v in stage.items()},
             "map": dict(full_builds=state["full"], rolls=state["rolls"], points_uploaded=state["up"],
@@ -908,7 +961,12 @@ def main():
     if args.workload == "stream":
         if world > 1:
             raise SystemExit("the stream workload is one sequence on one GPU (run N replicas for N GPUs)")
-        rec = run_replay(args, dev, local, args.steps, args.warmup) if args.drive else run_stream(args, dev, local, args.steps, args.warmup, args.stream_map_points, args.stream_frames)
+        if args.drive:
+            rec = run_replay(args, dev, local, args.steps, args.warmup)
+        elif args.stream_policy == "tiles":
+            rec = run_replay(args, dev, local, args.steps, args.warmup, d=synthetic_drive(args, dev, None))
+        else:
+            rec = run_stream(args, dev, local, args.steps, args.warmup, args.stream_map_points, args.stream_frames)
         out = {"metric": "rolling-map registered frames/s", "value": rec["frames_per_s"],
                "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": rec["ms_per_frame"], "higher_is_better": True, "scaling": "weak",
@@ -1174,9 +1232,13 @@ def main():
                 out["dense"] = dense_record(args, d, dev, local)
             if want(args, "stream"):
                 trace("stream ...")
-                out["stream"] = run_stream(args, dev, local, args.stream_steps, 10,
-                                           args.stream_map_points, args.stream_frames,
-                                           src=d["stream_src"] if rank == 0 and F >= 24 else None)
+                src = d["stream_src"] if rank == 0 and F >= 24 else None
+                if args.stream_policy == "tiles":
+                    out["stream"] = run_replay(args, dev, local, args.stream_steps, 10,
+                                               d=synthetic_drive(args, dev, src))
+                else:
+                    out["stream"] = run_stream(args, dev, local, args.stream_steps, 10,
+                                               args.stream_map_points, args.stream_frames, src=src)
         emit(out)
         if rc:
             sys.stderr.write("bench: GPU pose differs from the CPU path beyond the north-star tolerance: %r\n"
