@@ -150,6 +150,11 @@ struct velo_ctx {
     DevBuf<int64_t> d_frame_start;
     std::vector<BlockItem> items_h;   // frame-major
     std::vector<int32_t> fbs_h;
+    // host copies of the other work-item lists: kept alive here so that their uploads need no
+    // synchronisation (plan_frames runs once per FRAME in a stream; ev_plan = last upload)
+    std::vector<BlockItem> plan_late_h, plan_lo_h, plan_xcd_h;
+    std::vector<int32_t> plan_fbl_h;
+    hipEvent_t ev_plan = nullptr;
     DevBuf<BlockItem> items;          // frame-major (single-frame entry points index into it)
     DevBuf<BlockItem> items_first;    // the same items in launch order (launch_order)
     DevBuf<BlockItem> items_xcd;      // same blocks, dealt so that XCD r works on spatial slab r
@@ -291,6 +296,25 @@ struct velo_ctx {
     } while (0)
 
 namespace {
+
+// A map update rewrites the live sorted arrays / the fine-cell table in place.  If it fails after
+// it has started doing so (a HIP error, out of memory), the ctx must not keep pointing at a
+// half-updated map: the guard turns such a failure into "no map" (VELO_E_NOMAP on the next
+// registration, velo_map_reset recovers) -- never a silently inconsistent one.
+struct MapTxn {
+    velo_ctx* c;
+    bool touched = false, ok = false;
+    explicit MapTxn(velo_ctx* ctx) : c(ctx) {}
+    ~MapTxn()
+    {
+        if (touched && !ok) c->has_map = false;
+    }
+    int done(int rc)
+    {
+        ok = rc == VELO_OK;
+        return rc;
+    }
+};
 
 int ensure_temp(velo_ctx* c, size_t bytes)
 {
@@ -483,6 +507,8 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     size_t tb = 0;
     HIP_TRY(c, sort_pairs(nullptr, tb, c->keys.p, c->keys_sorted.p, c->idx.p, c->perm.p, n, bits, s));
     if (int rc = ensure_temp(c, tb)) return rc;
+    MapTxn txn(c);
+    txn.touched = true;  // from here on the live arrays (keys_sorted, perm, pts, the table) are rewritten
     HIP_TRY(c, sort_pairs(c->temp.p, tb, c->keys.p, c->keys_sorted.p, c->idx.p, c->perm.p, n, bits, s));
     const float4* old_pts = c->pts.p;
     if (carry) {
@@ -525,7 +551,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
         HIP_TRY(c, launch_count_invalid(c->nrm.p, (uint32_t)n, c->invalid_cnt.p, s));
         HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
-        return publish_map(c, mv, k_normals, invalid, 0, c->n_done_host);
+        return txn.done(publish_map(c, mv, k_normals, invalid, 0, c->n_done_host));
     }
     if (k_normals > 0) {
         HIP_TRY(c, launch_normals(mv, c->perm.p, k_normals, c->nrm.p, c->invalid_cnt.p, s));
@@ -534,7 +560,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
         HIP_TRY(c, hipMemsetAsync(c->nrm.p, 0, n * sizeof(float4), s));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
-    return publish_map(c, mv, k_normals, invalid, 0, k_normals > 0 ? n : 0);
+    return txn.done(publish_map(c, mv, k_normals, invalid, 0, k_normals > 0 ? n : 0));
 }
 
 // Sub-division of a freshly reset map: as configured, or (cfg.map_subdiv == 0) chosen from the
@@ -663,6 +689,8 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     HIP_TRY(c, reserve_slack(c->nrm_alt, total));
     HIP_TRY(c, reserve_slack(c->perm_alt, total));
     HIP_TRY(c, reserve_slack(c->keys_alt, total));
+    MapTxn txn(c);
+    txn.touched = true;  // (the merge writes the second set of arrays, but the table is updated in place)
     HIP_TRY(c, launch_merge(c->pts.p, c->nrm.p, c->perm.p, c->keys_sorted.p, (uint32_t)n_old,
                             c->raw_x.p, c->raw_y.p, c->raw_z.p, (uint32_t)n_old, c->nk_sorted.p,
                             c->nidx_sorted.p, (uint32_t)m, c->pts_alt.p, c->nrm_alt.p,
@@ -701,7 +729,7 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     HIP_TRY(c, hipStreamSynchronize(s));
     for (int a = 0; a < 3; ++a) c->map_mx[a] = mx[a];
     *done = 1;
-    return publish_map(c, g, k, invalid, 1, c->n_done_host);
+    return txn.done(publish_map(c, g, k, invalid, 1, c->n_done_host));
 }
 
 
@@ -845,6 +873,11 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     for (int f = 0; f < n_frames; ++f)
         if (frame_start[f + 1] < frame_start[f]) return c->fail(VELO_E_INVALID, "frame_start must ascend");
     if (frame_start[n_frames] >= INT32_MAX) return c->fail(VELO_E_RANGE, "too many query points");
+    // the previous plan's uploads read the host vectors rewritten below: normally long complete
+    if (c->ev_plan)
+        HIP_TRY(c, hipEventSynchronize(c->ev_plan));
+    else
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
     c->n_frames = n_frames;
     ++c->frames_gen;
     c->frame_start.assign(frame_start, frame_start + n_frames + 1);
@@ -908,8 +941,10 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
         max_rows = std::max(max_rows, (size_t)std::max(c->ni_late, c->ni_conv));
     }
     if (lat_sparse) {  // plain 256-query items, frame-major, for the hinted iterations
-        std::vector<BlockItem> late;
-        std::vector<int32_t> fbl((size_t)n_frames + 1, 0);
+        std::vector<BlockItem>& late = c->plan_late_h;
+        std::vector<int32_t>& fbl = c->plan_fbl_h;
+        late.clear();
+        fbl.assign((size_t)n_frames + 1, 0);
         for (int f = 0; f < n_frames; ++f) {
             fbl[f] = (int32_t)late.size();
             for (int64_t q = frame_start[f]; q < frame_start[f + 1]; q += kLinThreads) {
@@ -929,7 +964,6 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
                                       hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipMemcpyAsync(c->fbs_late.p, fbl.data(), fbl.size() * sizeof(int32_t),
                                       hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors go out of scope
             c->ni_late = (int)late.size();
         }
     }
@@ -940,7 +974,8 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     HIP_TRY(c, c->poses.reserve((size_t)maxb * 12));
     HIP_TRY(c, c->acc.reserve((size_t)maxb * kAccStride));
     HIP_TRY(c, c->stats.reserve((size_t)maxb * VELO_MAX_ITERS));
-    std::vector<BlockItem> lo;  // the same items in launch order (registrations)
+    std::vector<BlockItem>& lo = c->plan_lo_h;  // the same items in launch order (registrations)
+    lo.clear();
     if (ni) {
         HIP_TRY(c, hipMemcpyAsync(c->items.p, c->items_h.data(), ni * sizeof(BlockItem),
                                   hipMemcpyHostToDevice, c->stream));
@@ -949,7 +984,8 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
         HIP_TRY(c, hipMemcpyAsync(c->items_first.p, lo.data(), ni * sizeof(BlockItem), hipMemcpyHostToDevice,
                                   c->stream));
     }
-    std::vector<BlockItem> xcd;
+    std::vector<BlockItem>& xcd = c->plan_xcd_h;
+    xcd.clear();
     if (c->cfg.sort_frames == 1 && ni) {
         // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an XCD, each
         // with its own 4 MiB L2).  With cell-sorted queries, eighth r of every frame covers
@@ -975,7 +1011,8 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     HIP_TRY(c, hipMemcpyAsync(c->d_frame_start.p, c->frame_start.data(),
                               ((size_t)n_frames + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
                               c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be reused
+    // every source above is a ctx member that lives until the next plan: no wait here
+    HIP_TRY(c, hipEventRecord(c->ev_plan, c->stream));
     return VELO_OK;
 }
 
@@ -1347,6 +1384,7 @@ void velo_destroy(velo_ctx* c)
     if (c->ev_pend) (void)hipEventDestroy(c->ev_pend);
     if (c->h_dec_stage) (void)hipHostFree(c->h_dec_stage);
     if (c->ev_inc) (void)hipEventDestroy(c->ev_inc);
+    if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_call0) (void)hipEventDestroy(c->ev_call0);
     if (c->ev_call1) (void)hipEventDestroy(c->ev_call1);
@@ -1669,8 +1707,8 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
         const int dims[3] = {old.nx, old.ny, old.nz};
         int rc = anchor ? rebuild_map(c, old.h, k, nullptr, nullptr, carry ? &cr : nullptr)
                         : rebuild_map(c, old.h, k, org, dims);
-        if (rc) {  // restore the old list; the old sorted map is still in place
-            swap_raw();
+        if (rc) {  // restore the old point list (if the rebuild had started rewriting the sorted
+            swap_raw();  // arrays the ctx now has NO map, see MapTxn: velo_map_reset recovers)
             c->raw_n = n;
         }
         return rc;
@@ -1687,6 +1725,8 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
         HIP_TRY(c, reserve_slack(c->nk_sorted, n - kept));  // sorted keys of the removed points
         HIP_TRY(c, launch_removed_keys(c->keys_sorted.p, c->flags.p, c->offs.p, n, c->nk_sorted.p, s));
     }
+    MapTxn txn(c);
+    txn.touched = true;  // the table is remapped in place below
     HIP_TRY(c, launch_compact_sorted(c->pts.p, c->nrm.p, c->perm.p, c->keys_sorted.p, n, c->flags.p,
                                      c->offs.p, c->roffs.p, c->pts_alt.p, c->nrm_alt.p,
                                      c->perm_alt.p, c->keys_alt.p, s));
@@ -1720,7 +1760,7 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     for (int a = 0; a < 3; ++a) c->map_mx[a] = mm.mx[a];
-    return publish_map(c, g, k, invalid, 1, c->n_done_host);
+    return txn.done(publish_map(c, g, k, invalid, 1, c->n_done_host));
 }
 
 int velo_map_set_margins(velo_ctx* c, const int32_t margin[3])
