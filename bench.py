@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--no-timing", action="store_true", help="skip per-launch HIP events (A/B their overhead)")
     ap.add_argument("--exchange", choices=["capi", "torch"], default="capi",
                     help="N > 1 transport of the increments: RCCL behind the C ABI, or torch.distributed")
+    ap.add_argument("--capi-timeout-s", type=int, default=120,
+                    help="N > 1: seconds the C-ABI RCCL transport gets (bring-up + self-test + its measurement) before the "
+                         "line measured with torch.distributed's transport is printed instead")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--workload", choices=["batch", "stream"], default="batch",
                     help="batch = BASELINE configs[1] (the headline line); stream = configs[2]: "
@@ -1005,7 +1008,11 @@ def main():
     # should the communicator fail to come up -- the line says which one ran.
     transport = "torch.distributed"
     gathered = None
-    if exchange and not one_dev and args.exchange == "capi":
+    selftest = None
+
+    def negotiate_capi():
+        """bring up the C-ABI communicator on every rank (or on none); True when it is in use"""
+        nonlocal transport, gathered
         # Every rank takes part in every collective of the negotiation whatever fails locally: rank 0
         # broadcasts the id or None, then all ranks agree on `ok` (a rank that skipped the broadcast
         # would leave the others blocked in it).
@@ -1033,6 +1040,27 @@ def main():
         if ok:
             transport = "velo_exchange_increments (RCCL via the C ABI)"
             gathered = torch.empty((3, n_q * world), dtype=torch.float32, device=dev)
+        return bool(ok)
+
+    def capi_selftest():
+        """one exchange of known content on the real communicator: rank r contributes 5 (r + 1) points
+        (x = r, y = index, z = -r); every rank must get all of them back in RANK ORDER -- the first
+        time the pack runs behind a world > 1 all-gather on hardware"""
+        n = 5 * (rank + 1)
+        mine = torch.zeros((3, 8 * world + 8), dtype=torch.float32, device=dev)
+        mine[0, :n], mine[1, :n], mine[2, :n] = float(rank), torch.arange(n, device=dev, dtype=torch.float32), -float(rank)
+        torch.cuda.synchronize()
+        counts, total = ctx.exchange_increments(mine[0].data_ptr(), mine[1].data_ptr(), mine[2].data_ptr(), n,
+                                                gathered[0].data_ptr(), gathered[1].data_ptr(),
+                                                gathered[2].data_ptr(), gathered.shape[1], after_async_increment=False)
+        ctx.synchronize()
+        want = np.concatenate([np.stack([np.full(5 * (r + 1), r, np.float32), np.arange(5 * (r + 1), dtype=np.float32),
+                                         np.full(5 * (r + 1), -r, np.float32)]) for r in range(world)], axis=1)
+        got = gathered[:, :total].cpu().numpy()
+        if counts != [5 * (r + 1) for r in range(world)] or not np.array_equal(got, want):
+            raise SystemExit("bench: velo_exchange_increments returned the wrong blocks on rank %d" % rank)
+        return "rank-order exchange of known content verified on %d ranks" % world
+
     side = torch.cuda.Stream() if exchange else None
     ev_inc = [torch.cuda.Event(), torch.cuda.Event()] if exchange else None
     ev_free = [None, None]  # side stream is done reading increment buffer b
@@ -1104,66 +1132,131 @@ def main():
         state["cur"] = b ^ 1
 
     trace("map + frames resident")
-    # settle: the first process on a freshly leased box showed one-off 40 ms host stalls inside the
-    # first ~100 launches (runtime pools growing); a quarter of a second of the same untimed steps
-    # (--settle-s / 2.5 ms steps) absorbs them before the W warm-up steps the contract asks for
-    # (a FIXED number of steps, the same on every rank: with N > 1 every step carries a collective)
-    # The harness is Python: a generation-2 garbage collection of this process's heap takes 30-40 ms
-    # (15 steps' worth) and strikes once every ~160 steps -- collect now, keep the collector off
-    # for the timed region (re-enabled after it)
-    gc.collect()
-    gc.disable()
-    for _ in range(int(round(args.settle_s / 0.0025))):
-        step(False)
+
+    def measure():
+        """settle + warm-up + the K timed steps with whatever transport is in effect"""
+        nonlocal pending, pending_n
+        pending, pending_n = [], 0
+        state.update(cur=0, prev=None, exchanged_points=0, appends=0, appended_points=0)
+        ev_free[0] = ev_free[1] = None
+        # settle: the first process on a freshly leased box showed one-off 40 ms host stalls inside the
+        # first ~100 launches (runtime pools growing); a quarter of a second of the same untimed steps
+        # (--settle-s / 2.5 ms steps) absorbs them before the W warm-up steps the contract asks for
+        # (a FIXED number of steps, the same on every rank: with N > 1 every step carries a collective)
+        # The harness is Python: a generation-2 garbage collection of this process's heap takes 30-40 ms
+        # (15 steps' worth) and strikes once every ~160 steps -- collect now, keep the collector off
+        # for the timed region (re-enabled after it)
+        gc.collect()
+        gc.disable()
+        for _ in range(int(round(args.settle_s / 0.0025))):
+            step(False)
+            torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step(False)
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    trace("warm-up done")
-    ctx.pairs_total(reset=True)
-    state["exchanged_points"] = state["appends"] = state["appended_points"] = 0
-    if world > 1:
-        dist.barrier()
-    lin_ms, lin_n, lin_first, lin_min, n_samples = 0.0, 0, 0.0, 1e30, 0
-    t0 = time.perf_counter()
-    step_t = []
-    for k in range(args.steps):
-        sample = (not args.no_timing) and (k % max(args.time_every, 1) == 0)
+        trace("warm-up done")
+        ctx.pairs_total(reset=True)
+        state["exchanged_points"] = state["appends"] = state["appended_points"] = 0
+        if world > 1:
+            dist.barrier()
+        lin_ms, lin_n, lin_first, lin_min, n_samples = 0.0, 0, 0.0, 1e30, 0
+        t0 = time.perf_counter()
+        step_t = []
+        for k in range(args.steps):
+            sample = (not args.no_timing) and (k % max(args.time_every, 1) == 0)
+            step_t.append(time.perf_counter())
+            step(sample)
+            if sample:
+                # HIP events on the ctx stream, read back after this step's work is enqueued
+                # (fetch synchronises the stream; it is part of the timed region on purpose)
+                ctx.icp_batch_fetch()
+                if exchange:
+                    start_increment()
+                tm_k = ctx.last_timing()
+                lin_ms += tm_k["linearize_ms"]
+                lin_n += tm_k["linearize_launches"]
+                lin_first += tm_k["linearize_first_ms"]
+                lin_min = min(lin_min, tm_k["linearize_min_ms"])
+                n_samples += 1
+        if exchange and state["prev"] is not None:
+            finish_exchange(state["prev"])                # drain the pipeline inside the timed region
+            state["prev"] = None
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        gc.enable()
         step_t.append(time.perf_counter())
-        step(sample)
-        if sample:
-            # HIP events on the ctx stream, read back after this step's work is enqueued
-            # (fetch synchronises the stream; it is part of the timed region on purpose)
-            ctx.icp_batch_fetch()
-            if exchange:
-                start_increment()
-            tm_k = ctx.last_timing()
-            lin_ms += tm_k["linearize_ms"]
-            lin_n += tm_k["linearize_launches"]
-            lin_first += tm_k["linearize_first_ms"]
-            lin_min = min(lin_min, tm_k["linearize_min_ms"])
-            n_samples += 1
-    if exchange and state["prev"] is not None:
-        finish_exchange(state["prev"])                # drain the pipeline inside the timed region
-        state["prev"] = None
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    step_t.append(time.perf_counter())
-    trace("timed region done; host ms per step: " + " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip(step_t[:-1], step_t[1:])))
-    pairs_rank = ctx.pairs_total(reset=True)          # counted on the device over the K timed steps
-    res = ctx.icp_batch_fetch()
-    ctx.set_timing(0)
-    ns = max(n_samples, 1)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    pr = torch.tensor([float(pairs_rank)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(pr, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    total_pairs = float(pr.item())
+        trace("timed region done; host ms per step: " + " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip(step_t[:-1], step_t[1:])))
+        pairs_rank = ctx.pairs_total(reset=True)          # counted on the device over the K timed steps
+        res = ctx.icp_batch_fetch()
+        ctx.set_timing(0)
+        ns = max(n_samples, 1)
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        pr = torch.tensor([float(pairs_rank)], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            dist.all_reduce(pr, op=dist.ReduceOp.SUM)
+        elapsed = float(el.item())
+        total_pairs = float(pr.item())
+
+        return dict(elapsed=elapsed, total_pairs=total_pairs, res=res, lin_ms=lin_ms, lin_n=lin_n, lin_first=lin_first,
+                    lin_min=lin_min, ns=ns, transport=transport, exchanged=state["exchanged_points"],
+                    appends=state["appends"], appended=state["appended_points"])
+
+    def basic_line(m, note=None):
+        """the contract's fields from one measurement (what a watchdog can still print)"""
+        o = {"metric": "ICP correspondence-pairs/s", "value": m["total_pairs"] / m["elapsed"],
+             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+             "ms_per_step": 1e3 * m["elapsed"] / args.steps, "higher_is_better": True,
+             "scaling": "weak", "vs_baseline": None, "dtype": "f32 points, f64 pose/accumulators",
+             "data": "synthetic",
+             "config": {"workload": "BASELINE configs[1]: 115200-pt HDL-64E frame vs %d-pt map, "
+                                    "%d ICP iters, d_max %.2f m, voxel %.2f m; %d frames per step "
+                                    "per GPU, resident in HBM" % (args.map_points, args.iters, args.d_max, args.voxel, F),
+                        "frames_per_step_per_gpu": F, "points_per_frame": n_q // max(F, 1),
+                        "map_points": args.map_points, "iters": args.iters,
+                        "parallelism": "frame-parallel x%d" % world},
+             "frames_per_s": world * F * args.steps / m["elapsed"], "total_pairs": m["total_pairs"]}
+        if note:
+            o["exchange"] = {"ranks": world, "transport": m["transport"], "note": note,
+                             "points_exchanged": m["exchanged"], "points_appended": m["appended"]}
+        return o
+
+    # N > 1 with the C-ABI transport (the default): that RCCL path cannot be exercised before it meets a
+    # multi-GPU node, and a collective that never completes cannot be cancelled -- so the run is
+    # measured with torch.distributed's transport FIRST, and a watchdog holds that line: if the C-ABI
+    # communicator, its self-test or its measurement does not finish in --capi-timeout-s, rank 0 prints
+    # the line it has (marked) and every rank leaves.  Otherwise the line is the C-ABI transport's.
+    m_safe = None
+    watchdog = None
+    if exchange and not one_dev and args.exchange == "capi":
+        if world > 1:
+            m_safe = measure()
+            trace("torch.distributed transport measured: %.3f ms per step" % (1e3 * m_safe["elapsed"] / args.steps))
+
+            def give_up():
+                sys.stderr.write("bench: the C-ABI RCCL transport did not finish within %d s on rank %d\n"
+                                 % (args.capi_timeout_s, rank))
+                if rank == 0:
+                    emit(basic_line(m_safe, "measured with torch.distributed (nccl = RCCL) collectives; the C-ABI transport "
+                                            "(velo_comm_init / velo_exchange_increments) did not complete within %d s and "
+                                            "was NOT measured" % args.capi_timeout_s))
+                os._exit(0)
+
+            import threading
+            watchdog = threading.Timer(float(args.capi_timeout_s), give_up)
+            watchdog.daemon = True
+            watchdog.start()
+            ctx.map_reset(*d["map"], args.voxel, args.k_normals)   # the same starting map for the second measurement
+        if negotiate_capi() and world > 1:
+            selftest = capi_selftest()
+            trace(selftest)
+    m = measure()
+    if watchdog is not None:
+        watchdog.cancel()
+    elapsed, total_pairs, res = m["elapsed"], m["total_pairs"], m["res"]
+    lin_ms, lin_n, lin_first, lin_min, ns = m["lin_ms"], m["lin_n"], m["lin_first"], m["lin_min"], m["ns"]
 
     # sanity: the timed work really registered the frames
     worst = max(float(np.linalg.norm(np.array(list(r.T)).reshape(3, 4)[:, 3] - d["Ttrue"][i].reshape(3, 4)[:, 3]))
@@ -1194,9 +1287,9 @@ def main():
         if exchange:
             c_rank, c_world = ctx.comm_info()
             out["exchange"] = {"ranks": c_world if gathered is not None else world,   # velo_comm_info: what the communicator really spans
-                               "verified": ("rank-order pack kernel vs numpy for W = 1..64 (tests/test_gpu_comm.py); "
-                                            "RCCL transport at world > 1 first exercised by this run"
-                                            if world > 1 else "single rank: the collectives are degenerate"),
+                               "verified": (selftest or ("rank-order pack kernel vs numpy for W = 1..64 (tests/test_gpu_comm.py)"
+                                                         if world > 1 else "single rank: the collectives are degenerate")),
+                               "torch_transport_ms_per_step": (1e3 * m_safe["elapsed"] / args.steps) if m_safe else None,
                                "increments": "every frame of every batch",
                                "transport": transport + ((" " + dist.get_backend()) if world > 1 and gathered is None else ""),
                                "points_exchanged": state["exchanged_points"], "map_appends": state["appends"],
