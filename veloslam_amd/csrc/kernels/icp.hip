@@ -342,6 +342,9 @@ constexpr int kLatItems = 2048;  // launches below this many workgroups use the 
 #define VELO_CERT_SLACK 0.015f  // measured: 0.005-0.02 within 1%, 0.05 +3%, 0.10 +5% (batch); dense single frame 0.68 vs 0.73 ms
 #endif
 constexpr float kCertSlack = VELO_CERT_SLACK;  // metres searched beyond the hinted point (tuning only)
+#ifndef VELO_BALL_PROBE
+#define VELO_BALL_PROBE 1
+#endif
 #ifndef VELO_UBM
 #define VELO_UBM 0
 #endif
@@ -566,8 +569,33 @@ __device__ __forceinline__ int ball_window(float b, float inv_hf, int S)
     return min(S, (int)floorf(sqrtf(b) * 1.00001f * inv_hf + 1.001f));
 }
 
+// index range of fine row (Fz+dz, Fy+dy) inside the ball of squared radius `bound` around the
+// query (conservative: rounded outwards); clip1: only the cells Fx-1..Fx+1.  false = nothing.
 template <bool STATS, bool HASH>
-__device__ void search_ball(const MapView& mv, float qx, float qy, float qz, float ub,
+__device__ __forceinline__ bool ball_row(const MapView& mv, const QueryCell& g, int dz, int dy,
+                                         float bound, float xf, float hf, float inv_hf, float mg,
+                                         bool clip1, int& jlo, int& jhi, Tally<STATS>& tl)
+{
+    const int zz = g.Fz + dz, yy = g.Fy + dy;
+    if (zz < 0 || zz >= mv.fz || yy < 0 || yy >= mv.fy) return false;
+    const float bz = axis_gap(dz, g.tz, hf, mg), by = axis_gap(dy, g.ty, hf, mg);
+    const float rb2 = (bz * bz + by * by) * 0.99999f;
+    if (rb2 > bound) return false;
+    // half-width of the ball in this row, in fine cells, rounded outwards
+    const float w = (sqrtf(fmaxf(bound - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
+    int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
+    if (clip1) {
+        x0 = max(x0, g.Fx - 1);
+        x1 = min(x1, g.Fx + 1);
+    }
+    if (x0 > x1) return false;
+    const uint32_t row = ((uint32_t)zz * (uint32_t)mv.fy + (uint32_t)yy) * (uint32_t)mv.fx;
+    tl.table(2, 4);
+    return row_range32<HASH>(mv, row, x0, x1, jlo, jhi);
+}
+
+template <bool STATS, bool HASH>
+__device__ void search_ball(const MapView& mv, float qx, float qy, float qz, float ub, bool probe,
                             SearchLds& L, int tid, float& bd, int& bj, float& cert, Tally<STATS>& tl)
 {
     const QueryCell g = locate(mv, qx, qy, qz);
@@ -580,6 +608,51 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
     // map point within sqrt(cov) at the end has been looked at and `sd` (second-smallest
     // distance seen) bounds everything but the winner -- a certificate, as in the cooperative
     // form.  (Without it a straggler of this path came back as a straggler at every iteration.)
+#if VELO_BALL_PROBE
+    // A straggler whose 3x3x3 block held NOTHING has no bound but d_max: its ball is a whole voxel
+    // wide, all (2S+1)^2 rows, and the wavefront runs for it (a third of the stragglers of an
+    // unhinted launch, round 3).  Probe first where a slightly misplaced frame finds its surface:
+    // the query's own row at full width and the rows straight above / below / beside it (cells
+    // Fx-1..Fx+1), nearest first.  The probe only tightens the bound -- some map point lies that
+    // close, so the winner is no further; the search proper below still visits everything within
+    // it in index order, so ties resolve as ever.
+    if (probe) {
+        float pb = ub;
+        int nr = 0;
+        int jlo, jhi;
+        if (ball_row<STATS, HASH>(mv, g, 0, 0, pb, xf, hf, inv_hf, mg, false, jlo, jhi, tl)) {
+            L.hi[nr][tid] = jhi;
+            L.lo[nr][tid] = jlo;
+            ++nr;
+        }
+        int k = 2, side = 0;
+#pragma unroll 1
+        while (k <= S) {
+            while (nr < kMaxRanges && k <= S) {
+                const int dz = side == 0 ? k : (side == 1 ? -k : 0);
+                const int dy = side == 2 ? k : (side == 3 ? -k : 0);
+                if (ball_row<STATS, HASH>(mv, g, dz, dy, pb, xf, hf, inv_hf, mg, true, jlo, jhi, tl)) {
+                    L.hi[nr][tid] = jhi;
+                    L.lo[nr][tid] = jlo;
+                    ++nr;
+                }
+                if (++side == 4) {
+                    side = 0;
+                    ++k;
+                }
+            }
+            int pj = -1;
+            float sd_unused = pb;
+            walk_ranges<VELO_WALK_W>(mv, qx, qy, qz, L, tid, nr, pb, pj, sd_unused, tl);
+            nr = 0;
+            const float far = axis_gap(k, 1.0f, hf, mg);  // nearest any probe row at offset >= k can be
+            if (far * far * 0.99999f > pb) break;
+        }
+        ub = fminf(ub, pb);
+    }
+#else
+    (void)probe;
+#endif
     float cov = cover_of(ub, mv.h);
     float sd = cov;
     bd = cov;
@@ -700,31 +773,6 @@ __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, fl
 
 // ---- stage B for the LATENCY kernel (k_linearize_lat: a single frame, a few hundred
 // workgroups -- nothing hides a memory round trip, and registers are plentiful) -------------
-// index range of fine row (Fz+dz, Fy+dy) inside the ball of squared radius `bound` around the
-// query (conservative: rounded outwards); clip1: only the cells Fx-1..Fx+1.  false = nothing.
-template <bool STATS, bool HASH>
-__device__ __forceinline__ bool ball_row(const MapView& mv, const QueryCell& g, int dz, int dy,
-                                         float bound, float xf, float hf, float inv_hf, float mg,
-                                         bool clip1, int& jlo, int& jhi, Tally<STATS>& tl)
-{
-    const int zz = g.Fz + dz, yy = g.Fy + dy;
-    if (zz < 0 || zz >= mv.fz || yy < 0 || yy >= mv.fy) return false;
-    const float bz = axis_gap(dz, g.tz, hf, mg), by = axis_gap(dy, g.ty, hf, mg);
-    const float rb2 = (bz * bz + by * by) * 0.99999f;
-    if (rb2 > bound) return false;
-    // half-width of the ball in this row, in fine cells, rounded outwards
-    const float w = (sqrtf(fmaxf(bound - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
-    int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
-    if (clip1) {
-        x0 = max(x0, g.Fx - 1);
-        x1 = min(x1, g.Fx + 1);
-    }
-    if (x0 > x1) return false;
-    const uint32_t row = ((uint32_t)zz * (uint32_t)mv.fy + (uint32_t)yy) * (uint32_t)mv.fx;
-    tl.table(2, 4);
-    return row_range32<HASH>(mv, row, x0, x1, jlo, jhi);
-}
-
 // per-lane form.  Called by every lane of the wavefront (`active` = this lane is a straggler):
 // the loops synchronise with __any.
 template <bool STATS, bool HASH>
@@ -1036,7 +1084,7 @@ __device__ __forceinline__ void linearize_body(
                     }
                 } else if (queued) {
                     const float ub = bd;
-                    search_ball<STATS, HASH>(mv, qx, qy, qz, ub, s_u.s, lane, bd, bj, rho_new_out, tl);
+                    search_ball<STATS, HASH>(mv, qx, qy, qz, ub, bj < 0, s_u.s, lane, bd, bj, rho_new_out, tl);
                 }
             } else {
                 while (need) {
