@@ -342,6 +342,15 @@ constexpr int kLatItems = 2048;  // launches below this many workgroups use the 
 #define VELO_CERT_SLACK 0.015f  // measured: 0.005-0.02 within 1%, 0.05 +3%, 0.10 +5% (batch); dense single frame 0.68 vs 0.73 ms
 #endif
 constexpr float kCertSlack = VELO_CERT_SLACK;  // metres searched beyond the hinted point (tuning only)
+#ifndef VELO_OWN_FIRST_S
+#define VELO_OWN_FIRST_S 4  // sub-division from which stage A probes the query's own fine cell first (99 = never)
+#endif
+#ifndef VELO_OWN_FIRST_LAT
+#define VELO_OWN_FIRST_LAT 0  // 1: also in the latency kernel (W >= 8) -- measured: stream ICP 0.59 -> 0.63 ms, off
+#endif
+#ifndef VELO_OWN_FIRST_R
+#define VELO_OWN_FIRST_R 1.0f
+#endif
 #ifndef VELO_BALL_PROBE
 #define VELO_BALL_PROBE 1
 #endif
@@ -466,6 +475,7 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
     cert = 0.0f;  // radius (m) around the query inside which the winner is the only map point
     gr_out = 0.0f;
     if (!g.near) return kFinal;  // no voxel of the 27 exists: no candidates at all
+    // (ub0 may be tightened below by the own-cell probe; bd follows it before the walk)
     const float hf = mv.h / (float)mv.S;
     const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
     // conservative distances from the query to the faces of its own fine cell, squared;
@@ -494,6 +504,28 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
     // 32-bit row arithmetic (mod 2^32): key of cell (Fx = 0, Fy + dy, Fz + dz)
     const uint32_t sy = (uint32_t)mv.fx, sz = (uint32_t)mv.fx * (uint32_t)mv.fy;
     const uint32_t rowc = ((uint32_t)g.Fz * (uint32_t)mv.fy + (uint32_t)g.Fy) * (uint32_t)mv.fx;
+#if VELO_OWN_FIRST_S < 99
+    // Dense maps (fine cells holding several points each: S >= VELO_OWN_FIRST_S): look into the
+    // query's OWN fine cell first.  A point found there bounds the winner, and with that bound most
+    // of the 26 cells around are pruned before their candidates are fetched -- on a 10 M-point map
+    // an unhinted or loosely hinted query otherwise examines 80-100 candidates.  A bound only (with
+    // the certificate slack added, as for a hint): the walk below still finds the winner itself.
+    // (only while the bound is loose -- a radius beyond VELO_OWN_FIRST_R fine cells: a tightly
+    // hinted query prunes the block by itself, and the probe would cost it candidates and slack)
+    if ((VELO_OWN_FIRST_LAT || W < 8) && mv.S >= VELO_OWN_FIRST_S && ub0 > (VELO_OWN_FIRST_R * VELO_OWN_FIRST_R) * hf * hf &&
+        (unsigned)g.Fx < (unsigned)mv.fx && (unsigned)g.Fy < (unsigned)mv.fy && (unsigned)g.Fz < (unsigned)mv.fz) {
+        int jlo, jhi;
+        row_range32<HASH>(mv, rowc, g.Fx, g.Fx, jlo, jhi);
+        tl.table(2, 4);
+        float pb = ub0;
+        for (int j = jhi - 1; j >= jlo; --j) pb = fminf(pb, dist2(mv.pts[(unsigned)j], qx, qy, qz));
+        tl.candidates((unsigned)max(jhi - jlo, 0));
+        if (pb < ub0) {
+            const float rs = sqrtf(pb) * 1.000001f + 1e-7f + kCertSlack;
+            ub0 = fminf(ub0, rs * rs * 1.00001f);
+        }
+    }
+#endif
     int nr = 0;
     if (g.Fx + 1 >= 0 && g.Fx - 1 < mv.fx && ABL < 3) {
 #pragma unroll
@@ -531,6 +563,7 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
     }
 #undef VELO_PRUNED
     if (ABL >= 2) nr = min(nr, 0);
+    bd = ub0;
     float sd = ub0;  // everything not scanned inside the block is further than sqrt(ub0)
     walk_ranges<W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd, tl);
     if (ABL >= 1) return kFinal;
