@@ -1219,3 +1219,51 @@ def test_rolling_a_5m_point_map_incremental_equals_full_rebuild():
     finally:
         inc.close()
         ful.close()
+
+
+def test_pending_increments_equal_the_explicit_path(wl, comp):
+    """velo_increment_pending / velo_pending_count / velo_pending_fetch / velo_map_append_pending: the
+    device-side list must hold exactly what velo_increment_dev returns, frame after frame, and merging
+    it must leave the map velo_map_append_dev of the same points leaves (bit for bit) -- with the pose
+    given explicitly and with the pose the last registration left on the device."""
+    import torch
+    mx, my, mz = wl["map"]
+    a = capi.Context(0, max_batch=2, map_margin=4)
+    b = capi.Context(0, max_batch=2, map_margin=4)
+    try:
+        for c in (a, b):
+            c.map_reset(mx, my, mz, 1.0, 16)
+        want = []
+        for k, f in enumerate(wl["frames"][:2]):
+            for c in (a, b):
+                c.frames_upload([comp[k]])
+            ra = a.icp_batch([f["T0"]], 6, 1.0)[0]
+            rb = b.icp_batch([f["T0"]], 6, 1.0)[0]
+            assert list(ra.T) == list(rb.T)
+            n = comp[k][0].size
+            buf = torch.empty((3, n), dtype=torch.float32, device="cuda")
+            cnt = b.increment_dev(0, np.array(list(rb.T)), 3, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr())
+            want.append(buf[:, :cnt].cpu().numpy())
+            if k == 0:
+                a.increment_pending(0, np.array(list(ra.T)), 3)     # explicit pose
+                assert a.pending_count(wait=False) == 0             # in flight: not counted, by definition
+            else:
+                a.increment_pending(0, None, 3)                     # the pose the registration left on the device
+                assert a.pending_count(wait=False) == want[0].shape[1]
+            assert a.pending_count(wait=True) == sum(w.shape[1] for w in want)
+        allw = np.concatenate(want, axis=1)
+        assert allw.shape[1] > 10
+        px, py, pz = a.pending_fetch()
+        assert np.array_equal(np.stack([px, py, pz]), allw)
+        assert a.map_append_pending() == allw.shape[1] and a.pending_count() == 0 and a.map_append_pending() == 0
+        dev = torch.from_numpy(allw).cuda()
+        torch.cuda.synchronize()
+        b.map_append_dev(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), allw.shape[1])
+        ga, gb = a.map_download(), b.map_download()
+        for key in ("cell_start", "perm", "x", "y", "z"):
+            assert np.array_equal(ga[key], gb[key]), key
+        for key in ("nx", "ny", "nz"):
+            assert np.array_equal(ga[key].view(np.uint32), gb[key].view(np.uint32)), key
+    finally:
+        a.close()
+        b.close()
