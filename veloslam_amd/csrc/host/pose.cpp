@@ -566,7 +566,7 @@ int velo_carposes_read(const char* path, velo_pose* poses, size_t cap, size_t* n
     *n_out = v.size();
     if (!poses) return VELO_OK;
     if (v.size() > cap) return VELO_E_RANGE;
-    std::memcpy(poses, v.data(), v.size() * sizeof(velo_pose));
+    if (!v.empty()) std::memcpy(poses, v.data(), v.size() * sizeof(velo_pose));  // (memcpy(.., nullptr, 0) is UB)
     return VELO_OK;
 }
 
