@@ -66,8 +66,8 @@ typedef struct velo_cfg {
     int32_t use_graph;      /* 1: replay a registration's launch sequence as one hipGraph
                                (cfg == NULL enables it) */
     int32_t map_subdiv;     /* sub-cells per voxel edge of the map sort order; 0 (default) = chosen
-                               at velo_map_reset from the map's density: round(1.6 rho^0.2), rho =
-                               points per occupied voxel, clamped to [2, 8]; velo_map_info.subdiv
+                               at velo_map_reset from the map's density: round(max(1.6 rho^0.2,
+                               1.137 rho^0.314)), rho = points per occupied voxel, clamped to [2, 8]; velo_map_info.subdiv
                                reports the value in use */
     int32_t use_hints;      /* temporal coherence, exact either way.  1: bound each query's search by
                                its previous correspondence; 2: also skip the search when last

@@ -236,10 +236,11 @@ vo_map* vo_map_build(const float* x, const float* y, const float* z, size_t n, f
 
 /* Sub-division chosen from the map's density (subdiv == 0 in the calls below): rho = points per
  * OCCUPIED voxel (voxels anchored on the component-wise minimum; the count does not depend on a
- * whole-voxel margin), S = round(1.6 rho^0.2) clamped to [2, 8] -- a fit of the measured optima:
- * S = 3 at rho = 22 (1 M-point map), 4 at 67 (3 M), 5 at 200-220 (9-10 M): finer
- * cells mean fewer candidates per cell but more stragglers while the pose is still off, and a
- * larger table.  Resolved once, when a map is reset. */
+ * whole-voxel margin), S = round(max(1.6 rho^0.2, 1.137 rho^0.314)) clamped to [2, 8] -- a fit of
+ * the measured optima: S = 3 at rho = 22 (1 M-point map), 4 at 67 (3 M), 6 at 200-220 (9-10 M; 5
+ * until round 3, when bounds taken before the block search moved the optimum of dense maps up:
+ * DESIGN.md): finer cells mean fewer candidates per cell but more stragglers while the pose is
+ * still off, and a larger table.  Resolved once, when a map is reset. */
 int vo_auto_subdiv(const float* x, const float* y, const float* z, size_t n, float voxel)
 {
     if (n == 0 || !(voxel > 0)) return 3;
@@ -270,7 +271,8 @@ int vo_auto_subdiv(const float* x, const float* y, const float* z, size_t n, flo
     }
     free(occ);
     const double rho = (double)n / (double)n_occ;
-    int S = (int)floor(1.6 * pow(rho, 0.2) + 0.5);
+    const double a = 1.6 * pow(rho, 0.2), b = 1.137 * pow(rho, 0.314);
+    int S = (int)floor((a > b ? a : b) + 0.5);
     return S < 2 ? 2 : (S > 8 ? 8 : S);
 }
 

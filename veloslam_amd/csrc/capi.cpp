@@ -565,7 +565,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
 
 // Sub-division of a freshly reset map: as configured, or (cfg.map_subdiv == 0) chosen from the
 // density exactly as oracle/icp.c vo_auto_subdiv does: rho = points per occupied voxel,
-// S = round(1.6 rho^0.2) clamped to [2, 8].  Kept until the next velo_map_reset.
+// S = round(max(1.6 rho^0.2, 1.137 rho^0.314)) clamped to [2, 8].  Kept until the next velo_map_reset.
 int resolve_subdiv(velo_ctx* c, float voxel)
 {
     if (c->cfg.map_subdiv > 0) {
@@ -601,7 +601,8 @@ int resolve_subdiv(velo_ctx* c, float voxel)
     HIP_TRY(c, hipStreamSynchronize(s));
     if (occ == 0) return VELO_OK;
     const double rho = (double)c->raw_n / (double)occ;
-    const int S = (int)std::floor(1.6 * std::pow(rho, 0.2) + 0.5);
+    const double a = 1.6 * std::pow(rho, 0.2), b = 1.137 * std::pow(rho, 0.314);
+    const int S = (int)std::floor((a > b ? a : b) + 0.5);
     c->map_S = S < 2 ? 2 : (S > 8 ? 8 : S);
     return VELO_OK;
 }
