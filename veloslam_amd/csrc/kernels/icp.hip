@@ -969,7 +969,7 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 };
 
 #ifndef VELO_COOP_MAX
-#define VELO_COOP_MAX 8  // (both forms certify now; 64 frames: 16 -> 2.27 ms, 4..8 -> 2.22, 2 -> 2.26, 0 -> 2.38)
+#define VELO_COOP_MAX 4  // (both forms certify; round 3, per-lane search with ball window + probe: 0 / 1 / 2 / 4 / 8 / 16 -> headline 2234 / 2165 / 2153 / 2120 / 2129 / 2138 us, dense 10 M map 1382 / 1374 / 1378 / 1371 / 1457 / 1698)
 #endif
 #ifndef VELO_COOP_MAX_LAT
 #define VELO_COOP_MAX_LAT 16  // (4 takes 20 us off the second launch on a dense map, but only the
