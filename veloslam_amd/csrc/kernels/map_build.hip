@@ -221,7 +221,13 @@ hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell
 // One thread per map point.  The running k-best list lives in LDS as
 // [slot][thread] (stride = blockDim: bank-conflict free), because a
 // dynamically indexed per-thread array would otherwise go to scratch memory.
-constexpr int kNrmThreads = 128;
+#ifndef VELO_NRM_W
+#define VELO_NRM_W 4  // candidate loads in flight per trip of the neighbour search
+#endif
+#ifndef VELO_NRM_THREADS
+#define VELO_NRM_THREADS 128
+#endif
+constexpr int kNrmThreads = VELO_NRM_THREADS;
 constexpr int kMinNb = 5;
 constexpr float kNormalRadius = 0.99f;
 
@@ -316,12 +322,12 @@ __device__ __forceinline__ int collect_knn(const MapView& mv, const uint32_t* __
                     if (!row_range_rt(mv, row, fa, fb, j0, j1)) continue;
                     // four candidate loads in flight per trip (the walk is a latency chain);
                     // a slot past the end repeats the last index and is masked
-                    for (int jb = j0; jb < j1; jb += 4) {
-                        float4 cpt[4];
+                    for (int jb = j0; jb < j1; jb += VELO_NRM_W) {
+                        float4 cpt[VELO_NRM_W];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) cpt[u] = mv.pts[min(jb + u, j1 - 1)];
+                        for (int u = 0; u < VELO_NRM_W; ++u) cpt[u] = mv.pts[min(jb + u, j1 - 1)];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < VELO_NRM_W; ++u) {
                             const int j = jb + u;
                             const float d2 = dist2(cpt[u], qx, qy, qz);
                             if (j >= j1 || !(d2 <= r2)) continue;
