@@ -194,6 +194,7 @@ struct velo_ctx {
     uint32_t* h_pend_total = nullptr;  // pinned: count of the increment in flight
     hipEvent_t ev_pend = nullptr;
     bool pend_outstanding = false;
+    uint8_t* h_result = nullptr;      // pinned: poses + per-iteration statistics of a fetch
     uint32_t* h_inc_total = nullptr;  // pinned: count of the asynchronous increment
     uint8_t* h_dec_stage = nullptr;   // pinned: packets + per-packet plan of one decode call
     size_t h_dec_cap = 0;
@@ -1237,10 +1238,16 @@ int fetch_icp(velo_ctx* c, velo_icp_result* out)
     if (c->last_iters < 1) return c->fail(VELO_E_INVALID, "no registration has run");
     HIP_TRY(c, hipSetDevice(c->device));
     const int F = c->n_frames, iters = c->last_iters;
-    std::vector<double> T((size_t)F * 12);
-    std::vector<velo_icp_iter> st((size_t)F * VELO_MAX_ITERS);
-    HIP_TRY(c, hipMemcpyAsync(T.data(), c->poses.p, T.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(st.data(), c->stats.p, st.size() * sizeof(velo_icp_iter),
+    // results land in pinned host memory: a copy into pageable memory is staged and waited for
+    // inside the call, twice per registration -- a visible share of a single frame's 0.4 ms
+    const size_t t_bytes = (size_t)c->cfg.max_batch * 12 * sizeof(double);
+    const size_t s_bytes = (size_t)c->cfg.max_batch * VELO_MAX_ITERS * sizeof(velo_icp_iter);
+    if (!c->h_result) HIP_TRY(c, hipHostMalloc((void**)&c->h_result, t_bytes + s_bytes, 0));
+    const double* T = reinterpret_cast<const double*>(c->h_result);
+    const velo_icp_iter* st = reinterpret_cast<const velo_icp_iter*>(c->h_result + t_bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->h_result, c->poses.p, (size_t)F * 12 * sizeof(double), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_result + t_bytes, c->stats.p, (size_t)F * VELO_MAX_ITERS * sizeof(velo_icp_iter),
                               hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int f = 0; f < F; ++f) {
@@ -1381,6 +1388,7 @@ void velo_destroy(velo_ctx* c)
         if (c->ev_T0[b]) (void)hipEventDestroy(c->ev_T0[b]);
     }
     if (c->h_inc_total) (void)hipHostFree(c->h_inc_total);
+    if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_pend_total) (void)hipHostFree(c->h_pend_total);
     if (c->ev_pend) (void)hipEventDestroy(c->ev_pend);
     if (c->h_dec_stage) (void)hipHostFree(c->h_dec_stage);
