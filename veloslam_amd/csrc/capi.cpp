@@ -195,6 +195,8 @@ struct velo_ctx {
     hipEvent_t ev_pend = nullptr;
     bool pend_outstanding = false;
     uint8_t* h_result = nullptr;      // pinned: poses + per-iteration statistics of a fetch
+    int32_t* h_starts = nullptr;      // pinned: beam offsets of a decode
+    size_t h_starts_cap = 0;
     uint32_t* h_inc_total = nullptr;  // pinned: count of the asynchronous increment
     uint8_t* h_dec_stage = nullptr;   // pinned: packets + per-packet plan of one decode call
     size_t h_dec_cap = 0;
@@ -1389,6 +1391,7 @@ void velo_destroy(velo_ctx* c)
     }
     if (c->h_inc_total) (void)hipHostFree(c->h_inc_total);
     if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->h_starts) (void)hipHostFree(c->h_starts);
     if (c->h_pend_total) (void)hipHostFree(c->h_pend_total);
     if (c->ev_pend) (void)hipEventDestroy(c->ev_pend);
     if (c->h_dec_stage) (void)hipHostFree(c->h_dec_stage);
@@ -2122,8 +2125,14 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
 
     const veloslam::SortedPoseView tm(poses, n_poses);  // the caller's store, read in place: O(log n) per packet
     // working set = what the unfinished frame still needs + the new packets
-    std::vector<uint8_t> bytes(st.bytes);
-    bytes.insert(bytes.end(), packets, packets + n_new * 1206);
+    // (a parse that starts from fresh state -- every call of velo_decode -- reads the caller's
+    // packets in place: no 360 KB copy per frame in front of the copy into the pinned stage)
+    std::vector<uint8_t> bytes_joined;
+    if (!st.bytes.empty()) {
+        bytes_joined = st.bytes;
+        bytes_joined.insert(bytes_joined.end(), packets, packets + n_new * 1206);
+    }
+    const uint8_t* const bytes_p = st.bytes.empty() ? packets : bytes_joined.data();
     std::vector<int64_t> times(st.t);
     times.insert(times.end(), pkt_t_us, pkt_t_us + n_new);
     std::vector<int16_t> blk(st.blk);
@@ -2156,7 +2165,7 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
         c->dk_frame_packets[0] = st.frame_packets;
     }
     for (size_t p = n_pend; p < n_pkt; ++p) {
-        const uint8_t* d = bytes.data() + p * 1206;
+        const uint8_t* d = bytes_p + p * 1206;
         veloslam::PoseTransform tr;
         tm.interpolate(times[p], &tr);
         if (!inited) {  // :992-1001
@@ -2223,7 +2232,7 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
                     break;
                 }
         for (size_t p = p0; p < n_pkt; ++p) {
-            nx.bytes.insert(nx.bytes.end(), bytes.begin() + p * 1206, bytes.begin() + (p + 1) * 1206);
+            nx.bytes.insert(nx.bytes.end(), bytes_p + p * 1206, bytes_p + (p + 1) * 1206);
             nx.t.push_back(times[p]);
             nx.table.insert(nx.table.end(), table.begin() + p * 12, table.begin() + (p + 1) * 12);
             nx.tvalid.push_back(tvalid[p]);
@@ -2242,7 +2251,7 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
         c->dk_frame_t.resize((size_t)nfr);
         c->dk_frame_packets.resize((size_t)nfr);
     }
-    const uint8_t* packets_all = bytes.data();
+    const uint8_t* packets_all = bytes_p;
     // ---- device side
     const size_t n_ret = n_pkt * 384;
     HIP_TRY(c, c->dk_keys.reserve(n_ret));
@@ -2305,8 +2314,17 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     HIP_TRY(c, sort_pairs(c->temp.p, tb, c->dk_keys.p, c->dk_keys2.p, c->dk_idx.p, c->dk_order.p, n_ret, key_bits,
                           s));
     HIP_TRY(c, launch_key_starts(c->dk_keys2.p, n_ret, n_keys, c->dk_starts.p, s));
-    std::vector<int32_t> starts((size_t)n_keys + 1);
-    HIP_TRY(c, hipMemcpyAsync(starts.data(), c->dk_starts.p, starts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    // (pinned landing zone: a copy into pageable memory is staged and waited for inside the call)
+    const size_t n_starts = (size_t)n_keys + 1;
+    if (n_starts > c->h_starts_cap) {
+        if (c->h_starts) (void)hipHostFree(c->h_starts);
+        c->h_starts = nullptr;
+        c->h_starts_cap = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_starts, (n_starts + 256) * sizeof(int32_t), 0));
+        c->h_starts_cap = n_starts + 256;
+    }
+    int32_t* const starts = c->h_starts;
+    HIP_TRY(c, hipMemcpyAsync(starts, c->dk_starts.p, n_starts * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     const size_t n_valid = nfr > 0 ? (size_t)starts[(size_t)nfr * 64] : 0;
     HIP_TRY(c, c->dk_x.reserve(std::max<size_t>(n_valid, 1)));
