@@ -40,6 +40,13 @@ struct HDLFrame {
     std::shared_ptr<PoseTransform> carpose;
     bool isInMemory, isOnHardDrive;
     std::atomic<unsigned char> count;
+    // where the frame lives in its capture (HDLFrame.h:37-46): name of the file, offset of the
+    // record that holds its first firing block, and how many blocks of that packet belong to the
+    // previous frame.  firstPacket / numPackets (not in the reference) say the same in packets of
+    // the capture as velo_pcap_read returns it: numPackets includes the packet that closes the frame.
+    int64_t filenameTime, fileStartPos;
+    int64_t firstPacket;
+    int32_t numPackets;
     uint8_t skips;
 
     int numBeams() const { return beamStart.empty() ? 0 : (int)beamStart.size() - 1; }

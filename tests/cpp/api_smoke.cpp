@@ -7,7 +7,9 @@
 #include <fstream>
 #include <iostream>
 #include <vector>
+#include <thread>
 #include <veloslam/HDLFrame.hpp>
+#include <veloslam/HDLManager.hpp>
 #include <veloslam/MapManager.hpp>
 #include <veloslam/TransformManager.hpp>
 
@@ -71,9 +73,143 @@ static int load_mode(const std::string& path, double qx, double qy)
     return 0;
 }
 
+// HDLManager as a store of frames that are already in memory (no GPU, no context): the time
+// queries of TimeLine, the overwrite rule of addData, waitForFrame, and the cache that clears
+// the points of unreferenced frames
+static int hdl_store_mode()
+{
+    using namespace veloslam;
+    HDLManager hm(nullptr, 8);
+    auto mk = [](int64_t t, float v) {
+        auto f = std::make_shared<HDLFrame>();
+        f->timestamp = t;
+        const int32_t bs[2] = {0, 2};
+        const float p[2] = {v, v + 1};
+        f->setPoints(p, p, p, nullptr, nullptr, bs, 1);
+        return f;
+    };
+    std::printf("empty %d %d %d\n", (int)(bool)hm.getRecentFrame(), (int)(bool)hm.getFrameNear(5), (int)hm.getRangeBetween(0, 9).size());
+    for (int64_t t : {300, 100, 200, 500}) hm.addFrame(mk(t, (float)t));   // out of order on purpose
+    std::printf("count %d\n", hm.getNumberOfFrames());
+    std::printf("order");
+    for (auto& f : hm.getAllFrameMeta()) std::printf(" %lld", (long long)f->timestamp);
+    std::printf("\nrecent %lld\n", (long long)hm.getRecentFrame()->timestamp);
+    std::printf("at %d %d\n", (int)(bool)hm.getFrameAt(200), (int)(bool)hm.getFrameAt(201));
+    std::printf("near");
+    for (int64_t t : {-50, 100, 149, 150, 151, 349, 400, 401, 9000}) std::printf(" %lld", (long long)hm.getFrameNear(t)->timestamp);
+    std::printf("\nrange");
+    for (auto& f : hm.getRangeBetween(160, 420)) std::printf(" %lld", (long long)f->timestamp);
+    std::printf("\n");
+    // a second frame with a stamp already present replaces the first (TimeLine::addData)
+    hm.addFrame(mk(200, 7.0f));
+    std::printf("overwrite %d %g\n", hm.getNumberOfFrames(), hm.getFrameAt(200)->x[0]);
+    // cache: capacity 3, five frames go in -> the two oldest arrivals lose their points ...
+    {
+        HDLManager h1(nullptr, 3);
+        for (int64_t t : {30, 10, 20, 50, 40}) h1.addFrame(mk(t, (float)t));
+        std::printf("cached %d in_memory", h1.cachedFrames());
+        for (auto& f : h1.getAllFrameMeta()) std::printf(" %d", (int)f->isInMemory);
+        std::printf("\n");
+    }
+    // ... unless somebody holds them: a held frame is put back, the next unreferenced one goes
+    {
+        HDLManager h2(nullptr, 1);
+        auto a = mk(1, 1.0f), b = mk(2, 2.0f), c = mk(3, 3.0f);
+        h2.addFrame(a);
+        FrameRef hold = h2.getFrameAt(1);
+        h2.addFrame(b);
+        h2.addFrame(c);
+        std::printf("held %d %d %d count %d\n", (int)a->isInMemory, (int)b->isInMemory, (int)c->isInMemory, (int)a->count.load());
+        hold = FrameRef();
+        h2.cleanCache();
+        std::printf("released %d %d count %d\n", (int)a->isInMemory, (int)c->isInMemory, (int)a->count.load());
+        std::printf("gone %d\n", (int)(bool)h2.getFrameAt(2));   // neither in memory nor on a capture
+    }
+    // waitForFrame: times out without data, returns the newest frame once a producer adds one
+    HDLManager h3(nullptr, 8);
+    const bool none = !(bool)h3.waitForFrame(std::chrono::microseconds(2000));
+    std::thread producer([&] {
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        h3.addFrame(mk(42, 4.0f));
+    });
+    FrameRef got = h3.waitForFrame(std::chrono::microseconds(5000000));
+    producer.join();
+    const bool again = (bool)h3.waitForFrame(std::chrono::microseconds(2000));
+    std::printf("wait %d %lld %d\n", (int)none, got ? (long long)got->timestamp : -1LL, (int)again);
+    return 0;
+}
+
+// HDLManager::loadOffline over a recorded drive, every frame prepared (GPU decode) and written out
+// for the test to compare with the one-pass decode of the same capture
+static int hdl_mode(const std::string& dir, const std::string& out)
+{
+    using namespace veloslam;
+    MapManager mgr(10.0f, 0);
+    if (!mgr.context()) {
+        std::cerr << "no context: " << mgr.lastError() << std::endl;
+        return 4;
+    }
+    HDLManager hm(mgr.context(), 2);
+    auto stubs_before = hm.getNumberOfFrames();
+    if (hm.loadOffline(dir + "/carposes.txt", dir + "/drive.pcap") && hm.getNumberOfFrames() > 0 &&
+        hm.getRecentFrame()) {
+        std::cerr << "a frame was prepared without a calibration" << std::endl;
+        return 5;
+    }
+    std::printf("nocalib %s\n", hm.lastError());
+    if (!hm.setCalibFile(dir + "/db.xml") || !hm.loadOffline(dir + "/carposes.txt", dir + "/drive.pcap")) {
+        std::cerr << hm.lastError() << std::endl;
+        return 3;
+    }
+    std::printf("frames %d %d transforms %d\n", stubs_before, hm.getNumberOfFrames(), hm.getNumberOfTransforms());
+    std::ofstream os(out, std::ios::binary);
+    const auto metas = hm.getAllFrameMeta();
+    for (size_t k = 0; k < metas.size(); ++k) {
+        const auto& m = metas[k];
+        const PoseTransform stub_pose = *m->carpose;
+        if (m->isInMemory) return 8;
+        FrameRef f = hm.getFrameAt(m->timestamp);
+        if (!f || !f->isInMemory) {
+            std::cerr << "frame " << k << ": " << hm.lastError() << std::endl;
+            return 6;
+        }
+        const int64_t head[6] = {f->timestamp, f->fileStartPos, f->skips, f->firstPacket, f->numPackets, (int64_t)f->numPoints()};
+        os.write(reinterpret_cast<const char*>(head), sizeof head);
+        os.write(reinterpret_cast<const char*>(f->beamStart.data()), 65 * 4);
+        const double pose[12] = {stub_pose.T[0], stub_pose.T[1], stub_pose.T[2], stub_pose.R[0], stub_pose.R[1], stub_pose.R[2],
+                                 f->carpose->T[0], f->carpose->T[1], f->carpose->T[2], f->carpose->R[0], f->carpose->R[1], f->carpose->R[2]};
+        os.write(reinterpret_cast<const char*>(pose), sizeof pose);
+        const size_t n = f->numPoints();
+        os.write(reinterpret_cast<const char*>(f->x.data()), 4 * n);
+        os.write(reinterpret_cast<const char*>(f->y.data()), 4 * n);
+        os.write(reinterpret_cast<const char*>(f->z.data()), 4 * n);
+        os.write(reinterpret_cast<const char*>(f->intensity.data()), 4 * n);
+        std::vector<uint16_t> az(n);
+        std::vector<float> dist(n);
+        for (size_t i = 0; i < n; ++i) az[i] = f->pointsMeta[i].azimuth, dist[i] = f->pointsMeta[i].distance;
+        os.write(reinterpret_cast<const char*>(az.data()), 2 * n);
+        os.write(reinterpret_cast<const char*>(dist.data()), 4 * n);
+    }
+    // capacity 2: only the frames prepared last still hold points; preparing the first again decodes it again
+    int in_mem = 0;
+    for (auto& m : metas) in_mem += m->isInMemory ? 1 : 0;
+    FrameRef again = hm.getFrameNear(metas.front()->timestamp - 5);
+    std::printf("in_memory %d again %zu\n", in_mem, again ? again->numPoints() : (size_t)0);
+    // the device-side half: resident in HBM, registered from there
+    size_t npts = 0;
+    if (!hm.prepareResident(metas.back(), &npts)) {
+        std::cerr << hm.lastError() << std::endl;
+        return 7;
+    }
+    std::printf("resident %zu\n", npts);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
+    if (std::string(argv[1]) == "--hdl-store") return hdl_store_mode();
+    if (std::string(argv[1]) == "--hdl") return argc < 4 ? 2 : hdl_mode(argv[2], argv[3]);
     if (std::string(argv[1]) == "--tiles") return argc < 3 ? 2 : tiles_mode(argv[2]);
     if (std::string(argv[1]) == "--load") return argc < 5 ? 2 : load_mode(argv[2], std::atof(argv[3]), std::atof(argv[4]));
     const std::string dir = argv[1];

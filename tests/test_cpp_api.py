@@ -21,7 +21,7 @@ def build_exe():
         glob.glob(os.path.join(ROOT, "include", "veloslam", "*.hpp"))
     if (not os.path.exists(EXE)) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["hipcc", "-std=c++17", "-O2", "-x", "c++", src, "-I", os.path.join(ROOT, "include"),
-                               "-L", csrc, "-lveloslam_amd", "-Wl,-rpath," + csrc, "-o", EXE])
+                               "-L", csrc, "-lveloslam_amd", "-Wl,-rpath," + csrc, "-pthread", "-o", EXE])
     return EXE
 
 

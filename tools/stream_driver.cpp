@@ -2,14 +2,14 @@
 // they sit on: a recorded drive (veloslam_amd/drive.py layout: drive.pcap, carposes.txt, db.xml,
 // world.map, truth.txt) is replayed frame by frame against a rolling device map --
 //
-//   velo_pcap_read + velo_pcap_index          the capture and its frame index (readFrameInformation)
-//   TransformManager::loadFromTxtFile         the pose track (HDLManager::loadOffline, HDLManager.cxx:103-117)
-//   velo_load_corrections                     db.xml
+//   HDLManager::setCalibFile + loadOffline    db.xml; the pose track, the capture and its frame index -> one
+//                                             stub per revolution (HDLManager.cxx:98-112)
 //   MapManager::load                          the accumulated map, as tiles
-//   per frame: velo_decode (packets in, compensated frame resident in HBM) -> velo_decode_to_frames
-//              -> MapManager::registerResident (rolls the device map to the prior's ROI: evict the
-//                 tiles that left, append the ones that entered; 20 ICP iterations; accepted
-//                 increment to the device-side pending list, merged every append_threshold points)
+//   per frame: HDLManager::prepareResident (the frame's packets in, decoded + compensated frame
+//              resident in HBM) -> MapManager::registerResident (rolls the device map to the
+//              prior's ROI: evict the tiles that left, append the ones that entered; 20 ICP
+//              iterations; accepted increment to the device-side pending list, merged every
+//              append_threshold points)
 //
 // The prior is what the reference's INS would give: the interpolated car pose (x, y, angles from
 // carposes.txt -- the format has no z: z is carried from the previous registration) plus the
@@ -27,6 +27,7 @@
 #include <fstream>
 #include <string>
 #include <vector>
+#include "veloslam/HDLManager.hpp"
 #include "veloslam/MapManager.hpp"
 #include "veloslam/TransformManager.hpp"
 
@@ -50,34 +51,6 @@ int main(int argc, char** argv)
         else if (a == "--threshold" && i + 1 < argc) threshold = std::atoi(argv[++i]);
         else if (a == "--no-integrate") integrate = false;
     }
-    // ---- the drive
-    size_t n_pkt = 0;
-    const std::string pcap = dir + "/drive.pcap";
-    if (velo_pcap_read(pcap.c_str(), nullptr, nullptr, 0, &n_pkt) || n_pkt == 0) {
-        std::fprintf(stderr, "cannot read %s\n", pcap.c_str());
-        return 3;
-    }
-    std::vector<uint8_t> packets(n_pkt * 1206);
-    std::vector<int64_t> times(n_pkt);
-    velo_pcap_read(pcap.c_str(), packets.data(), times.data(), n_pkt, &n_pkt);
-    const int64_t eight_h = 8LL * 3600 * 1000000;  // timevalToPtime (type_defs.cxx:69-72): the pose track's clock
-    for (auto& t : times) t += eight_h;
-    size_t n_idx = 0;
-    velo_pcap_index(pcap.c_str(), nullptr, 0, &n_idx);
-    std::vector<velo_frame_index> index(n_idx);
-    velo_pcap_index(pcap.c_str(), index.data(), n_idx, &n_idx);
-    TransformManager tm;
-    if (!tm.loadFromTxtFile(dir + "/carposes.txt", true)) {
-        std::fprintf(stderr, "cannot read carposes.txt\n");
-        return 3;
-    }
-    const std::vector<velo_pose> poses = tm.snapshot();
-    velo_laser_corr corr[64];
-    int32_t n_enabled = 0;
-    if (velo_load_corrections((dir + "/db.xml").c_str(), corr, &n_enabled)) {
-        std::fprintf(stderr, "cannot read db.xml\n");
-        return 3;
-    }
     double z0 = 0, patch = 10, voxel = 1, zero = 0;
     int k_normals = 16;
     std::vector<double> truth;
@@ -98,7 +71,15 @@ int main(int argc, char** argv)
         return 3;
     }
     velo_ctx* ctx = mgr.context();
-    const int n_frames = (int)n_idx;
+    // ---- the drive: one stub per revolution, points decoded on the GPU when asked for
+    HDLManager hdl(ctx);
+    if (!hdl.setCalibFile(dir + "/db.xml") || !hdl.loadOffline(dir + "/carposes.txt", dir + "/drive.pcap") ||
+        hdl.getNumberOfFrames() == 0) {
+        std::fprintf(stderr, "cannot load the drive: %s\n", hdl.lastError());
+        return 3;
+    }
+    const auto frames = hdl.getAllFrameMeta();
+    const int n_frames = (int)frames.size();
     RegisterOptions opt;
     opt.iters = 20;
     opt.d_max = 1.0f;
@@ -110,35 +91,21 @@ int main(int argc, char** argv)
     double z_prev = z0, worst = 0, t_decode = 0, t_register = 0;
     uint64_t pairs = 0;
     auto one = [&](int f, bool timed) -> bool {
-        const velo_frame_index& e = index[(size_t)f];
-        const bool last = f + 1 >= n_frames;
-        const size_t p0 = (size_t)e.first_packet;
-        const size_t p1 = last ? n_pkt : (size_t)index[(size_t)f + 1].first_packet + 1;  // incl. the packet that closes it
-        velo_decode_opts dop;
-        std::memset(&dop, 0, sizeof dop);
-        dop.struct_size = sizeof dop;
-        dop.initial_firing_skip = e.firing_skip;
-        std::memset(dop.laser_selection, 1, sizeof dop.laser_selection);
+        const std::shared_ptr<HDLFrame>& fr = frames[(size_t)f];
         const auto a = clk::now();
-        int32_t nf = 0;
-        size_t npts = 0;
-        if (velo_decode_set_options(ctx, &dop) ||
-            velo_decode(ctx, packets.data() + p0 * 1206, times.data() + p0, p1 - p0, corr, 64, poses.data(), poses.size(),
-                        last ? 1 : 0, nullptr, 0, &nf, &npts) ||
-            nf < 1 || velo_decode_to_frames(ctx)) {
-            std::fprintf(stderr, "decode of frame %d failed: %s (frames %d)\n", f, velo_last_error(ctx), nf);
+        if (!hdl.prepareResident(fr)) {
+            std::fprintf(stderr, "frame %d: %s\n", f, hdl.lastError());
             return false;
         }
         const double td = ms_since(a);
-        PoseTransform car;
-        tm.interpolateTransform(times[p0], &car);  // what the parser takes as the frame's carpose (HDLParser.cxx:993-1001)
+        const PoseTransform& car = *fr->carpose;  // the track interpolated at the frame's stamp (HDLManager.cxx:104-109)
         PoseTransform init;
         init.T[0] = car.T[0] + 0.15, init.T[1] = car.T[1] - 0.10, init.T[2] = z_prev + 0.03;
         init.R[0] = 0.2, init.R[1] = -0.1, init.R[2] = 0.4;  // frames keep ENU axes: the true rotation is the identity
         PoseTransform out;
         velo_icp_result res;
         const auto b = clk::now();
-        if (!mgr.registerResident(0, times[p0], init, opt, &out, &res)) {
+        if (!mgr.registerResident(0, fr->timestamp, init, opt, &out, &res)) {
             std::fprintf(stderr, "registerResident failed at frame %d: %s\n", f, mgr.lastError());
             return false;
         }

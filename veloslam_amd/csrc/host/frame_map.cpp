@@ -12,7 +12,8 @@ namespace veloslam {
 // ------------------------------------------------------------------ HDLFrame
 HDLFrame::HDLFrame()
     : timestamp(VELO_TIME_INVALID), carpose(new PoseTransform), isInMemory(false),
-      isOnHardDrive(false), count(0), skips(0)
+      isOnHardDrive(false), count(0), filenameTime(VELO_TIME_INVALID), fileStartPos(0), firstPacket(-1),
+      numPackets(0), skips(0)
 {
 }
 
