@@ -7,6 +7,7 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <iosfwd>
 #include <memory>
 #include <string>
 #include <utility>
@@ -57,6 +58,13 @@ struct HDLFrame {
     void setPoints(const float* px, const float* py, const float* pz, const float* pi,
                    const uint16_t* pkt, const int32_t* beam_start, int n_beams);
     void clear();  // HDLFrame.cxx:146-158
+    // the .hdlmeta record (operator<< / operator>>, HDLFrame.cxx:160-190): timestamp, filenameTime,
+    // fileStartPos, skips, isOnHardDrive, then the car pose record (type_defs.cxx:4-33).  ptime ->
+    // int64 microseconds; fileStartPos keeps glibc's 16-byte fpos_t (offset + a zero shift state):
+    // 132 bytes per frame.
+    static constexpr size_t kMetaBytes = 132;
+    bool writeMeta(std::ostream& os) const;
+    bool readMeta(std::istream& is);
 };
 
 void intrusive_ptr_add_ref(HDLFrame* p);

@@ -69,6 +69,16 @@ public:
     // isOnHardDrive}.  The reference returns void and prints; this returns false and sets lastError().
     bool loadOffline(const std::string& insTxt, const std::string& pcapfile);
 
+    // .hdlmeta / .insmeta (HDLManager.cxx:411-449; the reference names the files by the clock and
+    // finds them by scanning its buffer directory -- here the caller names them): the frame stubs
+    // and the pose track of a session.  Stubs read back are matched to the capture loadOffline
+    // holds by (fileStartPos, skips), so that they can be prepared; a stub of some other file
+    // stays a stub.
+    bool saveHDLMeta(const std::string& filename);
+    bool loadHDLMeta(const std::string& filename);
+    bool saveINSMeta(const std::string& filename) { return transMgr_->writeToMetaFile(filename); }
+    bool loadINSMeta(const std::string& filename);
+
     int getNumberOfFrames();
     int getNumberOfTransforms();
     void addFrame(std::shared_ptr<HDLFrame> frame);  // HDLManager.cxx:189-205 (no file-buffer mode)
@@ -126,6 +136,9 @@ private:
     std::vector<uint8_t> packets_;
     std::vector<int64_t> times_;       // + kClockShiftUs
     std::vector<velo_pose> poses_;     // snapshot of the pose track for velo_decode
+    std::vector<velo_frame_index> index_;
+    size_t nPackets_ = 0;
+    void bindToCapture(HDLFrame& f) const;  // (fileStartPos, skips) -> firstPacket / numPackets
     velo_laser_corr corr_[64];
     bool haveCalib_ = false;
     std::string err_;

@@ -31,6 +31,10 @@ public:
     bool interpolateTransform(int64_t t_us, PoseTransform* xform);
     // carposes.txt rows "x y yaw roll pitch v sec usec" (TransformManager.cxx:95-125)
     bool loadFromTxtFile(const std::string& filename, bool clearOldData = false);
+    // .insmeta (TransformManager.cxx:81-93, 127-134): the store as a stream of pose records
+    // (type_defs.cxx:4-33; ptime -> int64 microseconds), in time order
+    bool loadFromMetaFile(const std::string& filename, bool clearOldData = false);
+    bool writeToMetaFile(const std::string& filename);
     void setOriginLLH(const double LLH[3]);  // TransformManager.cxx:179-185
     const double* originXYZ() const { return originXYZ_; }
     // per-packet transform table for K1 (HDLParser.cxx:988-1007)

@@ -125,6 +125,35 @@ static int hdl_store_mode()
         std::printf("released %d %d count %d\n", (int)a->isInMemory, (int)c->isInMemory, (int)a->count.load());
         std::printf("gone %d\n", (int)(bool)h2.getFrameAt(2));   // neither in memory nor on a capture
     }
+    // .hdlmeta / .insmeta round trip (stubs only: no capture is loaded, nothing can be prepared)
+    {
+        const char* tmp = std::getenv("VELO_TMP");
+        const std::string d = tmp ? tmp : "/tmp";
+        HDLManager a(nullptr, 8), b(nullptr, 8);
+        for (int k = 0; k < 3; ++k) {
+            auto f = std::make_shared<HDLFrame>();
+            f->timestamp = 1000 + 100 * k;
+            f->filenameTime = 1000;
+            f->fileStartPos = 24 + 1264 * 300 * k;
+            f->skips = (uint8_t)(3 * k);
+            f->isOnHardDrive = true;
+            f->carpose->T[0] = 1.5 * k, f->carpose->R[2] = -7.25, f->carpose->V[1] = 0.125, f->carpose->timestamp = 999 + k;
+            f->carpose->seconds_pos = 0.5;
+            a.addFrame(f);
+            PoseTransform p = *f->carpose;
+            a.transformManager()->addTransform(p);
+        }
+        const bool ok = a.saveHDLMeta(d + "/s.hdlmeta") && a.saveINSMeta(d + "/s.insmeta") && b.loadHDLMeta(d + "/s.hdlmeta") &&
+                        b.loadINSMeta(d + "/s.insmeta");
+        std::ifstream sz(d + "/s.hdlmeta", std::ios::binary | std::ios::ate);
+        std::printf("meta %d %lld %d %d", (int)ok, (long long)sz.tellg(), b.getNumberOfFrames(), b.getNumberOfTransforms());
+        for (auto& f : b.getAllFrameMeta())
+            std::printf(" %lld/%lld/%lld/%d/%d/%g/%g/%g/%lld/%g", (long long)f->timestamp, (long long)f->filenameTime,
+                        (long long)f->fileStartPos, (int)f->skips, (int)f->isOnHardDrive, f->carpose->T[0], f->carpose->R[2],
+                        f->carpose->V[1], (long long)f->carpose->timestamp, f->carpose->seconds_pos);
+        std::printf("\nmeta_missing %d %d\n", (int)b.loadHDLMeta(d + "/none.hdlmeta"), (int)b.loadINSMeta(d + "/none.insmeta"));
+        std::printf("meta_unbound %d\n", (int)(bool)b.getRecentFrame());   // a stub of a capture that is not loaded
+    }
     // waitForFrame: times out without data, returns the newest frame once a producer adds one
     HDLManager h3(nullptr, 8);
     const bool none = !(bool)h3.waitForFrame(std::chrono::microseconds(2000));
@@ -202,6 +231,14 @@ static int hdl_mode(const std::string& dir, const std::string& out)
         return 7;
     }
     std::printf("resident %zu\n", npts);
+    // the stubs saved as .hdlmeta and read into a second manager that holds the same capture: same
+    // store, and the stubs can be prepared (they were matched to the capture by position and skip)
+    HDLManager h2(mgr.context(), 4);
+    if (!hm.saveHDLMeta(dir + "/s.hdlmeta") || !h2.setCalibFile(dir + "/db.xml") ||
+        !h2.loadOffline(dir + "/carposes.txt", dir + "/drive.pcap") || !h2.loadHDLMeta(dir + "/s.hdlmeta"))
+        return 9;
+    FrameRef r = h2.getRecentFrame();
+    std::printf("meta_reload %d %zu\n", h2.getNumberOfFrames(), r ? r->numPoints() : (size_t)0);
     return 0;
 }
 

@@ -105,14 +105,15 @@ def test_export_and_load_a_small_drive(tmp_path):
     assert np.allclose(d["calib"][:, :5], np.asarray(cal)[:, :5], rtol=0, atol=1e-12)
 
 
-def test_hdlmanager_frame_store_semantics():
+def test_hdlmanager_frame_store_semantics(tmp_path):
     """veloslam::HDLManager as the store a consumer pulls from (HDLManager.cxx:226-260 over
     TimeLine.h): sorted by stamp whatever the arrival order, exact / nearest lookups (a tie goes to
     the later frame, the ends clamp), the inclusive range, a repeated stamp overwrites, the cache
     clears the oldest unreferenced arrivals and puts held ones back, waitForFrame times out or hands
     over what a producer thread added.  No GPU: frames are in memory already."""
     exe = build_exe()
-    out = subprocess.run([exe, "--hdl-store"], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, "--hdl-store"], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, VELO_TMP=str(tmp_path)))
     assert out.returncode == 0, out.stderr
     lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
     assert lines["empty"] == "0 0 0" and lines["count"] == "4" and lines["order"] == "100 200 300 500"
@@ -124,6 +125,16 @@ def test_hdlmanager_frame_store_semantics():
     assert lines["cached"] == "3 in_memory 0 1 0 1 1"       # arrivals 30 10 20 50 40, capacity 3: 30 and 10 cleared
     assert lines["held"] == "1 0 0 count 1" and lines["released"] == "1 0 count 0" and lines["gone"] == "0"
     assert lines["wait"] == "1 42 0"
+    # .hdlmeta (HDLFrame.cxx:160-190) / .insmeta (type_defs.cxx:4-33) round trip: 132 bytes per frame
+    m = lines["meta"].split()
+    assert m[:4] == ["1", str(3 * 132), "3", "3"]
+    assert m[4:] == ["%d/1000/%d/%d/1/%g/-7.25/0.125/%d/0.5" % (1000 + 100 * k, 24 + 1264 * 300 * k, 3 * k, 1.5 * k, 999 + k)
+                     for k in range(3)]
+    assert lines["meta_missing"] == "0 0" and lines["meta_unbound"] == "0"
+    raw = open(os.path.join(str(tmp_path), "s.hdlmeta"), "rb").read()
+    assert int.from_bytes(raw[132 + 16:132 + 24], "little") == 24 + 1264 * 300 and raw[132 + 24:132 + 32] == bytes(8)
+    assert raw[132 + 32] == 3 and raw[132 + 33] == 1
+    assert os.path.getsize(os.path.join(str(tmp_path), "s.insmeta")) == 3 * 98
 
 
 @pytest.mark.gpu
@@ -193,6 +204,7 @@ def test_hdlmanager_offline_frames_equal_the_parser_reread(tmp_path, oracle):
     assert lines["in_memory"].split()[0] == "2"               # capacity 2: the first frame's points were cleared ...
     assert int(lines["in_memory"].split()[2]) > 50_000        # ... and come back by decoding it again
     assert int(lines["resident"]) > 50_000
+    assert lines["meta_reload"].split()[0] == "3" and int(lines["meta_reload"].split()[1]) == n   # the last frame again
 
 
 @pytest.mark.gpu

@@ -61,6 +61,68 @@ void HDLFrame::clear()
     isInMemory = false;
 }
 
+namespace {
+void put_pose(std::ostream& os, const PoseTransform& p)
+{
+    for (int i = 0; i < 3; ++i) {
+        os.write(reinterpret_cast<const char*>(&p.T[i]), 8);
+        os.write(reinterpret_cast<const char*>(&p.R[i]), 8);
+        os.write(reinterpret_cast<const char*>(&p.V[i]), 8);
+    }
+    os.write(reinterpret_cast<const char*>(&p.timestamp), 8);
+    os.write(reinterpret_cast<const char*>(&p.week_number), 2);
+    os.write(reinterpret_cast<const char*>(&p.milliseconds), 4);
+    os.write(reinterpret_cast<const char*>(&p.week_number_pos), 4);
+    os.write(reinterpret_cast<const char*>(&p.seconds_pos), 8);
+}
+void get_pose(std::istream& is, PoseTransform& p)
+{
+    for (int i = 0; i < 3; ++i) {
+        is.read(reinterpret_cast<char*>(&p.T[i]), 8);
+        is.read(reinterpret_cast<char*>(&p.R[i]), 8);
+        is.read(reinterpret_cast<char*>(&p.V[i]), 8);
+    }
+    is.read(reinterpret_cast<char*>(&p.timestamp), 8);
+    is.read(reinterpret_cast<char*>(&p.week_number), 2);
+    is.read(reinterpret_cast<char*>(&p.milliseconds), 4);
+    is.read(reinterpret_cast<char*>(&p.week_number_pos), 4);
+    is.read(reinterpret_cast<char*>(&p.seconds_pos), 8);
+}
+}  // namespace
+
+bool HDLFrame::writeMeta(std::ostream& os) const
+{
+    const int64_t pos[2] = {fileStartPos, 0};
+    const uint8_t flags[2] = {skips, (uint8_t)(isOnHardDrive ? 1 : 0)};
+    os.write(reinterpret_cast<const char*>(&timestamp), 8);
+    os.write(reinterpret_cast<const char*>(&filenameTime), 8);
+    os.write(reinterpret_cast<const char*>(pos), 16);
+    os.write(reinterpret_cast<const char*>(flags), 2);
+    put_pose(os, *carpose);
+    return (bool)os;
+}
+
+bool HDLFrame::readMeta(std::istream& is)
+{
+    int64_t pos[2] = {0, 0};
+    uint8_t flags[2] = {0, 0};
+    int64_t t = 0, ft = 0;
+    PoseTransform car;
+    is.read(reinterpret_cast<char*>(&t), 8);
+    is.read(reinterpret_cast<char*>(&ft), 8);
+    is.read(reinterpret_cast<char*>(pos), 16);
+    is.read(reinterpret_cast<char*>(flags), 2);
+    get_pose(is, car);
+    if (!is) return false;  // a truncated record leaves the frame untouched
+    timestamp = t;
+    filenameTime = ft;
+    fileStartPos = pos[0];
+    skips = flags[0];
+    isOnHardDrive = flags[1] != 0;
+    *carpose = car;
+    return true;
+}
+
 void intrusive_ptr_add_ref(HDLFrame* p) { ++p->count; }
 void intrusive_ptr_release(HDLFrame* p)
 {

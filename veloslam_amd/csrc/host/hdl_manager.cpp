@@ -4,6 +4,7 @@
 // kernels.  See include/veloslam/HDLManager.hpp for what is and is not carried over.
 #include <algorithm>
 #include <cstring>
+#include <fstream>
 #include "../../../include/veloslam/HDLManager.hpp"
 
 namespace veloslam {
@@ -59,11 +60,13 @@ bool HDLManager::loadOffline(const std::string& insTxt, const std::string& pcapf
         err_ = "cannot index the capture " + pcapfile;
         return false;
     }
-    std::vector<velo_frame_index> index(n_idx);
+    std::vector<velo_frame_index>& index = index_;
+    index.assign(n_idx, velo_frame_index());
     if (n_idx && velo_pcap_index(pcapfile.c_str(), index.data(), n_idx, &n_idx) != VELO_OK) {
         err_ = "cannot index the capture " + pcapfile;
         return false;
     }
+    nPackets_ = n_pkt;
     const int64_t name_time = n_pkt ? times_[0] : VELO_TIME_INVALID;
     for (size_t k = 0; k < n_idx; ++k) {
         const velo_frame_index& e = index[k];
@@ -74,10 +77,7 @@ bool HDLManager::loadOffline(const std::string& insTxt, const std::string& pcapf
         f->skips = (uint8_t)e.firing_skip;
         f->filenameTime = name_time;
         f->isOnHardDrive = true;
-        f->firstPacket = e.first_packet;
-        // up to and including the packet in which the next frame opens; the last frame runs to the end
-        const int64_t end = k + 1 < n_idx ? index[k + 1].first_packet + 1 : (int64_t)n_pkt;
-        f->numPackets = (int32_t)std::max<int64_t>(end - e.first_packet, 0);
+        bindToCapture(*f);
         // "readFrameInformation() can't determine carpose for each frame" (HDLManager.cxx:104-109)
         transMgr_->interpolateTransform(f->timestamp, f->carpose.get());
         addFrame(f);
@@ -87,6 +87,52 @@ bool HDLManager::loadOffline(const std::string& insTxt, const std::string& pcapf
         std::lock_guard<std::mutex> lock(framesMutex_);
         hasNewData_ = false;
     }
+    return true;
+}
+
+void HDLManager::bindToCapture(HDLFrame& f) const
+{
+    f.firstPacket = -1;
+    f.numPackets = 0;
+    for (size_t k = 0; k < index_.size(); ++k) {
+        const velo_frame_index& e = index_[k];
+        if (e.file_pos != f.fileStartPos || e.firing_skip != (int32_t)f.skips) continue;
+        f.firstPacket = e.first_packet;
+        // up to and including the packet in which the next frame opens; the last frame runs to the end
+        const int64_t end = k + 1 < index_.size() ? index_[k + 1].first_packet + 1 : (int64_t)nPackets_;
+        f.numPackets = (int32_t)std::max<int64_t>(end - e.first_packet, 0);
+        return;
+    }
+}
+
+bool HDLManager::saveHDLMeta(const std::string& filename)
+{
+    std::ofstream os(filename, std::ios::binary);
+    if (!os) return false;
+    for (const auto& f : getAllFrameMeta())   // TimeLine's operator<<: every frame, in time order
+        if (!f->writeMeta(os)) return false;
+    return (bool)os;
+}
+
+bool HDLManager::loadHDLMeta(const std::string& filename)
+{
+    std::ifstream is(filename, std::ios::binary);
+    if (!is) return false;
+    for (;;) {
+        auto f = std::make_shared<HDLFrame>();
+        if (!f->readMeta(is)) break;
+        bindToCapture(*f);
+        addFrame(f);   // a stamp already in the store is overwritten, as TimeLine::addData does
+    }
+    std::lock_guard<std::mutex> lock(framesMutex_);
+    hasNewData_ = false;
+    return true;
+}
+
+bool HDLManager::loadINSMeta(const std::string& filename)
+{
+    if (!transMgr_->loadFromMetaFile(filename, false)) return false;
+    poses_ = transMgr_->snapshot();
     return true;
 }
 

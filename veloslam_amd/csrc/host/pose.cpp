@@ -392,6 +392,23 @@ bool TransformManager::loadFromTxtFile(const std::string& filename, bool clearOl
     return true;
 }
 
+bool TransformManager::loadFromMetaFile(const std::string& filename, bool clearOldData)
+{
+    size_t n = 0;
+    if (velo_insmeta_read(filename.c_str(), nullptr, 0, &n) != VELO_OK) return false;  // "does not exist"
+    std::vector<velo_pose> v(n);
+    if (n && velo_insmeta_read(filename.c_str(), v.data(), n, &n) != VELO_OK) return false;
+    if (clearOldData) clearTransforms();
+    for (const velo_pose& p : v) addTransform(PoseTransform::fromC(p));
+    return true;
+}
+
+bool TransformManager::writeToMetaFile(const std::string& filename)
+{
+    const std::vector<velo_pose> v = snapshot();
+    return velo_insmeta_write(filename.c_str(), v.data(), v.size()) == VELO_OK;
+}
+
 void TransformManager::setOriginLLH(const double LLH[3])
 {
     originLLH_[0] = to_radius(LLH[0]);
