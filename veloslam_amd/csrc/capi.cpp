@@ -1187,7 +1187,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
                 if (e == hipSuccess)
                     e = launch_reduce_solve(c->partials.p, dc.fbs, c->n_frames, c->poses.p,
                                             c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
-                                            c->pairs_total.p, s);
+                                            c->pairs_total.p, s, (int)(c->partials.cap / kAccStride));
             }
             hipGraph_t g = nullptr;
             hipError_t e2 = hipStreamEndCapture(s, &g);
@@ -1226,7 +1226,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             Timed t(c, 1);
             HIP_TRY(c, launch_reduce_solve(c->partials.p, dc.fbs, c->n_frames, c->poses.p,
                                            c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
-                                           c->pairs_total.p, s));
+                                           c->pairs_total.p, s, (int)(c->partials.cap / kAccStride)));
         }
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev_call1, s));

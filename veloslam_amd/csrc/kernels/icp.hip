@@ -1435,13 +1435,16 @@ __device__ void se3_exp_apply(const double* xi, double* T)
 // blocks b0+g, b0+g+32, ... (32 independent load streams per column instead of one serial
 // chain over hundreds of partials); the group sums are then added in ascending g: a fixed
 // order, so the result is run-to-run bit reproducible.
+#ifndef VELO_SOLVE_SPEC
+#define VELO_SOLVE_SPEC 1
+#endif
 constexpr int kSolveThreads = 1024;
 constexpr int kSolveGroups = kSolveThreads / 32;
 __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     const double* __restrict__ partials, const int32_t* __restrict__ fbs,
     double* __restrict__ poses, velo_icp_iter* __restrict__ stats, int iter,
     double* __restrict__ acc_out, int do_update, double* __restrict__ poses_prev,
-    unsigned long long* __restrict__ pairs_total)
+    unsigned long long* __restrict__ pairs_total, int spec_rows)
 {
     __shared__ double s_g[kSolveGroups][32];
     __shared__ double s_acc[32];
@@ -1456,9 +1459,29 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
         // a frame of up to 512 rows is one round trip (it was four loads in flight, i.e. four trips
         // for a single frame's 450 rows).  Fixed order: run-to-run deterministic.
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int first = 0;
+        if (VELO_SOLVE_SPEC && f == 0 && spec_rows > 0 && k < kAccN) {
+            // Frame 0's rows start at row 0 whatever the plan says (the caller vouches for it with
+            // spec_rows = rows the buffer holds): its first pass is requested BEFORE the row range
+            // arrives and masked afterwards -- one memory round trip instead of two in a row, which
+            // is what a single frame's iteration waits for.  Same rows, same order: same bits.
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                v[u] = partials[(size_t)min(g + u * kSolveGroups, spec_rows - 1) * kAccStride + k];
+            const int e1 = fbs[1];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (g + u * kSolveGroups >= e1) v[u] = 0.0;
+            a0 += (v[0] + v[4]) + (v[8] + v[12]);
+            a1 += (v[1] + v[5]) + (v[9] + v[13]);
+            a2 += (v[2] + v[6]) + (v[10] + v[14]);
+            a3 += (v[3] + v[7]) + (v[11] + v[15]);
+            first = 16 * kSolveGroups;
+        }
         const int b0 = fbs[f], b1 = fbs[f + 1];
         if (k < kAccN && b1 > b0) {
-            for (int b = b0 + g; b < b1; b += 16 * kSolveGroups) {
+            for (int b = b0 + g + first; b < b1; b += 16 * kSolveGroups) {
                 double v[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
@@ -1529,13 +1552,13 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, double* poses_prev,
-                               unsigned long long* pairs_total, hipStream_t s)
+                               unsigned long long* pairs_total, hipStream_t s, int spec_rows)
 {
     (void)iters_total;
     if (n_frames == 0) return hipSuccess;
     hipLaunchKernelGGL(k_reduce_solve, dim3(n_frames), dim3(kSolveThreads), 0, s, partials,
                        frame_block_start, poses, stats, iter, acc_out, do_update, poses_prev,
-                       pairs_total);
+                       pairs_total, spec_rows);
     return hipGetLastError();
 }
 

@@ -160,7 +160,8 @@ hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, double* poses_prev,
-                               unsigned long long* pairs_total, hipStream_t s);
+                               unsigned long long* pairs_total, hipStream_t s, int spec_rows = 0);
+// (spec_rows > 0: frame_block_start[0] == 0 and `partials` holds at least spec_rows rows)
 hipError_t launch_frame_cellkeys(const FrameView& fv, const int64_t* d_frame_start, int n_frames,
                                  size_t n_total, const MapView& mv, const double* poses,
                                  uint32_t* keys, uint32_t* idx, hipStream_t s);
