@@ -117,6 +117,9 @@ def parse():
     ap.add_argument("--append-threshold", type=int, default=512,
                     help="stream: accepted increments are collected on the device and appended to the map "
                          "once this many points are pending (and always before the map rolls)")
+    ap.add_argument("--no-decode-overlap", action="store_true",
+                    help="stream: plan every frame's decode on the host when it is due instead of a frame ahead, "
+                         "while the GPU registers the previous one")
     ap.add_argument("--map-margin", type=int, default=16, help="stream: grid slack in x/y, voxels")
     ap.add_argument("--map-margin-z", type=int, default=2, help="stream: grid slack in z, voxels")
     ap.add_argument("--full-rebuild", action="store_true", help="stream: re-sort the whole map on every update (A/B)")
@@ -546,15 +549,27 @@ def run_replay(args, dev, local, steps, warmup, d=None):
                 state["full"] += 1
         state["res"] = rng
 
-    def one(f, timed):
+    plan = ctx.decode_plan_create()
+    planned = dict(f=None)
+
+    def plan_frame(f):
+        """host half of frame f's decode (velo_decode_plan_fill): no GPU work, the ctx is not touched"""
         e = idx[f]
         last = f + 1 >= nfr
         p0 = int(e.first_packet)
         p1 = len(times) if last else int(idx[f + 1].first_packet) + 1
+        ctx.decode_plan_fill(plan, pk[p0 * 1206:p1 * 1206], times[p0:p1], d["calib"], d["poses"], d["n_poses"],
+                             flush=last, initial_firing_skip=int(e.firing_skip))
+        planned["f"] = f
+
+    def one(f, f_next, timed):
+        e = idx[f]
+        p0 = int(e.first_packet)
         t = [time.perf_counter()]
-        ctx.decode_set_options(initial_firing_skip=int(e.firing_skip))
-        nf, _ = ctx.decode_resident(pk[p0 * 1206:p1 * 1206], times[p0:p1], d["calib"], d["poses"], d["n_poses"],
-                                    flush=last)
+        if planned["f"] != f:
+            plan_frame(f)
+        planned["f"] = None
+        nf, _ = ctx.decode_submit(plan)
         assert nf >= 1
         ctx.decode_to_frames()
         t.append(time.perf_counter())
@@ -563,9 +578,14 @@ def run_replay(args, dev, local, steps, warmup, d=None):
         T0 = synth.perturbed_guess(Tt, dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))
         roll_to(float(T0[3]), float(T0[7]), timed)
         t.append(time.perf_counter())
-        res = ctx.icp_batch(np.tile(T0, (ctx.n_frames, 1)), args.iters, args.d_max)[0]
-        t.append(time.perf_counter())
+        # registration and increment are enqueued; the host half of the NEXT frame's decode runs while
+        # the GPU iterates (MapManager::registerResident does the same through while_registering)
+        ctx.icp_batch_async(np.tile(T0, (ctx.n_frames, 1)), args.iters, args.d_max)
         ctx.increment_pending(0, None, 3)
+        if f_next is not None and not args.no_decode_overlap:
+            plan_frame(f_next)
+        res = ctx.icp_batch_fetch()[0]
+        t.append(time.perf_counter())
         if ctx.pending_count(False) >= max(args.append_threshold, 1):
             flush()
         t.append(time.perf_counter())
@@ -580,18 +600,19 @@ def run_replay(args, dev, local, steps, warmup, d=None):
 
     frame_at = lambda k: (k % period) if (k % period) < nfr else period - (k % period)  # noqa: E731
     for k in range(warmup):
-        one(frame_at(k), False)
+        one(frame_at(k), frame_at(k + 1), False)
     torch.cuda.synchronize()
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
     for k in range(steps):
-        one(frame_at(warmup + k), True)
+        one(frame_at(warmup + k), frame_at(warmup + k + 1) if k + 1 < steps else None, True)
     flush()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
     mi = ctx.map_info()
+    ctx.decode_plan_destroy(plan)
     ctx.close()
     if state["worst"] > 0.05:
         raise SystemExit("bench replay: registration diverged (%.3f m)" % state["worst"])
@@ -608,7 +629,8 @@ def run_replay(args, dev, local, steps, warmup, d=None):
             "pairs_per_s": state["pairs"] / elapsed, "stage_ms_per_frame": {k: 1e3 * v / steps for k, v in stage.items()},
             "map": dict(full_builds=state["full"], rolls=state["rolls"], points_uploaded=state["up"],
                         points_evicted=state["ev"], increment_flushes=state["flush"]),
-            "last_update": int(mi.last_update), "worst_pose_error_m": state["worst"]}
+            "last_update": int(mi.last_update), "worst_pose_error_m": state["worst"],
+            "decode_planned_ahead": not args.no_decode_overlap}
 
 
 # ------------------------------------------------------------------------- inputs

@@ -270,6 +270,24 @@ typedef struct velo_decode_opts {
     uint8_t laser_selection[64];
 } velo_decode_opts;
 int velo_decode_set_options(velo_ctx*, const velo_decode_opts* opts); /* NULL = defaults */
+/* velo_decode in its two halves.  The HOST half (the sequential part of the parser: pose
+ * interpolation and the 3x4 table per packet, frame splits, the 12 block owners per packet; staged
+ * in pinned memory the plan owns) touches neither the ctx nor the GPU: it may run while the ctx is
+ * busy registering the previous frame -- from the same thread between an asynchronous registration
+ * and its fetch, or from another thread (one thread per plan).  The DEVICE half consumes the plan.
+ * fill + submit == velo_decode of the same arguments with `opts` in place of the ctx's sticky
+ * velo_decode_set_options (NULL = defaults); always a parse from fresh state.  A plan is reusable
+ * (fill, submit, fill, ...); filling twice overwrites; submitting an unfilled plan is an error.
+ * velo_decode_plan_fill reports through velo_decode_plan_error, not velo_last_error. */
+typedef struct velo_decode_plan velo_decode_plan;
+int velo_decode_plan_create(velo_ctx*, velo_decode_plan** out);
+void velo_decode_plan_destroy(velo_decode_plan*);
+int velo_decode_plan_fill(velo_decode_plan*, const velo_decode_opts* opts, const uint8_t* packets,
+                          const int64_t* pkt_t_us, size_t n_pkt, const velo_laser_corr corr[64],
+                          int n_lasers, const velo_pose* poses, size_t n_poses, int flush,
+                          const double* crop_region, int crop_inside);
+int velo_decode_submit(velo_ctx*, velo_decode_plan*, int32_t* n_frames, size_t* n_points);
+const char* velo_decode_plan_error(const velo_decode_plan*);
 /* Copy the last decode back; any pointer may be NULL.  frame_start: n_frames+1; beam_start:
  * n_frames x 65 (absolute offsets); packet_index: index of the source packet of each point. */
 int velo_decode_fetch(velo_ctx*, float* x, float* y, float* z, float* intensity, uint16_t* azimuth,

@@ -90,6 +90,12 @@ public:
     // The device-side half only: decode + compensate, frame left RESIDENT in HBM as frame 0 of the
     // context (until the next decode on it); `frame` gets no points.  points (optional) = its size.
     bool prepareResident(const std::shared_ptr<HDLFrame>& frame, size_t* points = nullptr);
+    // The HOST half of prepareResident(frame), ahead of time: the sequential part of the parser (pose
+    // per packet, frame split, block owners) staged in pinned memory (velo_decode_plan_fill).  It
+    // touches neither the context nor the GPU, so it can run while the previous frame is being
+    // registered (RegisterOptions::while_registering); the prepareResident / prepareFrame of the same
+    // frame that follows then only submits the device half.  A plan for another frame is discarded.
+    bool planResident(const std::shared_ptr<HDLFrame>& frame);
 
     // HDLManager.cxx:226-260.  waitForFrame blocks up to `micro` for an addFrame().
     FrameRef waitForFrame(std::chrono::microseconds micro = std::chrono::microseconds(100000));
@@ -121,6 +127,9 @@ public:
 
 private:
     bool decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, int* n_decoded);
+    bool fillPlan(const HDLFrame& f);
+    velo_decode_plan* plan_ = nullptr;
+    const HDLFrame* planned_ = nullptr;   // the frame plan_ is filled for
     size_t lowerBound(int64_t t) const;       // first frame with timestamp >= t
     size_t nearestIndex(int64_t t) const;     // frames_ not empty
 

@@ -5,6 +5,7 @@
 // never allocated, so nothing can call it.  The cv::Mat index is
 // replaced by an ordered map keyed on the patch grid index.
 #pragma once
+#include <functional>
 #include <map>
 #include <memory>
 #include <set>
@@ -28,6 +29,10 @@ struct RegisterOptions {
     bool integrate = false;       // collect the accepted increment (device-side pending list) and
                                   // merge it into the map once append_threshold points are pending
     int append_threshold = 512;   // (1 = after every frame)
+    // Host work to do while the GPU registers: called once, after the registration (and the
+    // increment) have been enqueued and before their result is waited for -- e.g.
+    // HDLManager::planResident(next frame), which hides the host half of the next decode.
+    std::function<void()> while_registering;
 };
 
 // what the device map has been through (rolling-map bookkeeping; diagnostic)

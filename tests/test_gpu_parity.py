@@ -773,6 +773,57 @@ def test_gpu_decode_matches_oracle_parser(ctx, oracle, az_start, azcorr, with_po
     assert g["n_points"] == sum(dec.beam(f, b)[0].size for f in range(dec.num_frames) for b in range(64))
 
 
+def test_gpu_decode_planned_ahead_equals_decode(oracle):
+    """velo_decode_plan_fill + velo_decode_submit == velo_decode (== the oracle parser), with the
+    host half of the NEXT decode filled while the frames of the previous one are resident and being
+    registered: the plan touches neither the ctx nor its buffers (stream pipelining, configs[2])."""
+    pk, ts, cal, mo = _stream(3, 20000)
+    track = mo.ins_track(ts[0], ts[-1])
+    tl = oracle.Timeline()
+    for (T, R, V, t) in track:
+        tl.add(T, R, V, t)
+    poses, n = capi.make_poses(track)
+    buf = np.frombuffer(b"".join(pk), np.uint8).copy()
+    tt = np.asarray(ts, np.int64)
+    calib = np.ascontiguousarray(cal, np.float64).reshape(64, 9)
+    wl = make_workload(map_points=60_000, n_frames=1)
+    c = capi.Context(0, max_batch=4)
+    try:
+        plan = c.decode_plan_create()
+        with pytest.raises(capi.VeloError):
+            c.decode_submit(plan)                                    # nothing planned yet
+        for first_block, sel_seed in ((0, None), (5, 7)):
+            sel = None if sel_seed is None else (np.random.default_rng(sel_seed).uniform(0, 1, 64) < 0.8).astype(np.uint8)
+            dec = oracle.Decoder(cal, 64, tl)
+            if sel is not None:
+                dec.set_laser_selection(sel)
+            dec.set_skip(first_block)
+            for p, t in zip(pk, ts):
+                dec.packet(p, t)
+            dec.flush()
+            # something else is resident and registered while the plan is filled
+            c.map_reset(*wl["map"], 1.0, 16)
+            first = c.decode(pk[:320], ts[:320], cal, 64, poses, n, flush=True)
+            c.decode_to_frames()
+            T0 = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64), (c.n_frames, 1))
+            c.icp_batch_async(T0, 5, 1.0)
+            c.decode_plan_fill(plan, buf, tt, calib, poses, n, flush=True, initial_firing_skip=first_block,
+                               laser_selection=sel)
+            res = c.icp_batch_fetch()                                # still the frames of `first`
+            assert c.n_frames == first["n_frames"] and res[0].iters == 5
+            nf, npts = c.decode_submit(plan)
+            g = c.decode_fetch(nf, npts)
+            _check_decode(oracle, g, dec, dec.num_frames)
+            with pytest.raises(capi.VeloError):
+                c.decode_submit(plan)                                # a plan is consumed by its submit
+            # the ctx's own sticky options are not what a plan uses, and stay as they were
+            again = c.decode(pk, ts, cal, 64, poses, n, flush=True)
+            assert (again["n_points"] == g["n_points"]) == (first_block == 0 and sel is None)
+        c.decode_plan_destroy(plan)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("skip,first_block,n_lasers", [(0, 0, 64), (1, 0, 64), (2, 5, 64), (0, 7, 64), (1, 3, 16)])
 def test_gpu_decode_options_match_oracle_parser(oracle, skip, first_block, n_lasers):
     """The parser's remaining knobs (velo_decode_set_options): laser selection

@@ -9,7 +9,8 @@
 //              resident in HBM) -> MapManager::registerResident (rolls the device map to the
 //              prior's ROI: evict the tiles that left, append the ones that entered; 20 ICP
 //              iterations; accepted increment to the device-side pending list, merged every
-//              append_threshold points)
+//              append_threshold points); the HOST half of the next frame's decode (HDLManager::planResident)
+//              runs inside registerResident while the GPU iterates (RegisterOptions::while_registering)
 //
 // The prior is what the reference's INS would give: the interpolated car pose (x, y, angles from
 // carposes.txt -- the format has no z: z is carried from the previous registration) plus the
@@ -18,7 +19,7 @@
 //
 //   hipcc -std=c++17 -O2 -x c++ tools/stream_driver.cpp -Iinclude -Lveloslam_amd/csrc -lveloslam_amd \
 //         -Wl,-rpath,$PWD/veloslam_amd/csrc -o tools/stream_driver
-//   tools/stream_driver DIR [--steps 100] [--warmup 10] [--threshold 512] [--no-integrate]
+//   tools/stream_driver DIR [--steps 100] [--warmup 10] [--threshold 512] [--no-integrate] [--no-overlap]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -43,13 +44,14 @@ int main(int argc, char** argv)
     }
     const std::string dir = argv[1];
     int steps = 100, warmup = 10, threshold = 512;
-    bool integrate = true;
+    bool integrate = true, overlap = true;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
         else if (a == "--warmup" && i + 1 < argc) warmup = std::atoi(argv[++i]);
         else if (a == "--threshold" && i + 1 < argc) threshold = std::atoi(argv[++i]);
         else if (a == "--no-integrate") integrate = false;
+        else if (a == "--no-overlap") overlap = false;  // plan every frame's decode when it is due, not a frame ahead
     }
     double z0 = 0, patch = 10, voxel = 1, zero = 0;
     int k_normals = 16;
@@ -90,8 +92,11 @@ int main(int argc, char** argv)
 
     double z_prev = z0, worst = 0, t_decode = 0, t_register = 0;
     uint64_t pairs = 0;
-    auto one = [&](int f, bool timed) -> bool {
+    auto one = [&](int f, int f_next, bool timed) -> bool {
         const std::shared_ptr<HDLFrame>& fr = frames[(size_t)f];
+        // the host half of the NEXT frame's decode runs while the GPU registers this one
+        opt.while_registering = nullptr;
+        if (overlap && f_next >= 0) opt.while_registering = [&hdl, &frames, f_next] { hdl.planResident(frames[(size_t)f_next]); };
         const auto a = clk::now();
         if (!hdl.prepareResident(fr)) {
             std::fprintf(stderr, "frame %d: %s\n", f, hdl.lastError());
@@ -126,12 +131,12 @@ int main(int argc, char** argv)
     const int period = std::max(2 * n_frames - 2, 1);
     auto frame_at = [&](int k) { const int j = k % period; return j < n_frames ? j : period - j; };
     for (int k = 0; k < warmup; ++k)
-        if (!one(frame_at(k), false)) return 5;
+        if (!one(frame_at(k), frame_at(k + 1), false)) return 5;
     velo_synchronize(ctx);
     const MapStats s0 = mgr.stats();
     const auto t0 = clk::now();
     for (int k = 0; k < steps; ++k)
-        if (!one(frame_at(warmup + k), true)) return 5;
+        if (!one(frame_at(warmup + k), k + 1 < steps ? frame_at(warmup + k + 1) : -1, true)) return 5;
     mgr.flushIncrements();
     velo_synchronize(ctx);
     const double total_ms = ms_since(t0);
@@ -142,11 +147,11 @@ int main(int argc, char** argv)
     std::printf("{\"host\": \"C++ (include/veloslam/*.hpp)\", \"frames\": %d, \"frames_per_s\": %.2f, \"ms_per_frame\": %.4f, "
                 "\"stage_ms_per_frame\": {\"decode\": %.4f, \"register_roll_icp_increment\": %.4f}, "
                 "\"pairs_per_s\": %.4g, \"worst_pose_error_m\": %.15g, \"map_points\": %llu, \"map_subdiv\": %d, "
-                "\"last_update\": %d, \"tile_edge_m\": %g, "
+                "\"last_update\": %d, \"tile_edge_m\": %g, \"decode_planned_ahead\": %s, "
                 "\"map\": {\"full_builds\": %llu, \"rolls\": %llu, \"tiles_entered\": %llu, \"tiles_left\": %llu, "
                 "\"points_uploaded\": %llu, \"points_evicted\": %llu, \"increment_flushes\": %llu, \"increment_points\": %llu}}\n",
                 steps, 1e3 * steps / total_ms, total_ms / steps, t_decode / steps, t_register / steps,
-                (double)pairs / (total_ms * 1e-3), worst, (unsigned long long)mi.n_points, mi.subdiv, mi.last_update, patch,
+                (double)pairs / (total_ms * 1e-3), worst, (unsigned long long)mi.n_points, mi.subdiv, mi.last_update, patch, overlap ? "true" : "false",
                 (unsigned long long)(s1.full_builds - s0.full_builds), (unsigned long long)(s1.rolls - s0.rolls),
                 (unsigned long long)(s1.tiles_entered - s0.tiles_entered), (unsigned long long)(s1.tiles_left - s0.tiles_left),
                 (unsigned long long)(s1.points_uploaded - s0.points_uploaded),

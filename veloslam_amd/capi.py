@@ -86,7 +86,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
-    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_increment_pending", "velo_pending_count", "velo_pending_fetch", "velo_map_append_pending", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
+    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_decode_plan_create", "velo_decode_plan_destroy", "velo_decode_plan_fill", "velo_decode_submit", "velo_decode_plan_error", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_increment_pending", "velo_pending_count", "velo_pending_fetch", "velo_map_append_pending", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
     "velo_exchange_increments", "velo_exchange_plan", "velo_exchange_pack_dev", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_pcap_index", "velo_ins_to_pose",
@@ -165,6 +165,13 @@ def lib():
     L.velo_decode_set_options.argtypes = [vp, C.POINTER(DecodeOpts)]
     L.velo_decode_fetch.argtypes = [vp] * 13
     L.velo_decode_to_frames.argtypes = [vp]
+    L.velo_decode_plan_create.argtypes = [vp, C.POINTER(vp)]
+    L.velo_decode_plan_destroy.argtypes = [vp]
+    L.velo_decode_plan_destroy.restype = None
+    L.velo_decode_plan_fill.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_int]
+    L.velo_decode_submit.argtypes = [vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
+    L.velo_decode_plan_error.argtypes = [vp]
+    L.velo_decode_plan_error.restype = C.c_char_p
     L.velo_increment.argtypes = [vp, C.c_int, dp, C.c_int, vp, vp, vp, C.POINTER(C.c_size_t)]
     L.velo_increment_dev.argtypes = L.velo_increment.argtypes
     L.velo_increment_registered_async.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
@@ -605,8 +612,11 @@ class Context:
         self._chk(fn(self.h, _p(buf), _p(t), len(packets), _p(cal), n_lasers,
                      poses, n_poses, int(bool(flush)), _p(crop), int(bool(crop_inside)),
                      C.byref(nf), C.byref(npts)))
-        F, n = nf.value, npts.value
-        self._decoded_frames = F
+        self._decoded_frames = nf.value
+        return self.decode_fetch(nf.value, npts.value)
+
+    def decode_fetch(self, F, n):
+        """the last decode (F frames, n points) copied back to the host"""
         out = dict(n_frames=F, n_points=n,
                    x=np.empty(n, np.float32), y=np.empty(n, np.float32), z=np.empty(n, np.float32),
                    intensity=np.empty(n, np.float32), azimuth=np.empty(n, np.uint16),
@@ -642,6 +652,39 @@ class Context:
         self._chk(lib().velo_decode(self.h, _p(buf), _p(times_us), times_us.size, _p(calib),
                                     n_lasers, poses, n_poses, int(bool(flush)), None, 0,
                                     C.byref(nf), C.byref(npts)))
+        self._decoded_frames = nf.value
+        return nf.value, npts.value
+
+    # ---- the decode in its two halves (host plan / device submit)
+    def decode_plan_create(self):
+        h = C.c_void_p()
+        self._chk(lib().velo_decode_plan_create(self.h, C.byref(h)))
+        return h
+
+    @staticmethod
+    def decode_plan_destroy(plan):
+        lib().velo_decode_plan_destroy(plan)
+
+    @staticmethod
+    def decode_plan_fill(plan, buf, times_us, calib, poses, n_poses, n_lasers=64, flush=True,
+                         initial_firing_skip=0, points_skip=0, laser_selection=None):
+        """host half of velo_decode into `plan` (no GPU work, the ctx is not touched)"""
+        o = DecodeOpts()
+        o.struct_size = C.sizeof(DecodeOpts)
+        o.points_skip = points_skip
+        o.initial_firing_skip = initial_firing_skip
+        for i in range(64):
+            o.laser_selection[i] = 1 if laser_selection is None else int(bool(laser_selection[i]))
+        rc = lib().velo_decode_plan_fill(plan, C.byref(o), _p(buf), _p(times_us), times_us.size, _p(calib), n_lasers,
+                                         poses, n_poses, int(bool(flush)), None, 0)
+        if rc:
+            raise RuntimeError("velo_decode_plan_fill: %d %s" % (rc, lib().velo_decode_plan_error(plan).decode()))
+
+    def decode_submit(self, plan):
+        """device half: -> (n_frames, n_points), frames left on the device like decode_resident"""
+        nf = C.c_int32()
+        npts = C.c_size_t()
+        self._chk(lib().velo_decode_submit(self.h, plan, C.byref(nf), C.byref(npts)))
         self._decoded_frames = nf.value
         return nf.value, npts.value
 

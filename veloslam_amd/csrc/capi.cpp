@@ -76,12 +76,21 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
+    bool owned = true;
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        owned = true;
+    }
+    // a view into somebody else's allocation (PlanUpload: the slices of one staging buffer)
+    void alias(T* q)
+    {
+        release();
+        p = q;
+        owned = false;
     }
     hipError_t reserve(size_t n, bool keep = false, hipStream_t s = nullptr)
     {
@@ -147,6 +156,21 @@ struct velo_ctx {
     const float *ax = nullptr, *ay = nullptr, *az = nullptr;  // active (owned or adopted)
     int n_frames = 0;
     std::vector<int64_t> frame_start;
+    // Every small array a frame plan sends to the device (work items in their launch orders, block
+    // ranges, frame offsets) goes through ONE pinned staging buffer and ONE copy; the DevBufs below
+    // that hold them are views into `d` (six copies from pageable vectors per frame of a stream,
+    // each staged and launched on its own, were ~50 us of every frame).
+    struct PlanUpload {
+        uint8_t* h = nullptr;  // pinned
+        size_t h_cap = 0, used = 0;
+        DevBuf<uint8_t> d;
+        struct Slice {
+            void (*bind)(void* buf, uint8_t* base, size_t off);
+            void* buf;
+            size_t off;
+        };
+        std::vector<Slice> slices;
+    } plan_up;
     DevBuf<int64_t> d_frame_start;
     std::vector<BlockItem> items_h;   // frame-major
     std::vector<int32_t> fbs_h;
@@ -198,8 +222,6 @@ struct velo_ctx {
     int32_t* h_starts = nullptr;      // pinned: beam offsets of a decode
     size_t h_starts_cap = 0;
     uint32_t* h_inc_total = nullptr;  // pinned: count of the asynchronous increment
-    uint8_t* h_dec_stage = nullptr;   // pinned: packets + per-packet plan of one decode call
-    size_t h_dec_cap = 0;
     DevBuf<uint8_t> dk_stage;         // ... and their one device-side copy
     hipEvent_t ev_inc = nullptr;
     bool inc_pending = false;
@@ -268,6 +290,39 @@ struct velo_ctx {
         std::vector<int32_t> azdiff;
         std::vector<int16_t> blk;  // 12 per packet: 0 = unfinished frame, -1 = emitted earlier
     } dstream;
+    // What the HOST half of a decode (the sequential part of the parser) leaves for the DEVICE half:
+    // packets + per-packet plan laid out in one pinned staging buffer, the headers of the frames
+    // found, the parser state to carry on.  Filling one touches neither the ctx nor the GPU, so the
+    // next frame can be planned while the current one is being registered (velo_decode_plan_*).
+    struct DecodePlan {
+        bool filled = false;
+        size_t n_pkt = 0;
+        int nfr = 0, n_lasers = 64, crop_inside = 0;
+        bool crop = false, keep_state = false, flush = false;
+        double region[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long laser_mask = ~0ull;
+        velo_laser_corr corr[64];
+        std::vector<velo_pose> carposes;
+        std::vector<int64_t> frame_t;
+        std::vector<int32_t> frame_packets;
+        uint8_t* stage = nullptr;  // pinned, owned
+        size_t stage_cap = 0, stage_bytes = 0;
+        size_t o_pk = 0, o_blk = 0, o_perm = 0, o_tab = 0, o_tv = 0, o_az = 0;
+        DecodeStream st_next;
+        int code = 0;
+        char err[200] = {0};
+        ~DecodePlan()
+        {
+            if (stage) (void)hipHostFree(stage);
+        }
+        int fail(int c, const char* msg)
+        {
+            code = c;
+            snprintf(err, sizeof err, "%s", msg);
+            filled = false;
+            return c;
+        }
+    } dplan;
 
     // ---- timing
     bool timing = false;
@@ -807,6 +862,43 @@ int rounds_per_wave(const velo_ctx* c, int64_t n_queries, int r_max)
     return r;
 }
 
+// ---- PlanUpload: stage now, copy once, bind the views (plan_flush)
+template <typename T>
+int plan_add(velo_ctx* c, DevBuf<T>& dst, const T* src, size_t n)
+{
+    velo_ctx::PlanUpload& u = c->plan_up;
+    const size_t off = (u.used + 255) & ~(size_t)255, bytes = n * sizeof(T);
+    if (off + bytes > u.h_cap) {
+        const size_t want = std::max<size_t>((off + bytes) * 2, 1 << 16);
+        uint8_t* q = nullptr;
+        HIP_TRY(c, hipHostMalloc((void**)&q, want, 0));
+        if (u.h) {
+            std::memcpy(q, u.h, u.used);
+            (void)hipHostFree(u.h);
+        }
+        u.h = q;
+        u.h_cap = want;
+    }
+    if (bytes) std::memcpy(u.h + off, src, bytes);
+    u.used = off + bytes;
+    u.slices.push_back({[](void* buf, uint8_t* base, size_t o) { static_cast<DevBuf<T>*>(buf)->alias(reinterpret_cast<T*>(base + o)); },
+                        &dst, off});
+    return VELO_OK;
+}
+
+int plan_flush(velo_ctx* c)
+{
+    velo_ctx::PlanUpload& u = c->plan_up;
+    if (u.used) {
+        HIP_TRY(c, u.d.reserve(u.used + u.used / 2));
+        HIP_TRY(c, hipMemcpyAsync(u.d.p, u.h, u.used, hipMemcpyHostToDevice, c->stream));
+    }
+    for (const auto& sl : u.slices) sl.bind(sl.buf, u.d.p, sl.off);
+    u.slices.clear();
+    u.used = 0;
+    return VELO_OK;
+}
+
 int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, int rounds, int tail_pct,
                        int order, DevBuf<BlockItem>& d_items, DevBuf<int32_t>& d_fbs, int& n_out)
 {
@@ -833,13 +925,8 @@ int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, in
     big = launch_order(big, order);
     tail = launch_order(tail, order);
     big.insert(big.end(), tail.begin(), tail.end());
-    HIP_TRY(c, d_items.reserve(big.size()));
-    HIP_TRY(c, d_fbs.reserve((size_t)n_frames + 1));
-    HIP_TRY(c, hipMemcpyAsync(d_items.p, big.data(), big.size() * sizeof(BlockItem), hipMemcpyHostToDevice,
-                              c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_fbs.p, fbl.data(), fbl.size() * sizeof(int32_t), hipMemcpyHostToDevice,
-                              c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors go out of scope
+    if (int rc = plan_add(c, d_items, big.data(), big.size())) return rc;
+    if (int rc = plan_add(c, d_fbs, fbl.data(), fbl.size())) return rc;
     n_out = (int)big.size();
     return VELO_OK;
 }
@@ -882,6 +969,8 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
         HIP_TRY(c, hipEventSynchronize(c->ev_plan));
     else
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
+    c->plan_up.slices.clear();  // (a plan that failed half way leaves nothing behind)
+    c->plan_up.used = 0;
     c->n_frames = n_frames;
     ++c->frames_gen;
     c->frame_start.assign(frame_start, frame_start + n_frames + 1);
@@ -962,32 +1051,20 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
         }
         fbl[n_frames] = (int32_t)late.size();
         if (!late.empty()) {
-            HIP_TRY(c, c->items_late.reserve(late.size()));
-            HIP_TRY(c, c->fbs_late.reserve((size_t)n_frames + 1));
-            HIP_TRY(c, hipMemcpyAsync(c->items_late.p, late.data(), late.size() * sizeof(BlockItem),
-                                      hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(c->fbs_late.p, fbl.data(), fbl.size() * sizeof(int32_t),
-                                      hipMemcpyHostToDevice, c->stream));
+            if (int rc = plan_add(c, c->items_late, late.data(), late.size())) return rc;
+            if (int rc = plan_add(c, c->fbs_late, fbl.data(), fbl.size())) return rc;
             c->ni_late = (int)late.size();
         }
     }
-    HIP_TRY(c, c->items.reserve(std::max<size_t>(ni, 1)));
-    HIP_TRY(c, c->fbs.reserve((size_t)n_frames + 1));
-    HIP_TRY(c, c->d_frame_start.reserve((size_t)n_frames + 1));
     HIP_TRY(c, c->partials.reserve(max_rows * kAccStride));
     HIP_TRY(c, c->poses.reserve((size_t)maxb * 12));
     HIP_TRY(c, c->acc.reserve((size_t)maxb * kAccStride));
     HIP_TRY(c, c->stats.reserve((size_t)maxb * VELO_MAX_ITERS));
     std::vector<BlockItem>& lo = c->plan_lo_h;  // the same items in launch order (registrations)
     lo.clear();
-    if (ni) {
-        HIP_TRY(c, hipMemcpyAsync(c->items.p, c->items_h.data(), ni * sizeof(BlockItem),
-                                  hipMemcpyHostToDevice, c->stream));
-        lo = launch_order(c->items_h, VELO_ORDER_FIRST);
-        HIP_TRY(c, c->items_first.reserve(ni));
-        HIP_TRY(c, hipMemcpyAsync(c->items_first.p, lo.data(), ni * sizeof(BlockItem), hipMemcpyHostToDevice,
-                                  c->stream));
-    }
+    if (int rc = plan_add(c, c->items, c->items_h.data(), ni)) return rc;
+    if (ni) lo = launch_order(c->items_h, VELO_ORDER_FIRST);
+    if (int rc = plan_add(c, c->items_first, lo.data(), lo.size())) return rc;
     std::vector<BlockItem>& xcd = c->plan_xcd_h;
     xcd.clear();
     if (c->cfg.sort_frames == 1 && ni) {
@@ -1006,16 +1083,12 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
         for (size_t t = 0; t < longest; ++t)
             for (int r = 0; r < 8; ++r)
                 if (t < region[r].size()) xcd.push_back(region[r][t]);
-        HIP_TRY(c, c->items_xcd.reserve(ni));
-        HIP_TRY(c, hipMemcpyAsync(c->items_xcd.p, xcd.data(), ni * sizeof(BlockItem),
-                                  hipMemcpyHostToDevice, c->stream));
+        if (int rc = plan_add(c, c->items_xcd, xcd.data(), ni)) return rc;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->fbs.p, c->fbs_h.data(), ((size_t)n_frames + 1) * sizeof(int32_t),
-                              hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_frame_start.p, c->frame_start.data(),
-                              ((size_t)n_frames + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
-                              c->stream));
-    // every source above is a ctx member that lives until the next plan: no wait here
+    if (int rc = plan_add(c, c->fbs, c->fbs_h.data(), (size_t)n_frames + 1)) return rc;
+    if (int rc = plan_add(c, c->d_frame_start, c->frame_start.data(), (size_t)n_frames + 1)) return rc;
+    // one copy for all of the above; its source is the pinned stage, free again at ev_plan
+    if (int rc = plan_flush(c)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_plan, c->stream));
     return VELO_OK;
 }
@@ -1394,9 +1467,9 @@ void velo_destroy(velo_ctx* c)
     if (c->h_starts) (void)hipHostFree(c->h_starts);
     if (c->h_pend_total) (void)hipHostFree(c->h_pend_total);
     if (c->ev_pend) (void)hipEventDestroy(c->ev_pend);
-    if (c->h_dec_stage) (void)hipHostFree(c->h_dec_stage);
     if (c->ev_inc) (void)hipEventDestroy(c->ev_inc);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    if (c->plan_up.h) (void)hipHostFree(c->plan_up.h);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_call0) (void)hipEventDestroy(c->ev_call0);
     if (c->ev_call1) (void)hipEventDestroy(c->ev_call1);
@@ -2095,33 +2168,22 @@ int upload_calibration(velo_ctx* c, const velo_laser_corr corr[64])
 
 // Host half of the decode: the sequential part of the parser (12 integers per packet,
 // HDLParser.cxx:980-1055) run over [pending packets of the unfinished frame] + [new packets],
-// continuing from the parser state `st` carries; then the device half over the same packet set.
-static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* packets,
-                       const int64_t* pkt_t_us, size_t n_new, const velo_laser_corr corr[64],
-                       int n_lasers, const velo_pose* poses, size_t n_poses, int flush,
-                       const double* crop_region, int crop_inside, bool keep_state,
-                       int32_t* n_frames, size_t* n_points)
+// continuing from the parser state `st` carries.  Everything the device half needs ends up in P
+// (one pinned staging buffer); neither the ctx nor the GPU is touched.
+static int decode_plan_host(velo_ctx::DecodePlan& P, const velo_ctx::DecodeStream& st, const velo_decode_opts& dopts,
+                            const uint8_t* packets, const int64_t* pkt_t_us, size_t n_new,
+                            const velo_laser_corr corr[64], int n_lasers, const velo_pose* poses, size_t n_poses,
+                            int flush, const double* crop_region, int crop_inside, bool keep_state)
 {
+    P.filled = false;
+    P.code = 0;
     if ((n_new && (!packets || !pkt_t_us)) || !corr || (n_poses && !poses))
-        return c->fail(VELO_E_INVALID, "velo_decode: null argument");
+        return P.fail(VELO_E_INVALID, "velo_decode: null argument");
     if (n_lasers != 64 && n_lasers != 32 && n_lasers != 16)
-        return c->fail(VELO_E_INVALID, "n_lasers must be 64, 32 or 16");
-    velo_ctx::DecodeStream st_next_;
+        return P.fail(VELO_E_INVALID, "n_lasers must be 64, 32 or 16");
     const size_t n_pend = st.t.size();
     const size_t n_pkt = n_pend + n_new;
-    if (n_pkt == 0 || n_pkt > 60000) return c->fail(VELO_E_RANGE, "packets in flight must be in [1, 60000]");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (c->ax && c->ax == c->dk_x.p) {
-        // the resident frames ARE the previous decode's output (velo_decode_to_frames): this
-        // decode rewrites (and may reallocate) those buffers, so the adoption ends here --
-        // registration calls fail with VELO_E_INVALID until frames are uploaded/adopted again
-        c->ax = c->ay = c->az = nullptr;
-        c->n_frames = 0;
-        c->last_iters = 0;
-        ++c->frames_gen;
-    }
-    if (int rc = upload_calibration(c, corr)) return rc;
-    hipStream_t s = c->stream;
+    if (n_pkt == 0 || n_pkt > 60000) return P.fail(VELO_E_RANGE, "packets in flight must be in [1, 60000]");
 
     const veloslam::SortedPoseView tm(poses, n_poses);  // the caller's store, read in place: O(log n) per packet
     // working set = what the unfinished frame still needs + the new packets
@@ -2143,26 +2205,26 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     tvalid.resize(n_pkt, 0);
     std::vector<int32_t> azdiff(st.azdiff);
     azdiff.resize(n_pkt, 0);
-    c->dk_carposes.clear();
-    c->dk_frame_t.clear();
-    c->dk_frame_packets.clear();
+    P.carposes.clear();
+    P.frame_t.clear();
+    P.frame_packets.clear();
     // a parse that starts from fresh state begins at the configured block (getFrame's `skip`)
     const bool fresh = !st.inited && !st.open && st.t.empty() && st.last_az == -1;
-    int last_az = st.last_az, firing_skip = fresh ? c->dopts.initial_firing_skip : st.firing_skip, cur = 0;
-    const int pskip = c->dopts.points_skip;
+    int last_az = st.last_az, firing_skip = fresh ? dopts.initial_firing_skip : st.firing_skip, cur = 0;
+    const int pskip = dopts.points_skip;
     bool inited = st.inited, is_hdl64 = st.is_hdl64;
     veloslam::PoseTransform carpose = st.carpose;
     auto open_frame = [&]() {
-        c->dk_carposes.push_back(veloslam::PoseTransform().toC());
-        c->dk_frame_t.push_back(VELO_TIME_INVALID);
-        c->dk_frame_packets.push_back(0);
+        P.carposes.push_back(veloslam::PoseTransform().toC());
+        P.frame_t.push_back(VELO_TIME_INVALID);
+        P.frame_packets.push_back(0);
         perm.push_back(0);
     };
     open_frame();
     if (st.open) {  // header of the frame the previous call left unfinished
-        c->dk_carposes[0] = st.carpose0;
-        c->dk_frame_t[0] = st.frame_t;
-        c->dk_frame_packets[0] = st.frame_packets;
+        P.carposes[0] = st.carpose0;
+        P.frame_t[0] = st.frame_t;
+        P.frame_packets[0] = st.frame_packets;
     }
     for (size_t p = n_pend; p < n_pkt; ++p) {
         const uint8_t* d = bytes_p + p * 1206;
@@ -2170,9 +2232,9 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
         tm.interpolate(times[p], &tr);
         if (!inited) {  // :992-1001
             carpose = tr;
-            c->dk_carposes[cur] = tr.toC();
-            c->dk_frame_t[cur] = times[p];
-            c->dk_frame_packets[cur]++;
+            P.carposes[cur] = tr.toC();
+            P.frame_t[cur] = times[p];
+            P.frame_packets[cur]++;
             inited = true;
         }
         tr.timestamp = times[p];
@@ -2182,7 +2244,7 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
             std::memcpy(&table[p * 12], M.data(), 12 * sizeof(double));
             tvalid[p] = 1;
         }
-        c->dk_frame_packets[cur]++;  // :1009
+        P.frame_packets[cur]++;  // :1009
         int block = firing_skip;
         firing_skip = 0;
         int diffs[11];
@@ -2202,7 +2264,7 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
                 firing_skip = block;
                 perm[cur] = is_hdl64 ? 1 : 0;
                 ++cur;
-                if (cur >= 32000) return c->fail(VELO_E_RANGE, "too many frames in one decode call");
+                if (cur >= 32000) return P.fail(VELO_E_RANGE, "too many frames in one decode call");
                 open_frame();
                 inited = false;
             }
@@ -2212,6 +2274,7 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
         }
     }
     int nfr = cur;
+    P.st_next = velo_ctx::DecodeStream();
     if (keep_state && !flush) {
         // carry the parser on: keep the packets that hold blocks of the unfinished frame `cur`
         velo_ctx::DecodeStream nx;
@@ -2221,9 +2284,9 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
         nx.is_hdl64 = is_hdl64;
         nx.carpose = carpose;
         nx.open = true;
-        nx.carpose0 = c->dk_carposes[cur];
-        nx.frame_t = c->dk_frame_t[cur];
-        nx.frame_packets = c->dk_frame_packets[cur];
+        nx.carpose0 = P.carposes[cur];
+        nx.frame_t = P.frame_t[cur];
+        nx.frame_packets = P.frame_packets[cur];
         size_t p0 = n_pkt;
         for (size_t p = 0; p < n_pkt && p0 == n_pkt; ++p)
             for (int k = 0; k < 12; ++k)
@@ -2239,7 +2302,7 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
             nx.azdiff.push_back(azdiff[p]);
             for (int k = 0; k < 12; ++k) nx.blk.push_back(blk[p * 12 + k] == cur ? (int16_t)0 : (int16_t)-1);
         }
-        st_next_ = std::move(nx);
+        P.st_next = std::move(nx);
     }
     if (flush) {
         perm[cur] = is_hdl64 ? 1 : 0;
@@ -2247,12 +2310,76 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     } else {
         for (auto& b : blk)
             if (b == cur) b = -1;  // the unfinished frame is not emitted
-        c->dk_carposes.resize((size_t)nfr);
-        c->dk_frame_t.resize((size_t)nfr);
-        c->dk_frame_packets.resize((size_t)nfr);
+        P.carposes.resize((size_t)nfr);
+        P.frame_t.resize((size_t)nfr);
+        P.frame_packets.resize((size_t)nfr);
     }
-    const uint8_t* packets_all = bytes_p;
-    // ---- device side
+    // Packets and per-packet plan go up in ONE copy from a pinned staging buffer (six copies from
+    // pageable vectors each blocked the host for their staging).
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    P.o_pk = 0;
+    P.o_blk = al(P.o_pk + n_pkt * 1206);
+    P.o_perm = al(P.o_blk + blk.size() * sizeof(int16_t));
+    P.o_tab = al(P.o_perm + perm.size());
+    P.o_tv = al(P.o_tab + table.size() * sizeof(double));
+    P.o_az = al(P.o_tv + n_pkt);
+    P.stage_bytes = al(P.o_az + n_pkt * sizeof(int32_t));
+    if (P.stage_cap < P.stage_bytes) {
+        if (P.stage) (void)hipHostFree(P.stage);
+        P.stage = nullptr;
+        P.stage_cap = 0;
+        if (hipHostMalloc((void**)&P.stage, P.stage_bytes + P.stage_bytes / 2, 0) != hipSuccess) {
+            P.stage = nullptr;
+            return P.fail(VELO_E_NOMEM, "velo_decode: no pinned memory for the staging buffer");
+        }
+        P.stage_cap = P.stage_bytes + P.stage_bytes / 2;
+    }
+    std::memcpy(P.stage + P.o_pk, bytes_p, n_pkt * 1206);
+    std::memcpy(P.stage + P.o_blk, blk.data(), blk.size() * sizeof(int16_t));
+    std::memcpy(P.stage + P.o_perm, perm.data(), perm.size());
+    std::memcpy(P.stage + P.o_tab, table.data(), table.size() * sizeof(double));
+    std::memcpy(P.stage + P.o_tv, tvalid.data(), n_pkt);
+    std::memcpy(P.stage + P.o_az, azdiff.data(), n_pkt * sizeof(int32_t));
+    P.n_pkt = n_pkt;
+    P.nfr = nfr;
+    P.n_lasers = n_lasers;
+    std::memcpy(P.corr, corr, sizeof P.corr);
+    P.crop = crop_region != nullptr;
+    P.crop_inside = crop_inside;
+    for (int i = 0; i < 6; ++i) P.region[i] = crop_region ? crop_region[i] : 0.0;
+    P.laser_mask = 0;
+    for (int i = 0; i < 64; ++i)
+        if (dopts.laser_selection[i]) P.laser_mask |= 1ull << i;
+    P.keep_state = keep_state;
+    P.flush = flush != 0;
+    P.filled = true;
+    return VELO_OK;
+}
+
+// Device half: the planned packet set through the decode kernels.  `st` (optional) receives the
+// parser state the plan carries on.
+static int decode_submit(velo_ctx* c, velo_ctx::DecodePlan& P, velo_ctx::DecodeStream* st, int32_t* n_frames,
+                         size_t* n_points)
+{
+    if (!P.filled) return c->fail(VELO_E_INVALID, "velo_decode: nothing planned");
+    P.filled = false;  // (the staging buffer is free again at the synchronisation below)
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->ax && c->ax == c->dk_x.p) {
+        // the resident frames ARE the previous decode's output (velo_decode_to_frames): this
+        // decode rewrites (and may reallocate) those buffers, so the adoption ends here --
+        // registration calls fail with VELO_E_INVALID until frames are uploaded/adopted again
+        c->ax = c->ay = c->az = nullptr;
+        c->n_frames = 0;
+        c->last_iters = 0;
+        ++c->frames_gen;
+    }
+    if (int rc = upload_calibration(c, P.corr)) return rc;
+    hipStream_t s = c->stream;
+    const size_t n_pkt = P.n_pkt;
+    const int nfr = P.nfr;
+    c->dk_carposes = P.carposes;
+    c->dk_frame_t = P.frame_t;
+    c->dk_frame_packets = P.frame_packets;
     const size_t n_ret = n_pkt * 384;
     HIP_TRY(c, c->dk_keys.reserve(n_ret));
     HIP_TRY(c, c->dk_keys2.reserve(n_ret));
@@ -2260,49 +2387,27 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     HIP_TRY(c, c->dk_order.reserve(n_ret));
     const uint32_t n_keys = (uint32_t)std::max(nfr, 1) * 64u;
     HIP_TRY(c, c->dk_starts.reserve((size_t)n_keys + 1));
-    // Packets and per-packet plan go up in ONE copy from a pinned staging buffer (six copies from
-    // pageable vectors each blocked the host for their staging).  The buffer is free again at the
-    // synchronisation below, well before the next call.
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_pk = 0, o_blk = al(o_pk + n_pkt * 1206), o_perm = al(o_blk + blk.size() * sizeof(int16_t)),
-                 o_tab = al(o_perm + perm.size()), o_tv = al(o_tab + table.size() * sizeof(double)),
-                 o_az = al(o_tv + n_pkt), stage_bytes = al(o_az + n_pkt * sizeof(int32_t));
-    if (c->h_dec_cap < stage_bytes) {
-        if (c->h_dec_stage) (void)hipHostFree(c->h_dec_stage);
-        c->h_dec_stage = nullptr;
-        c->h_dec_cap = 0;
-        HIP_TRY(c, hipHostMalloc((void**)&c->h_dec_stage, stage_bytes + stage_bytes / 2, 0));
-        c->h_dec_cap = stage_bytes + stage_bytes / 2;
-    }
-    HIP_TRY(c, c->dk_stage.reserve(stage_bytes));
-    std::memcpy(c->h_dec_stage + o_pk, packets_all, n_pkt * 1206);
-    std::memcpy(c->h_dec_stage + o_blk, blk.data(), blk.size() * sizeof(int16_t));
-    std::memcpy(c->h_dec_stage + o_perm, perm.data(), perm.size());
-    std::memcpy(c->h_dec_stage + o_tab, table.data(), table.size() * sizeof(double));
-    std::memcpy(c->h_dec_stage + o_tv, tvalid.data(), n_pkt);
-    std::memcpy(c->h_dec_stage + o_az, azdiff.data(), n_pkt * sizeof(int32_t));
-    HIP_TRY(c, hipMemcpyAsync(c->dk_stage.p, c->h_dec_stage, stage_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, c->dk_stage.reserve(P.stage_bytes));
+    HIP_TRY(c, hipMemcpyAsync(c->dk_stage.p, P.stage, P.stage_bytes, hipMemcpyHostToDevice, s));
     DecodeView v;
-    v.pkts = c->dk_stage.p + o_pk;
-    v.blk_frame = reinterpret_cast<const int16_t*>(c->dk_stage.p + o_blk);
-    v.frame_perm = c->dk_stage.p + o_perm;
-    v.table = reinterpret_cast<const double*>(c->dk_stage.p + o_tab);
-    v.tvalid = c->dk_stage.p + o_tv;
-    v.az_diff = reinterpret_cast<const int32_t*>(c->dk_stage.p + o_az);
+    v.pkts = c->dk_stage.p + P.o_pk;
+    v.blk_frame = reinterpret_cast<const int16_t*>(c->dk_stage.p + P.o_blk);
+    v.frame_perm = c->dk_stage.p + P.o_perm;
+    v.table = reinterpret_cast<const double*>(c->dk_stage.p + P.o_tab);
+    v.tvalid = c->dk_stage.p + P.o_tv;
+    v.az_diff = reinterpret_cast<const int32_t*>(c->dk_stage.p + P.o_az);
     v.corr = c->dk_corr.p;
     v.lut_cos = c->dk_lutc.p;
     v.lut_sin = c->dk_luts.p;
     v.az_cos = c->dk_azc.p;
     v.az_sin = c->dk_azs.p;
     v.inv_lut = c->dk_invlut.p;
-    v.laser_mask = 0;
-    for (int i = 0; i < 64; ++i)
-        if (c->dopts.laser_selection[i]) v.laser_mask |= 1ull << i;
+    v.laser_mask = P.laser_mask;
     v.n_pkt = (int)n_pkt;
-    v.n_lasers = n_lasers;
-    v.crop = crop_region != nullptr;
-    v.crop_inside = crop_inside;
-    for (int i = 0; i < 6; ++i) v.region[i] = crop_region ? crop_region[i] : 0.0;
+    v.n_lasers = P.n_lasers;
+    v.crop = P.crop;
+    v.crop_inside = P.crop_inside;
+    for (int i = 0; i < 6; ++i) v.region[i] = P.region[i];
     HIP_TRY(c, launch_decode_keys(v, n_ret, c->dk_keys.p, c->dk_idx.p, s));
     // valid keys are < n_keys, the key of a dropped return is all ones: the low bits that cover
     // n_keys order both (one radix pass for a frame or two instead of four over 32 bits)
@@ -2349,13 +2454,75 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
     c->dk_frame_start[nfr] = (int64_t)n_valid;
     if (n_frames) *n_frames = nfr;
     if (n_points) *n_points = n_valid;
-    if (keep_state) {
-        if (flush)
-            st = velo_ctx::DecodeStream();  // everything emitted: the next packet starts afresh
+    if (P.keep_state && st) {
+        if (P.flush)
+            *st = velo_ctx::DecodeStream();  // everything emitted: the next packet starts afresh
         else
-            st = std::move(st_next_);
+            *st = std::move(P.st_next);
     }
     return VELO_OK;
+}
+
+static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* packets,
+                       const int64_t* pkt_t_us, size_t n_new, const velo_laser_corr corr[64],
+                       int n_lasers, const velo_pose* poses, size_t n_poses, int flush,
+                       const double* crop_region, int crop_inside, bool keep_state,
+                       int32_t* n_frames, size_t* n_points)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (decode_plan_host(c->dplan, st, c->dopts, packets, pkt_t_us, n_new, corr, n_lasers, poses, n_poses, flush,
+                         crop_region, crop_inside, keep_state))
+        return c->fail(c->dplan.code, "%s", c->dplan.err);
+    return decode_submit(c, c->dplan, &st, n_frames, n_points);
+}
+
+// ---- the two halves, separately: plan frame k + 1 on the host while the GPU registers frame k
+struct velo_decode_plan {
+    velo_ctx::DecodePlan P;
+    int device = 0;
+};
+
+int velo_decode_plan_create(velo_ctx* c, velo_decode_plan** out)
+{
+    if (!c || !out) return VELO_E_INVALID;
+    velo_decode_plan* p = new (std::nothrow) velo_decode_plan;
+    if (!p) return c->fail(VELO_E_NOMEM, "out of memory");
+    p->device = c->device;
+    *out = p;
+    return VELO_OK;
+}
+
+void velo_decode_plan_destroy(velo_decode_plan* p) { delete p; }
+
+const char* velo_decode_plan_error(const velo_decode_plan* p) { return p ? p->P.err : "null plan"; }
+
+int velo_decode_plan_fill(velo_decode_plan* p, const velo_decode_opts* opts, const uint8_t* packets,
+                          const int64_t* pkt_t_us, size_t n_pkt, const velo_laser_corr corr[64], int n_lasers,
+                          const velo_pose* poses, size_t n_poses, int flush, const double* crop_region,
+                          int crop_inside)
+{
+    if (!p) return VELO_E_INVALID;
+    velo_decode_opts d{};
+    d.struct_size = sizeof d;
+    std::memset(d.laser_selection, 1, sizeof d.laser_selection);
+    if (opts) {
+        if (opts->struct_size < sizeof d) return p->P.fail(VELO_E_INVALID, "velo_decode_opts.struct_size too small");
+        if (opts->points_skip < 0 || opts->initial_firing_skip < 0 || opts->initial_firing_skip > 12)
+            return p->P.fail(VELO_E_INVALID, "points_skip must be >= 0, initial_firing_skip in [0,12]");
+        d = *opts;
+        d.struct_size = sizeof d;
+    }
+    if (n_pkt == 0) return p->P.fail(VELO_E_RANGE, "n_pkt must be in [1, 60000]");
+    (void)hipSetDevice(p->device);  // (the pinned staging buffer may be allocated from this thread)
+    const velo_ctx::DecodeStream fresh;
+    return decode_plan_host(p->P, fresh, d, packets, pkt_t_us, n_pkt, corr, n_lasers, poses, n_poses, flush,
+                            crop_region, crop_inside, false);
+}
+
+int velo_decode_submit(velo_ctx* c, velo_decode_plan* p, int32_t* n_frames, size_t* n_points)
+{
+    if (!c || !p) return VELO_E_INVALID;
+    return decode_submit(c, p->P, nullptr, n_frames, n_points);
 }
 
 int velo_decode(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, size_t n_pkt,

@@ -482,7 +482,18 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
     }
     double T0s[4 * 12];
     for (int f = 0; f < 4; ++f) std::memcpy(T0s + 12 * f, T0.data(), sizeof(double) * 12);
-    if (velo_icp_batch(ctx_, T0s, o.iters, o.d_max, local)) {
+    if (velo_icp_batch_async(ctx_, T0s, o.iters, o.d_max)) {
+        err_ = velo_last_error(ctx_);
+        return false;
+    }
+    // the accepted increment joins the device-side pending list at the pose the registration
+    // leaves on the device: nothing is fetched, nothing blocks, so it is enqueued right behind
+    if (o.integrate && velo_increment_pending(ctx_, frame, nullptr, o.increment_min_count)) {
+        err_ = velo_last_error(ctx_);
+        return false;
+    }
+    if (o.while_registering) o.while_registering();  // the GPU is busy for ~0.5 ms: the caller's host work goes here
+    if (velo_icp_batch_fetch(ctx_, local)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
@@ -495,12 +506,6 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
     for (int i = 0; i < 3; ++i) p.V[i] = init.V[i];
     *out = p;
     if (o.integrate) {
-        // the accepted increment joins the device-side pending list at the pose the registration
-        // left on the device: nothing is fetched, nothing blocks
-        if (velo_increment_pending(ctx_, frame, nullptr, o.increment_min_count)) {
-            err_ = velo_last_error(ctx_);
-            return false;
-        }
         if (o.append_threshold <= 1) {  // "after every frame": wait for this one
             if (!flushIncrements()) return false;
         } else {

@@ -15,7 +15,10 @@ HDLManager::HDLManager(velo_ctx* ctx, int capacity)
     std::memset(corr_, 0, sizeof corr_);
 }
 
-HDLManager::~HDLManager() = default;
+HDLManager::~HDLManager()
+{
+    if (plan_) velo_decode_plan_destroy(plan_);
+}
 
 bool HDLManager::setCalibFile(const std::string& filename)
 {
@@ -167,9 +170,9 @@ void HDLManager::addFrame(std::shared_ptr<HDLFrame> frame)
     if (frame->isInMemory) pushCache(frame);
 }
 
-// ---- the decode behind prepareFrame / prepareResident ------------------------------------
-bool HDLManager::decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, int* n_decoded)
+bool HDLManager::fillPlan(const HDLFrame& f)
 {
+    planned_ = nullptr;
     if (!ctx_) {
         err_ = "no device context";
         return false;
@@ -183,6 +186,10 @@ bool HDLManager::decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, in
         err_ = "the frame is not part of the loaded capture";
         return false;
     }
+    if (!plan_ && velo_decode_plan_create(ctx_, &plan_) != VELO_OK) {
+        err_ = std::string("decode failed: ") + velo_last_error(ctx_);
+        return false;
+    }
     velo_decode_opts dop;
     std::memset(&dop, 0, sizeof dop);
     dop.struct_size = sizeof dop;
@@ -190,13 +197,35 @@ bool HDLManager::decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, in
     std::memset(dop.laser_selection, 1, sizeof dop.laser_selection);
     const size_t p0 = (size_t)f.firstPacket;
     const bool last = p0 + (size_t)f.numPackets >= times_.size();
-    int32_t nf = 0;
-    size_t n = 0;
     // a frame that closes inside its last packet is emitted by the split; the last frame of the
     // capture by the flush (HDLParser::getFrame's tail, HDLParser.cxx:539-543)
-    if (velo_decode_set_options(ctx_, &dop) != VELO_OK ||
-        velo_decode(ctx_, packets_.data() + p0 * 1206, times_.data() + p0, (size_t)f.numPackets, corr_, 64,
-                    poses_.data(), poses_.size(), last ? 1 : 0, nullptr, 0, &nf, &n) != VELO_OK) {
+    if (velo_decode_plan_fill(plan_, &dop, packets_.data() + p0 * 1206, times_.data() + p0, (size_t)f.numPackets, corr_,
+                              64, poses_.data(), poses_.size(), last ? 1 : 0, nullptr, 0) != VELO_OK) {
+        err_ = std::string("decode failed: ") + velo_decode_plan_error(plan_);
+        return false;
+    }
+    planned_ = &f;
+    return true;
+}
+
+bool HDLManager::planResident(const std::shared_ptr<HDLFrame>& frame)
+{
+    if (!frame || !frame->isOnHardDrive) {
+        err_ = "not a frame of the capture";
+        return false;
+    }
+    std::lock_guard<std::mutex> lock(decodeMutex_);
+    return fillPlan(*frame);
+}
+
+// ---- the decode behind prepareFrame / prepareResident ------------------------------------
+bool HDLManager::decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, int* n_decoded)
+{
+    if (planned_ != &f && !fillPlan(f)) return false;  // (planned ahead: only the device half is left)
+    planned_ = nullptr;
+    int32_t nf = 0;
+    size_t n = 0;
+    if (velo_decode_submit(ctx_, plan_, &nf, &n) != VELO_OK) {
         err_ = std::string("decode failed: ") + velo_last_error(ctx_);
         return false;
     }
