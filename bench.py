@@ -510,38 +510,57 @@ def run_replay(args, dev, local, steps, warmup, d=None):
             return (np.empty(0, np.float32),) * 3
         return np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)
 
-    def flush():
+    def take():
+        """the pending increments off the device (list emptied) into the host tiles; -> (x, y, z, ti, tj)"""
         n = ctx.pending_count(True)
         if not n:
-            return
+            e = np.empty(0, np.float32)
+            return e, e, e, np.empty(0, np.int64), np.empty(0, np.int64)
         x, y, z = ctx.pending_fetch()
-        ctx.map_append_pending()
+        ctx.pending_clear()
         ti, tj = drive.tile_index(x, y, pr)
         for k in range(n):   # (a few hundred points per flush)
             t = tile_of.setdefault((int(ti[k]), int(tj[k])), [np.empty(0, np.float32)] * 3)
             t[0], t[1], t[2] = np.append(t[0], x[k]), np.append(t[1], y[k]), np.append(t[2], z[k])
         state["flush"] += 1
+        return x, y, z, ti, tj
+
+    def flush():
+        """... and back up for the points in resident tiles (MapManager::flushIncrements)"""
+        x, y, z, ti, tj = take()
+        cur = state["res"]
+        if not x.size or cur is None:
+            return
+        keep = (ti >= cur[0]) & (ti <= cur[1]) & (tj >= cur[2]) & (tj <= cur[3])
+        if keep.any():
+            ctx.map_append(x[keep], y[keep], z[keep])
 
     def roll_to(x, y, timed):
         rng = tile_range(x, y)
         cur = state["res"]
         if cur == rng:
             return
+        # increments accepted so far: to the host tiles now, and -- those in tiles that stay resident --
+        # back up with the entering tiles in the roll's ONE append (MapManager::rollTo)
+        px, py, pz, pti, ptj = take() if cur is not None else ((np.empty(0, np.float32),) * 3 + (np.empty(0, np.int64),) * 2)
         if cur is not None and rng[0] <= cur[1] and rng[1] >= cur[0] and rng[2] <= cur[3] and rng[3] >= cur[2]:
-            flush()
             n0 = ctx.map_info().n_points
             lo = np.array([rng[0] * pr - pr / 2, rng[2] * pr - pr / 2, -big], np.float32)
             hi = np.array([np.nextafter(np.float32(rng[1] * pr + pr / 2), np.float32(-big)),
                            np.nextafter(np.float32(rng[3] * pr + pr / 2), np.float32(-big)), big], np.float32)
             if rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]:
                 ctx.map_evict_outside(lo, hi)
+            n1 = ctx.map_info().n_points
             ex, ey, ez = gather(rng, skip=cur)
-            if ex.size:
-                ctx.map_append(ex, ey, ez)
+            stays = ((pti >= max(rng[0], cur[0])) & (pti <= min(rng[1], cur[1])) &
+                     (ptj >= max(rng[2], cur[2])) & (ptj <= min(rng[3], cur[3])))
+            ux, uy, uz = np.concatenate([ex, px[stays]]), np.concatenate([ey, py[stays]]), np.concatenate([ez, pz[stays]])
+            if ux.size:
+                ctx.map_append(ux, uy, uz)
             if timed:
                 state["rolls"] += 1
                 state["up"] += int(ex.size)
-                state["ev"] += int(n0 - (ctx.map_info().n_points - ex.size))
+                state["ev"] += int(n0 - n1)
         else:
             ex, ey, ez = gather(rng)
             ctx.map_reset(ex, ey, ez, args.voxel, args.k_normals)

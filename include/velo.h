@@ -379,11 +379,15 @@ int velo_increment_wait(velo_ctx*, size_t* n_out);
  *                             the answer does not depend on how far the GPU has got);
  *   velo_pending_fetch        host copy of the list (for a host-side tile store); VELO_E_RANGE with
  *                             *n_out = the size needed beyond cap;
- *   velo_map_append_pending   merges the list into the map (velo_map_append_dev) and empties it. */
+ *   velo_map_append_pending   merges the list into the map (velo_map_append_dev) and empties it;
+ *   velo_pending_clear        empties it without touching the map -- for a host that fetched the
+ *                             list and decides itself what goes back up (MapManager: the points
+ *                             inside the resident tiles, folded into the next roll's one append). */
 int velo_increment_pending(velo_ctx*, int frame, const double* T, int min_count);
 int velo_pending_count(velo_ctx*, size_t* n, int wait);
 int velo_pending_fetch(velo_ctx*, float* x, float* y, float* z, size_t cap, size_t* n_out);
 int velo_map_append_pending(velo_ctx*, size_t* n_appended);
+int velo_pending_clear(velo_ctx*);
 
 /* Valid correspondence pairs processed by every registration iteration of this ctx since the
  * last reset, counted on the device (exact; lets a caller that never fetches per-batch results

@@ -74,7 +74,9 @@ public:
     // tile range is a box), one velo_map_append of the tiles that entered -- never a re-upload.
     // registerFrame / registerResident call it with the prior's position.
     bool rollTo(double x, double y, const RegisterOptions& opts);
-    // merge the pending increments into the device map and into the host tiles now
+    // The pending increments (device-side list) -> the host tiles, and -> the device map for those
+    // that lie in resident tiles (one velo_map_append).  A roll does not call this: it takes the list
+    // and folds the points into the ONE append that brings the entering tiles up (rollTo).
     bool flushIncrements();
     const MapStats& stats() const { return stats_; }
     // f3: drop every tile whose centre is further than `radius` (+ half a tile diagonal) from
@@ -106,6 +108,8 @@ private:
     int residentK_;
     MapStats stats_;
     std::vector<float> stage_x_, stage_y_, stage_z_;
+    std::vector<float> pend_x_, pend_y_, pend_z_;  // increments taken off the device, not yet back on it
+    bool takeIncrements();  // device list -> pend_*_ and the host tiles; the list is emptied
     mutable std::string err_;
 };
 

@@ -2780,6 +2780,15 @@ int velo_pending_fetch(velo_ctx* c, float* x, float* y, float* z, size_t cap, si
     return VELO_OK;
 }
 
+int velo_pending_clear(velo_ctx* c)
+{
+    if (!c) return VELO_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = pending_resolve(c, true)) return rc;  // (the increment in flight belongs to the list being dropped)
+    c->pend_n = 0;
+    return VELO_OK;
+}
+
 int velo_map_append_pending(velo_ctx* c, size_t* n_appended)
 {
     if (!c) return VELO_E_INVALID;

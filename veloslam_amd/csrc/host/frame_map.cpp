@@ -375,9 +375,12 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
     };
     const bool overlap = haveDevice_ && !dirty_ && same_cfg && i0 <= res_i1_ && i1 >= res_i0_ && j0 <= res_j1_ &&
                          j1 >= res_j0_;
+    // increments accepted so far go to the host tiles now; what of them lies in tiles that stay
+    // resident goes back up with the entering tiles, in the roll's ONE append (a flush of its own
+    // would be a second pass over the whole sorted map for a few dozen points)
+    pend_x_.clear(), pend_y_.clear(), pend_z_.clear();
+    if (haveDevice_ && !takeIncrements()) return false;
     if (overlap) {
-        // increments accepted so far belong to the map before it rolls (and to the host tiles)
-        if (!flushIncrements()) return false;
         velo_map_info mi;
         mi.struct_size = sizeof mi;
         velo_map_info_get(ctx_, &mi);
@@ -404,12 +407,21 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
             stats_.points_evicted += n_before - mi.n_points;
             size_t tiles = 0;
             gather(i0, i1, j0, j1, true, &tiles);
+            const size_t n_tile_points = stage_x_.size();
+            for (size_t k = 0; k < pend_x_.size(); ++k) {
+                // (entering tiles already hold their share: takeIncrements put it into the host tiles)
+                const auto t = getPatchIdx(pend_x_[k], pend_y_[k]);
+                const bool stays = t.first >= std::max(i0, res_i0_) && t.first <= std::min(i1, res_i1_) &&
+                                   t.second >= std::max(j0, res_j0_) && t.second <= std::min(j1, res_j1_);
+                if (!stays) continue;
+                stage_x_.push_back(pend_x_[k]), stage_y_.push_back(pend_y_[k]), stage_z_.push_back(pend_z_[k]);
+            }
             if (!stage_x_.empty() &&
                 velo_map_append(ctx_, stage_x_.data(), stage_y_.data(), stage_z_.data(), stage_x_.size())) {
                 err_ = velo_last_error(ctx_);
                 return false;
             }
-            stats_.points_uploaded += stage_x_.size();
+            stats_.points_uploaded += n_tile_points;
             stats_.tiles_entered += tiles;
             stats_.tiles_left += (uint64_t)std::max(0, (res_i1_ - res_i0_ + 1) * (res_j1_ - res_j0_ + 1) -
                                                            (std::min(i1, res_i1_) - std::max(i0, res_i0_) + 1) *
@@ -442,27 +454,45 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
     return true;
 }
 
-bool MapManager::flushIncrements()
+bool MapManager::takeIncrements()
 {
-    if (!ctx_) return false;
     size_t n = 0;
     if (velo_pending_count(ctx_, &n, 1)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
+    pend_x_.resize(n), pend_y_.resize(n), pend_z_.resize(n);
     if (n == 0) return true;
-    stage_x_.resize(n), stage_y_.resize(n), stage_z_.resize(n);
-    if (velo_pending_fetch(ctx_, stage_x_.data(), stage_y_.data(), stage_z_.data(), n, &n) ||
-        velo_map_append_pending(ctx_, nullptr)) {
+    if (velo_pending_fetch(ctx_, pend_x_.data(), pend_y_.data(), pend_z_.data(), n, &n) || velo_pending_clear(ctx_)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
     // the host tiles follow the device map (not the other way round: dirty_ stays as it was)
     const bool was_dirty = dirty_;
-    addPoints(stage_x_.data(), stage_y_.data(), stage_z_.data(), n);
+    addPoints(pend_x_.data(), pend_y_.data(), pend_z_.data(), n);
     dirty_ = was_dirty;
     ++stats_.increment_flushes;
     stats_.increment_points += n;
+    return true;
+}
+
+bool MapManager::flushIncrements()
+{
+    if (!ctx_) return false;
+    if (!takeIncrements()) return false;
+    if (pend_x_.empty() || !haveDevice_) return true;
+    // back up: the points in resident tiles (anything else waits in its host tile until that tile enters)
+    stage_x_.clear(), stage_y_.clear(), stage_z_.clear();
+    for (size_t k = 0; k < pend_x_.size(); ++k) {
+        const auto t = getPatchIdx(pend_x_[k], pend_y_[k]);
+        if (t.first < res_i0_ || t.first > res_i1_ || t.second < res_j0_ || t.second > res_j1_) continue;
+        stage_x_.push_back(pend_x_[k]), stage_y_.push_back(pend_y_[k]), stage_z_.push_back(pend_z_[k]);
+    }
+    pend_x_.clear(), pend_y_.clear(), pend_z_.clear();
+    if (!stage_x_.empty() && velo_map_append(ctx_, stage_x_.data(), stage_y_.data(), stage_z_.data(), stage_x_.size())) {
+        err_ = velo_last_error(ctx_);
+        return false;
+    }
     return true;
 }
 
