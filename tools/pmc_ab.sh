@@ -9,7 +9,7 @@ for v in "$@"; do
               "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" \
               "SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmcab_${v}_$i -- python3 tools/lin_probe.py --frames ${FRAMES:-64} --cfg ${CFG:-subdiv=0} --once > gpurun_out/pmcab_${v}_$i.log 2>&1
+    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmcab_${v}_$i -- python3 tools/lin_probe.py --frames ${FRAMES:-64} --cfg ${CFG:-subdiv=0} ${EXTRA} --once > gpurun_out/pmcab_${v}_$i.log 2>&1
   done
   python3 - "$v" <<'PY' > gpurun_out/pmc_ab_$v.txt
 import csv, glob, collections, sys

@@ -1743,15 +1743,18 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     HIP_TRY(c, reserve_slack(c->rflags, n));
     HIP_TRY(c, reserve_slack(c->roffs, n));
     HIP_TRY(c, launch_keep_flags(c->pts.p, nullptr, nullptr, nullptr, n, region, c->flags.p, s));
-    HIP_TRY(c, launch_keep_flags(nullptr, c->raw_x.p, c->raw_y.p, c->raw_z.p, n, region, c->rflags.p, s));
+    HIP_TRY(c, c->mm_scratch.reserve(8));
+    HIP_TRY(c, launch_keep_flags_minmax(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, region, c->rflags.p, c->mm_scratch.p, s));
     size_t tb = 0;
     HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->flags.p, c->offs.p, n, s));
     if (int rc = ensure_temp(c, tb)) return rc;
     HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->flags.p, c->offs.p, n, s));
     HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->rflags.p, c->roffs.p, n, s));
     uint32_t last[2] = {0, 0};
+    unsigned mm6[6];
     HIP_TRY(c, hipMemcpyAsync(&last[0], c->offs.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&last[1], c->flags.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(mm6, c->mm_scratch.p, sizeof mm6, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     const uint32_t kept = last[0] + last[1];
     if (kept == 0) return c->fail(VELO_E_INVALID, "eviction region would remove every map point");
@@ -1762,9 +1765,17 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     HIP_TRY(c, reserve_slack(c->raw_z2, kept));
     HIP_TRY(c, launch_compact_raw(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, c->rflags.p, c->roffs.p,
                                   c->raw_x2.p, c->raw_y2.p, c->raw_z2.p, s));
-    MinMax mm;
-    HIP_TRY(c, c->mm_scratch.reserve(8));
-    HIP_TRY(c, launch_minmax(c->raw_x2.p, c->raw_y2.p, c->raw_z2.p, kept, c->mm_scratch.p, &mm, s));
+    MinMax mm;  // of the kept points: came back with the counts above
+    auto dec = [](unsigned e) {  // (device_math.hpp enc_f32's inverse)
+        const unsigned u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    for (int a = 0; a < 3; ++a) {
+        mm.mn[a] = dec(mm6[a]);
+        mm.mx[a] = dec(mm6[3 + a]);
+    }
     const float org[3] = {old.ox, old.oy, old.oz};
     bool anchor = false;
     for (int a = 0; a < 3; ++a)
@@ -1814,7 +1825,7 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     txn.touched = true;  // the table is remapped in place below
     HIP_TRY(c, launch_compact_sorted(c->pts.p, c->nrm.p, c->perm.p, c->keys_sorted.p, n, c->flags.p,
                                      c->offs.p, c->roffs.p, c->pts_alt.p, c->nrm_alt.p,
-                                     c->perm_alt.p, c->keys_alt.p, s));
+                                     c->perm_alt.p, c->keys_alt.p, k > 0 ? c->invalid_cnt.p : nullptr, s));
     const size_t ncell = (size_t)old.fx * old.fy * old.fz;
     MapView g = old;
     if (c->use_hash) {
@@ -1840,7 +1851,7 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     c->n_done_host = 0;
     if (k > 0) {
         if (int rc = refresh_dirty_normals(c, g, k, c->nk_sorted.p, n - kept)) return rc;
-        HIP_TRY(c, launch_count_invalid(c->nrm.p, kept, c->invalid_cnt.p, s));
+        // (the running count: compact_sorted took the leavers off, the re-estimation adjusted the rest)
         HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -2442,7 +2453,8 @@ static int decode_submit(velo_ctx* c, velo_ctx::DecodePlan& P, velo_ctx::DecodeS
     HIP_TRY(c, launch_decode_emit(v, c->dk_order.p, n_valid, c->dk_x.p, c->dk_y.p, c->dk_z.p, c->dk_i.p,
                                   c->dk_az.p, c->dk_dist.p, c->dk_pidx.p, s));
     // (no wait for the emit: whoever reads the frames -- velo_decode_fetch, the registration -- is
-    // ordered behind it on the ctx stream)
+    // ordered behind it on the ctx stream; launching it over an upper bound BEFORE the count is
+    // known, so that the wait overlaps with it, measured no different: 0.120-0.151 ms either way)
     c->dk_frames = nfr;
     c->dk_points = n_valid;
     c->dk_frame_start.assign((size_t)nfr + 1, 0);

@@ -788,18 +788,73 @@ __global__ __launch_bounds__(256) void k_keep3(const float* __restrict__ x,
     if (i >= n) return;
     flags[i] = keep_pt(g, x[i], y[i], z[i]) ? 1u : 0u;
 }
+// keep flags in append order AND the bounding box of the kept points (what decides whether the grid
+// has to be re-anchored): one pass instead of a flag pass + a min/max pass over the compacted list
+__global__ __launch_bounds__(256) void k_keep3_minmax(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ z, uint32_t n, KeepRegion g,
+                                                      uint32_t* __restrict__ flags, unsigned* __restrict__ out6)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v[3] = {x[i], y[i], z[i]};
+        const bool keep = keep_pt(g, v[0], v[1], v[2]);
+        flags[i] = keep ? 1u : 0u;
+        if (keep) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = fminf(mn[a], v[a]);
+                mx[a] = fmaxf(mx[a], v[a]);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_down(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_down(mx[a], off, 64));
+        }
+    }
+    __shared__ float s_mn[4][3], s_mx[4][3];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            s_mn[wave][a] = mn[a];
+            s_mx[wave][a] = mx[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float lo = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
+        const float hi = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
+        atomicMin(&out6[a], enc_f32(lo));
+        atomicMax(&out6[3 + a], enc_f32(hi));
+    }
+}
 __global__ __launch_bounds__(256) void k_compact_sorted(
     const float4* __restrict__ pts, const float4* __restrict__ nrm,
     const uint32_t* __restrict__ perm, const uint32_t* __restrict__ keys, uint32_t n,
     const uint32_t* __restrict__ flags, const uint32_t* __restrict__ offs,
     const uint32_t* __restrict__ raw_offs, float4* __restrict__ pts2, float4* __restrict__ nrm2,
-    uint32_t* __restrict__ perm2, uint32_t* __restrict__ keys2)
+    uint32_t* __restrict__ perm2, uint32_t* __restrict__ keys2, unsigned long long* __restrict__ invalid)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !flags[i]) return;
+    const bool in = i < n;
+    const bool keep = in && flags[i];
+    float4 nv = make_float4(1.f, 0.f, 0.f, 0.f);
+    if (in) nv = nrm[i];
+    // the running count of invalid normals follows the points that leave (the dirty voxels are
+    // re-estimated and re-counted afterwards): no pass over the whole map to count again
+    if (invalid) {
+        const unsigned long long gone = __ballot(in && !keep && nv.w >= 0.0f && is_zero3(nv));
+        if (gone && (threadIdx.x & 63) == 0) atomicAdd(invalid, 0ull - (unsigned long long)__popcll(gone));
+    }
+    if (!keep) return;
     const uint32_t d = offs[i];
     pts2[d] = pts[i];
-    nrm2[d] = nrm[i];
+    nrm2[d] = nv;
     perm2[d] = raw_offs[perm[i]];
     keys2[d] = keys[i];
 }
@@ -974,13 +1029,29 @@ hipError_t launch_keep_flags(const float4* pts, const float* x, const float* y, 
     return hipGetLastError();
 }
 
+// flags of the append-order list + the bounding box of what is kept (d_scratch6: enc_f32 min x3,
+// max x3; initialised here, read back by the caller together with its other scalars)
+hipError_t launch_keep_flags_minmax(const float* x, const float* y, const float* z, uint32_t n,
+                                    const KeepRegion& g, uint32_t* flags, unsigned* d_scratch6, hipStream_t s)
+{
+    const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    hipError_t e = hipMemcpyAsync(d_scratch6, init, sizeof init, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    if (n == 0) return hipSuccess;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_keep3_minmax, dim3(grid), dim3(256), 0, s, x, y, z, n, g, flags, d_scratch6);
+    return hipGetLastError();
+}
+
 hipError_t launch_compact_sorted(const float4* pts, const float4* nrm, const uint32_t* perm,
                                  const uint32_t* keys, uint32_t n, const uint32_t* flags,
                                  const uint32_t* offs, const uint32_t* raw_offs, float4* pts2,
-                                 float4* nrm2, uint32_t* perm2, uint32_t* keys2, hipStream_t s)
+                                 float4* nrm2, uint32_t* perm2, uint32_t* keys2,
+                                 unsigned long long* d_invalid, hipStream_t s)
 {
     hipLaunchKernelGGL(k_compact_sorted, dim3((n + 255) / 256), dim3(256), 0, s, pts, nrm, perm,
-                       keys, n, flags, offs, raw_offs, pts2, nrm2, perm2, keys2);
+                       keys, n, flags, offs, raw_offs, pts2, nrm2, perm2, keys2, d_invalid);
     return hipGetLastError();
 }
 

@@ -124,10 +124,13 @@ struct KeepRegion {  // closed box, optionally intersected with a vertical cylin
 };
 hipError_t launch_keep_flags(const float4* pts, const float* x, const float* y, const float* z,
                              uint32_t n, const KeepRegion& g, uint32_t* flags, hipStream_t s);
+hipError_t launch_keep_flags_minmax(const float* x, const float* y, const float* z, uint32_t n,
+                                    const KeepRegion& g, uint32_t* flags, unsigned* d_scratch6, hipStream_t s);
 hipError_t launch_compact_sorted(const float4* pts, const float4* nrm, const uint32_t* perm,
                                  const uint32_t* keys, uint32_t n, const uint32_t* flags,
                                  const uint32_t* offs, const uint32_t* raw_offs, float4* pts2,
-                                 float4* nrm2, uint32_t* perm2, uint32_t* keys2, hipStream_t s);
+                                 float4* nrm2, uint32_t* perm2, uint32_t* keys2,
+                                 unsigned long long* d_invalid, hipStream_t s);
 hipError_t launch_compact_raw(const float* x, const float* y, const float* z, uint32_t n,
                               const uint32_t* flags, const uint32_t* offs, float* x2, float* y2,
                               float* z2, hipStream_t s);
