@@ -2,7 +2,8 @@
 // AddressSanitizer + UBSan (CPU build only: g++ -fsanitize=address,undefined over host/io.cpp,
 // host/pose.cpp, host/geodesy.cpp -- no GPU code involved).  Feeds velo_pcap_read / velo_pcap_index /
 // velo_carposes_read / velo_load_corrections / velo_insmeta_read truncated, bit-flipped and random
-// files, and velo_interp_pose / velo_packet_transforms random (also unsorted, duplicated) stores.
+// files, velo_interp_pose / velo_packet_transforms random (also unsorted, duplicated) stores, and the
+// host half of the packet decode (host/decode_plan.cpp) random packet streams.
 // The only requirement is: no crash, no sanitizer report, sane return codes.
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +12,7 @@
 #include <string>
 #include <vector>
 #include "velo.h"
+#include "../../veloslam_amd/csrc/host/decode_plan.hpp"
 
 static void write_file(const std::string& p, const std::vector<uint8_t>& b)
 {
@@ -113,6 +115,66 @@ int main(int argc, char** argv)
         velo_pose car;
         if (velo_packet_transforms(st.data(), n, pt.data(), 20, tab.data(), valid.data(), &car)) return 9;
         ++checked;
+    }
+    // the host half of the decode (host/decode_plan.cpp) on random packet streams: arbitrary
+    // azimuths (a split in any block, several per packet), garbage block ids, any number of packets,
+    // unsorted stamps, empty / tiny / unsorted pose stores, every option, fresh state and chains of
+    // chunked calls carrying the parser state; bad arguments must come back as error codes
+    {
+        velo_laser_corr corr[64];
+        std::memset(corr, 0, sizeof corr);
+        velo::DecodePlan P;
+        for (int r = 0; r < rounds; ++r) {
+            velo::DecodeStream st;
+            const int calls = 1 + (int)(rng() % 4);
+            for (int c = 0; c < calls; ++c) {
+                const size_t n = rng() % 24;
+                std::vector<uint8_t> pk2(n * 1206 + 1);
+                std::vector<int64_t> t2(n + 1);
+                unsigned a2 = rng() % 36000;
+                for (size_t i = 0; i < n; ++i) {
+                    t2[i] = 1000000 + (int64_t)(rng() % 100000) * (r % 5 == 0 ? 1 : (int64_t)i);
+                    for (size_t k = 0; k < 1206; ++k) pk2[i * 1206 + k] = (uint8_t)rng();
+                    if (r % 3) {  // mostly plausible azimuths, sometimes pure noise
+                        for (int b = 0; b < 12; ++b) {
+                            uint8_t* q = &pk2[i * 1206 + 100 * (size_t)b];
+                            q[0] = 0xff, q[1] = (rng() & 1) ? 0xdd : 0xee;
+                            q[2] = a2 & 0xff, q[3] = (uint8_t)(a2 >> 8);
+                            a2 = (a2 + 20 + rng() % 6000) % 36000;
+                        }
+                    }
+                }
+                const size_t np = r % 4 == 0 ? 0 : rng() % 6;
+                std::vector<velo_pose> ps2(np + 1);
+                for (size_t i = 0; i < np; ++i) {
+                    std::memset(&ps2[i], 0, sizeof(velo_pose));
+                    ps2[i].t_us = 1000000 + (int64_t)(rng() % 2000000);
+                    ps2[i].T[0] = (double)(rng() % 100), ps2[i].R[2] = (double)(rng() % 360);
+                    ps2[i].seconds_pos = (rng() % 5) ? 0.0 : -1.0;
+                }
+                velo_decode_opts o;
+                std::memset(&o, 0, sizeof o);
+                o.struct_size = sizeof o;
+                o.points_skip = (int)(rng() % 4);
+                o.initial_firing_skip = (int)(rng() % 13);
+                for (auto& l : o.laser_selection) l = (uint8_t)(rng() & 1);
+                const int lasers[4] = {64, 32, 16, 7};
+                const int nl = lasers[rng() % 4];
+                const double crop[6] = {-1, 1, -2, 2, -3, 3};
+                const int rc = velo::decode_plan_host(P, st, o, n ? pk2.data() : nullptr, n ? t2.data() : nullptr, n,
+                                                      (rng() % 16) ? corr : nullptr, nl, np ? ps2.data() : nullptr, np,
+                                                      (int)(rng() & 1), (rng() & 1) ? crop : nullptr, (int)(rng() & 1), true);
+                if (rc > 0) return 10;
+                if (rc == VELO_OK) {
+                    if (!P.filled || P.nfr < 0 || (size_t)P.nfr != P.carposes.size() || P.stage_bytes > P.stage_cap) return 11;
+                    const int16_t* blk = reinterpret_cast<const int16_t*>(P.stage + P.o_blk);
+                    for (size_t i = 0; i < P.n_pkt * 12; ++i)
+                        if (blk[i] < -1 || blk[i] >= P.nfr) return 12;   // an owner is an emitted frame or nobody
+                    st = P.flush ? velo::DecodeStream() : std::move(P.st_next);
+                }
+                ++checked;
+            }
+        }
     }
     std::printf("host fuzz: %ld cases, frames in the good capture: %zu\n", checked, n_ok);
     return 0;

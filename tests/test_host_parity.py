@@ -416,6 +416,86 @@ def test_pcap_frame_index_matches_the_parser(tmp_path, oracle):
     assert capi.lib().velo_pcap_index(path.encode(), small, 2, C.byref(n)) == -5 and n.value == 3
 
 
+def test_decode_host_half_matches_the_oracle_parser_without_a_gpu(tmp_path, oracle):
+    """The HOST half of the decode (host/decode_plan.cpp: HDLParser::processHDLPacket's sequential
+    part, HDLParser.cxx:980-1055) built with g++ under ASan + UBSan and run WITHOUT a GPU, one shot
+    and as a chunked stream (state carried as velo_decode_stream carries it): the frames it finds --
+    count, time stamp, packets per frame, the car pose each was compensated to -- are the oracle
+    parser's (oracle/decode.c), mid-packet splits and an initial firing skip included; every firing
+    block is owned by exactly one emitted frame; chunked == one shot."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    from veloslam_amd import synth
+    root = os.path.join(os.path.dirname(__file__), "..")
+    host = os.path.join(root, "veloslam_amd", "csrc", "host")
+    exe = str(tmp_path / "plan_dump")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-ffp-contract=off", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "plan_dump.cpp"), os.path.join(host, "decode_plan.cpp"),
+                           os.path.join(host, "pose.cpp"), os.path.join(host, "geodesy.cpp"), os.path.join(host, "io.cpp"),
+                           "-o", exe])
+    sc, mo, cal = synth.Scene(), synth.Motion(), synth.hdl64_calibration()
+    pk, ts = [], []
+    for f in range(3):                      # az_start 1.4 deg: the wrap falls on block 10 of a packet
+        p, t, _ = synth.make_frame_packets(sc, mo, f, cal, az_start=140)
+        pk += p
+        ts += t
+    pk, ts = pk[:700], ts[:700]
+    track = mo.ins_track(ts[0], ts[-1])
+    poses, n = capi.make_poses(track)
+    d = str(tmp_path)
+    open(os.path.join(d, "packets.bin"), "wb").write(b"".join(pk))
+    np.asarray(ts, np.int64).tofile(os.path.join(d, "times.i64"))
+    open(os.path.join(d, "poses.bin"), "wb").write(bytes(poses)[:n * C.sizeof(capi.Pose)])
+    np.ascontiguousarray(cal, np.float64).reshape(64, 9).tofile(os.path.join(d, "corr.bin"))
+
+    def run(first_block, pskip, chunks):
+        out = subprocess.run([exe, d, str(first_block), str(pskip)] + [str(c) for c in chunks],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (out.returncode, out.stderr[-3000:])
+        frames = [l.split() for l in out.stdout.splitlines() if l.startswith("frame ")]
+        total = [l.split() for l in out.stdout.splitlines() if l.startswith("total ")][0]
+        return frames, int(total[2]), int(total[4])
+
+    for first_block, pskip in ((0, 0), (5, 0), (0, 1)):
+        tl = oracle.Timeline()
+        for (T, R, V, t) in track:
+            tl.add(T, R, V, t)
+        dec = oracle.Decoder(cal, 64, tl)
+        dec.set_skip(first_block)
+        dec.set_points_skip(pskip)
+        for p, t in zip(pk, ts):
+            dec.packet(p, t)
+        dec.flush()
+        one, nfr, blocks = run(first_block, pskip, [0])
+        assert nfr == dec.num_frames == 3
+        for f, row in enumerate(one):
+            car, t_us, _ = dec.carpose(f)
+            assert int(row[3]) == t_us and int(row[5]) == dec.num_packets(f)
+            assert [float(v) for v in row[9:15]] == list(car.T) + list(car.R)
+        # every block the parser decodes belongs to exactly one frame.  Which blocks those are, literally
+        # (HDLParser.cxx:1013-1042): a packet starts at firingSkip, which a split sets to the block it
+        # happened in -- so the packet AFTER a split loses its head (SURVEY a8) -- and pointsSkip keeps
+        # every (k+1)-th block
+        expect, skip_next, last_az = 0, first_block, -1
+        for p in pk:
+            b0, skip_next = skip_next, 0
+            for b in range(b0, 12):
+                az = p[100 * b + 2] | (p[100 * b + 3] << 8)
+                if az < last_az:
+                    skip_next = b
+                if pskip == 0 or b % (pskip + 1) == 0:
+                    expect += 1
+                last_az = az
+        assert blocks == expect and 8000 < expect * (pskip + 1) < 8400
+        chunked, nfr2, blocks2 = run(first_block, pskip, [7, 1, 292, 1, 255, 0])
+        assert nfr2 == nfr and blocks2 == blocks
+        assert [r[3:] for r in chunked] == [r[3:] for r in one]
+
+
 def test_host_parsers_under_address_and_ub_sanitizers(tmp_path):
     """The file parsers (pcap read / index, carposes, .insmeta, db.xml) and the pose entry points of
     the HOST side, compiled with -fsanitize=address,undefined (CPU build only; the GPU pool offers no
@@ -430,8 +510,9 @@ def test_host_parsers_under_address_and_ub_sanitizers(tmp_path):
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
            "-ffp-contract=off", "-I", os.path.join(root, "include"),
            os.path.join(root, "tests", "cpp", "host_fuzz.cpp"), os.path.join(host, "io.cpp"),
-           os.path.join(host, "pose.cpp"), os.path.join(host, "geodesy.cpp"), "-o", exe]
+           os.path.join(host, "pose.cpp"), os.path.join(host, "geodesy.cpp"), os.path.join(host, "decode_plan.cpp"),
+           "-o", exe]
     subprocess.check_call(cmd)
     out = subprocess.run([exe, str(tmp_path), "300"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-3000:])
-    assert "host fuzz: 600 cases" in out.stdout
+    assert "host fuzz: " in out.stdout and int(out.stdout.split("host fuzz: ")[1].split()[0]) > 1000

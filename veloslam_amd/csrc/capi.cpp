@@ -9,6 +9,7 @@
 #include <memory>
 #include <dlfcn.h>
 #include "velo_internal.hpp"
+#include "host/decode_plan.hpp"
 #include "../../include/veloslam/TransformManager.hpp"
 
 // The handful of RCCL declarations the exchange needs, stated here so that the library builds
@@ -275,54 +276,12 @@ struct velo_ctx {
     std::vector<velo_pose> dk_carposes;
 
     velo_decode_opts dopts{};  // laser selection, points skip, initial firing skip (sticky)
-    // parser state carried across velo_decode_stream calls (HDLParser is stateful across packets)
-    struct DecodeStream {
-        int last_az = -1, firing_skip = 0;
-        bool inited = false, is_hdl64 = false, open = false;
-        veloslam::PoseTransform carpose;
-        velo_pose carpose0{};      // header of the unfinished frame
-        int64_t frame_t = VELO_TIME_INVALID;
-        int32_t frame_packets = 0;
-        // the packets that still hold firing blocks of the unfinished frame
-        std::vector<uint8_t> bytes, tvalid;
-        std::vector<int64_t> t;
-        std::vector<double> table;
-        std::vector<int32_t> azdiff;
-        std::vector<int16_t> blk;  // 12 per packet: 0 = unfinished frame, -1 = emitted earlier
-    } dstream;
-    // What the HOST half of a decode (the sequential part of the parser) leaves for the DEVICE half:
-    // packets + per-packet plan laid out in one pinned staging buffer, the headers of the frames
-    // found, the parser state to carry on.  Filling one touches neither the ctx nor the GPU, so the
-    // next frame can be planned while the current one is being registered (velo_decode_plan_*).
-    struct DecodePlan {
-        bool filled = false;
-        size_t n_pkt = 0;
-        int nfr = 0, n_lasers = 64, crop_inside = 0;
-        bool crop = false, keep_state = false, flush = false;
-        double region[6] = {0, 0, 0, 0, 0, 0};
-        unsigned long long laser_mask = ~0ull;
-        velo_laser_corr corr[64];
-        std::vector<velo_pose> carposes;
-        std::vector<int64_t> frame_t;
-        std::vector<int32_t> frame_packets;
-        uint8_t* stage = nullptr;  // pinned, owned
-        size_t stage_cap = 0, stage_bytes = 0;
-        size_t o_pk = 0, o_blk = 0, o_perm = 0, o_tab = 0, o_tv = 0, o_az = 0;
-        DecodeStream st_next;
-        int code = 0;
-        char err[200] = {0};
-        ~DecodePlan()
-        {
-            if (stage) (void)hipHostFree(stage);
-        }
-        int fail(int c, const char* msg)
-        {
-            code = c;
-            snprintf(err, sizeof err, "%s", msg);
-            filled = false;
-            return c;
-        }
-    } dplan;
+    // parser state carried across velo_decode_stream calls, and what the host half of a decode leaves
+    // for the device half (host/decode_plan.hpp: plain host code, no GPU types)
+    using DecodeStream = velo::DecodeStream;
+    using DecodePlan = velo::DecodePlan;
+    DecodeStream dstream;
+    DecodePlan dplan;
 
     // ---- timing
     bool timing = false;
@@ -2177,195 +2136,13 @@ int upload_calibration(velo_ctx* c, const velo_laser_corr corr[64])
 
 }  // namespace
 
-// Host half of the decode: the sequential part of the parser (12 integers per packet,
-// HDLParser.cxx:980-1055) run over [pending packets of the unfinished frame] + [new packets],
-// continuing from the parser state `st` carries.  Everything the device half needs ends up in P
-// (one pinned staging buffer); neither the ctx nor the GPU is touched.
-static int decode_plan_host(velo_ctx::DecodePlan& P, const velo_ctx::DecodeStream& st, const velo_decode_opts& dopts,
-                            const uint8_t* packets, const int64_t* pkt_t_us, size_t n_new,
-                            const velo_laser_corr corr[64], int n_lasers, const velo_pose* poses, size_t n_poses,
-                            int flush, const double* crop_region, int crop_inside, bool keep_state)
+// staging memory of a decode plan: pinned (the one copy up is then asynchronous)
+static void* plan_stage_alloc(size_t n)
 {
-    P.filled = false;
-    P.code = 0;
-    if ((n_new && (!packets || !pkt_t_us)) || !corr || (n_poses && !poses))
-        return P.fail(VELO_E_INVALID, "velo_decode: null argument");
-    if (n_lasers != 64 && n_lasers != 32 && n_lasers != 16)
-        return P.fail(VELO_E_INVALID, "n_lasers must be 64, 32 or 16");
-    const size_t n_pend = st.t.size();
-    const size_t n_pkt = n_pend + n_new;
-    if (n_pkt == 0 || n_pkt > 60000) return P.fail(VELO_E_RANGE, "packets in flight must be in [1, 60000]");
-
-    const veloslam::SortedPoseView tm(poses, n_poses);  // the caller's store, read in place: O(log n) per packet
-    // working set = what the unfinished frame still needs + the new packets
-    // (a parse that starts from fresh state -- every call of velo_decode -- reads the caller's
-    // packets in place: no 360 KB copy per frame in front of the copy into the pinned stage)
-    std::vector<uint8_t> bytes_joined;
-    if (!st.bytes.empty()) {
-        bytes_joined = st.bytes;
-        bytes_joined.insert(bytes_joined.end(), packets, packets + n_new * 1206);
-    }
-    const uint8_t* const bytes_p = st.bytes.empty() ? packets : bytes_joined.data();
-    std::vector<int64_t> times(st.t);
-    times.insert(times.end(), pkt_t_us, pkt_t_us + n_new);
-    std::vector<int16_t> blk(st.blk);
-    blk.resize(n_pkt * 12, -1);
-    std::vector<double> table(st.table);
-    table.resize(n_pkt * 12, 0.0);
-    std::vector<uint8_t> tvalid(st.tvalid), perm;
-    tvalid.resize(n_pkt, 0);
-    std::vector<int32_t> azdiff(st.azdiff);
-    azdiff.resize(n_pkt, 0);
-    P.carposes.clear();
-    P.frame_t.clear();
-    P.frame_packets.clear();
-    // a parse that starts from fresh state begins at the configured block (getFrame's `skip`)
-    const bool fresh = !st.inited && !st.open && st.t.empty() && st.last_az == -1;
-    int last_az = st.last_az, firing_skip = fresh ? dopts.initial_firing_skip : st.firing_skip, cur = 0;
-    const int pskip = dopts.points_skip;
-    bool inited = st.inited, is_hdl64 = st.is_hdl64;
-    veloslam::PoseTransform carpose = st.carpose;
-    auto open_frame = [&]() {
-        P.carposes.push_back(veloslam::PoseTransform().toC());
-        P.frame_t.push_back(VELO_TIME_INVALID);
-        P.frame_packets.push_back(0);
-        perm.push_back(0);
-    };
-    open_frame();
-    if (st.open) {  // header of the frame the previous call left unfinished
-        P.carposes[0] = st.carpose0;
-        P.frame_t[0] = st.frame_t;
-        P.frame_packets[0] = st.frame_packets;
-    }
-    for (size_t p = n_pend; p < n_pkt; ++p) {
-        const uint8_t* d = bytes_p + p * 1206;
-        veloslam::PoseTransform tr;
-        tm.interpolate(times[p], &tr);
-        if (!inited) {  // :992-1001
-            carpose = tr;
-            P.carposes[cur] = tr.toC();
-            P.frame_t[cur] = times[p];
-            P.frame_packets[cur]++;
-            inited = true;
-        }
-        tr.timestamp = times[p];
-        if (tr.seconds_pos != -1) {  // :1004-1007 (+ :1057-1062)
-            for (int a = 0; a < 3; ++a) tr.T[a] -= carpose.T[a];
-            const veloslam::Affine3x4 M = tr.getMatrix();
-            std::memcpy(&table[p * 12], M.data(), 12 * sizeof(double));
-            tvalid[p] = 1;
-        }
-        P.frame_packets[cur]++;  // :1009
-        int block = firing_skip;
-        firing_skip = 0;
-        int diffs[11];
-        for (int i = 0; i < 11; ++i) {
-            const int r1 = d[100 * (i + 1) + 2] | (d[100 * (i + 1) + 3] << 8);
-            const int r0 = d[100 * i + 2] | (d[100 * i + 3] << 8);
-            diffs[i] = (36000 + r1 - r0) % 36000;
-        }
-        std::sort(diffs, diffs + 11);
-        azdiff[p] = diffs[6];  // nth_element(..., 12/2): element 6 of 11, :1021-1026
-        for (; block < 12; ++block) {
-            const uint8_t* fd = d + 100 * block;
-            const unsigned id = fd[0] | (fd[1] << 8);
-            const int rot = fd[2] | (fd[3] << 8);
-            is_hdl64 |= (id != 0xeeff);
-            if (rot < last_az) {  // :1035-1039 -> splitFrame
-                firing_skip = block;
-                perm[cur] = is_hdl64 ? 1 : 0;
-                ++cur;
-                if (cur >= 32000) return P.fail(VELO_E_RANGE, "too many frames in one decode call");
-                open_frame();
-                inited = false;
-            }
-            // :1042 -- a skipped block still takes part in the split logic above
-            if (pskip == 0 || block % (pskip + 1) == 0) blk[p * 12 + block] = (int16_t)cur;
-            last_az = rot;
-        }
-    }
-    int nfr = cur;
-    P.st_next = velo_ctx::DecodeStream();
-    if (keep_state && !flush) {
-        // carry the parser on: keep the packets that hold blocks of the unfinished frame `cur`
-        velo_ctx::DecodeStream nx;
-        nx.last_az = last_az;
-        nx.firing_skip = firing_skip;
-        nx.inited = inited;
-        nx.is_hdl64 = is_hdl64;
-        nx.carpose = carpose;
-        nx.open = true;
-        nx.carpose0 = P.carposes[cur];
-        nx.frame_t = P.frame_t[cur];
-        nx.frame_packets = P.frame_packets[cur];
-        size_t p0 = n_pkt;
-        for (size_t p = 0; p < n_pkt && p0 == n_pkt; ++p)
-            for (int k = 0; k < 12; ++k)
-                if (blk[p * 12 + k] == cur) {
-                    p0 = p;
-                    break;
-                }
-        for (size_t p = p0; p < n_pkt; ++p) {
-            nx.bytes.insert(nx.bytes.end(), bytes_p + p * 1206, bytes_p + (p + 1) * 1206);
-            nx.t.push_back(times[p]);
-            nx.table.insert(nx.table.end(), table.begin() + p * 12, table.begin() + (p + 1) * 12);
-            nx.tvalid.push_back(tvalid[p]);
-            nx.azdiff.push_back(azdiff[p]);
-            for (int k = 0; k < 12; ++k) nx.blk.push_back(blk[p * 12 + k] == cur ? (int16_t)0 : (int16_t)-1);
-        }
-        P.st_next = std::move(nx);
-    }
-    if (flush) {
-        perm[cur] = is_hdl64 ? 1 : 0;
-        nfr = cur + 1;
-    } else {
-        for (auto& b : blk)
-            if (b == cur) b = -1;  // the unfinished frame is not emitted
-        P.carposes.resize((size_t)nfr);
-        P.frame_t.resize((size_t)nfr);
-        P.frame_packets.resize((size_t)nfr);
-    }
-    // Packets and per-packet plan go up in ONE copy from a pinned staging buffer (six copies from
-    // pageable vectors each blocked the host for their staging).
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    P.o_pk = 0;
-    P.o_blk = al(P.o_pk + n_pkt * 1206);
-    P.o_perm = al(P.o_blk + blk.size() * sizeof(int16_t));
-    P.o_tab = al(P.o_perm + perm.size());
-    P.o_tv = al(P.o_tab + table.size() * sizeof(double));
-    P.o_az = al(P.o_tv + n_pkt);
-    P.stage_bytes = al(P.o_az + n_pkt * sizeof(int32_t));
-    if (P.stage_cap < P.stage_bytes) {
-        if (P.stage) (void)hipHostFree(P.stage);
-        P.stage = nullptr;
-        P.stage_cap = 0;
-        if (hipHostMalloc((void**)&P.stage, P.stage_bytes + P.stage_bytes / 2, 0) != hipSuccess) {
-            P.stage = nullptr;
-            return P.fail(VELO_E_NOMEM, "velo_decode: no pinned memory for the staging buffer");
-        }
-        P.stage_cap = P.stage_bytes + P.stage_bytes / 2;
-    }
-    std::memcpy(P.stage + P.o_pk, bytes_p, n_pkt * 1206);
-    std::memcpy(P.stage + P.o_blk, blk.data(), blk.size() * sizeof(int16_t));
-    std::memcpy(P.stage + P.o_perm, perm.data(), perm.size());
-    std::memcpy(P.stage + P.o_tab, table.data(), table.size() * sizeof(double));
-    std::memcpy(P.stage + P.o_tv, tvalid.data(), n_pkt);
-    std::memcpy(P.stage + P.o_az, azdiff.data(), n_pkt * sizeof(int32_t));
-    P.n_pkt = n_pkt;
-    P.nfr = nfr;
-    P.n_lasers = n_lasers;
-    std::memcpy(P.corr, corr, sizeof P.corr);
-    P.crop = crop_region != nullptr;
-    P.crop_inside = crop_inside;
-    for (int i = 0; i < 6; ++i) P.region[i] = crop_region ? crop_region[i] : 0.0;
-    P.laser_mask = 0;
-    for (int i = 0; i < 64; ++i)
-        if (dopts.laser_selection[i]) P.laser_mask |= 1ull << i;
-    P.keep_state = keep_state;
-    P.flush = flush != 0;
-    P.filled = true;
-    return VELO_OK;
+    void* p = nullptr;
+    return hipHostMalloc(&p, n, 0) == hipSuccess ? p : nullptr;
 }
+static void plan_stage_free(void* p) { (void)hipHostFree(p); }
 
 // Device half: the planned packet set through the decode kernels.  `st` (optional) receives the
 // parser state the plan carries on.
@@ -2482,7 +2259,9 @@ static int decode_impl(velo_ctx* c, velo_ctx::DecodeStream& st, const uint8_t* p
                        int32_t* n_frames, size_t* n_points)
 {
     HIP_TRY(c, hipSetDevice(c->device));
-    if (decode_plan_host(c->dplan, st, c->dopts, packets, pkt_t_us, n_new, corr, n_lasers, poses, n_poses, flush,
+    c->dplan.alloc_fn = plan_stage_alloc;
+    c->dplan.free_fn = plan_stage_free;
+    if (velo::decode_plan_host(c->dplan, st, c->dopts, packets, pkt_t_us, n_new, corr, n_lasers, poses, n_poses, flush,
                          crop_region, crop_inside, keep_state))
         return c->fail(c->dplan.code, "%s", c->dplan.err);
     return decode_submit(c, c->dplan, &st, n_frames, n_points);
@@ -2500,6 +2279,8 @@ int velo_decode_plan_create(velo_ctx* c, velo_decode_plan** out)
     velo_decode_plan* p = new (std::nothrow) velo_decode_plan;
     if (!p) return c->fail(VELO_E_NOMEM, "out of memory");
     p->device = c->device;
+    p->P.alloc_fn = plan_stage_alloc;
+    p->P.free_fn = plan_stage_free;
     *out = p;
     return VELO_OK;
 }
@@ -2527,7 +2308,7 @@ int velo_decode_plan_fill(velo_decode_plan* p, const velo_decode_opts* opts, con
     if (n_pkt == 0) return p->P.fail(VELO_E_RANGE, "n_pkt must be in [1, 60000]");
     (void)hipSetDevice(p->device);  // (the pinned staging buffer may be allocated from this thread)
     const velo_ctx::DecodeStream fresh;
-    return decode_plan_host(p->P, fresh, d, packets, pkt_t_us, n_pkt, corr, n_lasers, poses, n_poses, flush,
+    return velo::decode_plan_host(p->P, fresh, d, packets, pkt_t_us, n_pkt, corr, n_lasers, poses, n_poses, flush,
                             crop_region, crop_inside, false);
 }
 
