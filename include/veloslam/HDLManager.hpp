@@ -129,7 +129,9 @@ private:
     bool decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, int* n_decoded);
     bool fillPlan(const HDLFrame& f);
     velo_decode_plan* plan_ = nullptr;
-    const HDLFrame* planned_ = nullptr;   // the frame plan_ is filled for
+    const HDLFrame* planned_ = nullptr;   // the frame plan_ is filled for ...
+    int64_t plannedFirst_ = -1;           // ... and where it sits in the capture
+    int plannedSkip_ = 0;
     size_t lowerBound(int64_t t) const;       // first frame with timestamp >= t
     size_t nearestIndex(int64_t t) const;     // frames_ not empty
 

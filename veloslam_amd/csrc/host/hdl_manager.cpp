@@ -42,6 +42,10 @@ bool HDLManager::loadOffline(const std::string& insTxt, const std::string& pcapf
         std::lock_guard<std::mutex> lock(cacheMutex_);
         cache_.clear();
     }
+    {
+        std::lock_guard<std::mutex> lock(decodeMutex_);
+        planned_ = nullptr;  // a plan made for the previous capture is void
+    }
     if (!transMgr_->loadFromTxtFile(insTxt, true)) {
         err_ = "cannot read the pose track " + insTxt;
         return false;
@@ -205,6 +209,8 @@ bool HDLManager::fillPlan(const HDLFrame& f)
         return false;
     }
     planned_ = &f;
+    plannedFirst_ = f.firstPacket;
+    plannedSkip_ = f.skips;
     return true;
 }
 
@@ -221,7 +227,10 @@ bool HDLManager::planResident(const std::shared_ptr<HDLFrame>& frame)
 // ---- the decode behind prepareFrame / prepareResident ------------------------------------
 bool HDLManager::decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, int* n_decoded)
 {
-    if (planned_ != &f && !fillPlan(f)) return false;  // (planned ahead: only the device half is left)
+    // (planned ahead: only the device half is left; the key is the frame AND where it sits in the
+    // capture -- an address alone can come back with another frame after a reload)
+    const bool planned = planned_ == &f && plannedFirst_ == f.firstPacket && plannedSkip_ == f.skips;
+    if (!planned && !fillPlan(f)) return false;
     planned_ = nullptr;
     int32_t nf = 0;
     size_t n = 0;
@@ -264,11 +273,18 @@ bool HDLManager::prepareResident(const std::shared_ptr<HDLFrame>& frame, size_t*
 FrameRef HDLManager::prepareFrame(std::shared_ptr<HDLFrame> frame)
 {
     if (!frame) return FrameRef();
-    if (frame->isInMemory) return FrameRef(frame);
+    auto held_if_in_memory = [&]() {
+        // the reference takes the pointer first and counts it later, so the cache may clear the frame
+        // in between ("MIGHT BE safe", HDLManager.h:181-186); here the check and the count are one step
+        // as far as updateCacheSize is concerned
+        std::lock_guard<std::mutex> lock(cacheMutex_);
+        return frame->isInMemory ? FrameRef(frame) : FrameRef();
+    };
+    if (FrameRef r = held_if_in_memory()) return r;
     if (!frame->isOnHardDrive) return FrameRef();
     {
         std::lock_guard<std::mutex> lock(decodeMutex_);
-        if (frame->isInMemory) return FrameRef(frame);  // another consumer got there first
+        if (FrameRef r = held_if_in_memory()) return r;  // another consumer got there first
         size_t n = 0;
         int nf = 0;
         if (!decodeFrame(*frame, false, &n, &nf)) return FrameRef();
@@ -301,8 +317,9 @@ FrameRef HDLManager::prepareFrame(std::shared_ptr<HDLFrame> frame)
         // stub's pose alone
         if (car[0].seconds_pos != -1) *frame->carpose = PoseTransform::fromC(car[0]);
     }
+    FrameRef held(frame);  // counted before the cache sees it
     pushCache(frame);
-    return FrameRef(frame);
+    return held;
 }
 
 // ---- consumers ----------------------------------------------------------------------------
