@@ -2449,6 +2449,19 @@ static int enqueue_increment(velo_ctx* c, int frame, const double* d_pose, int m
     const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
     HIP_TRY(c, c->flags.reserve(n + 1));
     HIP_TRY(c, c->offs.reserve(n + 1));
+#ifndef VELO_INC_FUSED
+#define VELO_INC_FUSED 1
+#endif
+    const size_t tiles = (n + kIncTilePoints - 1) / kIncTilePoints;
+    if (VELO_INC_FUSED && tiles <= kIncFusedMaxTiles) {
+        // a frame: two launches (flags + per-tile counts; bases + scatter) and the count's copy, instead of
+        // flags, memset, two scan launches, count copy and scatter; offs doubles as [tile counts | total]
+        HIP_TRY(c, c->offs.reserve(tiles + 1));
+        HIP_TRY(c, launch_increment_fused(c->ax + q0, c->ay + q0, c->az + q0, (uint32_t)n, c->mv, d_pose, min_count,
+                                          c->flags.p, c->offs.p, tx, ty, tz, c->offs.p + tiles, s));
+        HIP_TRY(c, hipMemcpyAsync(h_total, c->offs.p + tiles, sizeof *h_total, hipMemcpyDeviceToHost, s));
+        return VELO_OK;
+    }
     HIP_TRY(c, launch_increment_flags(c->ax + q0, c->ay + q0, c->az + q0, n, c->mv, d_pose, min_count,
                                       c->flags.p, s));
     HIP_TRY(c, hipMemsetAsync(c->flags.p + n, 0, sizeof(uint32_t), s));

@@ -173,6 +173,11 @@ hipError_t launch_permute3(const float* x, const float* y, const float* z, const
 hipError_t launch_increment_flags(const float* x, const float* y, const float* z, size_t n,
                                   const MapView& mv, const double* pose, int min_count,
                                   uint32_t* flags, hipStream_t s);
+constexpr uint32_t kIncTilePoints = 256;      // launch_increment_fused: points per workgroup ...
+constexpr uint32_t kIncFusedMaxTiles = 4096;  // ... and above this many workgroups (1 M points) the scan path
+hipError_t launch_increment_fused(const float* x, const float* y, const float* z, uint32_t n, const MapView& mv,
+                                  const double* pose, int min_count, uint32_t* flags, uint32_t* d_block_cnt,
+                                  float* ox, float* oy, float* oz, uint32_t* d_total, hipStream_t s);
 hipError_t exclusive_scan_u32(void* temp, size_t& temp_bytes, const uint32_t* in, uint32_t* out,
                               size_t n, hipStream_t s);
 hipError_t launch_increment_scatter(const float* x, const float* y, const float* z, size_t n,
