@@ -581,29 +581,38 @@ def run_replay(args, dev, local, steps, warmup, d=None):
                              flush=last, initial_firing_skip=int(e.firing_skip))
         planned["f"] = f
 
-    def one(f, f_next, timed):
-        e = idx[f]
-        p0 = int(e.first_packet)
-        t = [time.perf_counter()]
+    def decode_frame(f):
+        """the frame's packets up, decoded + compensated, resident as frame 0 of the ctx"""
         if planned["f"] != f:
             plan_frame(f)
         planned["f"] = None
         nf, _ = ctx.decode_submit(plan)
         assert nf >= 1
         ctx.decode_to_frames()
+
+    def one(f, f_next, timed):
+        e = idx[f]
+        p0 = int(e.first_packet)
+        t = [time.perf_counter()]
+        if state.get("resident") != f:
+            decode_frame(f)
+        state["resident"] = None
         t.append(time.perf_counter())
         ok, car = capi.interp_pose(d["poses"], d["n_poses"], int(times[p0]))
         Tt = np.array([1, 0, 0, car.T[0], 0, 1, 0, car.T[1], 0, 0, 1, state["z"]], np.float64)
         T0 = synth.perturbed_guess(Tt, dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))
         roll_to(float(T0[3]), float(T0[7]), timed)
         t.append(time.perf_counter())
-        # registration and increment are enqueued; the host half of the NEXT frame's decode runs while
-        # the GPU iterates (MapManager::registerResident does the same through while_registering)
-        ctx.icp_batch_async(np.tile(T0, (ctx.n_frames, 1)), args.iters, args.d_max)
+        # registration and increment are enqueued; the NEXT frame is decoded while the GPU iterates -- its
+        # packets go up and through the decode kernels right behind this frame's work (MapManager::
+        # registerResident does the same through while_registering); velo_icp_batch_finish waits for the
+        # registration only and returns the result of the frames that were resident at the start
+        ctx.icp_batch_start(np.tile(T0, (ctx.n_frames, 1)), args.iters, args.d_max)
         ctx.increment_pending(0, None, 3)
         if f_next is not None and not args.no_decode_overlap:
-            plan_frame(f_next)
-        res = ctx.icp_batch_fetch()[0]
+            decode_frame(f_next)      # (waits inside for its frame offsets, i.e. for this registration too:
+            state["resident"] = f_next  #  the `icp` stage below is registration + the next frame's decode)
+        res = ctx.icp_batch_finish()[0]
         t.append(time.perf_counter())
         if ctx.pending_count(False) >= max(args.append_threshold, 1):
             flush()

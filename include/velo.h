@@ -321,6 +321,13 @@ int velo_icp_batch(velo_ctx*, const double* T0, int iters, float d_max, velo_icp
  * (bench inner loop); fetch with velo_icp_batch_fetch. */
 int velo_icp_batch_async(velo_ctx*, const double* T0, int iters, float d_max);
 int velo_icp_batch_fetch(velo_ctx*, velo_icp_result* out);
+/* The pipelined pair for a stream of frames: start = velo_icp_batch_async + the result's copy to
+ * pinned host memory + an event; finish waits for that event ONLY and hands the results out.  Work
+ * enqueued on the ctx between the two -- velo_increment_pending of the frame, the NEXT frame's
+ * velo_decode_submit + velo_decode_to_frames -- is not waited for by finish and does not disturb it
+ * (the result belongs to the frames that were resident at start).  One start may be outstanding. */
+int velo_icp_batch_start(velo_ctx*, const double* T0, int iters, float d_max);
+int velo_icp_batch_finish(velo_ctx*, velo_icp_result* out);
 
 /* Diagnostics for parity tests on resident frame `frame`: one linearisation at
  * pose T.  corr (sorted map index or -1) and d2 may be NULL; acc = the 29

@@ -29,9 +29,12 @@ struct RegisterOptions {
     bool integrate = false;       // collect the accepted increment (device-side pending list) and
                                   // merge it into the map once append_threshold points are pending
     int append_threshold = 512;   // (1 = after every frame)
-    // Host work to do while the GPU registers: called once, after the registration (and the
-    // increment) have been enqueued and before their result is waited for -- e.g.
-    // HDLManager::planResident(next frame), which hides the host half of the next decode.
+    // Work to do while the GPU registers: called once, after the registration (and the increment)
+    // have been enqueued and before their result is waited for.  It may use the context: e.g.
+    // HDLManager::prepareResident(next frame) -- the next frame's packets go up and are decoded right
+    // behind this frame's registration, with no idle GPU in between, and are the resident frames when
+    // registerResident is called next (velo_icp_batch_start / _finish keep the result apart from that).
+    // What it must not do is register, or change the map.
     std::function<void()> while_registering;
 };
 

@@ -773,6 +773,58 @@ def test_gpu_decode_matches_oracle_parser(ctx, oracle, az_start, azcorr, with_po
     assert g["n_points"] == sum(dec.beam(f, b)[0].size for f in range(dec.num_frames) for b in range(64))
 
 
+def test_icp_start_finish_with_the_next_frame_decoded_in_between(oracle):
+    """velo_icp_batch_start / _finish (the stream's pipelined pair): the result handed out by finish
+    is bit for bit velo_icp_batch's, although between the two the increment was enqueued and the NEXT
+    frame was decoded and adopted on the same ctx (its resident frames replaced); the increment is
+    the one the unpipelined order yields; and the next frame, registered afterwards, is unaffected."""
+    pk, ts, cal, mo = _stream(3, 20000)
+    track = mo.ins_track(ts[0], ts[-1])
+    poses, n = capi.make_poses(track)
+    wl = make_workload(map_points=120_000, n_frames=1)
+    T_id = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+
+    def run(pipelined):
+        c = capi.Context(0, max_batch=4)
+        try:
+            c.map_reset(*wl["map"], 1.0, 16)
+            a = c.decode(pk[:310], ts[:310], cal, 64, poses, n, flush=False)
+            assert a["n_frames"] == 1
+            c.decode_to_frames()
+            T0 = np.tile(T_id, (c.n_frames, 1))
+            if pipelined:
+                c.icp_batch_start(T0, 8, 1.0)
+                c.increment_pending(0, None, 3)
+                b = c.decode(pk[310:], ts[310:], cal, 64, poses, n, flush=True)   # the next frame(s), same ctx
+                c.decode_to_frames()
+                nb = c.n_frames
+                r0 = c.icp_batch_finish()
+                assert len(r0) == 1
+            else:
+                r0 = c.icp_batch(T0, 8, 1.0)
+                c.increment_pending(0, None, 3)
+                b = c.decode(pk[310:], ts[310:], cal, 64, poses, n, flush=True)
+                c.decode_to_frames()
+                nb = c.n_frames
+            inc = c.pending_fetch() if c.pending_count(True) else (np.empty(0, np.float32),) * 3
+            r1 = c.icp_batch(np.tile(T_id, (nb, 1)), 5, 1.0)
+            return list(r0[0].T), [r0[0].iter[i].n_pairs for i in range(8)], [x.copy() for x in inc], \
+                [list(r.T) for r in r1], b["n_points"]
+        finally:
+            c.close()
+
+    pa, pb = run(True), run(False)
+    assert pa[0] == pb[0] and pa[1] == pb[1]
+    assert all(np.array_equal(x, y) for x, y in zip(pa[2], pb[2]))
+    assert pa[3] == pb[3] and pa[4] == pb[4]
+    c = capi.Context(0, max_batch=2)
+    try:
+        with pytest.raises(capi.VeloError):
+            c.icp_batch_finish()                       # nothing started
+    finally:
+        c.close()
+
+
 def test_gpu_decode_planned_ahead_equals_decode(oracle):
     """velo_decode_plan_fill + velo_decode_submit == velo_decode (== the oracle parser), with the
     host half of the NEXT decode filled while the frames of the previous one are resident and being

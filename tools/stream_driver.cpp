@@ -9,8 +9,9 @@
 //              resident in HBM) -> MapManager::registerResident (rolls the device map to the
 //              prior's ROI: evict the tiles that left, append the ones that entered; 20 ICP
 //              iterations; accepted increment to the device-side pending list, merged every
-//              append_threshold points); the HOST half of the next frame's decode (HDLManager::planResident)
-//              runs inside registerResident while the GPU iterates (RegisterOptions::while_registering)
+//              append_threshold points); the NEXT frame's decode (HDLManager::prepareResident) is issued inside
+//              registerResident while the GPU iterates (RegisterOptions::while_registering): its device half
+//              queues right behind this frame's registration
 //
 // The prior is what the reference's INS would give: the interpolated car pose (x, y, angles from
 // carposes.txt -- the format has no z: z is carried from the previous registration) plus the
@@ -51,7 +52,7 @@ int main(int argc, char** argv)
         else if (a == "--warmup" && i + 1 < argc) warmup = std::atoi(argv[++i]);
         else if (a == "--threshold" && i + 1 < argc) threshold = std::atoi(argv[++i]);
         else if (a == "--no-integrate") integrate = false;
-        else if (a == "--no-overlap") overlap = false;  // plan every frame's decode when it is due, not a frame ahead
+        else if (a == "--no-overlap") overlap = false;  // decode every frame when it is due, not during the previous registration
     }
     double z0 = 0, patch = 10, voxel = 1, zero = 0;
     int k_normals = 16;
@@ -91,17 +92,27 @@ int main(int argc, char** argv)
     opt.append_threshold = threshold;
 
     double z_prev = z0, worst = 0, t_decode = 0, t_register = 0;
+    int prepared = -1;  // the frame resident in HBM already (decoded during the previous registration)
     uint64_t pairs = 0;
     auto one = [&](int f, int f_next, bool timed) -> bool {
         const std::shared_ptr<HDLFrame>& fr = frames[(size_t)f];
-        // the host half of the NEXT frame's decode runs while the GPU registers this one
+        // the NEXT frame is decoded while the GPU registers this one: its packets go up and through the
+        // decode kernels right behind this frame's registration and increment
+        bool next_ok = true;
+        double t_next = 0;
         opt.while_registering = nullptr;
-        if (overlap && f_next >= 0) opt.while_registering = [&hdl, &frames, f_next] { hdl.planResident(frames[(size_t)f_next]); };
+        if (overlap && f_next >= 0)
+            opt.while_registering = [&hdl, &frames, f_next, &next_ok, &t_next] {
+                const auto a0 = clk::now();
+                next_ok = hdl.prepareResident(frames[(size_t)f_next]);
+                t_next = ms_since(a0);
+            };
         const auto a = clk::now();
-        if (!hdl.prepareResident(fr)) {
+        if (prepared != f && !hdl.prepareResident(fr)) {
             std::fprintf(stderr, "frame %d: %s\n", f, hdl.lastError());
             return false;
         }
+        prepared = -1;
         const double td = ms_since(a);
         const PoseTransform& car = *fr->carpose;  // the track interpolated at the frame's stamp (HDLManager.cxx:104-109)
         PoseTransform init;
@@ -114,10 +125,17 @@ int main(int argc, char** argv)
             std::fprintf(stderr, "registerResident failed at frame %d: %s\n", f, mgr.lastError());
             return false;
         }
-        const double tr = ms_since(b);
+        const double tr = ms_since(b) - t_next;
+        if (opt.while_registering) {
+            if (!next_ok) {
+                std::fprintf(stderr, "frame %d: %s\n", f_next, hdl.lastError());
+                return false;
+            }
+            prepared = f_next;
+        }
         z_prev = out.T[2];
         if (timed) {
-            t_decode += td;
+            t_decode += td + t_next;
             t_register += tr;
             pairs += res.total_pairs;
             if ((size_t)f * 3 + 2 < truth.size()) {

@@ -85,7 +85,7 @@ EXPORTS = [
     "velo_synchronize", "velo_map_reset", "velo_map_reset_dev", "velo_map_append",
     "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
-    "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_linearize",
+    "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_icp_batch_start", "velo_icp_batch_finish", "velo_linearize",
     "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_decode_plan_create", "velo_decode_plan_destroy", "velo_decode_plan_fill", "velo_decode_submit", "velo_decode_plan_error", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_increment_pending", "velo_pending_count", "velo_pending_fetch", "velo_map_append_pending", "velo_pending_clear", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
     "velo_exchange_increments", "velo_exchange_plan", "velo_exchange_pack_dev", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
@@ -154,6 +154,8 @@ def lib():
     L.velo_icp_batch.argtypes = [vp, dp, C.c_int, C.c_float, C.POINTER(IcpResult)]
     L.velo_icp_batch_async.argtypes = [vp, dp, C.c_int, C.c_float]
     L.velo_icp_batch_fetch.argtypes = [vp, C.POINTER(IcpResult)]
+    L.velo_icp_batch_start.argtypes = [vp, dp, C.c_int, C.c_float]
+    L.velo_icp_batch_finish.argtypes = [vp, C.POINTER(IcpResult)]
     L.velo_linearize.argtypes = [vp, C.c_int, dp, C.c_float, vp, vp, dp]
     L.velo_linearize_hints.argtypes = [vp, C.c_int]
     L.velo_solve_update.argtypes = [vp, dp, dp, C.POINTER(C.c_int32)]
@@ -568,6 +570,16 @@ class Context:
     def icp_batch_async(self, T0, iters=20, d_max=1.0):
         T0 = np.ascontiguousarray(T0, dtype=np.float64).reshape(self.n_frames, 12)
         self._chk(lib().velo_icp_batch_async(self.h, _d(T0), iters, d_max))
+
+    def icp_batch_start(self, T0, iters=20, d_max=1.0):
+        T0 = np.ascontiguousarray(T0, dtype=np.float64).reshape(self.n_frames, 12)
+        self._started_frames = self.n_frames
+        self._chk(lib().velo_icp_batch_start(self.h, _d(T0), iters, d_max))
+
+    def icp_batch_finish(self):
+        res = (IcpResult * max(getattr(self, "_started_frames", 1), 1))()
+        self._chk(lib().velo_icp_batch_finish(self.h, res))
+        return res
 
     def icp_batch_fetch(self):
         res = (IcpResult * self.n_frames)()

@@ -180,6 +180,9 @@ struct velo_ctx {
     std::vector<BlockItem> plan_late_h, plan_lo_h, plan_xcd_h;
     std::vector<int32_t> plan_fbl_h;
     hipEvent_t ev_plan = nullptr;
+    hipEvent_t ev_res = nullptr;      // velo_icp_batch_start .. _finish
+    int res_frames = 0, res_iters = 0;
+    bool res_pending = false;
     DevBuf<BlockItem> items;          // frame-major (single-frame entry points index into it)
     DevBuf<BlockItem> items_first;    // the same items in launch order (launch_order)
     DevBuf<BlockItem> items_xcd;      // same blocks, dealt so that XCD r works on spatial slab r
@@ -1266,24 +1269,26 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     return forget_hints_for_linearize(c, hint, n_all, s);
 }
 
-int fetch_icp(velo_ctx* c, velo_icp_result* out)
+// the poses and per-iteration statistics of the registration just enqueued, on their way to pinned
+// host memory (a copy into pageable memory is staged and waited for inside the call, twice per
+// registration -- a visible share of a single frame's 0.4 ms)
+int enqueue_result_copies(velo_ctx* c, int F)
 {
-    if (!out) return c->fail(VELO_E_INVALID, "out is null");
-    if (c->last_iters < 1) return c->fail(VELO_E_INVALID, "no registration has run");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const int F = c->n_frames, iters = c->last_iters;
-    // results land in pinned host memory: a copy into pageable memory is staged and waited for
-    // inside the call, twice per registration -- a visible share of a single frame's 0.4 ms
     const size_t t_bytes = (size_t)c->cfg.max_batch * 12 * sizeof(double);
     const size_t s_bytes = (size_t)c->cfg.max_batch * VELO_MAX_ITERS * sizeof(velo_icp_iter);
     if (!c->h_result) HIP_TRY(c, hipHostMalloc((void**)&c->h_result, t_bytes + s_bytes, 0));
-    const double* T = reinterpret_cast<const double*>(c->h_result);
-    const velo_icp_iter* st = reinterpret_cast<const velo_icp_iter*>(c->h_result + t_bytes);
     HIP_TRY(c, hipMemcpyAsync(c->h_result, c->poses.p, (size_t)F * 12 * sizeof(double), hipMemcpyDeviceToHost,
                               c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_result + t_bytes, c->stats.p, (size_t)F * VELO_MAX_ITERS * sizeof(velo_icp_iter),
                               hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VELO_OK;
+}
+
+void parse_results(velo_ctx* c, int F, int iters, velo_icp_result* out)
+{
+    const size_t t_bytes = (size_t)c->cfg.max_batch * 12 * sizeof(double);
+    const double* T = reinterpret_cast<const double*>(c->h_result);
+    const velo_icp_iter* st = reinterpret_cast<const velo_icp_iter*>(c->h_result + t_bytes);
     for (int f = 0; f < F; ++f) {
         velo_icp_result& r = out[f];
         std::memset(&r, 0, sizeof r);
@@ -1295,6 +1300,17 @@ int fetch_icp(velo_ctx* c, velo_icp_result* out)
             r.total_pairs += r.iter[i].n_pairs;
         }
     }
+}
+
+int fetch_icp(velo_ctx* c, velo_icp_result* out)
+{
+    if (!out) return c->fail(VELO_E_INVALID, "out is null");
+    if (c->last_iters < 1) return c->fail(VELO_E_INVALID, "no registration has run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int F = c->n_frames, iters = c->last_iters;
+    if (int rc = enqueue_result_copies(c, F)) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    parse_results(c, F, iters, out);
     if (c->timing) {
         double lin = 0, sol = 0, lin_first = 0, lin_min = 1e30;
         int nl = 0, ns = 0;
@@ -1428,6 +1444,7 @@ void velo_destroy(velo_ctx* c)
     if (c->ev_pend) (void)hipEventDestroy(c->ev_pend);
     if (c->ev_inc) (void)hipEventDestroy(c->ev_inc);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    if (c->ev_res) (void)hipEventDestroy(c->ev_res);
     if (c->plan_up.h) (void)hipHostFree(c->plan_up.h);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_call0) (void)hipEventDestroy(c->ev_call0);
@@ -1972,6 +1989,35 @@ int velo_icp_batch_async(velo_ctx* c, const double* T0, int iters, float d_max)
 {
     if (!c) return VELO_E_INVALID;
     return run_icp(c, T0, iters, d_max);
+}
+
+// start = async + the result copies + an event; finish waits for THAT event only: work enqueued on
+// the ctx stream after the start (the increment, the next frame's decode) is not waited for, and the
+// resident frames may already be the next ones
+int velo_icp_batch_start(velo_ctx* c, const double* T0, int iters, float d_max)
+{
+    if (!c) return VELO_E_INVALID;
+    c->res_pending = false;
+    if (int rc = run_icp(c, T0, iters, d_max)) return rc;
+    if (int rc = enqueue_result_copies(c, c->n_frames)) return rc;
+    if (!c->ev_res) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_res, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_res, c->stream));
+    c->res_frames = c->n_frames;
+    c->res_iters = c->last_iters;
+    c->res_pending = true;
+    return VELO_OK;
+}
+
+int velo_icp_batch_finish(velo_ctx* c, velo_icp_result* out)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!out) return c->fail(VELO_E_INVALID, "out is null");
+    if (!c->res_pending) return c->fail(VELO_E_INVALID, "no registration started with velo_icp_batch_start is outstanding");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev_res));
+    c->res_pending = false;
+    parse_results(c, c->res_frames, c->res_iters, out);
+    return VELO_OK;
 }
 
 int velo_icp_batch_fetch(velo_ctx* c, velo_icp_result* out)

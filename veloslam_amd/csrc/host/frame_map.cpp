@@ -512,7 +512,7 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
     }
     double T0s[4 * 12];
     for (int f = 0; f < 4; ++f) std::memcpy(T0s + 12 * f, T0.data(), sizeof(double) * 12);
-    if (velo_icp_batch_async(ctx_, T0s, o.iters, o.d_max)) {
+    if (velo_icp_batch_start(ctx_, T0s, o.iters, o.d_max)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
@@ -522,8 +522,11 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
         err_ = velo_last_error(ctx_);
         return false;
     }
-    if (o.while_registering) o.while_registering();  // the GPU is busy for ~0.5 ms: the caller's host work goes here
-    if (velo_icp_batch_fetch(ctx_, local)) {
+    // the GPU is busy for ~0.5 ms: the caller's work goes here -- host work, or the NEXT frame's decode
+    // on this very context (HDLManager::prepareResident: it queues behind the registration, and the
+    // result below belongs to the frames that were resident when it started)
+    if (o.while_registering) o.while_registering();
+    if (velo_icp_batch_finish(ctx_, local)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
