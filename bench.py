@@ -581,11 +581,16 @@ def run_replay(args, dev, local, steps, warmup, d=None):
                              flush=last, initial_firing_skip=int(e.firing_skip))
         planned["f"] = f
 
-    def decode_frame(f):
-        """the frame's packets up, decoded + compensated, resident as frame 0 of the ctx"""
+    def decode_frame(f, overlapped=False):
+        """the frame's packets up, decoded + compensated, resident as frame 0 of the ctx; overlapped: on
+        the ctx's second stream, concurrently with the registration in flight"""
         if planned["f"] != f:
             plan_frame(f)
         planned["f"] = None
+        if overlapped:
+            nf, _ = ctx.decode_submit_overlapped(plan)
+            assert nf >= 1
+            return
         nf, _ = ctx.decode_submit(plan)
         assert nf >= 1
         ctx.decode_to_frames()
@@ -610,8 +615,8 @@ def run_replay(args, dev, local, steps, warmup, d=None):
         ctx.icp_batch_start(np.tile(T0, (ctx.n_frames, 1)), args.iters, args.d_max)
         ctx.increment_pending(0, None, 3)
         if f_next is not None and not args.no_decode_overlap:
-            decode_frame(f_next)      # (waits inside for its frame offsets, i.e. for this registration too:
-            state["resident"] = f_next  #  the `icp` stage below is registration + the next frame's decode)
+            decode_frame(f_next, overlapped=True)   # (second stream: concurrent with the registration; the
+            state["resident"] = f_next              #  `icp` stage below is both)
         res = ctx.icp_batch_finish()[0]
         t.append(time.perf_counter())
         if ctx.pending_count(False) >= max(args.append_threshold, 1):

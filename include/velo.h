@@ -287,6 +287,14 @@ int velo_decode_plan_fill(velo_decode_plan*, const velo_decode_opts* opts, const
                           int n_lasers, const velo_pose* poses, size_t n_poses, int flush,
                           const double* crop_region, int crop_inside);
 int velo_decode_submit(velo_ctx*, velo_decode_plan*, int32_t* n_frames, size_t* n_points);
+/* velo_decode_submit + velo_decode_to_frames on a second stream of the ctx, CONCURRENTLY with the
+ * registration a velo_icp_batch_start put on the main stream (valid only between that start and its
+ * finish, once per registration; call velo_increment_pending for the frames being registered first:
+ * afterwards the resident frames are the new ones).  The decode writes the output set and the plan
+ * copy the running registration does not use (both alternate from call to call), waits on the device
+ * for everything older than that registration, and the main stream is held behind it, so whatever is
+ * enqueued next sees the new frames complete.  The call waits for the side stream only. */
+int velo_decode_submit_overlapped(velo_ctx*, velo_decode_plan*, int32_t* n_frames, size_t* n_points);
 const char* velo_decode_plan_error(const velo_decode_plan*);
 /* Copy the last decode back; any pointer may be NULL.  frame_start: n_frames+1; beam_start:
  * n_frames x 65 (absolute offsets); packet_index: index of the source packet of each point. */

@@ -96,6 +96,11 @@ public:
     // registered (RegisterOptions::while_registering); the prepareResident / prepareFrame of the same
     // frame that follows then only submits the device half.  A plan for another frame is discarded.
     bool planResident(const std::shared_ptr<HDLFrame>& frame);
+    // prepareResident for the NEXT frame while the context registers the current one (call it from
+    // RegisterOptions::while_registering): host half, then the device half on the context's second
+    // stream, concurrently with the registration (velo_decode_submit_overlapped).  The frame is
+    // resident, and everything enqueued afterwards sees it complete, when the call returns.
+    bool prepareResidentDuringRegistration(const std::shared_ptr<HDLFrame>& frame, size_t* points = nullptr);
 
     // HDLManager.cxx:226-260.  waitForFrame blocks up to `micro` for an addFrame().
     FrameRef waitForFrame(std::chrono::microseconds micro = std::chrono::microseconds(100000));
@@ -126,7 +131,7 @@ public:
     void operator=(const HDLManager&) = delete;
 
 private:
-    bool decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, int* n_decoded);
+    bool decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, int* n_decoded, bool overlapped = false);
     bool fillPlan(const HDLFrame& f);
     velo_decode_plan* plan_ = nullptr;
     const HDLFrame* planned_ = nullptr;   // the frame plan_ is filled for ...

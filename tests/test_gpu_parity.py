@@ -817,6 +817,55 @@ def test_icp_start_finish_with_the_next_frame_decoded_in_between(oracle):
     assert pa[0] == pb[0] and pa[1] == pb[1]
     assert all(np.array_equal(x, y) for x, y in zip(pa[2], pb[2]))
     assert pa[3] == pb[3] and pa[4] == pb[4]
+
+    # the same with the next frame decoded on the ctx's SECOND stream, concurrently with the registration
+    # (velo_decode_submit_overlapped), several frames in a row so that both output sets and both plan
+    # copies come round again: every registration and every increment as in the plain order
+    buf = np.frombuffer(b"".join(pk), np.uint8).copy()
+    tt = np.asarray(ts, np.int64)
+    calib = np.ascontiguousarray(cal, np.float64).reshape(64, 9)
+    cuts = [(0, 310, False), (300, 610, False), (0, 310, False), (300, 610, False), (600, len(pk), True)]
+
+    def chain(overlapped):
+        c = capi.Context(0, max_batch=4)
+        out = []
+        try:
+            c.map_reset(*wl["map"], 1.0, 16)
+            plan = c.decode_plan_create()
+            a, b, fl = cuts[0]
+            c.decode_plan_fill(plan, buf[a * 1206:b * 1206], tt[a:b], calib, poses, n, flush=fl)
+            c.decode_submit(plan)
+            c.decode_to_frames()
+            for k in range(len(cuts)):
+                nxt = cuts[k + 1] if k + 1 < len(cuts) else None
+                nq = c.n_frames
+                T0 = np.tile(T_id, (nq, 1))
+                if overlapped:
+                    c.icp_batch_start(T0, 6, 1.0)
+                    c.increment_pending(0, None, 3)
+                    if nxt:
+                        c.decode_plan_fill(plan, buf[nxt[0] * 1206:nxt[1] * 1206], tt[nxt[0]:nxt[1]], calib, poses, n, flush=nxt[2])
+                        c.decode_submit_overlapped(plan)
+                    r = c.icp_batch_finish()
+                else:
+                    r = c.icp_batch(T0, 6, 1.0)
+                    c.increment_pending(0, None, 3)
+                    if nxt:
+                        c.decode_plan_fill(plan, buf[nxt[0] * 1206:nxt[1] * 1206], tt[nxt[0]:nxt[1]], calib, poses, n, flush=nxt[2])
+                        c.decode_submit(plan)
+                        c.decode_to_frames()
+                out.append([list(x.T) for x in r][:nq])
+            npend = c.pending_count(True)
+            inc = c.pending_fetch() if npend else (np.empty(0, np.float32),) * 3
+            out.append([x.tolist() for x in inc])
+            with pytest.raises(capi.VeloError):
+                c.decode_submit_overlapped(plan)       # no registration in flight
+            c.decode_plan_destroy(plan)
+            return out
+        finally:
+            c.close()
+
+    assert chain(True) == chain(False)
     c = capi.Context(0, max_batch=2)
     try:
         with pytest.raises(capi.VeloError):

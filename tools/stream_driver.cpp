@@ -9,9 +9,9 @@
 //              resident in HBM) -> MapManager::registerResident (rolls the device map to the
 //              prior's ROI: evict the tiles that left, append the ones that entered; 20 ICP
 //              iterations; accepted increment to the device-side pending list, merged every
-//              append_threshold points); the NEXT frame's decode (HDLManager::prepareResident) is issued inside
-//              registerResident while the GPU iterates (RegisterOptions::while_registering): its device half
-//              queues right behind this frame's registration
+//              append_threshold points); the NEXT frame's decode (HDLManager::prepareResidentDuringRegistration)
+//              is issued inside registerResident (RegisterOptions::while_registering) and runs on the context's
+//              second stream, concurrently with this frame's registration
 //
 // The prior is what the reference's INS would give: the interpolated car pose (x, y, angles from
 // carposes.txt -- the format has no z: z is carried from the previous registration) plus the
@@ -104,7 +104,7 @@ int main(int argc, char** argv)
         if (overlap && f_next >= 0)
             opt.while_registering = [&hdl, &frames, f_next, &next_ok, &t_next] {
                 const auto a0 = clk::now();
-                next_ok = hdl.prepareResident(frames[(size_t)f_next]);
+                next_ok = hdl.prepareResidentDuringRegistration(frames[(size_t)f_next]);
                 t_next = ms_since(a0);
             };
         const auto a = clk::now();

@@ -86,7 +86,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_icp_batch_start", "velo_icp_batch_finish", "velo_linearize",
-    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_decode_plan_create", "velo_decode_plan_destroy", "velo_decode_plan_fill", "velo_decode_submit", "velo_decode_plan_error", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_increment_pending", "velo_pending_count", "velo_pending_fetch", "velo_map_append_pending", "velo_pending_clear", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
+    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_decode_plan_create", "velo_decode_plan_destroy", "velo_decode_plan_fill", "velo_decode_submit", "velo_decode_submit_overlapped", "velo_decode_plan_error", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_increment_pending", "velo_pending_count", "velo_pending_fetch", "velo_map_append_pending", "velo_pending_clear", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
     "velo_exchange_increments", "velo_exchange_plan", "velo_exchange_pack_dev", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_pcap_index", "velo_ins_to_pose",
@@ -172,6 +172,7 @@ def lib():
     L.velo_decode_plan_destroy.restype = None
     L.velo_decode_plan_fill.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_int]
     L.velo_decode_submit.argtypes = [vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
+    L.velo_decode_submit_overlapped.argtypes = L.velo_decode_submit.argtypes
     L.velo_decode_plan_error.argtypes = [vp]
     L.velo_decode_plan_error.restype = C.c_char_p
     L.velo_increment.argtypes = [vp, C.c_int, dp, C.c_int, vp, vp, vp, C.POINTER(C.c_size_t)]
@@ -699,6 +700,15 @@ class Context:
         npts = C.c_size_t()
         self._chk(lib().velo_decode_submit(self.h, plan, C.byref(nf), C.byref(npts)))
         self._decoded_frames = nf.value
+        return nf.value, npts.value
+
+    def decode_submit_overlapped(self, plan):
+        """device half + adoption on the side stream, during a registration begun with icp_batch_start"""
+        nf = C.c_int32()
+        npts = C.c_size_t()
+        self._chk(lib().velo_decode_submit_overlapped(self.h, plan, C.byref(nf), C.byref(npts)))
+        self._decoded_frames = nf.value
+        self.n_frames = nf.value
         return nf.value, npts.value
 
     def decode_to_frames(self):

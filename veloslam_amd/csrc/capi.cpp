@@ -164,7 +164,8 @@ struct velo_ctx {
     struct PlanUpload {
         uint8_t* h = nullptr;  // pinned
         size_t h_cap = 0, used = 0;
-        DevBuf<uint8_t> d;
+        DevBuf<uint8_t> d[2];  // alternating: the plan of the frames in flight stays intact while the next goes up
+        int sel = 0;
         struct Slice {
             void (*bind)(void* buf, uint8_t* base, size_t off);
             void* buf;
@@ -269,8 +270,17 @@ struct velo_ctx {
     DevBuf<double> dk_corr, dk_lutc, dk_luts, dk_azc, dk_azs;
     DevBuf<int32_t> dk_starts;
     DevBuf<uint32_t> dk_keys, dk_keys2, dk_idx, dk_order;
-    DevBuf<float> dk_x, dk_y, dk_z, dk_i, dk_dist;
-    DevBuf<uint16_t> dk_az, dk_pidx;
+    // decode outputs, two sets: a decode writes the set the PREVIOUS decode did not, so the frames of
+    // the previous decode stay intact (and may be being registered) while the next ones are produced
+    struct DecodeOut {
+        DevBuf<float> x, y, z, i, dist;
+        DevBuf<uint16_t> az, pidx;
+    } dk_out[2];
+    int dk_sel = 0;  // the set the last decode wrote
+    DevBuf<char> dk_temp;                // sort scratch of a decode on the side stream
+    hipStream_t side_stream = nullptr;   // velo_decode_submit_overlapped
+    hipEvent_t ev_mark = nullptr, ev_side = nullptr;
+    bool mark_valid = false;
     std::vector<double> dk_corr_host;      // calibration the device tables were built for
     int dk_frames = 0;
     size_t dk_points = 0;
@@ -851,11 +861,13 @@ int plan_add(velo_ctx* c, DevBuf<T>& dst, const T* src, size_t n)
 int plan_flush(velo_ctx* c)
 {
     velo_ctx::PlanUpload& u = c->plan_up;
+    u.sel ^= 1;
+    DevBuf<uint8_t>& d = u.d[u.sel];
     if (u.used) {
-        HIP_TRY(c, u.d.reserve(u.used + u.used / 2));
-        HIP_TRY(c, hipMemcpyAsync(u.d.p, u.h, u.used, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, d.reserve(u.used + u.used / 2));
+        HIP_TRY(c, hipMemcpyAsync(d.p, u.h, u.used, hipMemcpyHostToDevice, c->stream));
     }
-    for (const auto& sl : u.slices) sl.bind(sl.buf, u.d.p, sl.off);
+    for (const auto& sl : u.slices) sl.bind(sl.buf, d.p, sl.off);
     u.slices.clear();
     u.used = 0;
     return VELO_OK;
@@ -1445,6 +1457,9 @@ void velo_destroy(velo_ctx* c)
     if (c->ev_inc) (void)hipEventDestroy(c->ev_inc);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->ev_res) (void)hipEventDestroy(c->ev_res);
+    if (c->ev_mark) (void)hipEventDestroy(c->ev_mark);
+    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->plan_up.h) (void)hipHostFree(c->plan_up.h);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_call0) (void)hipEventDestroy(c->ev_call0);
@@ -1998,6 +2013,13 @@ int velo_icp_batch_start(velo_ctx* c, const double* T0, int iters, float d_max)
 {
     if (!c) return VELO_E_INVALID;
     c->res_pending = false;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // everything enqueued so far -- the previous frame's registration and increment included -- lies
+    // before this mark: what a decode on the side stream has to wait for before it may write the
+    // buffers those read (velo_decode_submit_overlapped)
+    if (!c->ev_mark) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_mark, c->stream));
+    c->mark_valid = true;
     if (int rc = run_icp(c, T0, iters, d_max)) return rc;
     if (int rc = enqueue_result_copies(c, c->n_frames)) return rc;
     if (!c->ev_res) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_res, hipEventDisableTiming));
@@ -2198,7 +2220,8 @@ static int decode_submit(velo_ctx* c, velo_ctx::DecodePlan& P, velo_ctx::DecodeS
     if (!P.filled) return c->fail(VELO_E_INVALID, "velo_decode: nothing planned");
     P.filled = false;  // (the staging buffer is free again at the synchronisation below)
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->ax && c->ax == c->dk_x.p) {
+    c->dk_sel ^= 1;  // write the other set
+    if (c->ax && c->ax == c->dk_out[c->dk_sel].x.p) {
         // the resident frames ARE the previous decode's output (velo_decode_to_frames): this
         // decode rewrites (and may reallocate) those buffers, so the adoption ends here --
         // registration calls fail with VELO_E_INVALID until frames are uploaded/adopted again
@@ -2266,15 +2289,15 @@ static int decode_submit(velo_ctx* c, velo_ctx::DecodePlan& P, velo_ctx::DecodeS
     HIP_TRY(c, hipMemcpyAsync(starts, c->dk_starts.p, n_starts * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     const size_t n_valid = nfr > 0 ? (size_t)starts[(size_t)nfr * 64] : 0;
-    HIP_TRY(c, c->dk_x.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_y.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_z.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_i.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_dist.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_az.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_pidx.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, launch_decode_emit(v, c->dk_order.p, n_valid, c->dk_x.p, c->dk_y.p, c->dk_z.p, c->dk_i.p,
-                                  c->dk_az.p, c->dk_dist.p, c->dk_pidx.p, s));
+    HIP_TRY(c, c->dk_out[c->dk_sel].x.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_out[c->dk_sel].y.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_out[c->dk_sel].z.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_out[c->dk_sel].i.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_out[c->dk_sel].dist.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_out[c->dk_sel].az.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, c->dk_out[c->dk_sel].pidx.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, launch_decode_emit(v, c->dk_order.p, n_valid, c->dk_out[c->dk_sel].x.p, c->dk_out[c->dk_sel].y.p, c->dk_out[c->dk_sel].z.p, c->dk_out[c->dk_sel].i.p,
+                                  c->dk_out[c->dk_sel].az.p, c->dk_out[c->dk_sel].dist.p, c->dk_out[c->dk_sel].pidx.p, s));
     // (no wait for the emit: whoever reads the frames -- velo_decode_fetch, the registration -- is
     // ordered behind it on the ctx stream; launching it over an upper bound BEFORE the count is
     // known, so that the wait overlaps with it, measured no different: 0.120-0.151 ms either way)
@@ -2361,7 +2384,46 @@ int velo_decode_plan_fill(velo_decode_plan* p, const velo_decode_opts* opts, con
 int velo_decode_submit(velo_ctx* c, velo_decode_plan* p, int32_t* n_frames, size_t* n_points)
 {
     if (!c || !p) return VELO_E_INVALID;
+    c->mark_valid = false;
     return decode_submit(c, p->P, nullptr, n_frames, n_points);
+}
+
+// velo_decode_submit + velo_decode_to_frames on the ctx's SIDE stream, concurrently with the
+// registration velo_icp_batch_start put on the main stream.  Safe because (a) the decode writes the
+// output set, and the frame plan the device copy, that the frames being registered do NOT use (both
+// alternate), (b) the side stream first waits for the mark velo_icp_batch_start recorded -- everything
+// older than the running registration, i.e. whatever still read those buffers -- and (c) the main
+// stream is made to wait for the side stream's end before anything enqueued LATER runs (the next
+// registration, an increment, a fetch).  The call itself waits only for the side stream.
+int velo_decode_submit_overlapped(velo_ctx* c, velo_decode_plan* p, int32_t* n_frames, size_t* n_points)
+{
+    if (!c || !p) return VELO_E_INVALID;
+    if (!c->mark_valid || !c->res_pending)
+        return c->fail(VELO_E_INVALID, "velo_decode_submit_overlapped needs a registration started with velo_icp_batch_start "
+                                       "and not yet finished");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->side_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    if (!c->ev_side) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    c->mark_valid = false;  // one overlapped decode per registration
+    HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_mark, 0));
+    hipStream_t main_stream = c->stream;
+    c->stream = c->side_stream;  // (decode_submit and plan_frames enqueue on c->stream)
+    std::swap(c->temp.p, c->dk_temp.p);
+    std::swap(c->temp.cap, c->dk_temp.cap);
+    int32_t nf = 0;
+    int rc = decode_submit(c, p->P, nullptr, &nf, n_points);
+    if (rc == VELO_OK && nf >= 1) rc = velo_decode_to_frames(c);
+    std::swap(c->temp.p, c->dk_temp.p);
+    std::swap(c->temp.cap, c->dk_temp.cap);
+    c->stream = main_stream;
+    // whatever happened: nothing enqueued on the main stream from now on may overtake the side stream
+    hipError_t e = hipEventRecord(c->ev_side, c->side_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, c->ev_side, 0);
+    if (rc) return rc;
+    if (e != hipSuccess) return c->fail(VELO_E_DEVICE, "side stream: %s", hipGetErrorString(e));
+    if (n_frames) *n_frames = nf;
+    if (nf < 1) return c->fail(VELO_E_NODATA, "the packets hold no complete revolution");
+    return VELO_OK;
 }
 
 int velo_decode(velo_ctx* c, const uint8_t* packets, const int64_t* pkt_t_us, size_t n_pkt,
@@ -2427,13 +2489,13 @@ int velo_decode_fetch(velo_ctx* c, float* x, float* y, float* z, float* intensit
     const size_t n = c->dk_points;
     hipStream_t s = c->stream;
     if (n) {
-        if (x) HIP_TRY(c, hipMemcpyAsync(x, c->dk_x.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
-        if (y) HIP_TRY(c, hipMemcpyAsync(y, c->dk_y.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
-        if (z) HIP_TRY(c, hipMemcpyAsync(z, c->dk_z.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
-        if (intensity) HIP_TRY(c, hipMemcpyAsync(intensity, c->dk_i.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
-        if (azimuth) HIP_TRY(c, hipMemcpyAsync(azimuth, c->dk_az.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
-        if (distance) HIP_TRY(c, hipMemcpyAsync(distance, c->dk_dist.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
-        if (packet_index) HIP_TRY(c, hipMemcpyAsync(packet_index, c->dk_pidx.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+        if (x) HIP_TRY(c, hipMemcpyAsync(x, c->dk_out[c->dk_sel].x.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (y) HIP_TRY(c, hipMemcpyAsync(y, c->dk_out[c->dk_sel].y.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (z) HIP_TRY(c, hipMemcpyAsync(z, c->dk_out[c->dk_sel].z.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (intensity) HIP_TRY(c, hipMemcpyAsync(intensity, c->dk_out[c->dk_sel].i.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (azimuth) HIP_TRY(c, hipMemcpyAsync(azimuth, c->dk_out[c->dk_sel].az.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+        if (distance) HIP_TRY(c, hipMemcpyAsync(distance, c->dk_out[c->dk_sel].dist.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (packet_index) HIP_TRY(c, hipMemcpyAsync(packet_index, c->dk_out[c->dk_sel].pidx.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
     }
     const size_t F = (size_t)c->dk_frames;
@@ -2449,7 +2511,7 @@ int velo_decode_to_frames(velo_ctx* c)
 {
     if (!c) return VELO_E_INVALID;
     if (c->dk_frames < 1) return c->fail(VELO_E_INVALID, "nothing decoded");
-    return velo_frames_adopt_dev(c, c->dk_frames, c->dk_x.p, c->dk_y.p, c->dk_z.p,
+    return velo_frames_adopt_dev(c, c->dk_frames, c->dk_out[c->dk_sel].x.p, c->dk_out[c->dk_sel].y.p, c->dk_out[c->dk_sel].z.p,
                                  c->dk_frame_start.data());
 }
 

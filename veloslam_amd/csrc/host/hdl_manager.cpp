@@ -225,7 +225,7 @@ bool HDLManager::planResident(const std::shared_ptr<HDLFrame>& frame)
 }
 
 // ---- the decode behind prepareFrame / prepareResident ------------------------------------
-bool HDLManager::decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, int* n_decoded)
+bool HDLManager::decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, int* n_decoded, bool overlapped)
 {
     // (planned ahead: only the device half is left; the key is the frame AND where it sits in the
     // capture -- an address alone can come back with another frame after a reload)
@@ -234,6 +234,15 @@ bool HDLManager::decodeFrame(const HDLFrame& f, bool to_frames, size_t* npts, in
     planned_ = nullptr;
     int32_t nf = 0;
     size_t n = 0;
+    if (overlapped) {  // device half + adoption on the side stream, next to the running registration
+        if (velo_decode_submit_overlapped(ctx_, plan_, &nf, &n) != VELO_OK) {
+            err_ = std::string("decode failed: ") + velo_last_error(ctx_);
+            return false;
+        }
+        if (npts) *npts = n;
+        if (n_decoded) *n_decoded = nf;
+        return true;
+    }
     if (velo_decode_submit(ctx_, plan_, &nf, &n) != VELO_OK) {
         err_ = std::string("decode failed: ") + velo_last_error(ctx_);
         return false;
@@ -263,6 +272,24 @@ bool HDLManager::prepareResident(const std::shared_ptr<HDLFrame>& frame, size_t*
     if (!decodeFrame(*frame, true, &n, &nf)) return false;
     if (nf != 1) {
         // the packets of one index entry hold one revolution: its closing split, or the flush
+        err_ = "the packets of the frame decode to more than one revolution";
+        return false;
+    }
+    if (points) *points = n;
+    return true;
+}
+
+bool HDLManager::prepareResidentDuringRegistration(const std::shared_ptr<HDLFrame>& frame, size_t* points)
+{
+    if (!frame || !frame->isOnHardDrive) {
+        err_ = "not a frame of the capture";
+        return false;
+    }
+    std::lock_guard<std::mutex> lock(decodeMutex_);
+    size_t n = 0;
+    int nf = 0;
+    if (!decodeFrame(*frame, true, &n, &nf, true)) return false;
+    if (nf != 1) {
         err_ = "the packets of the frame decode to more than one revolution";
         return false;
     }
