@@ -117,6 +117,8 @@ def parse():
     ap.add_argument("--append-threshold", type=int, default=512,
                     help="stream: accepted increments are collected on the device and appended to the map "
                          "once this many points are pending (and always before the map rolls)")
+    ap.add_argument("--no-roll-ahead", action="store_true",
+                    help="stream: roll the map when a frame is due instead of beside the previous frame's registration")
     ap.add_argument("--no-decode-overlap", action="store_true",
                     help="stream: plan every frame's decode on the host when it is due instead of a frame ahead, "
                          "while the GPU registers the previous one")
@@ -568,6 +570,31 @@ def run_replay(args, dev, local, steps, warmup, d=None):
                 state["full"] += 1
         state["res"] = rng
 
+    def roll_ahead(x, y, timed):
+        """roll_to for the NEXT frame's prior beside the registration in flight (MapManager::rollAhead):
+        eviction + append on the ctx's second stream; the pending increments stay pending"""
+        rng = tile_range(x, y)
+        cur = state["res"]
+        if cur is None or cur == rng:
+            return
+        if not (rng[0] <= cur[1] and rng[1] >= cur[0] and rng[2] <= cur[3] and rng[3] >= cur[2]):
+            return
+        ex, ey, ez = gather(rng, skip=cur)
+        evicts = rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]
+        lo = np.array([rng[0] * pr - pr / 2, rng[2] * pr - pr / 2, -big], np.float32)
+        hi = np.array([np.nextafter(np.float32(rng[1] * pr + pr / 2), np.float32(-big)),
+                       np.nextafter(np.float32(rng[3] * pr + pr / 2), np.float32(-big)), big], np.float32)
+        n0 = ctx.map_info().n_points
+        if not ctx.map_roll_overlapped(lo if evicts else None, hi if evicts else None, ex, ey, ez):
+            if ctx.map_info().n_points != n0:
+                state["res"] = None        # (an eviction went through, the append did not: rebuild from the tiles)
+            return
+        if timed:
+            state["rolls"] += 1
+            state["up"] += int(ex.size)
+            state["ev"] += int(n0 + ex.size - ctx.map_info().n_points)
+        state["res"] = rng
+
     plan = ctx.decode_plan_create()
     planned = dict(f=None)
 
@@ -617,6 +644,11 @@ def run_replay(args, dev, local, steps, warmup, d=None):
         if f_next is not None and not args.no_decode_overlap:
             decode_frame(f_next, overlapped=True)   # (second stream: concurrent with the registration; the
             state["resident"] = f_next              #  `icp` stage below is both)
+            if not args.no_roll_ahead:              # ... and so is the roll of the map to the next frame's ROI
+                ok2, car2 = capi.interp_pose(d["poses"], d["n_poses"], int(times[int(idx[f_next].first_packet)]))
+                Tn = synth.perturbed_guess(np.array([1, 0, 0, car2.T[0], 0, 1, 0, car2.T[1], 0, 0, 1, 0.0], np.float64),
+                                           dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))
+                roll_ahead(float(Tn[3]), float(Tn[7]), timed)
         res = ctx.icp_batch_finish()[0]
         t.append(time.perf_counter())
         if ctx.pending_count(False) >= max(args.append_threshold, 1):
@@ -663,7 +695,8 @@ def run_replay(args, dev, local, steps, warmup, d=None):
             "map": dict(full_builds=state["full"], rolls=state["rolls"], points_uploaded=state["up"],
                         points_evicted=state["ev"], increment_flushes=state["flush"]),
             "last_update": int(mi.last_update), "worst_pose_error_m": state["worst"],
-            "decode_planned_ahead": not args.no_decode_overlap}
+            "decode_planned_ahead": not args.no_decode_overlap,
+            "roll_ahead": not (args.no_decode_overlap or args.no_roll_ahead)}
 
 
 # ------------------------------------------------------------------------- inputs

@@ -49,7 +49,8 @@ enum {
     VELO_E_DEVICE = -3,   /* HIP runtime error (see velo_last_error) */
     VELO_E_NOMEM = -4,
     VELO_E_RANGE = -5,    /* grid beyond the 32-bit fine key / d_max > voxel / too many frames */
-    VELO_E_NODATA = -6    /* empty pose store etc. */
+    VELO_E_NODATA = -6,   /* empty pose store etc. */
+    VELO_E_AGAIN = -7     /* not in this mode: call the plain form (velo_map_roll_overlapped) */
 };
 
 typedef struct velo_ctx velo_ctx;
@@ -196,6 +197,17 @@ int velo_map_evict_outside(velo_ctx*, const float lo[3], const float hi[3]);
  * ground plane (z free) -- ROI_RANGE, "sensor detecting range" (MapManager.h:13) around the
  * current pose.  Same grid rules and refusal as velo_map_evict_outside. */
 int velo_map_evict_radius(velo_ctx*, const float center_xy[2], float radius);
+/* A roll of the map -- velo_map_evict_outside(lo, hi) (lo = hi = NULL: none) followed by
+ * velo_map_append(x, y, z, n) (n = 0: none) -- on a second stream of the ctx, CONCURRENTLY with the
+ * registration a velo_icp_batch_start put on the main stream (valid between that start and its finish,
+ * once per registration).  The registration keeps reading the map as it was: the updates write other
+ * copies of the sorted arrays, the fine table and the near-voxel flags, and wait on the device for
+ * everything older than the registration; whatever is enqueued afterwards sees the new map.  Same map
+ * as the two plain calls, bit for bit.  VELO_E_AGAIN (map unchanged by the refused update; an eviction
+ * that went through before a refused append stays): the update needs a re-anchor, a larger or a hashed
+ * table -- do it with the plain calls after velo_icp_batch_finish.  The call waits for the side stream. */
+int velo_map_roll_overlapped(velo_ctx*, const float lo[3], const float hi[3], const float* x, const float* y,
+                             const float* z, size_t n);
 /* Per-axis grid slack in voxels (cfg.map_margin sets all three): a vehicle wants tens of
  * voxels in x/y and one or two in z -- the dense fine-cell table grows with the product.
  * Takes effect at the next (re-)anchoring: velo_map_reset, or the rules above. */

@@ -42,6 +42,8 @@ struct RegisterOptions {
 struct MapStats {
     uint64_t full_builds = 0;        // velo_map_reset: first ROI, or voxel / k changed, or nothing could be kept
     uint64_t rolls = 0;              // ROI changes applied incrementally (evict + append entering tiles)
+    uint64_t rolls_ahead = 0;        // ... of which beside the previous frame's registration (rollAhead)
+    uint64_t rolls_refused = 0;      // rollAhead attempts the library refused (re-anchor needed): done by the plain roll
     uint64_t tiles_entered = 0, tiles_left = 0;
     uint64_t points_uploaded = 0;    // host tile points sent to the device by rolls
     uint64_t points_evicted = 0;
@@ -77,6 +79,13 @@ public:
     // tile range is a box), one velo_map_append of the tiles that entered -- never a re-upload.
     // registerFrame / registerResident call it with the prior's position.
     bool rollTo(double x, double y, const RegisterOptions& opts);
+    // rollTo for the NEXT frame's prior while the context registers the current one (call it from
+    // RegisterOptions::while_registering, after the next frame's decode): the eviction and the append
+    // run on the context's second stream beside the registration (velo_map_roll_overlapped).  The
+    // pending increments stay pending (they join the map at the next flush or plain roll).  Returns
+    // false without having changed anything when the roll cannot be done that way (first ROI, a jump,
+    // a re-anchor ...): the rollTo inside the next registerFrame / registerResident then does it.
+    bool rollAhead(double x, double y, const RegisterOptions& opts);
     // The pending increments (device-side list) -> the host tiles, and -> the device map for those
     // that lie in resident tiles (one velo_map_append).  A roll does not call this: it takes the list
     // and folds the points into the ONE append that brings the entering tiles up (rollTo).

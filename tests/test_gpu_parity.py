@@ -1284,6 +1284,87 @@ def test_config2_full_size_properties(oracle):
         c.close()
 
 
+def test_map_rolled_beside_a_registration_equals_the_plain_roll():
+    """velo_map_roll_overlapped: eviction + append on the second stream WHILE a registration runs on
+    the first.  Four rolls in a row (so that all three sets of sorted arrays, both tables and both
+    near-voxel maps come round), each beside a registration: (a) that registration's result is the
+    one it has with nothing beside it -- it saw the map as it was; (b) the map afterwards is the map
+    the plain velo_map_evict_outside + velo_map_append leave, bit for bit (sorted points, normals,
+    permutation, fine table, counts); (c) the next registration, on the new map, agrees too; (d) an
+    update that needs a re-anchor (or a larger table) is refused with VELO_E_AGAIN and changes nothing."""
+    from veloslam_amd import synth
+    sc = synth.Scene()
+    wx, wy, wz = sc.sample_map(900_000)
+    wl = make_workload(map_points=1000, n_frames=1)
+    f = wl["frames"][0]
+    s = f["sensor"]
+    big = 3.0e38
+    A = capi.Context(0, max_batch=2, map_margin=16)
+    B = capi.Context(0, max_batch=2, map_margin=16)
+    try:
+        for c in (A, B):
+            c.map_set_margins(16, 16, 2)
+        cx, cy, cz = A.compensate(s["x"], s["y"], s["z"], s["pkt"], f["table"])
+        px, py = float(f["T_true"][3]), float(f["T_true"][7])
+        half = 60.0
+
+        def box(x0):
+            return (wx >= x0 - half) & (wx < x0 + half) & (wy >= py - half) & (wy < py + half)
+
+        res = box(px)
+        for c in (A, B):
+            c.map_reset(wx[res], wy[res], wz[res], 1.0, 16)
+            c.frames_upload([(cx, cy, cz)])
+        T0 = f["T0"].reshape(1, 12)
+
+        def same():
+            a, b = A.map_download(), B.map_download()
+            ia, ib = A.map_info(), B.map_info()
+            assert ia.n_points == ib.n_points and list(ia.dims) == list(ib.dims) and list(ia.origin) == list(ib.origin)
+            assert ia.n_invalid_normals == ib.n_invalid_normals and ia.last_update == ib.last_update == 1
+            for k in ("cell_start", "perm", "x", "y", "z"):
+                assert np.array_equal(a[k], b[k]), k
+            for k in ("nx", "ny", "nz"):
+                assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+        x0 = px
+        for step in range(4):
+            x1 = x0 + 3.5          # (14 m in all: inside the 16-voxel slack, no grid change on the way)
+            new = box(x1)
+            entering = new & ~res
+            lo = np.array([x1 - half, py - half, -big], np.float32)
+            hi = np.array([np.nextafter(np.float32(x1 + half), np.float32(-big)),
+                           np.nextafter(np.float32(py + half), np.float32(-big)), big], np.float32)
+            # A: beside a registration; B: registration, then the plain calls
+            A.icp_batch_start(T0, 8, 1.0)
+            assert A.map_roll_overlapped(lo, hi, wx[entering], wy[entering], wz[entering])
+            ra = A.icp_batch_finish()[0]
+            rb = B.icp_batch(T0, 8, 1.0)[0]
+            B.map_evict_outside(lo, hi)
+            B.map_append(wx[entering], wy[entering], wz[entering])
+            assert list(ra.T) == list(rb.T) and [ra.iter[i].n_pairs for i in range(8)] == [rb.iter[i].n_pairs for i in range(8)]
+            same()
+            na, nb = A.icp_batch(T0, 8, 1.0)[0], B.icp_batch(T0, 8, 1.0)[0]   # on the rolled map
+            assert list(na.T) == list(nb.T)
+            res, x0 = (res & new) | entering, x1
+            with pytest.raises(capi.VeloError):
+                A.map_roll_overlapped(lo, hi, wx[:3], wy[:3], wz[:3])          # no registration in flight
+        # (d) points far below the origin need a re-anchor: refused, nothing changed
+        mi = A.map_info()
+        low = (np.full(5, mi.origin[0] - 40.0, np.float32), np.full(5, mi.origin[1] - 40.0, np.float32), np.zeros(5, np.float32))
+        before = A.map_download()
+        A.icp_batch_start(T0, 3, 1.0)
+        assert A.map_roll_overlapped(None, None, *low) is False
+        A.icp_batch_finish()
+        after = A.map_download()
+        assert A.map_info().n_points == mi.n_points and all(np.array_equal(before[k], after[k]) for k in ("x", "cell_start", "perm"))
+        A.map_append(*low)                                                      # the plain call does it
+        assert A.map_info().n_points == mi.n_points + 5 and A.map_info().last_update == 0
+    finally:
+        A.close()
+        B.close()
+
+
 def test_rolling_a_5m_point_map_incremental_equals_full_rebuild():
     """BASELINE configs[2] at size: a 5.5 M-point device map rolled three times
     -- evict everything beyond a radius of the moving pose, append the world points that came into

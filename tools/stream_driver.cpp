@@ -20,7 +20,7 @@
 //
 //   hipcc -std=c++17 -O2 -x c++ tools/stream_driver.cpp -Iinclude -Lveloslam_amd/csrc -lveloslam_amd \
 //         -Wl,-rpath,$PWD/veloslam_amd/csrc -o tools/stream_driver
-//   tools/stream_driver DIR [--steps 100] [--warmup 10] [--threshold 512] [--no-integrate] [--no-overlap]
+//   tools/stream_driver DIR [--steps 100] [--warmup 10] [--threshold 512] [--no-integrate] [--no-overlap] [--no-roll-ahead]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -45,14 +45,15 @@ int main(int argc, char** argv)
     }
     const std::string dir = argv[1];
     int steps = 100, warmup = 10, threshold = 512;
-    bool integrate = true, overlap = true;
+    bool integrate = true, overlap = true, roll_ahead = true;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
         else if (a == "--warmup" && i + 1 < argc) warmup = std::atoi(argv[++i]);
         else if (a == "--threshold" && i + 1 < argc) threshold = std::atoi(argv[++i]);
         else if (a == "--no-integrate") integrate = false;
-        else if (a == "--no-overlap") overlap = false;  // decode every frame when it is due, not during the previous registration
+        else if (a == "--no-overlap") overlap = false;
+        else if (a == "--no-roll-ahead") roll_ahead = false;  // roll the map when the frame is due, not beside the previous registration  // decode every frame when it is due, not during the previous registration
     }
     double z0 = 0, patch = 10, voxel = 1, zero = 0;
     int k_normals = 16;
@@ -102,9 +103,15 @@ int main(int argc, char** argv)
         double t_next = 0;
         opt.while_registering = nullptr;
         if (overlap && f_next >= 0)
-            opt.while_registering = [&hdl, &frames, f_next, &next_ok, &t_next] {
+            opt.while_registering = [&hdl, &mgr, &opt, &frames, f_next, &next_ok, &t_next, roll_ahead] {
                 const auto a0 = clk::now();
                 next_ok = hdl.prepareResidentDuringRegistration(frames[(size_t)f_next]);
+                // ... and the map is rolled to the next frame's ROI beside the registration as well (the
+                // prior's x, y come from the pose track, not from this registration's result)
+                if (next_ok && roll_ahead) {
+                    const PoseTransform& c2 = *frames[(size_t)f_next]->carpose;
+                    mgr.rollAhead(c2.T[0] + 0.15, c2.T[1] - 0.10, opt);
+                }
                 t_next = ms_since(a0);
             };
         const auto a = clk::now();
@@ -165,12 +172,13 @@ int main(int argc, char** argv)
     std::printf("{\"host\": \"C++ (include/veloslam/*.hpp)\", \"frames\": %d, \"frames_per_s\": %.2f, \"ms_per_frame\": %.4f, "
                 "\"stage_ms_per_frame\": {\"decode\": %.4f, \"register_roll_icp_increment\": %.4f}, "
                 "\"pairs_per_s\": %.4g, \"worst_pose_error_m\": %.15g, \"map_points\": %llu, \"map_subdiv\": %d, "
-                "\"last_update\": %d, \"tile_edge_m\": %g, \"decode_planned_ahead\": %s, "
-                "\"map\": {\"full_builds\": %llu, \"rolls\": %llu, \"tiles_entered\": %llu, \"tiles_left\": %llu, "
+                "\"last_update\": %d, \"tile_edge_m\": %g, \"decode_planned_ahead\": %s, \"roll_ahead\": %s, "
+                "\"map\": {\"full_builds\": %llu, \"rolls\": %llu, \"rolls_ahead\": %llu, \"rolls_refused\": %llu, \"tiles_entered\": %llu, \"tiles_left\": %llu, "
                 "\"points_uploaded\": %llu, \"points_evicted\": %llu, \"increment_flushes\": %llu, \"increment_points\": %llu}}\n",
                 steps, 1e3 * steps / total_ms, total_ms / steps, t_decode / steps, t_register / steps,
-                (double)pairs / (total_ms * 1e-3), worst, (unsigned long long)mi.n_points, mi.subdiv, mi.last_update, patch, overlap ? "true" : "false",
+                (double)pairs / (total_ms * 1e-3), worst, (unsigned long long)mi.n_points, mi.subdiv, mi.last_update, patch, overlap ? "true" : "false", (overlap && roll_ahead) ? "true" : "false",
                 (unsigned long long)(s1.full_builds - s0.full_builds), (unsigned long long)(s1.rolls - s0.rolls),
+                (unsigned long long)(s1.rolls_ahead - s0.rolls_ahead), (unsigned long long)(s1.rolls_refused - s0.rolls_refused),
                 (unsigned long long)(s1.tiles_entered - s0.tiles_entered), (unsigned long long)(s1.tiles_left - s0.tiles_left),
                 (unsigned long long)(s1.points_uploaded - s0.points_uploaded),
                 (unsigned long long)(s1.points_evicted - s0.points_evicted),

@@ -140,6 +140,17 @@ struct velo_ctx {
     DevBuf<uint32_t> keys_alt, perm_alt, nk, nk_sorted, nidx, nidx_sorted, rflags, roffs;
     DevBuf<float4> pts_alt, nrm_alt, nrm_raw;
     DevBuf<uint8_t> dirty, vox_occ, vox_near;
+    // second copies of what a registration reads and a rolling update would rewrite in place: with
+    // them an update writes the copy the running registration does not read (overlap_update)
+    DevBuf<int32_t> cell_start_alt;
+    DevBuf<uint8_t> vox_near_alt;
+    bool overlap_update = false;        // inside velo_map_roll_overlapped
+    int overlap_done = 0;               // ... updates published so far in this call
+    // a roll is TWO updates (evict, append): the second must not write the arrays the registration is
+    // still reading either -- which after the first swap are the "alt" ones -- so a third set steps in
+    DevBuf<float4> pts_3, nrm_3;
+    DevBuf<uint32_t> perm_3, keys_3;
+    hipStream_t overlap_main = nullptr;  // ... the main stream meanwhile
     DevBuf<int32_t> work;
     DevBuf<unsigned> work_cnt;  // [0] work-list length, [1] normals re-estimated
     unsigned n_done_host = 0;
@@ -212,6 +223,7 @@ struct velo_ctx {
     DevBuf<unsigned long long> pairs_total;  // pairs processed by every registration iteration so far
     DevBuf<float> d2;
     DevBuf<uint32_t> flags, offs;
+    DevBuf<uint32_t> inc_flags, inc_offs;  // the increment's own: a map update on the side stream uses flags / offs
     DevBuf<float> inc_x, inc_y, inc_z;
     DevBuf<uint64_t> sp_keys, sp_keys2;   // sparse insertion: voxel keys of the new points
     DevBuf<uint32_t> sp_idx, sp_idx2;
@@ -281,6 +293,7 @@ struct velo_ctx {
     hipStream_t side_stream = nullptr;   // velo_decode_submit_overlapped
     hipEvent_t ev_mark = nullptr, ev_side = nullptr;
     bool mark_valid = false;
+    bool roll_overlapped_done = false;  // one velo_map_roll_overlapped per registration
     std::vector<double> dk_corr_host;      // calibration the device tables were built for
     int dk_frames = 0;
     size_t dk_points = 0;
@@ -359,6 +372,21 @@ hipError_t reserve_slack(DevBuf<T>& b, size_t n)
     return b.reserve(n + n / 8 + 4096);  // a rolling map grows a little every frame
 }
 
+// overlapped update, second and later of a call: what "alt" points at is what the running
+// registration reads (the first update swapped it there); write a third set instead
+void overlap_rotate_alt(velo_ctx* c)
+{
+    if (!c->overlap_update || c->overlap_done == 0) return;
+    std::swap(c->pts_alt.p, c->pts_3.p);
+    std::swap(c->pts_alt.cap, c->pts_3.cap);
+    std::swap(c->nrm_alt.p, c->nrm_3.p);
+    std::swap(c->nrm_alt.cap, c->nrm_3.cap);
+    std::swap(c->perm_alt.p, c->perm_3.p);
+    std::swap(c->perm_alt.cap, c->perm_3.cap);
+    std::swap(c->keys_alt.p, c->keys_3.p);
+    std::swap(c->keys_alt.cap, c->keys_3.cap);
+}
+
 // normals of the points in dirty voxels, after the sorted arrays were updated in place
 // chg_keys: sorted fine keys of the added / removed points (nullptr: re-estimate every point of
 // the dirty voxels).  The number of normals really re-estimated lands in c->n_done_host once
@@ -389,17 +417,24 @@ int publish_map(velo_ctx* c, MapView mv, int k_normals, unsigned long long inval
     hipStream_t s = c->stream;
     const size_t nvox = (size_t)mv.nx * mv.ny * mv.nz;
     HIP_TRY(c, reserve_slack(c->vox_occ, nvox));
+    if (c->overlap_update && c->overlap_done == 0) {  // the running registration reads vox_near: build the other copy
+        std::swap(c->vox_near.p, c->vox_near_alt.p);
+        std::swap(c->vox_near.cap, c->vox_near_alt.cap);
+    }
+    if (c->overlap_update) ++c->overlap_done;
     HIP_TRY(c, reserve_slack(c->vox_near, nvox));
     HIP_TRY(c, launch_vox_near(mv, c->keys_sorted.p, c->vox_occ.p, c->vox_near.p, s));
     mv.vox_near = c->vox_near.p;
     c->mv = mv;
     c->has_map = true;
     ++c->map_gen;
-    // hints / certificates are indices and radii in the OLD map: forget them
+    // hints / certificates are indices and radii in the OLD map: forget them (overlapped update: the
+    // running registration is using them -- the reset queues behind it on the main stream)
+    hipStream_t hs = c->overlap_update ? c->overlap_main : s;
     if (c->hint.p && c->hint.cap)
-        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), s));
+        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), hs));
     if (c->rho.p && c->rho.cap)  // 0 = no certificate (negative values certify "no match")
-        HIP_TRY(c, hipMemsetAsync(c->rho.p, 0, c->rho.cap * sizeof(float), s));
+        HIP_TRY(c, hipMemsetAsync(c->rho.p, 0, c->rho.cap * sizeof(float), hs));
     c->info.n_points = (uint64_t)mv.n;
     c->info.n_cells = (uint64_t)mv.fx * mv.fy * mv.fz;
     c->info.origin[0] = mv.ox;
@@ -697,6 +732,9 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     g.fz = dims[2] * S;
     const size_t ncell = (size_t)g.fx * g.fy * g.fz;
     const size_t total = n_old + m;
+    if (c->overlap_update && (grew || c->use_hash || c->cfg.map_full_rebuild))
+        return VELO_OK;  // (done == 0.  A grown table could be built into the other copy -- tried: both copies
+                         //  then outgrow their allocations in turn, and the replay loses 20 %; refused instead)
     if (c->cfg.map_full_rebuild) {  // A/B switch: same grid, everything recomputed
         *done = 1;
         return rebuild_map(c, old.h, k, org, dims);
@@ -716,6 +754,7 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     HIP_TRY(c, sort_pairs(nullptr, tb, c->nk.p, c->nk_sorted.p, c->nidx.p, c->nidx_sorted.p, m, bits, s));
     if (int rc = ensure_temp(c, tb)) return rc;
     HIP_TRY(c, sort_pairs(c->temp.p, tb, c->nk.p, c->nk_sorted.p, c->nidx.p, c->nidx_sorted.p, m, bits, s));
+    overlap_rotate_alt(c);
     HIP_TRY(c, reserve_slack(c->pts_alt, total));
     HIP_TRY(c, reserve_slack(c->nrm_alt, total));
     HIP_TRY(c, reserve_slack(c->perm_alt, total));
@@ -732,8 +771,13 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
         HIP_TRY(c, hipStreamSynchronize(s));  // the old table may still be read by queued work
         HIP_TRY(c, reserve_slack(c->cell_start, ncell + 8));
         HIP_TRY(c, launch_cell_start(c->keys_alt.p, total, ncell, c->cell_start.p, s));
+    } else if (c->overlap_update && c->overlap_done == 0) {  // the running registration reads cell_start: write the other copy
+        HIP_TRY(c, reserve_slack(c->cell_start_alt, ncell + 8));
+        HIP_TRY(c, launch_table_shift(c->cell_start.p, c->cell_start_alt.p, ncell + 1, c->nk_sorted.p, (uint32_t)m, s));
+        std::swap(c->cell_start.p, c->cell_start_alt.p);
+        std::swap(c->cell_start.cap, c->cell_start_alt.cap);
     } else {
-        HIP_TRY(c, launch_table_shift(c->cell_start.p, ncell + 1, c->nk_sorted.p, (uint32_t)m, s));
+        HIP_TRY(c, launch_table_shift(c->cell_start.p, c->cell_start.p, ncell + 1, c->nk_sorted.p, (uint32_t)m, s));
     }
     std::swap(c->pts.p, c->pts_alt.p);
     std::swap(c->pts.cap, c->pts_alt.cap);
@@ -1603,6 +1647,10 @@ static int map_append_impl(velo_ctx* c, const float* x, const float* y, const fl
         return rc;
     }
     if (done) return VELO_OK;
+    if (c->overlap_update) {  // a re-anchor rewrites what the running registration reads: not here
+        c->raw_n = n_old;
+        return VELO_E_AGAIN;
+    }
     // re-anchor: new origin, full re-sort; the normals of the old points travel with them
     const int k = c->info.k_normals;
     if (k > 0 && !c->cfg.map_full_rebuild) {
@@ -1779,6 +1827,8 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
         std::swap(c->raw_z.p, c->raw_z2.p);
         std::swap(c->raw_z.cap, c->raw_z2.cap);
     };
+    if (c->overlap_update && (anchor || c->cfg.map_full_rebuild || c->use_hash))
+        return VELO_E_AGAIN;  // a rebuild rewrites what the running registration reads: not here (nothing changed yet)
     if (anchor || c->cfg.map_full_rebuild) {
         CarryNormals cr;
         const bool carry = anchor && k > 0 && !c->cfg.map_full_rebuild;
@@ -1800,6 +1850,7 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
         }
         return rc;
     }
+    overlap_rotate_alt(c);
     HIP_TRY(c, reserve_slack(c->pts_alt, kept));
     HIP_TRY(c, reserve_slack(c->nrm_alt, kept));
     HIP_TRY(c, reserve_slack(c->perm_alt, kept));
@@ -1821,8 +1872,13 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     MapView g = old;
     if (c->use_hash) {
         if (int rc = build_table(c, g, c->keys_alt.p, kept, ncell)) return rc;
+    } else if (c->overlap_update && c->overlap_done == 0) {
+        HIP_TRY(c, reserve_slack(c->cell_start_alt, ncell + 8));
+        HIP_TRY(c, launch_table_remap(c->cell_start.p, c->cell_start_alt.p, ncell + 1, c->offs.p, n, kept, s));
+        std::swap(c->cell_start.p, c->cell_start_alt.p);
+        std::swap(c->cell_start.cap, c->cell_start_alt.cap);
     } else {
-        HIP_TRY(c, launch_table_remap(c->cell_start.p, ncell + 1, c->offs.p, n, kept, s));
+        HIP_TRY(c, launch_table_remap(c->cell_start.p, c->cell_start.p, ncell + 1, c->offs.p, n, kept, s));
     }
     swap_raw();
     c->raw_n = kept;
@@ -1848,6 +1904,57 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     HIP_TRY(c, hipStreamSynchronize(s));
     for (int a = 0; a < 3; ++a) c->map_mx[a] = mm.mx[a];
     return txn.done(publish_map(c, g, k, invalid, 1, c->n_done_host));
+}
+
+// evict + append on the SIDE stream while the registration begun with velo_icp_batch_start runs on
+// the main one.  The registration reads pts / nrm / the fine table / vox_near of the map as it was;
+// the updates write other copies of all four (the sorted arrays have a third set for the second
+// update of the call), scratch of their own (the increment got its own flags / offsets), and wait on
+// the device for everything older than the registration.  What cannot be done that way -- a
+// re-anchor, a grown or hashed table -- is refused with VELO_E_AGAIN before anything changed.
+int velo_map_roll_overlapped(velo_ctx* c, const float lo[3], const float hi[3], const float* x, const float* y,
+                             const float* z, size_t n)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "velo_map_roll_overlapped before velo_map_reset");
+    if (!c->res_pending)
+        return c->fail(VELO_E_INVALID, "velo_map_roll_overlapped needs a registration started with velo_icp_batch_start "
+                                       "and not yet finished");
+    if (c->roll_overlapped_done) return c->fail(VELO_E_INVALID, "one overlapped roll per registration");
+    if ((lo == nullptr) != (hi == nullptr)) return c->fail(VELO_E_INVALID, "lo and hi go together");
+    if (n && (!x || !y || !z)) return c->fail(VELO_E_INVALID, "null point array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->side_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    if (!c->ev_side) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_mark, 0));
+    c->roll_overlapped_done = true;
+    hipStream_t main_stream = c->stream;
+    c->stream = c->side_stream;
+    std::swap(c->temp.p, c->dk_temp.p);
+    std::swap(c->temp.cap, c->dk_temp.cap);
+    c->overlap_update = true;
+    c->overlap_done = 0;
+    c->overlap_main = main_stream;
+    int rc = VELO_OK;
+    if (lo) {
+        KeepRegion g{};
+        for (int a = 0; a < 3; ++a) {
+            g.lo[a] = lo[a];
+            g.hi[a] = hi[a];
+        }
+        rc = evict_impl(c, g);
+    }
+    if (rc == VELO_OK && n) rc = map_append_impl(c, x, y, z, n, false);
+    c->overlap_update = false;
+    std::swap(c->temp.p, c->dk_temp.p);
+    std::swap(c->temp.cap, c->dk_temp.cap);
+    c->stream = main_stream;
+    hipError_t e = hipEventRecord(c->ev_side, c->side_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, c->ev_side, 0);
+    if (rc == VELO_E_AGAIN) return c->fail(VELO_E_AGAIN, "this update needs the map rebuilt: not beside a registration");
+    if (rc) return rc;
+    if (e != hipSuccess) return c->fail(VELO_E_DEVICE, "side stream: %s", hipGetErrorString(e));
+    return VELO_OK;
 }
 
 int velo_map_set_margins(velo_ctx* c, const int32_t margin[3])
@@ -2020,6 +2127,7 @@ int velo_icp_batch_start(velo_ctx* c, const double* T0, int iters, float d_max)
     if (!c->ev_mark) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev_mark, c->stream));
     c->mark_valid = true;
+    c->roll_overlapped_done = false;
     if (int rc = run_icp(c, T0, iters, d_max)) return rc;
     if (int rc = enqueue_result_copies(c, c->n_frames)) return rc;
     if (!c->ev_res) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_res, hipEventDisableTiming));
@@ -2555,8 +2663,8 @@ static int enqueue_increment(velo_ctx* c, int frame, const double* d_pose, int m
 {
     hipStream_t s = c->stream;
     const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
-    HIP_TRY(c, c->flags.reserve(n + 1));
-    HIP_TRY(c, c->offs.reserve(n + 1));
+    HIP_TRY(c, c->inc_flags.reserve(n + 1));
+    HIP_TRY(c, c->inc_offs.reserve(n + 1));
 #ifndef VELO_INC_FUSED
 #define VELO_INC_FUSED 1
 #endif
@@ -2564,22 +2672,22 @@ static int enqueue_increment(velo_ctx* c, int frame, const double* d_pose, int m
     if (VELO_INC_FUSED && tiles <= kIncFusedMaxTiles) {
         // a frame: two launches (flags + per-tile counts; bases + scatter) and the count's copy, instead of
         // flags, memset, two scan launches, count copy and scatter; offs doubles as [tile counts | total]
-        HIP_TRY(c, c->offs.reserve(tiles + 1));
+        HIP_TRY(c, c->inc_offs.reserve(tiles + 1));
         HIP_TRY(c, launch_increment_fused(c->ax + q0, c->ay + q0, c->az + q0, (uint32_t)n, c->mv, d_pose, min_count,
-                                          c->flags.p, c->offs.p, tx, ty, tz, c->offs.p + tiles, s));
-        HIP_TRY(c, hipMemcpyAsync(h_total, c->offs.p + tiles, sizeof *h_total, hipMemcpyDeviceToHost, s));
+                                          c->inc_flags.p, c->inc_offs.p, tx, ty, tz, c->inc_offs.p + tiles, s));
+        HIP_TRY(c, hipMemcpyAsync(h_total, c->inc_offs.p + tiles, sizeof *h_total, hipMemcpyDeviceToHost, s));
         return VELO_OK;
     }
     HIP_TRY(c, launch_increment_flags(c->ax + q0, c->ay + q0, c->az + q0, n, c->mv, d_pose, min_count,
-                                      c->flags.p, s));
-    HIP_TRY(c, hipMemsetAsync(c->flags.p + n, 0, sizeof(uint32_t), s));
+                                      c->inc_flags.p, s));
+    HIP_TRY(c, hipMemsetAsync(c->inc_flags.p + n, 0, sizeof(uint32_t), s));
     size_t tb = 0;
-    HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->flags.p, c->offs.p, n + 1, s));
+    HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->inc_flags.p, c->inc_offs.p, n + 1, s));
     if (int rc = ensure_temp(c, tb)) return rc;
-    HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->flags.p, c->offs.p, n + 1, s));
-    HIP_TRY(c, hipMemcpyAsync(h_total, c->offs.p + n, sizeof *h_total, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, launch_increment_scatter(c->ax + q0, c->ay + q0, c->az + q0, n, d_pose, c->flags.p,
-                                        c->offs.p, tx, ty, tz, s));
+    HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->inc_flags.p, c->inc_offs.p, n + 1, s));
+    HIP_TRY(c, hipMemcpyAsync(h_total, c->inc_offs.p + n, sizeof *h_total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, launch_increment_scatter(c->ax + q0, c->ay + q0, c->az + q0, n, d_pose, c->inc_flags.p,
+                                        c->inc_offs.p, tx, ty, tz, s));
     return VELO_OK;
 }
 
@@ -2760,17 +2868,17 @@ int velo_increment_all_registered_async(velo_ctx* c, int min_count, float* dox, 
     const size_t n = (size_t)c->frame_start[c->n_frames];
     const int ni = (int)c->items_h.size();
     if (n) {
-        HIP_TRY(c, c->flags.reserve(n + 1));
-        HIP_TRY(c, c->offs.reserve(n + 1));
+        HIP_TRY(c, c->inc_flags.reserve(n + 1));
+        HIP_TRY(c, c->inc_offs.reserve(n + 1));
         FrameView fv{c->ax, c->ay, c->az, nullptr};
-        HIP_TRY(c, launch_increment_flags_items(c->items.p, ni, fv, c->mv, c->poses.p, min_count, c->flags.p, s));
-        HIP_TRY(c, hipMemsetAsync(c->flags.p + n, 0, sizeof(uint32_t), s));
+        HIP_TRY(c, launch_increment_flags_items(c->items.p, ni, fv, c->mv, c->poses.p, min_count, c->inc_flags.p, s));
+        HIP_TRY(c, hipMemsetAsync(c->inc_flags.p + n, 0, sizeof(uint32_t), s));
         size_t tb = 0;
-        HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->flags.p, c->offs.p, n + 1, s));
+        HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->inc_flags.p, c->inc_offs.p, n + 1, s));
         if (int rc = ensure_temp(c, tb)) return rc;
-        HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->flags.p, c->offs.p, n + 1, s));
-        HIP_TRY(c, hipMemcpyAsync(c->h_inc_total, c->offs.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, launch_increment_scatter_items(c->items.p, ni, fv, c->poses.p, c->flags.p, c->offs.p,
+        HIP_TRY(c, exclusive_scan_u32(c->temp.p, tb, c->inc_flags.p, c->inc_offs.p, n + 1, s));
+        HIP_TRY(c, hipMemcpyAsync(c->h_inc_total, c->inc_offs.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, launch_increment_scatter_items(c->items.p, ni, fv, c->poses.p, c->inc_flags.p, c->inc_offs.p,
                                                   dox, doy, doz, s));
     }
     HIP_TRY(c, hipEventRecord(c->ev_inc, s));

@@ -454,6 +454,65 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
     return true;
 }
 
+bool MapManager::rollAhead(double x, double y, const RegisterOptions& o)
+{
+    if (!ctx_ || !haveDevice_ || dirty_) return false;
+    int i0, i1, j0, j1;
+    tileRange(x, y, i0, i1, j0, j1);
+    if (o.voxel != residentVoxel_ || o.k_normals != residentK_) return false;
+    if (i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_) return true;  // nothing to do
+    if (!(i0 <= res_i1_ && i1 >= res_i0_ && j0 <= res_j1_ && j1 >= res_j0_)) return false;  // a jump: plain rebuild
+    // entering tiles (as rollTo gathers them; the pending increments are not taken here)
+    stage_x_.clear(), stage_y_.clear(), stage_z_.clear();
+    size_t tiles = 0;
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            if (i >= res_i0_ && i <= res_i1_ && j >= res_j0_ && j <= res_j1_) continue;
+            auto it = patches_.find({i, j});
+            if (it == patches_.end() || it->second->size() == 0) continue;
+            const MapPatch& p = *it->second;
+            stage_x_.insert(stage_x_.end(), p.x.begin(), p.x.end());
+            stage_y_.insert(stage_y_.end(), p.y.begin(), p.y.end());
+            stage_z_.insert(stage_z_.end(), p.z.begin(), p.z.end());
+            ++tiles;
+        }
+    const bool evicts = i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_;
+    const float big = 3.0e38f;
+    const float lo[3] = {(float)(i0 * (double)patchRange_ - patchRange_ / 2.0),
+                         (float)(j0 * (double)patchRange_ - patchRange_ / 2.0), -big};
+    const float hi[3] = {std::nextafter((float)(i1 * (double)patchRange_ + patchRange_ / 2.0), -big),
+                         std::nextafter((float)(j1 * (double)patchRange_ + patchRange_ / 2.0), -big), big};
+    velo_map_info mi;
+    mi.struct_size = sizeof mi;
+    velo_map_info_get(ctx_, &mi);
+    const uint64_t n_before = mi.n_points;
+    const int rc = velo_map_roll_overlapped(ctx_, evicts ? lo : nullptr, evicts ? hi : nullptr, stage_x_.data(),
+                                            stage_y_.data(), stage_z_.data(), stage_x_.size());
+    velo_map_info_get(ctx_, &mi);
+    if (rc == VELO_E_AGAIN || rc == VELO_E_INVALID) {
+        // refused: what the device holds no longer matches a tile rectangle for sure (an eviction may
+        // have gone through) -- the plain roll rebuilds from the tiles
+        if (mi.n_points != n_before) dirty_ = true;
+        ++stats_.rolls_refused;
+        return false;
+    }
+    if (rc) {
+        err_ = velo_last_error(ctx_);
+        dirty_ = true;
+        return false;
+    }
+    stats_.points_evicted += n_before + stage_x_.size() - mi.n_points;
+    stats_.points_uploaded += stage_x_.size();
+    stats_.tiles_entered += tiles;
+    stats_.tiles_left += (uint64_t)std::max(0, (res_i1_ - res_i0_ + 1) * (res_j1_ - res_j0_ + 1) -
+                                                   (std::min(i1, res_i1_) - std::max(i0, res_i0_) + 1) *
+                                                       (std::min(j1, res_j1_) - std::max(j0, res_j0_) + 1));
+    ++stats_.rolls;
+    ++stats_.rolls_ahead;
+    res_i0_ = i0, res_i1_ = i1, res_j0_ = j0, res_j1_ = j1;
+    return true;
+}
+
 bool MapManager::takeIncrements()
 {
     size_t n = 0;

@@ -660,10 +660,13 @@ __global__ __launch_bounds__(256) void k_merge_new(
 // 18-step binary search per four entries over the whole table: 418 us on a 78 M-entry table, against
 // the ~130 us its 2 x 311 MB take to stream.)
 constexpr int kTableTile = 1024;  // entries per workgroup step: 256 threads x 4
-__global__ __launch_bounds__(256) void k_table_shift(int32_t* __restrict__ cell_start,
+// (src == dst: in place; src != dst: the shifted table is written to dst and src stays as it was --
+// a registration still running on the other stream keeps reading src)
+__global__ __launch_bounds__(256) void k_table_shift(const int32_t* src, int32_t* dst,
                                                      size_t n_entries,
                                                      const uint32_t* __restrict__ nk, uint32_t m)
 {
+    const bool oop = src != dst;
     __shared__ uint32_t s_j[2];
     const size_t n_tiles = (n_entries + kTableTile - 1) / kTableTile;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -673,9 +676,15 @@ __global__ __launch_bounds__(256) void k_table_shift(int32_t* __restrict__ cell_
         __syncthreads();
         const uint32_t jlo = s_j[0], jhi = s_j[1];
         __syncthreads();
-        if (jhi == 0) continue;  // every entry of the tile lies at or below the first new key
         const size_t c0 = t0 + (size_t)threadIdx.x * 4;
         if (c0 >= t1) continue;
+        if (jhi == 0) {  // every entry of the tile lies at or below the first new key: unchanged
+            if (oop) {
+                if (c0 + 3 < t1) *reinterpret_cast<int4*>(dst + c0) = *reinterpret_cast<const int4*>(src + c0);
+                else for (size_t c = c0; c < t1; ++c) dst[c] = src[c];
+            }
+            continue;
+        }
         uint32_t j = jlo;
         if (jhi != jlo) {  // new keys inside the tile: this quad's own count, searched in [jlo, jhi)
             uint32_t lo = jlo, hi = jhi;
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(256) void k_table_shift(int32_t* __restrict__ cell_
             j = lo;
         }
         if (c0 + 3 < t1) {
-            int4 v = *reinterpret_cast<int4*>(cell_start + c0);  // rows are 16-byte aligned
+            int4 v = *reinterpret_cast<const int4*>(src + c0);  // rows are 16-byte aligned
             v.x += (int)j;
             while (j < jhi && (size_t)nk[j] < c0 + 1) ++j;
             v.y += (int)j;
@@ -694,11 +703,11 @@ __global__ __launch_bounds__(256) void k_table_shift(int32_t* __restrict__ cell_
             v.z += (int)j;
             while (j < jhi && (size_t)nk[j] < c0 + 3) ++j;
             v.w += (int)j;
-            *reinterpret_cast<int4*>(cell_start + c0) = v;
+            *reinterpret_cast<int4*>(dst + c0) = v;
         } else {
             for (size_t c = c0; c < t1; ++c) {
                 while (j < jhi && (size_t)nk[j] < c) ++j;
-                cell_start[c] += (int)j;
+                dst[c] = src[c] + (int)j;
             }
         }
     }
@@ -877,17 +886,18 @@ __global__ __launch_bounds__(256) void k_compact_raw(const float* __restrict__ x
 // removes points in a few per cent of the table's key range; everywhere else "removed before this
 // position" is one number for a whole 1 024-entry tile (positions ascend with c), so the tile
 // streams (v - removed) instead of gathering offs[v] per entry.
-__global__ __launch_bounds__(256) void k_table_remap(int32_t* __restrict__ cell_start,
+__global__ __launch_bounds__(256) void k_table_remap(const int32_t* src, int32_t* dst,
                                                      size_t n_entries,
                                                      const uint32_t* __restrict__ offs, uint32_t n,
                                                      uint32_t kept)
 {
+    const bool oop = src != dst;  // (as k_table_shift)
     __shared__ uint32_t s_r[2];
     const size_t n_tiles = (n_entries + kTableTile - 1) / kTableTile;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t t0 = tile * kTableTile, t1 = min(t0 + (size_t)kTableTile, n_entries);
         if (threadIdx.x < 2) {
-            const uint32_t v = (uint32_t)cell_start[threadIdx.x ? t1 - 1 : t0];
+            const uint32_t v = (uint32_t)src[threadIdx.x ? t1 - 1 : t0];
             s_r[threadIdx.x] = v < n ? v - offs[v] : n - kept;  // points removed before position v
         }
         __syncthreads();
@@ -896,18 +906,18 @@ __global__ __launch_bounds__(256) void k_table_remap(int32_t* __restrict__ cell_
         const size_t c0 = t0 + (size_t)threadIdx.x * 4;
         if (c0 >= t1) continue;
         if (r0 == r1) {
-            if (r0 == 0) continue;  // nothing removed below this tile: entries unchanged
+            if (r0 == 0 && !oop) continue;  // nothing removed below this tile: entries unchanged
             if (c0 + 3 < t1) {
-                int4 v = *reinterpret_cast<int4*>(cell_start + c0);
+                int4 v = *reinterpret_cast<const int4*>(src + c0);
                 v.x -= (int)r0, v.y -= (int)r0, v.z -= (int)r0, v.w -= (int)r0;
-                *reinterpret_cast<int4*>(cell_start + c0) = v;
+                *reinterpret_cast<int4*>(dst + c0) = v;
             } else {
-                for (size_t c = c0; c < t1; ++c) cell_start[c] -= (int)r0;
+                for (size_t c = c0; c < t1; ++c) dst[c] = src[c] - (int)r0;
             }
         } else {
             for (size_t c = c0; c < min(c0 + 4, t1); ++c) {
-                const uint32_t v = (uint32_t)cell_start[c];
-                cell_start[c] = (int32_t)(v < n ? offs[v] : kept);
+                const uint32_t v = (uint32_t)src[c];
+                dst[c] = (int32_t)(v < n ? offs[v] : kept);
             }
         }
     }
@@ -952,11 +962,11 @@ hipError_t launch_merge(const float4* pts, const float4* nrm, const uint32_t* pe
     return hipGetLastError();
 }
 
-hipError_t launch_table_shift(int32_t* cell_start, size_t n_entries, const uint32_t* nk, uint32_t m,
+hipError_t launch_table_shift(const int32_t* src, int32_t* dst, size_t n_entries, const uint32_t* nk, uint32_t m,
                               hipStream_t s)
 {
     hipLaunchKernelGGL(k_table_shift, dim3(grid_for((n_entries + kTableTile - 1) / kTableTile, 1, 16384)), dim3(256), 0,
-                       s, cell_start, n_entries, nk, m);
+                       s, src, dst, n_entries, nk, m);
     return hipGetLastError();
 }
 
@@ -1064,11 +1074,11 @@ hipError_t launch_compact_raw(const float* x, const float* y, const float* z, ui
     return hipGetLastError();
 }
 
-hipError_t launch_table_remap(int32_t* cell_start, size_t n_entries, const uint32_t* offs, uint32_t n,
+hipError_t launch_table_remap(const int32_t* src, int32_t* dst, size_t n_entries, const uint32_t* offs, uint32_t n,
                               uint32_t kept, hipStream_t s)
 {
     hipLaunchKernelGGL(k_table_remap, dim3(grid_for((n_entries + kTableTile - 1) / kTableTile, 1, 16384)), dim3(256), 0, s,
-                       cell_start, n_entries, offs, n, kept);
+                       src, dst, n_entries, offs, n, kept);
     return hipGetLastError();
 }
 
