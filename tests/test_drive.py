@@ -237,3 +237,19 @@ def test_cpp_stream_driver_rolls_the_device_map_and_matches_python(tmp_path):
     assert rec["map"]["points_evicted"] == cpp["map"]["points_evicted"]
     assert rec["map_points_mean"] == cpp["map_points"]            # the two hosts left the same map behind
     assert abs(rec["worst_pose_error_m"] - cpp["worst_pose_error_m"]) < 1e-9
+    # the pipelining changes WHEN things run, not what comes out: with the next frame decoded on the
+    # second stream but the map rolled when due, the drive replays exactly as with nothing overlapped
+    # (same poses to the last digit printed, same map); rolling ahead as well only defers the pending
+    # increments past the roll (they join at the next flush), which moves the poses by micrometres
+    runs = {}
+    for flags in (["--no-roll-ahead"], ["--no-overlap"]):
+        o = subprocess.run([exe, str(tmp_path), "--steps", "12", "--warmup", "1", "--threshold", "64"] + flags,
+                           capture_output=True, text=True, timeout=600)
+        assert o.returncode == 0, o.stderr[-2000:]
+        runs[flags[0]] = json.loads(o.stdout.strip().splitlines()[-1])
+    a, b = runs["--no-roll-ahead"], runs["--no-overlap"]
+    assert a["worst_pose_error_m"] == b["worst_pose_error_m"] and a["map_points"] == b["map_points"]
+    assert a["map"]["points_evicted"] == b["map"]["points_evicted"] and a["map"]["rolls"] == b["map"]["rolls"]
+    assert a["decode_planned_ahead"] and not b["decode_planned_ahead"] and a["map"]["rolls_ahead"] == 0
+    assert cpp["roll_ahead"] and cpp["map"]["rolls_ahead"] + cpp["map"]["rolls_refused"] >= 1
+    assert abs(cpp["worst_pose_error_m"] - b["worst_pose_error_m"]) < 1e-4 and cpp["map"]["rolls"] == b["map"]["rolls"]
