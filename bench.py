@@ -107,7 +107,10 @@ def parse():
                          "when it changes (host tiles); radius = round 2's loop: every --evict-every frames evict "
                          "beyond ROI_RANGE of the pose and append the world points that came within range (device-resident world)")
     ap.add_argument("--stream-frames", type=int, default=64, help="distinct synthetic frames (played forwards and backwards)")
-    ap.add_argument("--stream-steps", type=int, default=100, help="stream sub-record: timed frames")
+    ap.add_argument("--stream-steps", type=int, default=256, help="stream sub-record: timed frames")
+    ap.add_argument("--stream-warmup", type=int, default=128,
+                    help="stream sub-record: untimed frames first (128 = once forwards and backwards through the "
+                         "64-frame drive: every buffer has seen its largest size)")
     ap.add_argument("--stream-map-points", type=int, default=12_000_000,
                     help="points of the whole scene the rolling map is cut from")
     ap.add_argument("--stream-subdiv", type=int, default=0)
@@ -1415,7 +1418,7 @@ def main():
                 trace("stream ...")
                 src = d["stream_src"] if rank == 0 and F >= 24 else None
                 if args.stream_policy == "tiles":
-                    out["stream"] = run_replay(args, dev, local, args.stream_steps, 10,
+                    out["stream"] = run_replay(args, dev, local, args.stream_steps, args.stream_warmup,
                                                d=synthetic_drive(args, dev, src))
                 else:
                     out["stream"] = run_stream(args, dev, local, args.stream_steps, 10,
