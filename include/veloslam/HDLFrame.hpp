@@ -62,6 +62,16 @@ struct HDLFrame {
     // fileStartPos, skips, isOnHardDrive, then the car pose record (type_defs.cxx:4-33).  ptime ->
     // int64 microseconds; fileStartPos keeps glibc's 16-byte fpos_t (offset + a zero shift state):
     // 132 bytes per frame.
+    // the debug dumps (HDLFrame.cxx:36-125): `<dir>/<stamp>-points.txt` (x, y, z, intensity per line,
+    // 9 significant digits, beams back to back), `-pointsMeta.txt` (azimuth, distance, three flags),
+    // `-others.txt` (car pose, memory / disk state, file position, skips); and one beam (or, beamId
+    // outside 0..63, all but the last -- the reference's range) as an ASCII .pcd with the fields
+    // x y z intensity, the way pcl::io::savePCDFileASCII lays a PointXYZI cloud out.  <stamp> is
+    // boost's to_iso_string of the time stamp (YYYYMMDDTHHMMSS[.ffffff]).  dumpToImage (OpenCV) is
+    // not carried over.
+    bool dumpToFiles(const std::string& dirname) const;
+    bool dumpToPCD(const std::string& dirname, int beamId = -1) const;
+    static std::string isoString(int64_t t_us);
     static constexpr size_t kMetaBytes = 132;
     bool writeMeta(std::ostream& os) const;
     bool readMeta(std::istream& is);

@@ -154,6 +154,21 @@ static int hdl_store_mode()
         std::printf("\nmeta_missing %d %d\n", (int)b.loadHDLMeta(d + "/none.hdlmeta"), (int)b.loadINSMeta(d + "/none.insmeta"));
         std::printf("meta_unbound %d\n", (int)(bool)b.getRecentFrame());   // a stub of a capture that is not loaded
     }
+    // debug dumps (HDLFrame.cxx:36-125)
+    {
+        const char* tmp = std::getenv("VELO_TMP");
+        const std::string d = tmp ? tmp : "/tmp";
+        HDLFrame f;
+        f.timestamp = 1467590400123456LL + 8LL * 3600 * 1000000;   // 2016-07-04 08:00:00.123456 on the +8 h clock
+        const int32_t bs[4] = {0, 2, 2, 5};
+        const float px[5] = {1.5f, -2.25f, 3.f, 4.f, 5.f}, pi[5] = {10, 20, 30, 40, 50};
+        f.setPoints(px, px, px, pi, nullptr, bs, 3);
+        f.pointsMeta.resize(5);
+        f.pointsMeta[1].azimuth = 35999, f.pointsMeta[1].distance = 12.5f;
+        const bool ok = f.dumpToFiles(d) && f.dumpToPCD(d, 2) && f.dumpToPCD(d, -1);
+        std::printf("dump %d %s %s %s\n", (int)ok, HDLFrame::isoString(f.timestamp).c_str(), HDLFrame::isoString(0).c_str(),
+                    HDLFrame::isoString(951782400000000LL).c_str());   // 2000-02-29
+    }
     // waitForFrame: times out without data, returns the newest frame once a producer adds one
     HDLManager h3(nullptr, 8);
     const bool none = !(bool)h3.waitForFrame(std::chrono::microseconds(2000));

@@ -135,6 +135,18 @@ def test_hdlmanager_frame_store_semantics(tmp_path):
     assert int.from_bytes(raw[132 + 16:132 + 24], "little") == 24 + 1264 * 300 and raw[132 + 24:132 + 32] == bytes(8)
     assert raw[132 + 32] == 3 and raw[132 + 33] == 1
     assert os.path.getsize(os.path.join(str(tmp_path), "s.insmeta")) == 3 * 98
+    # the debug dumps (HDLFrame.cxx:36-125): names carry boost's to_iso_string of the stamp
+    assert lines["dump"] == "1 20160704T080000.123456 19700101T000000 20000229T000000"
+    d = str(tmp_path)
+    pts = open(os.path.join(d, "20160704T080000.123456-points.txt")).read().split("\n")
+    assert pts[0].split("\t") == ["1.5", "1.5", "1.5", "10"] and len(pts) == 6
+    meta = open(os.path.join(d, "20160704T080000.123456-pointsMeta.txt")).read().split("\n")
+    assert meta[1] == "35999\t12.5\t0\t0\t0"
+    pcd = open(os.path.join(d, "20160704T080000.123456-2.pcd")).read().split("\n")
+    assert pcd[2] == "FIELDS x y z intensity" and pcd[6] == "WIDTH 3" and pcd[9] == "POINTS 3" and pcd[10] == "DATA ascii"
+    assert pcd[11] == "3 3 3 30" and pcd[13] == "5 5 5 50"
+    allb = open(os.path.join(d, "20160704T080000.123456--1.pcd")).read().split("\n")
+    assert allb[6] == "WIDTH 5"           # (3 beams here: "all" = beams 0..62 of however many there are)
 
 
 @pytest.mark.gpu

@@ -3,6 +3,7 @@
 // plumbing: no arithmetic beyond tile indexing lives here.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include "../../../include/veloslam/MapManager.hpp"
@@ -121,6 +122,88 @@ bool HDLFrame::readMeta(std::istream& is)
     isOnHardDrive = flags[1] != 0;
     *carpose = car;
     return true;
+}
+
+std::string HDLFrame::isoString(int64_t t_us)
+{
+    if (t_us == VELO_TIME_INVALID) return "not-a-date-time";
+    int64_t sec = t_us / 1000000, frac = t_us % 1000000;
+    if (frac < 0) {
+        frac += 1000000;
+        --sec;
+    }
+    int64_t days = sec / 86400, rem = sec % 86400;
+    if (rem < 0) {
+        rem += 86400;
+        --days;
+    }
+    // civil date from days since 1970-01-01 (proleptic Gregorian)
+    const int64_t z = days + 719468, era = (z >= 0 ? z : z - 146096) / 146097;
+    const int64_t doe = z - era * 146097, yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100), mp = (5 * doy + 2) / 153;
+    const int d = (int)(doy - (153 * mp + 2) / 5 + 1), m = (int)(mp < 10 ? mp + 3 : mp - 9);
+    const long long y = (long long)(yoe + era * 400 + (m <= 2 ? 1 : 0));
+    char buf[64];
+    if (frac)
+        std::snprintf(buf, sizeof buf, "%04lld%02d%02dT%02d%02d%02d.%06d", y, m, d, (int)(rem / 3600), (int)(rem / 60 % 60),
+                      (int)(rem % 60), (int)frac);
+    else
+        std::snprintf(buf, sizeof buf, "%04lld%02d%02dT%02d%02d%02d", y, m, d, (int)(rem / 3600), (int)(rem / 60 % 60),
+                      (int)(rem % 60));
+    return buf;
+}
+
+bool HDLFrame::dumpToFiles(const std::string& dirname) const
+{
+    const std::string base = dirname + "/" + isoString(timestamp);
+    {
+        std::ofstream ofs(base + "-points.txt");
+        if (!ofs) return false;
+        ofs.precision(9);
+        for (size_t i = 0; i < x.size(); ++i)
+            ofs << x[i] << '\t' << y[i] << '\t' << z[i] << '\t' << (i < intensity.size() ? intensity[i] : 0.0f) << '\n';
+    }
+    {
+        std::ofstream ofs(base + "-pointsMeta.txt");
+        if (!ofs) return false;
+        for (const PointMeta& m : pointsMeta)
+            ofs << m.azimuth << '\t' << m.distance << '\t' << (int)m.intensityFlag << '\t' << (int)m.distanceFlag << '\t'
+                << (int)m.flags << '\n';
+    }
+    std::ofstream ofs(base + "-others.txt");
+    if (!ofs) return false;
+    ofs.precision(17);
+    if (carpose) {
+        ofs << "T " << carpose->T[0] << ' ' << carpose->T[1] << ' ' << carpose->T[2] << "\nR " << carpose->R[0] << ' '
+            << carpose->R[1] << ' ' << carpose->R[2] << "\nV " << carpose->V[0] << ' ' << carpose->V[1] << ' '
+            << carpose->V[2] << "\nt " << isoString(carpose->timestamp) << '\n';
+    }
+    ofs << '\n' << isInMemory << '\t' << isOnHardDrive << '\t' << (int)count.load() << '\n' << isoString(filenameTime) << '\n'
+        << (long long)fileStartPos << '\n' << (int)skips << std::endl;
+    return (bool)ofs;
+}
+
+bool HDLFrame::dumpToPCD(const std::string& dirname, int beamId) const
+{
+    if (numBeams() == 0) return false;
+    int startBeam, endBeam;
+    if (beamId < 0 || beamId > 63) {  // HDLFrame.cxx:110-116: "all" stops one beam short there too
+        startBeam = 0;
+        endBeam = 63;
+    } else {
+        startBeam = beamId;
+        endBeam = beamId + 1;
+    }
+    const CloudView c = getPointsAsOneCloud(startBeam, endBeam);
+    std::ofstream ofs(dirname + "/" + isoString(timestamp) + "-" + std::to_string(beamId) + ".pcd");
+    if (!ofs) return false;
+    ofs << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\n"
+           "COUNT 1 1 1 1\nWIDTH "
+        << c.size << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << c.size << "\nDATA ascii\n";
+    ofs.precision(8);  // (pcl writes floats with 8 significant digits)
+    for (size_t i = 0; i < c.size; ++i)
+        ofs << c.x[i] << ' ' << c.y[i] << ' ' << c.z[i] << ' ' << (c.intensity ? c.intensity[i] : 0.0f) << '\n';
+    return (bool)ofs;
 }
 
 void intrusive_ptr_add_ref(HDLFrame* p) { ++p->count; }
