@@ -860,6 +860,18 @@ def test_icp_start_finish_with_the_next_frame_decoded_in_between(oracle):
             out.append([x.tolist() for x in inc])
             with pytest.raises(capi.VeloError):
                 c.decode_submit_overlapped(plan)       # no registration in flight
+            if overlapped:
+                # packets without a complete revolution: refused (VELO_E_NODATA), and the ctx is still usable
+                c.icp_batch_start(np.tile(T_id, (c.n_frames, 1)), 2, 1.0)
+                c.decode_plan_fill(plan, buf[:40 * 1206], tt[:40], calib, poses, n, flush=False)
+                with pytest.raises(capi.VeloError):
+                    c.decode_submit_overlapped(plan)
+                c.icp_batch_finish()
+                a, b, fl = cuts[0]
+                c.decode_plan_fill(plan, buf[a * 1206:b * 1206], tt[a:b], calib, poses, n, flush=fl)
+                c.decode_submit(plan)
+                c.decode_to_frames()
+                assert c.icp_batch(np.tile(T_id, (c.n_frames, 1)), 2, 1.0)[0].iters == 2
             c.decode_plan_destroy(plan)
             return out
         finally:
@@ -1338,6 +1350,9 @@ def test_map_rolled_beside_a_registration_equals_the_plain_roll():
             # A: beside a registration; B: registration, then the plain calls
             A.icp_batch_start(T0, 8, 1.0)
             assert A.map_roll_overlapped(lo, hi, wx[entering], wy[entering], wz[entering])
+            if step == 0:
+                with pytest.raises(capi.VeloError):                            # one overlapped roll per registration
+                    A.map_roll_overlapped(None, None, wx[:3], wy[:3], wz[:3])
             ra = A.icp_batch_finish()[0]
             rb = B.icp_batch(T0, 8, 1.0)[0]
             B.map_evict_outside(lo, hi)
