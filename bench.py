@@ -1405,24 +1405,30 @@ def main():
                                               "F%d_M%d" % (F, args.map_points), cbar)
         trace("roofline done")
         if single and not exchange:
-            if want(args, "incl_h2d"):
-                trace("incl_h2d ...")
-                out["incl_h2d"] = incl_h2d_record(args, d, dev, ctx, max(args.steps, 4))
-            if want(args, "single_frame"):
-                trace("single_frame ...")
-                out["single_frame"] = single_frame_record(args, d, local)
-            if want(args, "dense"):
-                trace("dense ...")
-                out["dense"] = dense_record(args, d, dev, local)
-            if want(args, "stream"):
-                trace("stream ...")
-                src = d["stream_src"] if rank == 0 and F >= 24 else None
-                if args.stream_policy == "tiles":
-                    out["stream"] = run_replay(args, dev, local, args.stream_steps, args.stream_warmup,
-                                               d=synthetic_drive(args, dev, src))
-                else:
-                    out["stream"] = run_stream(args, dev, local, args.stream_steps, 10,
-                                               args.stream_map_points, args.stream_frames, src=src)
+            # the sub-records ride on the headline line: one of them failing must not take the line with
+            # it (it is reported in its place, loudly, and the exit code says so)
+            def sub(name, fn):
+                nonlocal rc
+                if not want(args, name):
+                    return
+                trace(name + " ...")
+                try:
+                    out[name] = fn()
+                except (Exception, SystemExit) as e:  # noqa: BLE001
+                    out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    sys.stderr.write("bench: sub-record %s failed: %r\n" % (name, e))
+                    rc = rc or 3
+
+            sub("incl_h2d", lambda: incl_h2d_record(args, d, dev, ctx, max(args.steps, 4)))
+            sub("single_frame", lambda: single_frame_record(args, d, local))
+            sub("dense", lambda: dense_record(args, d, dev, local))
+            src = d["stream_src"] if rank == 0 and F >= 24 else None
+            if args.stream_policy == "tiles":
+                sub("stream", lambda: run_replay(args, dev, local, args.stream_steps, args.stream_warmup,
+                                                 d=synthetic_drive(args, dev, src)))
+            else:
+                sub("stream", lambda: run_stream(args, dev, local, args.stream_steps, 10,
+                                                 args.stream_map_points, args.stream_frames, src=src))
         emit(out)
         if rc:
             sys.stderr.write("bench: GPU pose differs from the CPU path beyond the north-star tolerance: %r\n"
