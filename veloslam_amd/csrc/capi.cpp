@@ -1487,6 +1487,7 @@ void velo_destroy(velo_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);  // (pinned buffers below may still be its sources)
     (void)velo_comm_destroy(c);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     for (int b = 0; b < 2; ++b) {
