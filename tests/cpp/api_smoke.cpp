@@ -6,11 +6,13 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <vector>
 #include <thread>
 #include <veloslam/HDLFrame.hpp>
 #include <veloslam/HDLManager.hpp>
 #include <veloslam/MapManager.hpp>
+#include <veloslam/PacketFile.hpp>
 #include <veloslam/TransformManager.hpp>
 
 template <typename T>
@@ -257,9 +259,75 @@ static int hdl_mode(const std::string& dir, const std::string& out)
     return 0;
 }
 
+// PacketFileWriter / PacketFileReader (the reference's vtkPacketFileWriter / vtkPacketFileReader):
+// a capture written packet by packet -- lidar and position packets mixed, a length the writer must
+// refuse -- read back record by record, re-read from a remembered position, and held to the bulk
+// C functions
+static int pcapfile_mode(const std::string& dir)
+{
+    using namespace veloslam;
+    const std::string path = dir + "/w.pcap";
+    std::vector<unsigned char> lidar(1206), pos(512), odd(100);
+    for (size_t i = 0; i < lidar.size(); ++i) lidar[i] = (unsigned char)(i * 7);
+    for (size_t i = 0; i < pos.size(); ++i) pos[i] = (unsigned char)(255 - i);
+    PacketFileWriter w;
+    if (w.writePacket(lidar.data(), 1206, 5)) return 3;            // not open
+    if (!w.open(path)) return 3;
+    const int64_t t0 = 1467590400000000LL;
+    bool ok = w.writePacket(lidar.data(), 1206, t0);
+    lidar[0] = 1;
+    ok = ok && w.writePacket(lidar.data(), 1206, t0 + 553);
+    ok = ok && w.writePacket(pos.data(), 512, t0 + 600);
+    const bool refused = !w.writePacket(odd.data(), 100, t0 + 700);
+    lidar[0] = 2;
+    ok = ok && w.writePacket(lidar.data(), 1206, t0 + 1106);
+    w.close();
+    std::printf("written %d refused %d open %d\n", (int)ok, (int)refused, (int)w.isOpen());
+    PacketFileReader r;
+    if (!r.open(path) || !r.open(path)) return 4;                  // a second open of the same file is a no-op
+    const unsigned char* d = nullptr;
+    unsigned int n = 0;
+    int64_t t = 0, posn[8];
+    int k = 0;
+    std::printf("records");
+    for (;;) {
+        r.getFilePosition(&posn[k]);
+        if (!r.nextPacket(d, n, t)) break;
+        std::printf(" %u@%lld:%u/%lld", n, (long long)posn[k], (unsigned)d[0], (long long)(t - t0));
+        ++k;
+    }
+    std::printf("\nclosed %d\n", (int)!r.isOpen());                // the end of the file closes the reader
+    if (!r.open(path)) return 4;
+    r.setFilePosition(&posn[2]);                                   // the position packet again, then the last lidar packet
+    r.nextPacket(d, n, t);
+    const unsigned n2 = n;
+    r.nextPacket(d, n, t);
+    std::printf("reread %u %u:%u\n", n2, n, (unsigned)d[0]);
+    // the bulk reader sees the three lidar packets; the bulk writer writes byte for byte the same file
+    size_t cnt = 0;
+    std::vector<uint8_t> pk(4 * 1206);
+    std::vector<int64_t> ts(4);
+    if (velo_pcap_read(path.c_str(), pk.data(), ts.data(), 4, &cnt)) return 5;
+    std::printf("bulk %zu %u %u %u %lld\n", cnt, (unsigned)pk[0], (unsigned)pk[1206], (unsigned)pk[2412], (long long)(ts[2] - t0));
+    const std::string p2 = dir + "/w2.pcap", p3 = dir + "/w3.pcap";
+    if (velo_pcap_write(p2.c_str(), pk.data(), ts.data(), 3)) return 5;
+    PacketFileWriter w3;
+    if (!w3.open(p3)) return 5;
+    for (int i = 0; i < 3; ++i) w3.writePacket(pk.data() + (size_t)i * 1206, 1206, ts[(size_t)i]);
+    w3.close();
+    std::ifstream a(p2, std::ios::binary), b(p3, std::ios::binary);
+    const std::string sa((std::istreambuf_iterator<char>(a)), std::istreambuf_iterator<char>()),
+        sb((std::istreambuf_iterator<char>(b)), std::istreambuf_iterator<char>());
+    std::printf("same_bytes %d %zu\n", (int)(sa == sb), sa.size());
+    PacketFileReader bad;
+    std::printf("missing %d %d\n", (int)bad.open(dir + "/none.pcap"), (int)!bad.getLastError().empty());
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
+    if (std::string(argv[1]) == "--pcapfile") return argc < 3 ? 2 : pcapfile_mode(argv[2]);
     if (std::string(argv[1]) == "--hdl-store") return hdl_store_mode();
     if (std::string(argv[1]) == "--hdl") return argc < 4 ? 2 : hdl_mode(argv[2], argv[3]);
     if (std::string(argv[1]) == "--tiles") return argc < 3 ? 2 : tiles_mode(argv[2]);

@@ -105,6 +105,31 @@ def test_export_and_load_a_small_drive(tmp_path):
     assert np.allclose(d["calib"][:, :5], np.asarray(cal)[:, :5], rtol=0, atol=1e-12)
 
 
+def test_packet_file_reader_and_writer_classes(tmp_path):
+    """veloslam::PacketFileWriter / PacketFileReader -- the reference's vtkPacketFileWriter /
+    vtkPacketFileReader without libpcap (vtkPacketFileWriter.cxx:118-161, vtkPacketFileReader.h:166-197):
+    lidar (1206) and position (512) packets get their 42-byte prefixes, any other length is refused;
+    the reader returns every UDP payload with its record time, closes itself at the end, re-reads
+    from a remembered position; the bulk C functions see the same capture, and the class writes
+    byte for byte what velo_pcap_write writes."""
+    exe = build_exe()
+    out = subprocess.run([exe, "--pcapfile", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    assert lines["written"] == "1 refused 1 open 0"
+    # size @ file position : first payload byte / microseconds after the first record
+    assert lines["records"] == "1206@24:0/0 1206@1288:1/553 512@2552:255/600 1206@3122:2/1106"
+    assert lines["closed"] == "1" and lines["reread"] == "512 1206:2"
+    assert lines["bulk"] == "3 0 1 2 1106"
+    assert lines["same_bytes"] == "1 %d" % (24 + 3 * 1264) and lines["missing"] == "0 1"
+    raw = open(os.path.join(str(tmp_path), "w.pcap"), "rb").read()
+    assert len(raw) == 24 + 3 * 1264 + (16 + 42 + 512)
+    pos_rec = raw[24 + 2 * 1264:24 + 2 * 1264 + 16 + 42]
+    assert pos_rec[8:12] == (554).to_bytes(4, "little")                       # caplen of a position packet
+    assert pos_rec[16 + 34:16 + 38] == bytes([0x20, 0x74, 0x20, 0x74])        # ports 8308 -> 8308
+    assert pos_rec[16 + 38:16 + 40] == bytes([0x02, 0x08])                    # UDP length 520
+
+
 def test_hdlmanager_frame_store_semantics(tmp_path):
     """veloslam::HDLManager as the store a consumer pulls from (HDLManager.cxx:226-260 over
     TimeLine.h): sorted by stamp whatever the arrival order, exact / nearest lookups (a tie goes to
