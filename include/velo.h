@@ -22,6 +22,22 @@
  * Entry points whose name ends in _dev take DEVICE pointers (already resident in
  * HBM, e.g. torch tensors); the others take host pointers and stage them.
  * There is no CPU fallback anywhere: without a GPU velo_create fails.
+ *
+ * STREAM CONTRACT of the _dev entry points (and of every call that is handed a
+ * device pointer: velo_frames_adopt_dev, velo_increment_*_async, velo_exchange_*).
+ * The ctx enqueues its work on its OWN stream, created hipStreamNonBlocking: it does
+ * NOT synchronise with the NULL stream or with any stream of the caller.  Therefore
+ *   (1) whatever PRODUCED the buffers passed in (a fill, a copy, a kernel on the
+ *       caller's stream -- e.g. torch.full / tensor.cuda() on torch's stream) must
+ *       have COMPLETED, or be ordered before the ctx stream, when the call is made:
+ *       synchronise the producing stream first (hipStreamSynchronize /
+ *       torch.cuda.synchronize()), or make both sides one stream with
+ *       velo_set_stream(ctx, producer_stream);
+ *   (2) results written into caller buffers are complete after velo_synchronize(ctx)
+ *       (or for work enqueued later on the ctx stream); a consumer on another stream
+ *       must wait for that, the ctx does not signal foreign streams;
+ *   (3) the buffers must stay allocated and unmodified until then.
+ * Host-pointer entry points have no such requirement: they stage and order themselves.
  */
 #ifndef VELO_H
 #define VELO_H

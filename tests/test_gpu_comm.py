@@ -20,6 +20,7 @@ def test_exchange_requires_a_communicator():
     try:
         assert c.comm_info() == (0, 0)
         buf = torch.zeros((3, 8), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         with pytest.raises(capi.VeloError):
             c.exchange_increments(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), 4,
                                   buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), 8)
@@ -96,6 +97,8 @@ def test_rank_order_pack_matches_numpy_for_any_world(world):
             d_recv = torch.from_numpy(recv).cuda()
             cap = total + 7
             out = torch.full((3, cap), -7.0, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()    # velo.h stream contract: the fill / upload ran on torch's stream, the pack
+                                        # runs on the ctx's own non-blocking stream (round 3's red driver run)
             got = c.exchange_pack_dev(d_recv.data_ptr(), counts, pad_used, out[0].data_ptr(), out[1].data_ptr(),
                                       out[2].data_ptr(), cap)
             c.synchronize()
@@ -113,6 +116,7 @@ def test_rank_order_pack_refuses_bad_plans():
         buf = torch.zeros(3 * 4 * 16, dtype=torch.float32, device="cuda")
         out = torch.zeros((3, 64), dtype=torch.float32, device="cuda")
         args = (out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+        torch.cuda.synchronize()                            # producers on torch's stream done (velo.h stream contract)
         with pytest.raises(capi.VeloError) as e:            # capacity
             c.exchange_pack_dev(buf.data_ptr(), [16, 16, 16, 16], 16, *args, 63)
         assert e.value.code == -5

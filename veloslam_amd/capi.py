@@ -22,6 +22,25 @@ KERNEL_AUTO, KERNEL_THROUGHPUT, KERNEL_LATENCY = 0, 1, 2  # velo_cfg.force_kerne
 VELO_TIME_INVALID = -(2 ** 63)
 
 
+# include/velo.h, "STREAM CONTRACT": a ctx runs on its own non-blocking stream, so whatever produced a device
+# buffer handed to a *_dev / *_async / exchange call must have completed before the call.  A caller that makes
+# its buffers with torch can install a hook here (tests/conftest.py does: torch.cuda.current_stream().synchronize)
+# and every call below that takes device pointers runs it first.  None (default) = the caller orders its
+# producers itself, which is what bench.py's timed loops do.
+_producer_sync = None
+
+
+def set_producer_sync(fn):
+    """fn() is called before every entry point that is handed device pointers (None: no hook)."""
+    global _producer_sync
+    _producer_sync = fn
+
+
+def _order_producers():
+    if _producer_sync is not None:
+        _producer_sync()
+
+
 class VeloError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("velo error %d: %s" % (code, msg))
@@ -469,6 +488,7 @@ class Context:
         self._chk(lib().velo_map_reset(self.h, _p(x), _p(y), _p(z), x.size, voxel, k_normals))
 
     def map_reset_dev(self, px, py, pz, n, voxel=1.0, k_normals=16):
+        _order_producers()
         self._chk(lib().velo_map_reset_dev(self.h, px, py, pz, n, voxel, k_normals))
 
     def map_append(self, x, y, z):
@@ -476,6 +496,7 @@ class Context:
         self._chk(lib().velo_map_append(self.h, _p(x), _p(y), _p(z), x.size))
 
     def map_append_dev(self, px, py, pz, n):
+        _order_producers()
         self._chk(lib().velo_map_append_dev(self.h, px, py, pz, n))
 
     def map_append_sparse(self, x, y, z, min_count):
@@ -485,6 +506,7 @@ class Context:
         return k.value
 
     def map_append_sparse_dev(self, px, py, pz, n, min_count):
+        _order_producers()
         k = C.c_size_t()
         self._chk(lib().velo_map_append_sparse_dev(self.h, px, py, pz, n, min_count, C.byref(k)))
         return k.value
@@ -549,6 +571,7 @@ class Context:
         return ox, oy, oz
 
     def compensate_dev(self, px, py, pz, ppkt, n, ptab, n_pkt, pox, poy, poz):
+        _order_producers()
         self._chk(lib().velo_compensate_dev(self.h, px, py, pz, ppkt, n, ptab, n_pkt, pox, poy, poz))
 
     # ---- ICP
@@ -571,6 +594,7 @@ class Context:
         self.n_frames = len(frames)
 
     def frames_adopt_dev(self, px, py, pz, frame_start):
+        _order_producers()
         fs = np.ascontiguousarray(frame_start, dtype=np.int64)
         self._chk(lib().velo_frames_adopt_dev(self.h, fs.size - 1, px, py, pz, _p(fs)))
         self.n_frames = fs.size - 1
@@ -741,9 +765,11 @@ class Context:
         return ox[:k].copy(), oy[:k].copy(), oz[:k].copy()
 
     def increment_registered_async(self, frame, min_count, pox, poy, poz):
+        _order_producers()
         self._chk(lib().velo_increment_registered_async(self.h, frame, min_count, pox, poy, poz))
 
     def increment_all_registered_async(self, min_count, pox, poy, poz):
+        _order_producers()
         self._chk(lib().velo_increment_all_registered_async(self.h, min_count, pox, poy, poz))
 
     # ---- multi-GPU exchange (RCCL behind the C ABI)
@@ -759,6 +785,7 @@ class Context:
 
     def exchange_increments(self, px, py, pz, n_local, pox, poy, poz, cap, after_async_increment=True):
         """-> (counts per rank, total); blocks land in rank order in the output device arrays"""
+        _order_producers()
         _, world = self.comm_info()
         counts = np.zeros(max(world, 1), np.int32)
         tot = C.c_size_t()
@@ -768,6 +795,7 @@ class Context:
 
     def exchange_pack_dev(self, precv, counts, pad, pox, poy, poz, cap):
         """the rank-order pack of velo_exchange_increments alone (any world size on one GPU)"""
+        _order_producers()
         cnt = np.ascontiguousarray(counts, np.int32)
         tot = C.c_size_t()
         self._chk(lib().velo_exchange_pack_dev(self.h, precv, _p(cnt), cnt.size, pad, pox, poy, poz, cap,
@@ -805,6 +833,7 @@ class Context:
         return cnt.value
 
     def increment_dev(self, frame, T, min_count, pox, poy, poz):
+        _order_producers()
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)
         cnt = C.c_size_t()
         self._chk(lib().velo_increment_dev(self.h, frame, _d(T), min_count, pox, poy, poz,
