@@ -6,8 +6,8 @@ rc_all=0
 for i in 1 2 3; do
   timeout 1500 python -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/suite_x3/run$i.log 2>&1
   rc=$?
-  tail -n 6 gpurun_out/suite_x3/run$i.log > gpurun_out/suite_x3/run$i.tail.txt
-  echo "run $i rc=$rc: $(tail -n 1 gpurun_out/suite_x3/run$i.log)"
+  grep -E "passed|failed|error" gpurun_out/suite_x3/run$i.log > gpurun_out/suite_x3/run$i.tail.txt
+  echo "run $i rc=$rc: $(cat gpurun_out/suite_x3/run$i.tail.txt)"
   [ $rc -ne 0 ] && rc_all=$rc
 done
 exit $rc_all
