@@ -86,11 +86,16 @@ def parse():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the increment exchange + map append path even with one rank")
     ap.add_argument("--no-timing", action="store_true", help="skip per-launch HIP events (A/B their overhead)")
-    ap.add_argument("--exchange", choices=["capi", "torch"], default="capi",
-                    help="N > 1 transport of the increments: RCCL behind the C ABI, or torch.distributed")
+    ap.add_argument("--exchange", choices=["auto", "capi", "torch"], default="auto",
+                    help="N > 1 transport of the increments: RCCL behind the C ABI, or torch.distributed "
+                         "(auto = capi, except in the one-device functional check)")
     ap.add_argument("--capi-timeout-s", type=int, default=120,
-                    help="N > 1: seconds the C-ABI RCCL transport gets (bring-up + self-test + its measurement) before the "
-                         "line measured with torch.distributed's transport is printed instead")
+                    help="N > 1: seconds the C-ABI RCCL transport gets (bring-up + self-test + its measurement, in "
+                         "fresh child processes) before the line measured with torch.distributed's transport is "
+                         "printed instead, marked capi_transport: timeout")
+    ap.add_argument("--capi-child", action="store_true",
+                    help="internal: this process is the C-ABI-transport trial a rank of an N > 1 run started "
+                         "(gloo rendezvous, RCCL only behind the C ABI; exit 5 = timed out, 6 = communicator refused)")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--workload", choices=["batch", "stream"], default="batch",
                     help="batch = BASELINE configs[1] (the headline line); stream = configs[2]: "
@@ -999,6 +1004,52 @@ def launch_ranks(args):
     return rc
 
 
+def run_capi_children(args, rank, world, dev, emit_err):
+    """Each rank of an N > 1 run starts one child (this script with --capi-child) that measures with the
+    C-ABI RCCL transport; returns (status, rank 0's parsed JSON line or None), the status agreed by all
+    ranks: "ok" | "timeout" | "unavailable" | "failed"."""
+    import socket
+    import subprocess
+    box = [None]
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            box[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(box, src=0)
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(box[0]), RANK=str(rank), WORLD_SIZE=str(world),
+               LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"))
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    argv = [a for a in sys.argv[1:] if a != "--capi-child"]
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--capi-child"], env=env,
+                         stdout=subprocess.PIPE)
+    code = None
+    try:
+        outb, _ = p.communicate(timeout=args.capi_timeout_s + 45)
+        code = p.returncode
+    except subprocess.TimeoutExpired:
+        p.kill()                       # exactly the process started above
+        outb, _ = p.communicate()
+        code = 5
+    line = None
+    for txt in outb.decode(errors="replace").splitlines():
+        if txt.lstrip().startswith("{") and '"metric"' in txt:
+            try:
+                line = json.loads(txt)
+            except ValueError:
+                line = None
+    # 0 ok, 1 failed, 2 unavailable (exit 6), 3 timeout (exit 5 / killed): the worst over the ranks decides
+    mine = {0: 0, 6: 2, 5: 3}.get(code, 1)
+    if rank == 0 and mine == 0 and line is None:
+        mine = 1
+    if mine:
+        emit_err("bench: C-ABI transport child of rank %d ended with exit code %s\n" % (rank, code))
+    t = torch.tensor([mine], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return ["ok", "failed", "unavailable", "timeout"][int(t.item())], line
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -1037,7 +1088,9 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_dev:
+        if one_dev or args.capi_child:
+            # (a trial child keeps torch's RCCL out of the picture: the only collectives on the GPU
+            # in that process are the C ABI's own)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -1314,33 +1367,58 @@ def main():
                              "points_exchanged": m["exchanged"], "points_appended": m["appended"]}
         return o
 
-    # N > 1 with the C-ABI transport (the default): that RCCL path cannot be exercised before it meets a
-    # multi-GPU node, and a collective that never completes cannot be cancelled -- so the run is
-    # measured with torch.distributed's transport FIRST, and a watchdog holds that line: if the C-ABI
-    # communicator, its self-test or its measurement does not finish in --capi-timeout-s, rank 0 prints
-    # the line it has (marked) and every rank leaves.  Otherwise the line is the C-ABI transport's.
+    # N > 1 with the C-ABI transport (the default).  That RCCL path cannot be exercised before it meets a
+    # multi-GPU node, and a collective that never completes cannot be cancelled from inside its process.
+    # So the ranks the launcher started measure with torch.distributed's transport FIRST and keep that
+    # result; then every rank starts ONE FRESH CHILD PROCESS (--capi-child: gloo rendezvous on a port of
+    # its own, RCCL only behind the C ABI) that brings the communicator up, self-tests it on the real ranks
+    # and measures.  A child that hangs is killed by its parent after --capi-timeout-s (its own watchdog
+    # leaves with exit code 5 before that); a child whose communicator is refused leaves with 6.  The
+    # parents -- healthy processes with a healthy process group -- agree on the outcome: the line is the
+    # children's (C-ABI transport, `capi_transport: "ok"`) or the one already measured, marked
+    # `capi_transport: "timeout" | "unavailable" | "failed"`.  No process that hung on the GPU ever exits 0.
+    want_capi = args.exchange == "capi" or (args.exchange == "auto" and not one_dev)
     m_safe = None
+    capi_status = None
+    child_line = None
+    if exchange and want_capi and world > 1 and not args.capi_child:
+        m_safe = measure()
+        trace("torch.distributed transport measured: %.3f ms per step" % (1e3 * m_safe["elapsed"] / args.steps))
+        capi_status, child_line = run_capi_children(args, rank, world, dev, emit_err=sys.stderr.write)
+        trace("C-ABI transport trial: %s" % capi_status)
+        if rank == 0:
+            if capi_status == "ok":
+                out = child_line
+                out["capi_transport"] = "ok"
+                out.setdefault("exchange", {})["torch_transport_ms_per_step"] = 1e3 * m_safe["elapsed"] / args.steps
+                out["exchange"]["trial"] = "measured in fresh child processes (one per rank), see bench.py"
+            else:
+                out = basic_line(m_safe, "measured with torch.distributed (%s) collectives; the C-ABI transport "
+                                         "(velo_comm_init / velo_exchange_increments), tried in fresh child "
+                                         "processes, ended as: %s -- it was NOT measured"
+                                 % (dist.get_backend(), capi_status))
+                out["capi_transport"] = capi_status
+            emit(out)
+        ctx.close()
+        dist.destroy_process_group()
+        return
     watchdog = None
-    if exchange and not one_dev and args.exchange == "capi":
-        if world > 1:
-            m_safe = measure()
-            trace("torch.distributed transport measured: %.3f ms per step" % (1e3 * m_safe["elapsed"] / args.steps))
-
+    if exchange and want_capi:
+        if args.capi_child:
             def give_up():
-                sys.stderr.write("bench: the C-ABI RCCL transport did not finish within %d s on rank %d\n"
-                                 % (args.capi_timeout_s, rank))
-                if rank == 0:
-                    emit(basic_line(m_safe, "measured with torch.distributed (nccl = RCCL) collectives; the C-ABI transport "
-                                            "(velo_comm_init / velo_exchange_increments) did not complete within %d s and "
-                                            "was NOT measured" % args.capi_timeout_s))
-                os._exit(0)
+                sys.stderr.write("bench: C-ABI transport trial timed out on rank %d\n" % rank)
+                os._exit(5)     # a process that may be stuck inside a collective never exits 0
 
             import threading
             watchdog = threading.Timer(float(args.capi_timeout_s), give_up)
             watchdog.daemon = True
             watchdog.start()
-            ctx.map_reset(*d["map"], args.voxel, args.k_normals)   # the same starting map for the second measurement
-        if negotiate_capi() and world > 1:
+        ok = negotiate_capi()
+        if args.capi_child:
+            if not ok:
+                sys.stderr.write("bench: C-ABI communicator refused on rank %d\n" % rank)
+                ctx.close()
+                os._exit(6)
             selftest = capi_selftest()
             trace(selftest)
     m = measure()

@@ -46,3 +46,28 @@ def test_gpus_flag_starts_that_many_ranks_and_relays_one_line():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["exchange"]["ranks"] == 2
     assert out["frames_per_s"] > 0 and "FUNCTIONAL" in out["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_refused_capi_communicator_at_world_2_falls_back_on_every_rank_and_marks_the_line():
+    """the first contact of the C-ABI RCCL transport with more than one rank must not be
+    able to hang or blank the run.  Reachable on a one-GPU box: two ranks on GPU 0 (gloo rendezvous) ask for
+    --exchange capi; every rank measures with the torch transport first, then tries the C-ABI transport in a
+    fresh child process; RCCL refuses two ranks on one device, the children leave with a non-zero code (6 =
+    refused, 5 = their own watchdog), the parents agree, and rank 0 prints the line it holds, marked.  The
+    run ends, with ONE line, exit code 0 (no process that touched a failing collective exits 0: the children
+    did not), and a machine-readable capi_transport field (bench.py watchdog)."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "4", "--settle-s", "0.01",
+              "--map-points", "200000", "--no-cpu-baseline", "--no-subrecords", "--exchange", "capi",
+              "--capi-timeout-s", "90"],
+             env={"VELO_BENCH_ONE_DEVICE": "1"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert out["capi_transport"] in ("ok", "unavailable", "timeout", "failed")
+    if out["capi_transport"] != "ok":
+        assert "NOT measured" in out["exchange"]["note"]
+        assert out["exchange"]["transport"].startswith("torch.distributed")
+        assert "ended with exit code" in r.stderr
