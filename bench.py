@@ -1019,7 +1019,13 @@ def run_capi_children(args, rank, world, dev, emit_err):
     env = dict(os.environ)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(box[0]), RANK=str(rank), WORLD_SIZE=str(world),
                LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"))
-    env.pop("TORCHELASTIC_RUN_ID", None)
+    # the launcher's elastic-agent variables must not reach the child: with TORCHELASTIC_USE_AGENT_STORE set,
+    # env:// rendezvous makes every rank a CLIENT of the agent's store at MASTER_PORT -- on the child's own
+    # port nobody serves, and the children would wait for each other forever (found on the GPU box)
+    for k in [k for k in env if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+                                                                       "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE",
+                                                                       "ROLE_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")]:
+        env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     argv = [a for a in sys.argv[1:] if a != "--capi-child"]
     p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--capi-child"], env=env,
@@ -1360,7 +1366,7 @@ def main():
                                     "per GPU, resident in HBM" % (args.map_points, args.iters, args.d_max, args.voxel, F),
                         "frames_per_step_per_gpu": F, "points_per_frame": n_q // max(F, 1),
                         "map_points": args.map_points, "iters": args.iters,
-                        "parallelism": "frame-parallel x%d" % world},
+                        "parallelism": "frame-parallel x%d" % world + (" (FUNCTIONAL CHECK: all ranks on one device, gloo)" if one_dev else "")},
              "frames_per_s": world * F * args.steps / m["elapsed"], "total_pairs": m["total_pairs"]}
         if note:
             o["exchange"] = {"ranks": world, "transport": m["transport"], "note": note,
@@ -1407,6 +1413,11 @@ def main():
         if args.capi_child:
             def give_up():
                 sys.stderr.write("bench: C-ABI transport trial timed out on rank %d\n" % rank)
+                try:
+                    import faulthandler
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)   # where it hangs
+                except Exception:  # noqa: BLE001
+                    pass
                 os._exit(5)     # a process that may be stuck inside a collective never exits 0
 
             import threading

@@ -66,7 +66,10 @@ def test_refused_capi_communicator_at_world_2_falls_back_on_every_rank_and_marks
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0
-    assert out["capi_transport"] in ("ok", "unavailable", "timeout", "failed")
+    # (measured on the MI355X box: RCCL answers ncclInvalidUsage for two ranks on one device -> "unavailable",
+    # in ~6 s; "timeout" is what a hang gives -- seen when the children inherited the launcher's agent-store
+    # variables and waited for each other, which is how that bug was found)
+    assert out["capi_transport"] in ("ok", "unavailable", "timeout")
     if out["capi_transport"] != "ok":
         assert "NOT measured" in out["exchange"]["note"]
         assert out["exchange"]["transport"].startswith("torch.distributed")

@@ -1373,6 +1373,19 @@ def test_map_rolled_beside_a_registration_equals_the_plain_roll():
         A.icp_batch_finish()
         after = A.map_download()
         assert A.map_info().n_points == mi.n_points and all(np.array_equal(before[k], after[k]) for k in ("x", "cell_start", "perm"))
+        # (e) ADVICE r3: the refusal holds for the PAIR -- an eviction that would go through together with
+        # entering points that need a re-anchor (or a larger table) must leave the map as it was (the
+        # eviction used to publish its map before the append found out)
+        lo_e = np.array([x0 - half + 7.0, py - half, -big], np.float32)         # would evict a 7 m strip
+        hi_e = np.array([x0 + half, py + half, big], np.float32)
+        far = (np.full(5, mi.origin[0] + (mi.dims[0] + 3) * 1.0, np.float32), np.full(5, py, np.float32), np.zeros(5, np.float32))
+        for pts in (low, far):                                                  # below the origin / beyond the dims
+            A.icp_batch_start(T0, 3, 1.0)
+            assert A.map_roll_overlapped(lo_e, hi_e, *pts) is False
+            A.icp_batch_finish()
+            assert A.map_info().n_points == mi.n_points
+            again = A.map_download()
+            assert all(np.array_equal(before[k], again[k]) for k in ("x", "cell_start", "perm"))
         A.map_append(*low)                                                      # the plain call does it
         assert A.map_info().n_points == mi.n_points + 5 and A.map_info().last_update == 0
     finally:

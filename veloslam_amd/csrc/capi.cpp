@@ -1074,7 +1074,9 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
             c->ni_late = (int)late.size();
         }
     }
-    HIP_TRY(c, c->partials.reserve(max_rows * kAccStride));
+    // (with slack: in the pipelined stream plan_frames runs on the side stream while a registration still reads
+    //  these rows -- a frame a few points larger than every one before must not reallocate under it)
+    HIP_TRY(c, reserve_slack(c->partials, (max_rows + max_rows / 4 + 64) * kAccStride));
     HIP_TRY(c, c->poses.reserve((size_t)maxb * 12));
     HIP_TRY(c, c->acc.reserve((size_t)maxb * kAccStride));
     HIP_TRY(c, c->stats.reserve((size_t)maxb * VELO_MAX_ITERS));
@@ -1924,6 +1926,39 @@ int velo_map_roll_overlapped(velo_ctx* c, const float lo[3], const float hi[3], 
     if (c->roll_overlapped_done) return c->fail(VELO_E_INVALID, "one overlapped roll per registration");
     if ((lo == nullptr) != (hi == nullptr)) return c->fail(VELO_E_INVALID, "lo and hi go together");
     if (n && (!x || !y || !z)) return c->fail(VELO_E_INVALID, "null point array");
+    // "Refused before anything changed" has to hold for the PAIR: the eviction publishes its map
+    // before the append can find out that the entering points need a re-anchor or a larger table -- the
+    // caller then saw n_points move, took the device map for dirty and rebuilt it from the host tiles.
+    // Everything the append's refusal depends on is known here: the entering points are host arrays, and an
+    // eviction that goes ahead beside a registration keeps the grid (origin, dims) -- one that would
+    // re-anchor is refused by evict_impl itself before it changes anything.
+    if (c->use_hash || c->cfg.map_full_rebuild)
+        return c->fail(VELO_E_AGAIN, "this update needs the map rebuilt: not beside a registration");
+    if (n) {
+        float mn[3] = {x[0], y[0], z[0]}, mx[3] = {x[0], y[0], z[0]};
+        const float* src[3] = {x, y, z};
+        for (int a = 0; a < 3; ++a) {
+            float lo_a = src[a][0], hi_a = src[a][0];
+            bool finite = true;
+            for (size_t i = 0; i < n; ++i) {
+                const float v = src[a][i];
+                finite &= std::isfinite(v);
+                lo_a = std::min(lo_a, v);
+                hi_a = std::max(hi_a, v);
+            }
+            if (!finite) return c->fail(VELO_E_INVALID, "map points must be finite");
+            mn[a] = lo_a;
+            mx[a] = hi_a;
+        }
+        const float org[3] = {c->mv.ox, c->mv.oy, c->mv.oz};
+        const int dims[3] = {c->mv.nx, c->mv.ny, c->mv.nz};
+        for (int a = 0; a < 3; ++a) {
+            // (the same float expressions append_incremental decides with)
+            const float ext = floorf((mx[a] - org[a]) * c->mv.inv_h);
+            if (mn[a] < org[a] || !(ext < 2.0e9f) || (int)ext + 1 > dims[a])
+                return c->fail(VELO_E_AGAIN, "the entering points need the grid re-anchored or grown: not beside a registration");
+        }
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->side_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     if (!c->ev_side) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
@@ -2398,13 +2433,13 @@ static int decode_submit(velo_ctx* c, velo_ctx::DecodePlan& P, velo_ctx::DecodeS
     HIP_TRY(c, hipMemcpyAsync(starts, c->dk_starts.p, n_starts * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     const size_t n_valid = nfr > 0 ? (size_t)starts[(size_t)nfr * 64] : 0;
-    HIP_TRY(c, c->dk_out[c->dk_sel].x.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_out[c->dk_sel].y.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_out[c->dk_sel].z.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_out[c->dk_sel].i.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_out[c->dk_sel].dist.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_out[c->dk_sel].az.reserve(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(c, c->dk_out[c->dk_sel].pidx.reserve(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, reserve_slack(c->dk_out[c->dk_sel].x, std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, reserve_slack(c->dk_out[c->dk_sel].y, std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, reserve_slack(c->dk_out[c->dk_sel].z, std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, reserve_slack(c->dk_out[c->dk_sel].i, std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, reserve_slack(c->dk_out[c->dk_sel].dist, std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, reserve_slack(c->dk_out[c->dk_sel].az, std::max<size_t>(n_valid, 1)));
+    HIP_TRY(c, reserve_slack(c->dk_out[c->dk_sel].pidx, std::max<size_t>(n_valid, 1)));
     HIP_TRY(c, launch_decode_emit(v, c->dk_order.p, n_valid, c->dk_out[c->dk_sel].x.p, c->dk_out[c->dk_sel].y.p, c->dk_out[c->dk_sel].z.p, c->dk_out[c->dk_sel].i.p,
                                   c->dk_out[c->dk_sel].az.p, c->dk_out[c->dk_sel].dist.p, c->dk_out[c->dk_sel].pidx.p, s));
     // (no wait for the emit: whoever reads the frames -- velo_decode_fetch, the registration -- is

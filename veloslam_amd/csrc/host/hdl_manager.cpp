@@ -101,9 +101,14 @@ void HDLManager::bindToCapture(HDLFrame& f) const
 {
     f.firstPacket = -1;
     f.numPackets = 0;
-    for (size_t k = 0; k < index_.size(); ++k) {
+    // the index is in capture order, i.e. ascending in file_pos: a binary search, not a scan per frame
+    // (loadOffline / loadHDLMeta call this once per frame: 36 k frames for an hour's drive)
+    size_t k = (size_t)(std::lower_bound(index_.begin(), index_.end(), f.fileStartPos,
+                                         [](const velo_frame_index& e, int64_t pos) { return e.file_pos < pos; }) -
+                        index_.begin());
+    for (; k < index_.size() && index_[k].file_pos == f.fileStartPos; ++k) {
         const velo_frame_index& e = index_[k];
-        if (e.file_pos != f.fileStartPos || e.firing_skip != (int32_t)f.skips) continue;
+        if (e.firing_skip != (int32_t)f.skips) continue;
         f.firstPacket = e.first_packet;
         // up to and including the packet in which the next frame opens; the last frame runs to the end
         const int64_t end = k + 1 < index_.size() ? index_[k + 1].first_packet + 1 : (int64_t)nPackets_;

@@ -96,12 +96,30 @@ bool PacketFileReader::nextPacket(const unsigned char*& data, unsigned int& data
     if (!f_) return false;
     for (;;) {
         unsigned char rh[16];
-        if (std::fread(rh, 1, 16, f_) != 16) break;
+        const long at = std::ftell(f_);
+        const size_t got = std::fread(rh, 1, 16, f_);
+        if (got == 0) break;  // a clean end of file
+        // a damaged capture must not look like a clean end: say where it broke
+        auto damaged = [&](const char* what) {
+            lastError_ = fileName_ + ": " + what + " at offset " + std::to_string(at);
+        };
+        if (got != 16) {
+            damaged("truncated record header");
+            break;
+        }
         const uint32_t sec = rd32(rh, swap_), frac = rd32(rh + 4, swap_), incl = rd32(rh + 8, swap_);
-        if (incl > (1u << 20)) break;  // corrupt
+        if (incl > (1u << 20)) {
+            damaged("corrupt record (captured length beyond 1 MiB)");
+            break;
+        }
         rec_.resize(incl);
-        if (incl && std::fread(rec_.data(), 1, incl, f_) != incl) break;
-        // the "udp" filter: Ethernet II, IPv4 without options, protocol 17
+        if (incl && std::fread(rec_.data(), 1, incl, f_) != incl) {
+            damaged("truncated record");
+            break;
+        }
+        // the "udp" filter: Ethernet II, IPv4 WITHOUT options (IHL = 5: the fixed 42-byte strip of
+        // vtkPacketFileReader.h:166-197 is only a UDP payload then), protocol 17; VLAN-tagged frames and
+        // IPv4 options are skipped -- no HDL sensor or the reference's writer produces them
         if (incl < 42 || rec_[12] != 0x08 || rec_[13] != 0x00 || (rec_[14] & 0x0f) != 5 || rec_[23] != 17) continue;
         data = rec_.data() + 42;
         dataLength = incl - 42;
