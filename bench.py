@@ -80,7 +80,7 @@ def parse():
                     help="pending increment points that trigger a map append (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true", help="skip dense / single_frame / stream / incl_h2d")
-    ap.add_argument("--only", default="", help="comma list of sub-records to run (dense,single_frame,stream,incl_h2d)")
+    ap.add_argument("--only", default="", help="comma list of sub-records to run (dense,single_frame,stream,incl_h2d,knn32_100m)")
     ap.add_argument("--time-every", type=int, default=20,
                     help="bracket the linearise launches with HIP events in every k-th timed step")
     ap.add_argument("--force-exchange", action="store_true",
@@ -133,6 +133,10 @@ def parse():
     ap.add_argument("--map-margin", type=int, default=16, help="stream: grid slack in x/y, voxels")
     ap.add_argument("--map-margin-z", type=int, default=2, help="stream: grid slack in z, voxels")
     ap.add_argument("--full-rebuild", action="store_true", help="stream: re-sort the whole map on every update (A/B)")
+    ap.add_argument("--knn-map-points", type=int, default=100_000_000, help="knn32_100m sub-record (BASELINE configs[4])")
+    ap.add_argument("--knn-k", type=int, default=32)
+    ap.add_argument("--knn-subdiv", type=int, default=0)
+    ap.add_argument("--knn-hash-load", type=int, default=0)
     ap.add_argument("--dense-map-points", type=int, default=10_000_000)
     ap.add_argument("--dense-frames", type=int, default=16)
     ap.add_argument("--dense-subdiv", type=int, default=0)
@@ -689,7 +693,25 @@ def run_replay(args, dev, local, steps, warmup, d=None):
     ctx.close()
     if state["worst"] > 0.05:
         raise SystemExit("bench replay: registration diverged (%.3f m)" % state["worst"])
-    return {"frames_per_s": steps / elapsed, "ms_per_frame": 1e3 * elapsed / steps, "frames": steps,
+    fps = steps / elapsed
+    tr = traffic_for("stream")
+    roof = None
+    if tr:
+        # BASELINE configs[2] "sustained frames/s + rocprof HBM GB/s": the fabric-side bytes every kernel of a
+        # frame moves (PMC, per dispatch, summed: profiles/collect.sh on the C++ replay of the same drive) x
+        # the frames per second of THIS run = the sustained rate; beside it the rate while a kernel runs
+        roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "traffic_bytes_per_frame": tr["hbm_bytes_per_frame"],
+                "sustained_GBps": tr["hbm_bytes_per_frame"] * fps / 1e9,
+                "sustained_frac": tr["hbm_bytes_per_frame"] * fps / 1e9 / HBM_PEAK_GBPS,
+                "kernel_us_per_frame": tr["kernel_us_per_frame"],
+                "GBps_while_a_kernel_runs": tr["GBps_while_a_kernel_runs"],
+                "by_family": tr["by_family"], "traffic_source": tr["source"],
+                "note": "a frame of the stream is ~60 small launches on a chip it cannot fill (one frame = 450 "
+                        "workgroups on 256 CUs): bound by launch and memory LATENCY, which is why the sustained "
+                        "fraction of the HBM peak is small; the bytes are PMC counters (reads by request size + "
+                        "WRITE_SIZE), not a model"}
+    return {"frames_per_s": fps, "ms_per_frame": 1e3 * elapsed / steps, "frames": steps, "roofline": roof,
             "host": "Python (C ABI through ctypes)",
             "workload": "BASELINE configs[2], %s: %d frames 1 m apart (pcap + frame index + pose track), played "
                         "forwards and backwards, through a pre-mapped world of %d tiles of %.0f m; per frame: decode of "
@@ -876,6 +898,103 @@ def dense_record(args, d, dev, local):
                working_set_bytes=ws, working_set_over_infinity_cache=ws / (256.0 * 2 ** 20),
                pairs_per_s=pairs / el, ms_per_registration_batch=1e3 * el / 3,
                map_build_s=build_s, worst_pose_error_m=worst, traffic_key=key)
+    ctx.close()
+    return rec
+
+
+def knn_record(args, d, dev, local):
+    """BASELINE configs[4]: dense-map stress -- a 100 M-point map of the scene (built on the GPU: sorted,
+    fine table, k = 32 PCA normals), the 32 nearest neighbours of every point of one HDL-64E frame
+    (velo_knn_dev: results stay in HBM), with the kernel's roofline record, and the 20-iteration
+    registration of the same frame against that map beside it."""
+    M, k = args.knn_map_points, args.knn_k
+    mx, my, mz = d["scene"].sample_map_device(M, dev)
+    ctx = capi.Context(local, max_batch=2, map_subdiv=args.knn_subdiv, map_hash_load=args.knn_hash_load,
+                       use_hints=0 if args.no_hints else args.hints, use_graph=0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.map_reset_dev(mx.data_ptr(), my.data_ptr(), mz.data_ptr(), M, args.voxel, min(k, 32))
+    ctx.synchronize()
+    build_s = time.perf_counter() - t0
+    del mx, my, mz
+    mi = ctx.map_info()
+    fs = d["frame_start"][:2]
+    n = int(fs[1])
+    ctx.frames_adopt_dev(d["cx"].data_ptr(), d["cy"].data_ptr(), d["cz"].data_ptr(), fs)
+    T = d["Ttrue"][0]
+    idx = torch.empty((n, k), dtype=torch.int32, device=dev)
+    d2 = torch.empty((n, k), dtype=torch.float32, device=dev)
+    cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    args_k = (0, T, args.voxel, k, idx.data_ptr(), d2.data_ptr(), cnt.data_ptr())
+    for _ in range(2):
+        ctx.knn_dev(*args_k)
+    torch.cuda.synchronize()
+    reps = 5
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:     # (ctx and torch share one stream here: the events bracket the launch)
+        a.record()
+        ctx.knn_dev(*args_k)
+        b.record()
+    torch.cuda.synchronize()
+    us = sorted(1e3 * a.elapsed_time(b) for a, b in evs)
+    launch_us = us[len(us) // 2]
+    st = ctx.knn_dev(*args_k, stats=True)
+    found = float(cnt.to(torch.float64).mean().item())
+    full = float((cnt == k).to(torch.float64).mean().item())
+    # bytes: query side = coordinates in, k x (index + distance) + the count out; map side = what the search
+    # asked for (16 B per candidate point; per fine row looked up two 4-byte table entries, or one 16-byte
+    # slot per cell of the row through the hash), capped by what is resident (points + table: a byte of
+    # the map does not have to cross the fabric twice in a launch)
+    hashed = mi.table_kind == 1
+    q_bytes = n * (12 + 8 * k + 4) + 96
+    tab_req = st["cells"] * 16 if hashed else st["rows"] * 8
+    map_req = st["candidates"] * 16 + tab_req
+    resident = int(mi.n_points) * 16 + int(mi.table_slots) * (16 if hashed else 4)
+    alg = q_bytes + min(map_req, resident)
+    key = "knn%d_M%d" % (k, M)
+    tr = traffic_for(key)
+    rec = {"workload": "BASELINE configs[4]: %d-NN of one %d-pt HDL-64E frame in a %d-pt map (%d x %d x %d voxels "
+                       "of %.1f m, sub-division %d, %s fine table), d_max %.1f m; results left in HBM"
+                       % (k, n, M, mi.dims[0], mi.dims[1], mi.dims[2], args.voxel, mi.subdiv,
+                          "hashed" if hashed else "dense", args.voxel),
+           "map_points": M, "k": k, "queries": n, "map_subdiv": int(mi.subdiv),
+           "table": {"kind": "hash" if hashed else "dense", "slots": int(mi.table_slots),
+                     "occupied_cells": int(mi.table_occupied), "bytes": int(mi.table_slots) * (16 if hashed else 4),
+                     "fine_cells": int(mi.n_cells),
+                     # (the dense table does not count its occupied cells: tools/knn_sweep.py downloads it and does)
+                     "occupancy": (float(mi.table_occupied) / max(float(mi.table_slots), 1.0)) if hashed else None,
+                     "points_per_occupied_cell": (float(mi.n_points) / max(float(mi.table_occupied), 1.0)) if hashed else None},
+           "map_build_s": build_s, "ms_per_frame": 1e-3 * launch_us, "launch_us_all": us,
+           "neighbours_found_mean": found, "queries_with_all_k": full,
+           "queries_per_s": n / (1e-6 * launch_us), "neighbour_pairs_per_s": found * n / (1e-6 * launch_us),
+           "search": {"candidates_per_query": st["candidates"] / max(st["queries"], 1),
+                      "rows_per_query": st["rows"] / max(st["queries"], 1),
+                      "cells_per_query": st["cells"] / max(st["queries"], 1)},
+           "roofline": {"bound": "hbm", "kernel": "k_knn<32>", "achieved": alg / (1e-6 * launch_us) / 1e9,
+                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (1e-6 * launch_us) / 1e9 / HBM_PEAK_GBPS,
+                        "algorithmic_bytes_per_launch": alg, "query_bytes_per_launch": q_bytes,
+                        "map_requested_bytes_per_launch": map_req, "map_resident_bytes": resident,
+                        "avg_launch_us": launch_us,
+                        "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                        "traffic_source": tr["source"] if tr else None,
+                        "traffic_rocprof_avg_launch_us": tr.get("rocprof_avg_launch_us") if tr else None,
+                        "traffic_GBps": (tr["hbm_bytes_per_launch"] / (1e-6 * launch_us) / 1e9) if tr else None,
+                        "note": "one thread per query, exact ball search with a k-best list in LDS: bound by "
+                                "dependent L2 / LDS round trips per lane, not by HBM -- 115 200 queries are 900 "
+                                "workgroups, less than 4 per CU; the fraction says how far from a stream it is"}}
+    # the registration of the same frame against the same 100 M-point map, for the record
+    T0 = d["T0"][:1]
+    for _ in range(3):
+        res = ctx.icp_batch(T0, args.iters, args.d_max)
+    lat = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        res = ctx.icp_batch(T0, args.iters, args.d_max)
+        lat.append(time.perf_counter() - t0)
+    err = float(np.linalg.norm(np.array(list(res[0].T)).reshape(3, 4)[:, 3] - d["Ttrue"][0].reshape(3, 4)[:, 3]))
+    rec["registration_1nn"] = {"ms_per_registration": 1e3 * float(np.median(lat)), "iters": args.iters,
+                               "pairs": int(res[0].total_pairs), "pose_error_m": err}
     ctx.close()
     return rec
 
@@ -1511,6 +1630,7 @@ def main():
             sub("incl_h2d", lambda: incl_h2d_record(args, d, dev, ctx, max(args.steps, 4)))
             sub("single_frame", lambda: single_frame_record(args, d, local))
             sub("dense", lambda: dense_record(args, d, dev, local))
+            sub("knn32_100m", lambda: knn_record(args, d, dev, local))
             src = d["stream_src"] if rank == 0 and F >= 24 else None
             if args.stream_policy == "tiles":
                 sub("stream", lambda: run_replay(args, dev, local, args.stream_steps, args.stream_warmup,

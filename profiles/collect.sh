@@ -7,7 +7,7 @@
 # with --kernel-trace only (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md,
 # rocprofv3 PMC slots); the program itself follows `--`.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
@@ -20,5 +20,19 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 2 --warmup 1 $B > $OUT/bench_sq.json 2> $OUT/bench_sq.err
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_tcc -- python3 bench.py --steps 2 --warmup 1 $B > $OUT/bench_tcc.json 2> $OUT/bench_tcc.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_stream -- python3 bench.py --workload stream --steps 100 --warmup 10 --stream-frames 32 > $OUT/bench_stream.json 2> $OUT/bench_stream.err
+# BASELINE configs[4]: the k-NN kernel on the 100 M-point map (sub-record knn32_100m), same three passes
+K="--no-cpu-baseline --only knn32_100m --steps 3 --warmup 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/knn_trace -- python3 bench.py $K > $OUT/bench_knn_trace.json 2> $OUT/bench_knn_trace.err
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/knn_rdreq -- python3 bench.py $K > $OUT/bench_knn_rdreq.json 2> $OUT/bench_knn_rdreq.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/knn_write -- python3 bench.py $K > $OUT/bench_knn_write.json 2> $OUT/bench_knn_write.err
+# BASELINE configs[2]: HBM bytes per frame of the stream -- the C++ replay (tools/stream_driver: the program itself
+# after `--`), every kernel of every frame counted; a recorded drive exported first
+D=/tmp/drv_$R
+python3 bench.py --export-drive $D > $OUT/export.json 2> $OUT/export.err
+SD="$PWD/tools/stream_driver $D --steps 200 --warmup 20"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stream_trace -- $SD > $OUT/stream_trace.json 2> $OUT/stream_trace.err
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/stream_rdreq -- $SD > $OUT/stream_rdreq.json 2> $OUT/stream_rdreq.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/stream_write -- $SD > $OUT/stream_write.json 2> $OUT/stream_write.err
+$SD > $OUT/stream_plain.json 2> $OUT/stream_plain.err
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 400 $OUT/bench_default.json

@@ -22,7 +22,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + R)
 DST = os.path.join(ROOT, "profiles", R)
@@ -138,6 +138,112 @@ for k, grids in summary.items():
             traffic["K1_grid%s" % g] = dict(kernel=k, read_bytes=rd, write_bytes=wr, pmc_bytes=rd + wr,
                                             points=n_pts, algorithmic_bytes=(26 * n_pts) if n_pts else None,
                                             pmc_over_algorithmic=((rd + wr) / (26 * n_pts)) if n_pts else None)
+
+
+# ---- the k-NN kernel of BASELINE configs[4] (bench.py sub-record knn32_100m): launches of k_knn<32, false>
+def by_kernel(sub):
+    """kernel short name -> counter -> list of per-dispatch values (all configurations together)"""
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv")):
+        for r in rows_in_order(f, "Dispatch_Id"):
+            out[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def trace_durations(sub):
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(SRC, sub, "*", "*_kernel_trace.csv")):
+        for r in rows_in_order(f, "Dispatch_Id"):
+            out[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return out
+
+
+def read_bytes(cs):
+    return sum(m * sum(cs.get("TCC_EA0_RDREQ_%s_sum" % c, [])) for c, m in (("32B", 32), ("64B", 64), ("128B", 128)))
+
+
+krd, kwr, kdur = by_kernel("knn_rdreq"), by_kernel("knn_write"), trace_durations("knn_trace")
+for k in krd:
+    if "k_knn<32, false>" not in k:
+        continue
+    n = len(krd[k]["TCC_EA0_RDREQ_128B_sum"])
+    nw = len(kwr.get(k, {}).get("WRITE_SIZE", []))
+    if not n or not nw:
+        continue
+    rd = read_bytes(krd[k]) / n
+    wr = sum(kwr[k]["WRITE_SIZE"]) / nw * 1024
+    d = kdur.get(k, [])
+    try:
+        kb = json.load(open(os.path.join(SRC, "bench_knn_trace.json")))["knn32_100m"]
+        key = "knn%d_M%d" % (kb["k"], kb["map_points"])
+    except Exception:  # noqa: BLE001
+        key = "knn32_M100000000"
+    traffic[key] = dict(kernel=k, read_bytes=rd, write_bytes=wr, hbm_bytes_per_launch=rd + wr, launches_counted=n,
+                        rocprof_avg_launch_us=(sum(d) / len(d)) if d else None, rocprof_launches=len(d),
+                        source="profiles/%s/pmc_knn_stream.json" % R,
+                        correction="reads = 32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B; writes = WRITE_SIZE")
+
+# ---- the stream (BASELINE configs[2]): every kernel of the C++ replay, bytes and time per frame
+srd, swr, sdur = by_kernel("stream_rdreq"), by_kernel("stream_write"), trace_durations("stream_trace")
+
+
+def family(k):
+    for pat, fam in (("k_linearize", "registration (k_linearize_lat)"), ("k_reduce_solve", "registration (k_reduce_solve)"),
+                     ("k_decode", "decode"), ("k_key_starts", "decode"), ("k_compensate", "decode"),
+                     ("k_increment", "increment"), ("k_normals", "roll: normals"),
+                     ("k_merge", "roll: merge / compact"), ("k_compact", "roll: merge / compact"), ("k_keep", "roll: merge / compact"),
+                     ("k_table", "roll: fine table"), ("k_mark", "roll: dirty voxels"), ("k_select", "roll: dirty voxels"),
+                     ("k_vox", "roll: dirty voxels"), ("rocprim", "sorts / scans (rocPRIM)")):
+        if pat in k:
+            return fam
+    return "other"
+
+
+if srd and swr:
+    frames_pmc = max(len(v.get("TCC_EA0_RDREQ_128B_sum", [])) for k, v in srd.items() if "k_decode_emit" in k) if any("k_decode_emit" in k for k in srd) else 0
+    frames_wr = max(len(v.get("WRITE_SIZE", [])) for k, v in swr.items() if "k_decode_emit" in k) if any("k_decode_emit" in k for k in swr) else 0
+    frames_tr = max((len(v) for k, v in sdur.items() if "k_decode_emit" in k), default=0)
+    fam = collections.defaultdict(lambda: dict(read_bytes=0.0, write_bytes=0.0, kernel_us=0.0, launches=0))
+    per_kernel = {}
+    for k, cs in srd.items():
+        fam[family(k)]["read_bytes"] += read_bytes(cs) / max(frames_pmc, 1)
+        per_kernel.setdefault(k, {})["read_bytes_per_frame"] = read_bytes(cs) / max(frames_pmc, 1)
+    for k, cs in swr.items():
+        fam[family(k)]["write_bytes"] += sum(cs.get("WRITE_SIZE", [])) * 1024 / max(frames_wr, 1)
+        per_kernel.setdefault(k, {})["write_bytes_per_frame"] = sum(cs.get("WRITE_SIZE", [])) * 1024 / max(frames_wr, 1)
+    for k, d in sdur.items():
+        fam[family(k)]["kernel_us"] += sum(d) / max(frames_tr, 1)
+        fam[family(k)]["launches"] += len(d) / max(frames_tr, 1)
+        per_kernel.setdefault(k, {}).update(kernel_us_per_frame=sum(d) / max(frames_tr, 1), launches_per_frame=len(d) / max(frames_tr, 1))
+    tot_b = sum(v["read_bytes"] + v["write_bytes"] for v in fam.values())
+    tot_us = sum(v["kernel_us"] for v in fam.values())
+    plain = None
+    try:
+        plain = json.loads(open(os.path.join(SRC, "stream_plain.json")).read().strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        pass
+    traffic["stream"] = dict(frames_counted=dict(pmc_read=frames_pmc, pmc_write=frames_wr, trace=frames_tr),
+                             hbm_bytes_per_frame=tot_b, kernel_us_per_frame=tot_us,
+                             GBps_while_a_kernel_runs=(tot_b / (tot_us * 1e-6) / 1e9) if tot_us else None,
+                             by_family={k: v for k, v in sorted(fam.items(), key=lambda kv: -(kv[1]["read_bytes"] + kv[1]["write_bytes"]))},
+                             plain_run_frames_per_s=(plain or {}).get("frames_per_s"),
+                             sustained_GBps_at_plain_rate=(tot_b * plain["frames_per_s"] / 1e9) if plain and plain.get("frames_per_s") else None,
+                             source="profiles/%s/pmc_knn_stream.json" % R,
+                             program="tools/stream_driver (C++: veloslam::HDLManager + MapManager over the C ABI), 200 timed + 20 "
+                                     "warm-up frames of the exported synthetic drive; three rocprofv3 passes (kernel trace; read "
+                                     "requests by size class; WRITE_SIZE), counters per dispatch summed over every kernel and "
+                                     "divided by the frames decoded (k_decode_emit dispatches).  Copies (packets in, results "
+                                     "out: < 0.5 MB per frame) are not kernels and are not in these bytes",
+                             correction="reads = 32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B; writes = WRITE_SIZE")
+    json.dump(dict(knn={k: dict(rd=dict(krd[k]), wr=dict(kwr.get(k, {}))) for k in krd if "k_knn" in k},
+                   stream_per_kernel=per_kernel),
+              open(os.path.join(DST, "pmc_knn_stream.json"), "w"), indent=1)
+    st = sorted(glob.glob(os.path.join(SRC, "stream_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    if st:
+        shutil.copy(st[-1], os.path.join(DST, "kernel_stats_stream_cpp.csv"))
+st = sorted(glob.glob(os.path.join(SRC, "knn_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+if st:
+    shutil.copy(st[-1], os.path.join(DST, "kernel_stats_knn.csv"))
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 for nm in ("bench_default.json", "bench_stream.json", "bench_trace.json"):

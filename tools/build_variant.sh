@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/build_variant.sh <name> <extra hipcc flags...>   (A/B builds of the linearise TU)
 set -e
-cd /root/repo/veloslam_amd/csrc
+cd "$(dirname "$0")/../veloslam_amd/csrc"
 name=$1; shift
 mkdir -p build/variants
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -c ${SRC:-kernels/icp.hip} -o build/variants/icp_$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|k_linearizeILb0ELi1E" -A7 | grep -E "error|VGPRs:|Scratch" | tr '\n' ' '

@@ -105,7 +105,7 @@ EXPORTS = [
     "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_roll_overlapped", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_icp_batch_start", "velo_icp_batch_finish", "velo_linearize",
-    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_decode_plan_create", "velo_decode_plan_destroy", "velo_decode_plan_fill", "velo_decode_submit", "velo_decode_submit_overlapped", "velo_decode_plan_error", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_increment_pending", "velo_pending_count", "velo_pending_fetch", "velo_map_append_pending", "velo_pending_clear", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
+    "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_knn_dev", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_decode_plan_create", "velo_decode_plan_destroy", "velo_decode_plan_fill", "velo_decode_submit", "velo_decode_submit_overlapped", "velo_decode_plan_error", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_increment_pending", "velo_pending_count", "velo_pending_fetch", "velo_map_append_pending", "velo_pending_clear", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
     "velo_exchange_increments", "velo_exchange_plan", "velo_exchange_pack_dev", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_pcap_index", "velo_ins_to_pose",
@@ -180,6 +180,7 @@ def lib():
     L.velo_linearize_hints.argtypes = [vp, C.c_int]
     L.velo_solve_update.argtypes = [vp, dp, dp, C.POINTER(C.c_int32)]
     L.velo_knn.argtypes = [vp, C.c_int, dp, C.c_float, C.c_int, vp, vp, vp]
+    L.velo_knn_dev.argtypes = [vp, C.c_int, dp, C.c_float, C.c_int, vp, vp, vp, vp]
     L.velo_decode.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_int, C.POINTER(Pose), C.c_size_t, C.c_int,
                               vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
     L.velo_decode_stream.argtypes = L.velo_decode.argtypes
@@ -647,6 +648,16 @@ class Context:
         cnt = np.empty(n, np.int32)
         self._chk(lib().velo_knn(self.h, frame, _d(T), d_max, k, _p(idx), _p(d2), _p(cnt)))
         return idx, d2, cnt
+
+    def knn_dev(self, frame, T, d_max, k, pidx, pd2, pcount=None, stats=False):
+        """velo_knn_dev: results stay on the device; stats=True -> the counting instantiation's dict"""
+        _order_producers()
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)
+        st = (C.c_uint64 * 4)() if stats else None
+        self._chk(lib().velo_knn_dev(self.h, frame, _d(T), d_max, k, pidx, pd2, pcount, st))
+        if stats:
+            return dict(queries=int(st[0]), candidates=int(st[1]), rows=int(st[2]), cells=int(st[3]))
+        return None
 
     def decode(self, packets, times_us, calib, n_lasers=64, poses=None, n_poses=0, flush=True,
                crop_region=None, crop_inside=False, stream=False):

@@ -145,6 +145,8 @@ struct velo_ctx {
     DevBuf<int32_t> cell_start_alt;
     DevBuf<uint8_t> vox_near_alt;
     bool overlap_update = false;        // inside velo_map_roll_overlapped
+    DevBuf<double> knn_T;               // velo_knn_dev: the pose on the device ...
+    double* h_knn_T = nullptr;          // ... and its pinned source
     int overlap_done = 0;               // ... updates published so far in this call
     // a roll is TWO updates (evict, append): the second must not write the arrays the registration is
     // still reading either -- which after the first swap are the "alt" ones -- so a third set steps in
@@ -1498,6 +1500,7 @@ void velo_destroy(velo_ctx* c)
     }
     if (c->h_inc_total) (void)hipHostFree(c->h_inc_total);
     if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->h_knn_T) (void)hipHostFree(c->h_knn_T);
     if (c->h_starts) (void)hipHostFree(c->h_starts);
     if (c->h_pend_total) (void)hipHostFree(c->h_pend_total);
     if (c->ev_pend) (void)hipEventDestroy(c->ev_pend);
@@ -2688,6 +2691,34 @@ int velo_knn(velo_ctx* c, int frame, const double T[12], float d_max, int k, int
     HIP_TRY(c, hipMemcpyAsync(d2, dd.p, n * (size_t)k * sizeof(float), hipMemcpyDeviceToHost, s));
     if (count) HIP_TRY(c, hipMemcpyAsync(count, dc.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    return VELO_OK;
+}
+
+int velo_knn_dev(velo_ctx* c, int frame, const double T[12], float d_max, int k, int32_t* d_idx, float* d_d2,
+                 int32_t* d_count, uint64_t stats[4])
+{
+    if (!c) return VELO_E_INVALID;
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
+    if (frame < 0 || frame >= c->n_frames) return c->fail(VELO_E_INVALID, "frame index out of range");
+    if (!T || !d_idx || !d_d2) return c->fail(VELO_E_INVALID, "null argument");
+    if (k < 1 || k > VELO_MAX_KNORMALS) return c->fail(VELO_E_INVALID, "k must be in [1,%d]", VELO_MAX_KNORMALS);
+    if (!(d_max > 0.0f) || !(d_max <= c->mv.h))
+        return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv.h);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
+    if (n == 0) return VELO_OK;
+    // the pose goes through the ctx's pinned pair like a registration's (no pageable copy, no wait)
+    HIP_TRY(c, c->knn_T.reserve(12));
+    if (!c->h_knn_T) HIP_TRY(c, hipHostMalloc((void**)&c->h_knn_T, 12 * sizeof(double), 0));
+    HIP_TRY(c, hipStreamSynchronize(s));  // (the previous call's copy out of h_knn_T; a diagnostics path)
+    std::memcpy(c->h_knn_T, T, 12 * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(c->knn_T.p, c->h_knn_T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    unsigned long long st[4] = {0, 0, 0, 0};
+    HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, c->knn_T.p, d_max * d_max, k, d_idx, d_d2,
+                          d_count, s, stats ? st : nullptr));
+    if (stats)
+        for (int i = 0; i < 4; ++i) stats[i] = st[i];
     return VELO_OK;
 }
 

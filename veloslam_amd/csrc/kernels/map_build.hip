@@ -263,11 +263,14 @@ __device__ __forceinline__ void jacobi_rot(double A[3][3], double V[3][3], int p
 // Margins keep every pruning test conservative (cell membership is decided in float).
 // TIE_RAW: equal distances are ordered by the append-order index perm[j] (normals: grid
 // independent) instead of the sorted index j (velo_knn's documented order).
-template <bool TIE_RAW>
+// STATS (velo_knn_dev's counting instantiation only): n_cand += candidate points fetched (16 B each),
+// n_rows += fine rows looked up in the table (2 x 4 B dense; one 16-byte slot per cell of the row, hashed).
+template <bool TIE_RAW, bool STATS = false>
 __device__ __forceinline__ int collect_knn(const MapView& mv, const uint32_t* __restrict__ perm,
                                            float qx, float qy, float qz, float r2, int k,
                                            float (*s_d)[kNrmThreads], int (*s_i)[kNrmThreads],
-                                           int tid)
+                                           int tid, unsigned* n_cand = nullptr, unsigned* n_rows = nullptr,
+                                           unsigned* n_cells = nullptr)
 {
     auto before = [&](float d2, int j, float pd, int pi) -> bool {
         if (d2 != pd) return d2 < pd;
@@ -319,7 +322,12 @@ __device__ __forceinline__ int collect_knn(const MapView& mv, const uint32_t* __
                     if (fa > fb) continue;
                     const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
                     int j0, j1;
+                    if constexpr (STATS) {
+                        *n_rows += 1;
+                        *n_cells += (unsigned)(fb - fa + 1);
+                    }
                     if (!row_range_rt(mv, row, fa, fb, j0, j1)) continue;
+                    if constexpr (STATS) *n_cand += (unsigned)(j1 - j0);
                     // four candidate loads in flight per trip (the walk is a latency chain);
                     // a slot past the end repeats the last index and is masked
                     for (int jb = j0; jb < j1; jb += VELO_NRM_W) {
@@ -511,7 +519,10 @@ __global__ __launch_bounds__(256) void k_removed_keys(const uint32_t* __restrict
 
 // a10 with k > 1: the k nearest map points of every (transformed) query within d_max,
 // ascending (d2, sorted index); rows of idx/d2 are padded with -1 / +inf.
-template <int KMAX>
+// [0] queries, [1] candidate points fetched, [2] fine rows looked up, [3] fine cells those rows span
+__device__ unsigned long long g_knn_stats[4];
+
+template <int KMAX, bool STATS = false>
 __global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __restrict__ x,
                                                      const float* __restrict__ y,
                                                      const float* __restrict__ z, int n,
@@ -527,21 +538,38 @@ __global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __
     if (i >= n) return;
     double px, py, pz;
     xform(T, x[i], y[i], z[i], px, py, pz);
-    const int cnt = collect_knn<false>(mv, nullptr, (float)px, (float)py, (float)pz, dmax2, k, s_d,
-                                       s_i, tid);
+    unsigned nc = 0, nr = 0, ncell = 0;
+    const int cnt = collect_knn<false, STATS>(mv, nullptr, (float)px, (float)py, (float)pz, dmax2, k, s_d,
+                                              s_i, tid, &nc, &nr, &ncell);
     for (int m = 0; m < k; ++m) {
         idx[(size_t)i * k + m] = m < cnt ? s_i[m][tid] : -1;
         d2o[(size_t)i * k + m] = m < cnt ? s_d[m][tid] : INFINITY;
     }
     if (count) count[i] = cnt;
+    if constexpr (STATS) {
+        atomicAdd(&g_knn_stats[0], 1ull);
+        atomicAdd(&g_knn_stats[1], (unsigned long long)nc);
+        atomicAdd(&g_knn_stats[2], (unsigned long long)nr);
+        atomicAdd(&g_knn_stats[3], (unsigned long long)ncell);
+    }
 }
 
 hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
                       const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
-                      hipStream_t s)
+                      hipStream_t s, unsigned long long* stats_out)
 {
     if (n == 0) return hipSuccess;
     const int grid = (int)((n + kNrmThreads - 1) / kNrmThreads);
+    if (stats_out) {  // counting instantiation (widest list: the LDS footprint is not what is measured here)
+        const unsigned long long z4[4] = {0, 0, 0, 0};
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z4, sizeof z4);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_knn<VELO_MAX_KNORMALS, true>), dim3(grid), dim3(kNrmThreads), 0, s, mv, x, y, z,
+                           (int)n, T, dmax2, k, idx, d2, count);
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+        return hipMemcpyFromSymbol(stats_out, HIP_SYMBOL(g_knn_stats), sizeof z4);
+    }
     if (k <= 8)
         hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(kNrmThreads), 0, s, mv, x, y, z, (int)n, T, dmax2,
                            k, idx, d2, count);

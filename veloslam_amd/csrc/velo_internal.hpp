@@ -154,7 +154,9 @@ hipError_t launch_count_occupied_voxels(const float* x, const float* y, const fl
 
 hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
                       const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
-                      hipStream_t s);
+                      hipStream_t s, unsigned long long* stats_out = nullptr);
+// (stats_out != nullptr: the counting instantiation; waits for the stream; [0] queries, [1] candidate points
+//  fetched, [2] fine rows looked up, [3] fine cells those rows span)
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, int32_t* hint, float* rho,
