@@ -35,4 +35,12 @@ rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_E
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/stream_write -- $SD > $OUT/stream_write.json 2> $OUT/stream_write.err
 $SD > $OUT/stream_plain.json 2> $OUT/stream_plain.err
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-tail -c 400 $OUT/bench_default.json
+
+# the raw CSVs are > 64 MiB (more than gpurun carries back): summarise HERE, keep the summaries
+python3 profiles/summarize.py $R > $OUT/summarize.log 2>&1
+mkdir -p gpurun_out/summary_$R
+cp -r profiles/$R gpurun_out/summary_$R/
+cp profiles/traffic.json gpurun_out/summary_$R/traffic.json
+cp $OUT/*.json $OUT/summarize.log gpurun_out/summary_$R/ 2>/dev/null
+for f in $OUT/*.err; do tail -n 5 "$f" > gpurun_out/summary_$R/$(basename "$f").tail; done
+rm -rf $OUT

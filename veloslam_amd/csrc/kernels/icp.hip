@@ -335,6 +335,25 @@ __device__ __forceinline__ void nearest_scan(const MapView& mv, float qx, float 
 //            ball of radius sqrt(min(best, dmax2)): rows pruned by a conservative bound, the
 //            x-extent of each row cut to the ball, descending index, '<='.  Compaction keeps
 //            a handful of stragglers from stalling every wavefront of the workgroup.
+// Square roots of the search are BOUNDS, never results (distances are compared squared): radii searched, radii
+// certified, row half-widths -- each used with an explicit margin (x 1.000001 + 1e-7 upwards, x 0.999999 - 1e-6
+// downwards, 1e-5 relative on windows).  sqrtf() is the correctly rounded form, ~14 VALU instructions on gfx950
+// (v_sqrt_f32 + a Newton correction + denormal scaling); the bare instruction is good to 1 ulp (1.2e-7 relative;
+// a denormal argument may come back as 0, which the absolute terms of the margins cover), an eighth of the
+// smallest margin.  Two of them sat on the path of EVERY certified query (|q - hint|, |q - c|): 26 of the 279
+// VALU instructions of a converged wavefront-round (round 4).
+#ifndef VELO_FAST_SQRT
+#define VELO_FAST_SQRT 1
+#endif
+__device__ __forceinline__ float bsqrt(float x)
+{
+#if VELO_FAST_SQRT
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+
 constexpr int kMaxRanges = 9;
 constexpr int kLatItems = 2048;  // launches below this many workgroups use the latency kernel unless the
                                  // caller says which (registrations do: kLatQueries, plan_frames)
@@ -452,7 +471,7 @@ __device__ __forceinline__ int finish_block(float bd, float sd, float gr, float&
 {
     const bool final = bd <= gr * gr * 0.99999f;
     // second-best scanned / pruned-cell bound / block faces, rounded down
-    cert = final ? fmaxf(fminf(sqrtf(sd) * 0.999999f, gr) - 1e-6f, 0.0f) : 0.0f;
+    cert = final ? fmaxf(fminf(bsqrt(sd) * 0.999999f, gr) - 1e-6f, 0.0f) : 0.0f;
     return final ? kFinal : kStraggler;
 }
 
@@ -521,7 +540,7 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
         for (int j = jhi - 1; j >= jlo; --j) pb = fminf(pb, dist2(mv.pts[(unsigned)j], qx, qy, qz));
         tl.candidates((unsigned)max(jhi - jlo, 0));
         if (pb < ub0) {
-            const float rs = sqrtf(pb) * 1.000001f + 1e-7f + kCertSlack;
+            const float rs = bsqrt(pb) * 1.000001f + 1e-7f + kCertSlack;
             ub0 = fminf(ub0, rs * rs * 1.00001f);
         }
     }
@@ -580,14 +599,14 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
 // voxel (the row window ends there)
 __device__ __forceinline__ float cover_of(float b, float h)
 {
-    const float r = sqrtf(b) * 1.000001f + 1e-7f + kCertSlack;
+    const float r = bsqrt(b) * 1.000001f + 1e-7f + kCertSlack;
     return fminf(r * r * 1.00001f, h * h);
 }
 
 // certified radius after a ball search: second-best examined / radius covered / one voxel
 __device__ __forceinline__ float ball_certificate(float sd, float cov, float h, float mg)
 {
-    return fmaxf(fminf(sqrtf(fminf(sd, cov)) * 0.999999f, h - 2.0f * mg) - 1e-6f, 0.0f);
+    return fmaxf(fminf(bsqrt(fminf(sd, cov)) * 0.999999f, h - 2.0f * mg) - 1e-6f, 0.0f);
 }
 
 // lower bound (rounded down) of the distance from the query to fine row offset d along one axis
@@ -599,7 +618,7 @@ __device__ __forceinline__ float axis_gap(int d, float t, float hf, float mg)
 // rows of the (2R+1)^2 window a ball of squared radius b can reach (R <= S since b <= h^2)
 __device__ __forceinline__ int ball_window(float b, float inv_hf, int S)
 {
-    return min(S, (int)floorf(sqrtf(b) * 1.00001f * inv_hf + 1.001f));
+    return min(S, (int)floorf(bsqrt(b) * 1.00001f * inv_hf + 1.001f));
 }
 
 // index range of fine row (Fz+dz, Fy+dy) inside the ball of squared radius `bound` around the
@@ -615,7 +634,7 @@ __device__ __forceinline__ bool ball_row(const MapView& mv, const QueryCell& g, 
     const float rb2 = (bz * bz + by * by) * 0.99999f;
     if (rb2 > bound) return false;
     // half-width of the ball in this row, in fine cells, rounded outwards
-    const float w = (sqrtf(fmaxf(bound - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
+    const float w = (bsqrt(fmaxf(bound - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
     int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
     if (clip1) {
         x0 = max(x0, g.Fx - 1);
@@ -709,7 +728,7 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
                 if ((unsigned)(g.Fz + dz) < (unsigned)mv.fz && (unsigned)(g.Fy + dy) < (unsigned)mv.fy &&
                     !(rb2 > cov)) {
                     // half-width of the ball in this row, in fine cells, rounded outwards
-                    const float w = (sqrtf(fmaxf(cov - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
+                    const float w = (bsqrt(fmaxf(cov - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
                     const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
                     if (x0 <= x1) {
                         int jlo, jhi;
@@ -766,7 +785,7 @@ __device__ __forceinline__ void search_ball_wave(const MapView& mv, float qx, fl
                                  : fmaxf(((float)(abs(dy) - 1) + (dy > 0 ? 1.0f - g.ty : g.ty)) * hf - mg, 0.0f);
         const float rb2 = (bz * bz + by * by) * 0.99999f;
         if (rb2 > ub) continue;
-        const float w = (sqrtf(fmaxf(ub - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
+        const float w = (bsqrt(fmaxf(ub - rb2, 0.0f)) * 1.00001f + mg) * inv_hf;
         const int x0 = max((int)floorf(xf - w), 0), x1 = min((int)floorf(xf + w), mv.fx - 1);
         if (x0 > x1) continue;
         const uint32_t row = ((uint32_t)zz * (uint32_t)mv.fy + (uint32_t)yy) * (uint32_t)mv.fx;
@@ -916,7 +935,7 @@ __device__ __forceinline__ void search_ball_wave_lat(const MapView& mv, float qx
         for (int off = 32; off > 0; off >>= 1) pb = fminf(pb, __shfl_xor(pb, off, 64));
         if (pb < ub) {
             // a map point at sqrt(pb): search that far plus the certificate slack, no further
-            const float rs = sqrtf(pb) * 1.000001f + 1e-7f + kCertSlack;
+            const float rs = bsqrt(pb) * 1.000001f + 1e-7f + kCertSlack;
             ub = fminf(ub, rs * rs * 1.00001f);
             R = ball_window(ub, inv_hf, S);
         }
@@ -1056,7 +1075,7 @@ __device__ __forceinline__ void linearize_body(
                     tl.candidates(1);
                     tl.addq(rho ? 4 : 0);
                     const float d1sq = dist2(mv.pts[(unsigned)hj], qx, qy, qz);
-                    const float d1 = sqrtf(d1sq) * 1.000001f + 1e-7f;
+                    const float d1 = bsqrt(d1sq) * 1.000001f + 1e-7f;
                     if (rho) {
                         double cx, cy, cz;
                         xform(poses_prev + 12 * (size_t)it.frame, sxq, syq, szq, cx, cy, cz);
@@ -1065,7 +1084,7 @@ __device__ __forceinline__ void linearize_body(
                         // a query that has not moved at all (converged pose: bit-identical q)
                         // sees exactly last iteration's distances: the certificate holds verbatim
                         const bool still = (ex == 0.0f) && (ey == 0.0f) && (ez == 0.0f);
-                        const float delta = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * 1.000001f + 1e-7f;
+                        const float delta = bsqrt(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * 1.000001f + 1e-7f;
                         const float room = still ? rho_in : (rho_in - delta) * 0.999999f - 1e-7f;
                         if (d1 < room) {
                             certified = true;
@@ -1128,7 +1147,7 @@ __device__ __forceinline__ void linearize_body(
                     // the ball is searched a little beyond the bound (never past one voxel:
                     // the row window covers that) so that the outcome certifies a radius and
                     // a far-off correspondence is not searched again at every iteration
-                    const float rsq = sqrtf(__shfl(bd, src, 64)) + kCertSlack;
+                    const float rsq = bsqrt(__shfl(bd, src, 64)) + kCertSlack;
                     const float sub = fminf(rsq * rsq, mv.h * mv.h);
                     float rbd, rsd;
                     int rbj;
@@ -1143,7 +1162,7 @@ __device__ __forceinline__ void linearize_body(
                         // the cell-assignment rounding everywhere else)
                         const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
                         if (bj >= 0)
-                            rho_new_out = fmaxf(fminf(sqrtf(rsd) * 0.999999f, mv.h - 2.0f * mg) - 1e-6f, 0.0f);
+                            rho_new_out = fmaxf(fminf(bsqrt(rsd) * 0.999999f, mv.h - 2.0f * mg) - 1e-6f, 0.0f);
                     }
                 }
             }
@@ -1151,7 +1170,14 @@ __device__ __forceinline__ void linearize_body(
             xform(T, sxq, syq, szq, px, py, pz);
             nearest_scan(mv, (float)px, (float)py, (float)pz, bd, bj);
         }
-        double J0 = 0, J1 = 0, J2 = 0, J3 = 0, J4 = 0, J5 = 0, r = 0, valid = 0;
+        // The wavefront's tile {J0..J5, r, valid}[lane] is written INSIDE the branch that computes it, and a
+        // lane without a contribution writes zeros in a branch of its own: with the eight values carried out
+        // of the nested conditions as variables the compiler zero-initialised them three times over (24
+        // v_mov_b64 per wavefront-round, round 4 ISA reading) before the common stores.
+        // (The wavefront's own search ranges are dead here: its tile may overwrite them.  DS operations of one
+        // wavefront execute in order; the fences only pin the compiler.)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        bool contributes = false;
         if (live) {
             const bool ok = (bj >= 0) && (bd <= dmax2);
             // (a certified, unmoved query with a still-valid match keeps its state: no stores)
@@ -1182,28 +1208,26 @@ __device__ __forceinline__ void linearize_body(
                     const double nx = nf.x, ny = nf.y, nz = nf.z;
                     const double dx = px - (double)mf.x, dy = py - (double)mf.y,
                                  dz = pz - (double)mf.z;
-                    r = fma(nx, dx, fma(ny, dy, nz * dz));
-                    J0 = fma(py, nz, -(pz * ny));
-                    J1 = fma(pz, nx, -(px * nz));
-                    J2 = fma(px, ny, -(py * nx));
-                    J3 = nx;
-                    J4 = ny;
-                    J5 = nz;
-                    valid = 1.0;
+                    s_u.r.v[6][lane] = fma(nx, dx, fma(ny, dy, nz * dz));
+                    s_u.r.v[0][lane] = fma(py, nz, -(pz * ny));
+                    s_u.r.v[1][lane] = fma(pz, nx, -(px * nz));
+                    s_u.r.v[2][lane] = fma(px, ny, -(py * nx));
+                    s_u.r.v[3][lane] = nx;
+                    s_u.r.v[4][lane] = ny;
+                    s_u.r.v[5][lane] = nz;
+                    s_u.r.v[7][lane] = 1.0;
+                    contributes = true;
+                    asm volatile("" ::: "memory");  // (keeps these stores in this branch)
                 }
             }
         }
-        // the wavefront's own search ranges are dead: its tile may overwrite them.  DS
-        // operations of one wavefront execute in order; the fences only pin the compiler.
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        s_u.r.v[0][lane] = J0;
-        s_u.r.v[1][lane] = J1;
-        s_u.r.v[2][lane] = J2;
-        s_u.r.v[3][lane] = J3;
-        s_u.r.v[4][lane] = J4;
-        s_u.r.v[5][lane] = J5;
-        s_u.r.v[6][lane] = r;
-        s_u.r.v[7][lane] = valid;
+        if (!contributes) {
+            double zero = 0.0;
+            asm volatile("" : "+v"(zero));  // one register pair for all eight stores
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) s_u.r.v[k8][lane] = zero;
+            asm volatile("" ::: "memory");
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (col < kAccN) {
             const int e0 = half * 32;
