@@ -40,7 +40,7 @@ typedef enum { ncclInt32 = 2, ncclFloat32 = 7 } ncclDataType_t;
 #define VELO_ORDER_CONV 0
 #endif
 #ifndef VELO_LATE_ROUNDS
-#define VELO_LATE_ROUNDS 3
+#define VELO_LATE_ROUNDS 4  // (a power of two <= 4 since round 4: items are aligned nodes of the frame's summation tree)
 #endif
 #ifndef VELO_LAT_SPARSE_MIN_S
 #define VELO_LAT_SPARSE_MIN_S 4
@@ -55,7 +55,7 @@ typedef enum { ncclInt32 = 2, ncclFloat32 = 7 } ncclDataType_t;
 #define VELO_MIN_SLOT_ROUNDS 2.5
 #endif
 #ifndef VELO_CONV_ROUNDS
-#define VELO_CONV_ROUNDS 6
+#define VELO_CONV_ROUNDS 4  // (was 6: converged launch 68 us against ~70; see VELO_LATE_ROUNDS)
 #endif
 #ifndef VELO_CONV_FROM
 #define VELO_CONV_FROM 5
@@ -204,6 +204,9 @@ struct velo_ctx {
     // workgroup (plan_frames); ni_late == 0 = not in use
     DevBuf<BlockItem> items_late;
     DevBuf<int32_t> fbs_late;
+    DevBuf<RowLayout> lay, lay_late, lay_conv;   // per frame: how its rows tile the summation tree (k_reduce_solve)
+    RowLayout lay0_h{}, lay0_late_h{}, lay0_conv_h{};  // frame 0's, by value with the launch
+    std::vector<RowLayout> plan_lay_h, plan_lay2_h;
     int ni_late = 0;
     // third decomposition, for the iterations from VELO_CONV_FROM on (hardly any query searches
     // any more: coarser items)
@@ -875,8 +878,9 @@ std::vector<BlockItem> launch_order(const std::vector<BlockItem>& items, int mod
 int rounds_per_wave(const velo_ctx* c, int64_t n_queries, int r_max)
 {
     const double wave_rounds = (double)n_queries / 64.0;
-    int r = r_max;
-    while (r > 1 && wave_rounds / r < VELO_MIN_SLOT_ROUNDS * (double)c->wave_slots) --r;
+    int r = 1;
+    while (r * 2 <= std::min(r_max, 4)) r *= 2;  // 1 / 2 / 4: an item is an aligned node of the summation tree
+    while (r > 1 && wave_rounds / r < VELO_MIN_SLOT_ROUNDS * (double)c->wave_slots) r >>= 1;
     return r;
 }
 
@@ -919,34 +923,52 @@ int plan_flush(velo_ctx* c)
     return VELO_OK;
 }
 
+static int log2i(int v)
+{
+    int l = 0;
+    while ((1 << (l + 1)) <= v) ++l;
+    return l;
+}
+
 int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, int rounds, int tail_pct,
-                       int order, DevBuf<BlockItem>& d_items, DevBuf<int32_t>& d_fbs, int& n_out)
+                       int order, DevBuf<BlockItem>& d_items, DevBuf<int32_t>& d_fbs, DevBuf<RowLayout>& d_lay,
+                       RowLayout& lay0, std::vector<RowLayout>& lay_h, int& n_out)
 {
     std::vector<BlockItem> big, tail;
     std::vector<int32_t> fbl((size_t)n_frames + 1, 0);
-    const int per_big = kLinNT * rounds;
+    lay_h.assign((size_t)n_frames, RowLayout{0, 0, 0, 0});
+    const int per_big = kLinNT * rounds;   // rounds: 1 / 2 / 4 (rounds_per_wave)
+    const int32_t rbits = (int32_t)((uint32_t)log2i(rounds) << kItemRowBits);
     int32_t slot = 0;
     for (int f = 0; f < n_frames; ++f) {
         fbl[f] = slot;
         const int64_t nqf = frame_start[f + 1] - frame_start[f];
+        // (both regions start at multiples of their item size from the frame's first query: every item is an
+        // aligned node of the frame's summation tree)
         const int64_t big_end = frame_start[f] + (nqf * (100 - tail_pct) / 100) / per_big * per_big;
+        int nbig = 0;
         for (int64_t q = frame_start[f]; q < frame_start[f + 1];) {
             const int64_t step = q < big_end ? per_big : kLinNT;
             BlockItem it;
             it.frame = f;
             it.q0 = (int32_t)q;
             it.q1 = (int32_t)std::min<int64_t>(q + step, frame_start[f + 1]);
-            it.slot = slot++;
+            it.slot = slot++ | (q < big_end ? rbits : 0);
+            nbig += q < big_end ? 1 : 0;
             (q < big_end ? big : tail).push_back(it);
             q += step;
         }
+        lay_h[(size_t)f] = RowLayout{0, nbig, log2i(rounds), (int32_t)((nqf + kLinNT - 1) / kLinNT)};
     }
     fbl[n_frames] = slot;
+    if (slot >= (1 << kItemRowBits)) return c->fail(VELO_E_RANGE, "too many work items");
     big = launch_order(big, order);
     tail = launch_order(tail, order);
     big.insert(big.end(), tail.begin(), tail.end());
     if (int rc = plan_add(c, d_items, big.data(), big.size())) return rc;
     if (int rc = plan_add(c, d_fbs, fbl.data(), fbl.size())) return rc;
+    if (int rc = plan_add(c, d_lay, lay_h.data(), lay_h.size())) return rc;
+    lay0 = lay_h[0];
     n_out = (int)big.size();
     return VELO_OK;
 }
@@ -957,22 +979,25 @@ struct Decomposition {
     const int32_t* fbs;
     int n;
     int lat_lanes;  // latency kernel: queries per wavefront the items are cut for
+    const RowLayout* lay;   // device, per frame
+    const RowLayout* lay0;  // host, frame 0's
 };
 
 Decomposition decomposition_for(velo_ctx* c, int it, bool hinted, bool sorted_queries)
 {
     if (sorted_queries)
         return {c->cfg.sort_frames == 1 ? c->items_xcd.p : c->items_first.p, c->fbs.p, (int)c->items_h.size(),
-                c->lat_first_lanes};
-    if (it >= VELO_CONV_FROM && c->ni_conv > 0 && hinted) return {c->items_conv.p, c->fbs_conv.p, c->ni_conv, 64};
-    if (it > 0 && c->ni_late > 0 && hinted) return {c->items_late.p, c->fbs_late.p, c->ni_late, 64};
+                c->lat_first_lanes, c->lay.p, &c->lay0_h};
+    if (it >= VELO_CONV_FROM && c->ni_conv > 0 && hinted)
+        return {c->items_conv.p, c->fbs_conv.p, c->ni_conv, 64, c->lay_conv.p, &c->lay0_conv_h};
+    if (it > 0 && c->ni_late > 0 && hinted) return {c->items_late.p, c->fbs_late.p, c->ni_late, 64, c->lay_late.p, &c->lay0_late_h};
     // latency kernel, sparse first iteration: it pays where stragglers are expensive -- fine cells
     // full of points (S >= 4: first launch 304 -> 132 us on a 9 M-point map); on a light map (S = 3,
     // 1 M points) the 13 us it saves are less than the eight times as many partial rows cost the
     // solve: there the 256-query items serve every iteration
     if (c->plan_lat && c->lat_first_lanes < 64 && c->ni_late > 0 && c->mv.S < VELO_LAT_SPARSE_MIN_S)
-        return {c->items_late.p, c->fbs_late.p, c->ni_late, 64};
-    return {c->items_first.p, c->fbs.p, (int)c->items_h.size(), c->lat_first_lanes};
+        return {c->items_late.p, c->fbs_late.p, c->ni_late, 64, c->lay_late.p, &c->lay0_late_h};
+    return {c->items_first.p, c->fbs.p, (int)c->items_h.size(), c->lat_first_lanes, c->lay.p, &c->lay0_h};
 }
 
 int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
@@ -996,43 +1021,65 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     c->frame_start.assign(frame_start, frame_start + n_frames + 1);
     c->items_h.clear();
     c->fbs_h.assign((size_t)n_frames + 1, 0);
-    // rounds of 256 queries per workgroup.  Measured on config 2 (16 x 115 200 queries): 1 round
-    // = 60 us per launch, 2 = 66, 4 = 70 -- more, smaller workgroups balance better than the
-    // start-up they cost, so the default is one round; cfg.rounds_per_block overrides.
-    int rounds = 1;
-    if (c->cfg.rounds_per_block > 0) rounds = std::min(c->cfg.rounds_per_block, 64);
-    int per_block = kLinThreads * rounds;
     // Which kernel the registrations of these frames run on: fewer than kLatQueries queries (~4
     // frames) leave most of the chip idle -- a latency problem, 256-query items for the latency
-    // kernel.  Otherwise the throughput kernel (workgroups of kLinNT threads), whose items are
-    // sized in rounds per wavefront (rounds_per_wave): up to 4 in the first, unhinted iteration.
+    // kernel (which exists for the ball search only).  Otherwise the throughput kernel (workgroups of
+    // kLinNT threads), whose items are sized in rounds per wavefront (rounds_per_wave): up to 4 in
+    // the first, unhinted iteration.
     const int64_t total_q = frame_start[n_frames];
-    c->plan_lat = c->cfg.force_kernel == 2 || (c->cfg.force_kernel != 1 && total_q < kLatQueries);
+    c->plan_lat = c->cfg.linearize_variant == VELO_VARIANT_BALL &&
+                  (c->cfg.force_kernel == 2 || (c->cfg.force_kernel != 1 && total_q < kLatQueries));
+    const int nt = c->plan_lat ? kLinThreads : kLinNT;  // threads of the workgroups these items are cut for
+    // Every item is an ALIGNED NODE of its frame's summation tree (kernels/icp.hip, linearize_body): nt x R
+    // queries, R = rounds per wavefront in {1, 2, 4}, starting a multiple of that from the frame's first query.
+    // cfg.rounds_per_block (rounds of 256 queries per item, tuning / tests) is rounded down to such a size.
+    int R = 1;
+    if (c->cfg.rounds_per_block > 0) {
+        const int want = std::min(c->cfg.rounds_per_block, 64) * kLinThreads / nt;
+        while (R * 2 <= std::min(want, 4)) R *= 2;
+    }
     const bool planned = c->cfg.rounds_per_block <= 0 && !c->plan_lat;
-    if (planned) per_block = kLinNT * rounds_per_wave(c, total_q, VELO_FIRST_ROUNDS);
+    if (planned) R = rounds_per_wave(c, total_q, VELO_FIRST_ROUNDS);
+    int per_block = nt * R;
     // latency kernel: the first iteration runs kLatFirstLanes queries per wavefront (one round per
     // item), the hinted ones all 64 -- a second, 256-query decomposition below
     const bool lat_sparse = c->plan_lat && c->cfg.rounds_per_block <= 0 && kLatFirstLanes < 64;
     c->lat_first_lanes = lat_sparse ? kLatFirstLanes : 64;
-    if (lat_sparse) per_block = (kLinThreads / 64) * kLatFirstLanes;
+    if (lat_sparse) {
+        R = 1;
+        per_block = (kLinThreads / 64) * kLatFirstLanes;
+    }
+    const int32_t rbits = (int32_t)((uint32_t)log2i(R) << kItemRowBits);
+    std::vector<RowLayout>& lay_h = c->plan_lay_h;
+    lay_h.assign((size_t)n_frames, RowLayout{0, 0, 0, 0});
     for (int f = 0; f < n_frames; ++f) {
         c->fbs_h[f] = (int32_t)c->items_h.size();
         // (planned: the head of every frame in one-round items -- launched item-major from the
-        // ends of the frames backwards, those are the last workgroups of the launch)
+        // ends of the frames backwards, those are the last workgroups of the launch; the head ends on a
+        // multiple of the large item size, so that the large items are aligned too)
         const int64_t nqf = frame_start[f + 1] - frame_start[f];
-        const int64_t head_end = planned ? frame_start[f] + nqf * VELO_FIRST_HEAD_PCT / 100 / kLinNT * kLinNT
+        const int64_t head_end = planned ? frame_start[f] + nqf * VELO_FIRST_HEAD_PCT / 100 / per_block * per_block
                                          : frame_start[f];
+        int nbig = 0;
         for (int64_t q = frame_start[f]; q < frame_start[f + 1];) {
             const int64_t step = q < head_end ? kLinNT : per_block;
             BlockItem it;
             it.frame = f;
             it.q0 = (int32_t)q;
             it.q1 = (int32_t)std::min<int64_t>(q + step, frame_start[f + 1]);
-            it.slot = (int32_t)c->items_h.size();
+            it.slot = (int32_t)c->items_h.size() | (q < head_end ? 0 : rbits);
+            nbig += q < head_end ? 0 : 1;
             c->items_h.push_back(it);
             q += step;
         }
+        if (planned)   // head small rows (kLinNT queries), then large ones: slots of kLinNT queries
+            lay_h[(size_t)f] = RowLayout{(int32_t)((head_end - frame_start[f]) / kLinNT), nbig, log2i(R),
+                                         (int32_t)((nqf + kLinNT - 1) / kLinNT)};
+        else           // uniform rows: one slot each
+            lay_h[(size_t)f] = RowLayout{0, 0, 0, nbig};
     }
+    if (c->items_h.size() >= ((size_t)1 << kItemRowBits)) return c->fail(VELO_E_RANGE, "too many work items");
+    c->lay0_h = lay_h[0];
     c->fbs_h[n_frames] = (int32_t)c->items_h.size();
     const size_t ni = c->items_h.size();
     // The hinted iterations of a batch run on coarser items: their work is even (hinted /
@@ -1046,10 +1093,12 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     size_t max_rows = std::max<size_t>(ni, 1);
     if (planned) {
         if (int rc = plan_decomposition(c, frame_start, n_frames, rounds_per_wave(c, total_q, VELO_LATE_ROUNDS),
-                                        VELO_LATE_TAIL_PCT, VELO_ORDER_LATE, c->items_late, c->fbs_late, c->ni_late))
+                                        VELO_LATE_TAIL_PCT, VELO_ORDER_LATE, c->items_late, c->fbs_late, c->lay_late,
+                                        c->lay0_late_h, c->plan_lay2_h, c->ni_late))
             return rc;
         if (int rc = plan_decomposition(c, frame_start, n_frames, rounds_per_wave(c, total_q, VELO_CONV_ROUNDS),
-                                        VELO_CONV_TAIL_PCT, VELO_ORDER_CONV, c->items_conv, c->fbs_conv, c->ni_conv))
+                                        VELO_CONV_TAIL_PCT, VELO_ORDER_CONV, c->items_conv, c->fbs_conv, c->lay_conv,
+                                        c->lay0_conv_h, c->plan_lay2_h, c->ni_conv))
             return rc;
         max_rows = std::max(max_rows, (size_t)std::max(c->ni_late, c->ni_conv));
     }
@@ -1071,8 +1120,13 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
         }
         fbl[n_frames] = (int32_t)late.size();
         if (!late.empty()) {
+            std::vector<RowLayout>& l2 = c->plan_lay2_h;   // uniform 256-query rows: one slot each
+            l2.assign((size_t)n_frames, RowLayout{0, 0, 0, 0});
+            for (int f = 0; f < n_frames; ++f) l2[(size_t)f].nslots = fbl[f + 1] - fbl[f];
             if (int rc = plan_add(c, c->items_late, late.data(), late.size())) return rc;
             if (int rc = plan_add(c, c->fbs_late, fbl.data(), fbl.size())) return rc;
+            if (int rc = plan_add(c, c->lay_late, l2.data(), l2.size())) return rc;
+            c->lay0_late_h = l2[0];
             c->ni_late = (int)late.size();
         }
     }
@@ -1108,6 +1162,7 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
         if (int rc = plan_add(c, c->items_xcd, xcd.data(), ni)) return rc;
     }
     if (int rc = plan_add(c, c->fbs, c->fbs_h.data(), (size_t)n_frames + 1)) return rc;
+    if (int rc = plan_add(c, c->lay, lay_h.data(), lay_h.size())) return rc;
     if (int rc = plan_add(c, c->d_frame_start, c->frame_start.data(), (size_t)n_frames + 1)) return rc;
     // one copy for all of the above; its source is the pinned stage, free again at ev_plan
     if (int rc = plan_flush(c)) return rc;
@@ -1280,9 +1335,9 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
                                      it == 0 ? nullptr : c->poses_prev.p,  // (first iteration: stale hints)
                                      false, c->plan_lat ? 2 : 1, s, dc.lat_lanes);
                 if (e == hipSuccess)
-                    e = launch_reduce_solve(c->partials.p, dc.fbs, c->n_frames, c->poses.p,
+                    e = launch_reduce_solve(c->partials.p, dc.fbs, dc.lay, c->n_frames, c->poses.p,
                                             c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
-                                            c->pairs_total.p, s, (int)(c->partials.cap / kAccStride));
+                                            c->pairs_total.p, s, (int)(c->partials.cap / kAccStride), dc.lay0);
             }
             hipGraph_t g = nullptr;
             hipError_t e2 = hipStreamEndCapture(s, &g);
@@ -1319,9 +1374,9 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         }
         {
             Timed t(c, 1);
-            HIP_TRY(c, launch_reduce_solve(c->partials.p, dc.fbs, c->n_frames, c->poses.p,
+            HIP_TRY(c, launch_reduce_solve(c->partials.p, dc.fbs, dc.lay, c->n_frames, c->poses.p,
                                            c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
-                                           c->pairs_total.p, s, (int)(c->partials.cap / kAccStride)));
+                                           c->pairs_total.p, s, (int)(c->partials.cap / kAccStride), dc.lay0));
         }
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev_call1, s));
@@ -2255,7 +2310,7 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
                                 // (the frames are cut for one kernel: say which, item counts no longer do)
                                 c->cfg.linearize_variant == VELO_VARIANT_BALL ? (c->plan_lat ? 2 : 1) : c->cfg.force_kernel,
                                 s, c->lat_first_lanes));
-    HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p + frame, 1, c->poses.p, nullptr, 0, 1,
+    HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p + frame, c->lay.p + frame, 1, c->poses.p, nullptr, 0, 1,
                                    c->acc.p, 0, nullptr, nullptr, s));
     if (corr)
         HIP_TRY(c, hipMemcpyAsync(corr, c->corr.p + q0, (q1 - q0) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -2278,10 +2333,14 @@ int velo_solve_update(velo_ctx* c, const double acc[29], double T[12], int32_t* 
     hipStream_t s = c->stream;
     DevBuf<double> part, pose;
     DevBuf<int32_t> fbs;
+    DevBuf<RowLayout> lay;
     DevBuf<velo_icp_iter> st;
     HIP_TRY(c, part.reserve(kAccStride));
     HIP_TRY(c, pose.reserve(12));
     HIP_TRY(c, fbs.reserve(2));
+    HIP_TRY(c, lay.reserve(1));
+    const RowLayout one{0, 0, 0, 1};  // one row: the root
+    HIP_TRY(c, hipMemcpyAsync(lay.p, &one, sizeof one, hipMemcpyHostToDevice, s));
     HIP_TRY(c, st.reserve(VELO_MAX_ITERS));
     double row[kAccStride] = {0};
     std::memcpy(row, acc, kAccN * sizeof(double));
@@ -2290,7 +2349,7 @@ int velo_solve_update(velo_ctx* c, const double acc[29], double T[12], int32_t* 
     HIP_TRY(c, hipMemcpyAsync(pose.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(fbs.p, range, sizeof range, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));  // the sources are stack arrays
-    HIP_TRY(c, launch_reduce_solve(part.p, fbs.p, 1, pose.p, st.p, 0, 1, nullptr, 1, nullptr, nullptr, s));
+    HIP_TRY(c, launch_reduce_solve(part.p, fbs.p, lay.p, 1, pose.p, st.p, 0, 1, nullptr, 1, nullptr, nullptr, s));
     velo_icp_iter it0;
     HIP_TRY(c, hipMemcpyAsync(T, pose.p, 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&it0, st.p, sizeof it0, hipMemcpyDeviceToHost, s));

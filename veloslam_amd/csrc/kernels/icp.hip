@@ -1008,17 +1008,17 @@ __device__ __forceinline__ void linearize_body(
     const BlockItem* __restrict__ items, const FrameView& fv, const MapView& mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
     int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint,
-    float* __restrict__ rho, const double* __restrict__ poses_prev, LinLds* s_uw, double (*s_w)[32],
+    float* __restrict__ rho, const double* __restrict__ poses_prev, LinLds* s_uw, double (*s_run)[2][64],
     int lat_lanes = 64)
 {
     const BlockItem it = items[blockIdx.x];
     const double* __restrict__ T = poses + 12 * (size_t)it.frame;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    // (the wavefront index is uniform: as a scalar it keeps the round loop's bookkeeping out of the VGPRs)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
     LinLds& s_u = s_uw[wave];
     const int ia = c_ia[col], ib = c_ib[col];
-    double colsum = 0.0;
     Tally<STATS> tl;
     if constexpr (STATS) {
         if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_lin_stats[11], 1ull);
@@ -1030,10 +1030,30 @@ __device__ __forceinline__ void linearize_body(
     // lock-step: in the first iteration (a fifth of the queries are stragglers on a dense map) 8
     // queries per wavefront put eight times as many searches in flight -- first launch 304 -> 132 us
     // on a 9 M-point map, 80 -> 62 on 1 M; later iterations use all 64 lanes (9 us against 15).
-    const int qpr = LAT ? (NT / 64) * lat_lanes : NT;  // queries per round of the workgroup
-    for (int base = it.q0; base < it.q1; base += qpr) {
-        const int q = LAT ? base + wave * lat_lanes + lane : base + tid;
-        const bool live = q < it.q1 && (!LAT || lane < lat_lanes);
+    //
+    // CANONICAL SUMMATION (round 4; DESIGN.md "ICP semantics", Reduction).  The 29 sums of a frame are defined
+    // as an aligned binary tree over LEAVES of 8 consecutive queries of the frame (leaf = one fma chain from
+    // +0.0 over its entries in order; a node = left child + right child; a child beyond the end of the frame
+    // is +0.0).  A work item covers an aligned block of 2^m leaves and writes that node; how a frame is cut
+    // into items (rounds per wavefront, which kernel, how many frames share the launch, how many CUs the
+    // planner assumed) no longer touches a single bit of the frame's sums, hence of its poses.
+    //   wavefront w of an item: the aligned block of 64 R queries at q0 + w 64 R (R = rounds per wavefront,
+    //   1 / 2 / 4, in the top bits of `slot`), 64 consecutive queries per round: each half-wavefront's 32
+    //   entries are four chains of 8 (leaves) joined as (c0 + c1) + (c2 + c3), the two halves by one cross-lane
+    //   exchange (lower + upper); the R rounds are joined by the same tree (running and parked node in LDS);
+    //   wavefronts through LDS, pairwise.
+    //   Sparse first iteration of the latency kernel (lat_lanes of 8 / 16 / 32): lanes 0 .. lat_lanes-1 of
+    //   wavefront w hold the queries q0 + w lat_lanes + lane -- a leaf (or two, four) per wavefront.
+    const int logR = (int)((unsigned)it.slot >> 28);
+    const int R = 1 << logR;
+    const int row_out = it.slot & 0x0fffffff;
+    const bool sparse = LAT && lat_lanes < 64;
+    const int wblock = sparse ? it.q0 + wave * lat_lanes : it.q0 + wave * (64 * R);  // (wavefront-uniform)
+    int rounds_done = 0;
+    for (int rr = 0; rr < R; ++rr) {
+        if (wblock + rr * 64 >= it.q1) break;  // nothing left for this wavefront (zeros change no sum)
+        const int q = wblock + rr * 64 + lane;  // 64 consecutive queries per round: neighbours on the scan line
+        const bool live = q < it.q1 && (!sparse || lane < lat_lanes);
         const unsigned uq = (unsigned)q;  // (never negative: no sign extension in the addressing)
         float sxq = 0.f, syq = 0.f, szq = 0.f;
         int hj = -1;
@@ -1231,11 +1251,52 @@ __device__ __forceinline__ void linearize_body(
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (col < kAccN) {
             const int e0 = half * 32;
-#pragma unroll 8
-            for (int e = 0; e < 32; ++e)
-                colsum = fma(s_u.r.v[ia][e0 + e], s_u.r.v[ib][e0 + e], colsum);
+            // four leaves of 8 queries, one after the other (all four at once would keep 32 16-byte LDS
+            // reads in flight: 80 bytes of scratch per lane at this kernel's 72 registers)
+            auto leaf = [&](int eb) {
+                double cs = 0.0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs = fma(s_u.r.v[ia][eb + e], s_u.r.v[ib][eb + e], cs);
+                return cs;
+            };
+            double hsum = leaf(e0) + leaf(e0 + 8);
+            asm volatile("" : "+v"(hsum));  // (the second pair's reads start after the first pair is summed)
+            const double hs2 = leaf(e0 + 16) + leaf(e0 + 24);
+            hsum = hsum + hs2;
+            // the two half-wavefronts of a round hold the two 32-query nodes of one 64-query node: joined here
+            // (lower + upper, computed on both sides), so that a round stays 64 CONSECUTIVE queries -- with the
+            // halves on separate 128-query runs the unhinted launch lost 14 % (392 against 344 us)
+            {
+                // v_permlane32_swap (gfx950): (a, b) -> a' = {a[0..31], b[0..31]}, b' = {a[32..63], b[32..63]};
+                // with a = b = x every lane gets the lower half's value in a' and the upper half's in b'
+                const unsigned long long xb = (unsigned long long)__double_as_longlong(hsum);
+                const unsigned xl = (unsigned)xb, xh = (unsigned)(xb >> 32);
+                const auto pl = __builtin_amdgcn_permlane32_swap(xl, xl, false, false);
+                const auto ph = __builtin_amdgcn_permlane32_swap(xh, xh, false, false);
+                const double lower = __longlong_as_double((long long)(((unsigned long long)ph[0] << 32) | pl[0]));
+                const double upper = __longlong_as_double((long long)(((unsigned long long)ph[1] << 32) | pl[1]));
+                hsum = lower + upper;
+            }
+            // the rounds of this half-wavefront, joined by the same aligned tree (rr is uniform).  The running
+            // node and the parked one live in LDS, 16 bytes per lane and round against the 32 KB the column
+            // sums read: in a register pair the running node was the one value too many (8 bytes of scratch)
+            if (rr & 1) {
+                double t = s_run[wave][0][lane] + hsum;
+                if (rr & 2) t = s_run[wave][1][lane] + t;
+                s_run[wave][0][lane] = t;
+            } else {
+                if (rr & 2) s_run[wave][1][lane] = s_run[wave][0][lane];
+                s_run[wave][0][lane] = hsum;
+            }
         }
+        rounds_done = rr + 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    double colsum = 0.0;
+    if (col < kAccN && rounds_done > 0) {
+        colsum = s_run[wave][0][lane];
+        // a wavefront that ran out of queries after its third round of four still holds (u0 + u1) parked
+        if (rounds_done == 3) colsum = s_run[wave][1][lane] + colsum;
     }
     if constexpr (STATS) {
         stat_add(8, tl.bytes);
@@ -1243,15 +1304,15 @@ __device__ __forceinline__ void linearize_body(
         stat_add(10, tl.tab);
         stat_add(12, tl.qbytes);
     }
-    // halves -> wave (shuffle), waves -> block (LDS), fixed order
-    const double other = __shfl_down(colsum, 32, 64);
-    if (half == 0) s_w[wave][col] = colsum + other;
+    // halves -> wave (shuffle), waves -> block (LDS): the next levels of the same tree
+    if (half == 0) s_run[wave][1][col] = colsum;  // (the parked level is free again)
     __syncthreads();
     if (tid < kAccN) {
-        double t = s_w[0][tid];
-#pragma unroll
-        for (int w = 1; w < NT / 64; ++w) t += s_w[w][tid];
-        partials[(size_t)it.slot * kAccStride + tid] = t;
+        static_assert(NT == 64 || NT == 128 || NT == 256, "one, two or four wavefronts per work item");
+        double t = s_run[0][1][tid];
+        if constexpr (NT >= 128) t = t + s_run[1][1][tid];
+        if constexpr (NT == 256) t = t + (s_run[2][1][tid] + s_run[3][1][tid]);
+        partials[(size_t)row_out * kAccStride + tid] = t;
     }
 }
 
@@ -1264,9 +1325,9 @@ __global__ __launch_bounds__(kLinNT, (HASH ? VELO_LIN_WAVES - 1 : VELO_LIN_WAVES
     float* __restrict__ rho, const double* __restrict__ poses_prev)
 {
     __shared__ LinLds s_uw[kLinNT / 64];
-    __shared__ double s_w[kLinNT / 64][32];
+    __shared__ double s_run[kLinNT / 64][2][64];
     linearize_body<WRITE_CORR, VARIANT, STATS, false, HASH, kLinNT>(items, fv, mv, poses, dmax2, partials, corr,
-                                                                    d2out, hint, rho, poses_prev, s_uw, s_w);
+                                                                    d2out, hint, rho, poses_prev, s_uw, s_run);
 }
 
 template <bool WRITE_CORR, bool STATS, bool HASH = false>
@@ -1277,9 +1338,9 @@ __global__ __launch_bounds__(kLinThreads, 4) void k_linearize_lat(
     float* __restrict__ rho, const double* __restrict__ poses_prev, int lat_lanes)
 {
     __shared__ LinLds s_uw[kLinThreads / 64];
-    __shared__ double s_w[4][32];
+    __shared__ double s_run[kLinThreads / 64][2][64];
     linearize_body<WRITE_CORR, 1, STATS, true, HASH, kLinThreads>(items, fv, mv, poses, dmax2, partials, corr,
-                                                                  d2out, hint, rho, poses_prev, s_uw, s_w, lat_lanes);
+                                                                  d2out, hint, rho, poses_prev, s_uw, s_run, lat_lanes);
 }
 
 hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)
@@ -1455,71 +1516,94 @@ __device__ void se3_exp_apply(const double* xi, double* T)
     for (int i = 0; i < 12; ++i) T[i] = N[i];
 }
 
-// One 1024-thread workgroup per frame.  Thread (g = tid/32, k = tid%32) sums column k of the
-// blocks b0+g, b0+g+32, ... (32 independent load streams per column instead of one serial
-// chain over hundreds of partials); the group sums are then added in ascending g: a fixed
-// order, so the result is run-to-run bit reproducible.
+// One 1024-thread workgroup per frame: the upper levels of the frame's CANONICAL tree (see linearize_body).
+// A frame's rows are aligned nodes of that tree, in frame order, of two sizes at most: `head` small rows,
+// `nbig` rows 2^mlog times as large, small rows again to the end (the planner's one-round items in front of /
+// behind the large ones; a uniform decomposition is head = 0, mlog = 0).  On the grid of SMALL nodes ("slots")
+// a large row sits in the first slot of its block and the others are +0.0 -- x + 0.0 = x, so the aligned
+// binary tree over the slots is the frame's tree whatever the row sizes were.  Thread (g = tid / 32,
+// k = tid % 32) reduces column k of the B consecutive slots g B .. (g + 1) B - 1 (B = a power of two >= 16
+// with 32 B >= slots): 16 loads in flight per trip (one trip for a single frame's 450 rows), a fixed tree
+// over the 16, trips joined through a carry stack in LDS (trip c joins as the binary counter c says);
+// then the 32 group nodes pairwise.  Nothing here depends on how many rows there are per slot, per group or
+// per launch -- only on the queries of the frame.
 #ifndef VELO_SOLVE_SPEC
 #define VELO_SOLVE_SPEC 1
 #endif
 constexpr int kSolveThreads = 1024;
 constexpr int kSolveGroups = kSolveThreads / 32;
+constexpr int kSolveStack = 8;  // trips per group <= 2^8: 32 x 16 x 256 slots per frame
+
+__device__ __forceinline__ int slot_row(int slot, int head, int nbig, int mlog, int nrows)
+{
+    int row;
+    if (slot < head) {
+        row = slot;
+    } else {
+        const int d = slot - head;
+        if (d < (nbig << mlog))
+            row = (d & ((1 << mlog) - 1)) == 0 ? head + (d >> mlog) : -1;
+        else
+            row = head + nbig + (d - (nbig << mlog));
+    }
+    return row < nrows ? row : -1;
+}
+
 __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
-    const double* __restrict__ partials, const int32_t* __restrict__ fbs,
+    const double* __restrict__ partials, const int32_t* __restrict__ fbs, const int4* __restrict__ layout,
     double* __restrict__ poses, velo_icp_iter* __restrict__ stats, int iter,
     double* __restrict__ acc_out, int do_update, double* __restrict__ poses_prev,
-    unsigned long long* __restrict__ pairs_total, int spec_rows)
+    unsigned long long* __restrict__ pairs_total, int spec_rows, int4 lay0)
 {
     __shared__ double s_g[kSolveGroups][32];
     __shared__ double s_acc[32];
     __shared__ double s_pose[12];
+    __shared__ double s_stack[kSolveStack][kSolveThreads];
     const int f = blockIdx.x, k = threadIdx.x & 31, g = threadIdx.x >> 5;
     // the frame's pose travels with the partial sums (one memory round trip, not two in a row)
     double pose_k = 0.0;
     if (threadIdx.x < 12) pose_k = poses[12 * (size_t)f + threadIdx.x];
     {
-        // The kernel is a chain of memory round trips, not bandwidth: every group asks for ALL its
-        // rows of a pass at once (16 unconditional loads on clamped row numbers, masked after):
-        // a frame of up to 512 rows is one round trip (it was four loads in flight, i.e. four trips
-        // for a single frame's 450 rows).  Fixed order: run-to-run deterministic.
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int first = 0;
-        if (VELO_SOLVE_SPEC && f == 0 && spec_rows > 0 && k < kAccN) {
-            // Frame 0's rows start at row 0 whatever the plan says (the caller vouches for it with
-            // spec_rows = rows the buffer holds): its first pass is requested BEFORE the row range
-            // arrives and masked afterwards -- one memory round trip instead of two in a row, which
-            // is what a single frame's iteration waits for.  Same rows, same order: same bits.
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                v[u] = partials[(size_t)min(g + u * kSolveGroups, spec_rows - 1) * kAccStride + k];
-            const int e1 = fbs[1];
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (g + u * kSolveGroups >= e1) v[u] = 0.0;
-            a0 += (v[0] + v[4]) + (v[8] + v[12]);
-            a1 += (v[1] + v[5]) + (v[9] + v[13]);
-            a2 += (v[2] + v[6]) + (v[10] + v[14]);
-            a3 += (v[3] + v[7]) + (v[11] + v[15]);
-            first = 16 * kSolveGroups;
+        // Frame 0's rows start at row 0 and its layout comes with the launch (lay0, spec_rows = rows the
+        // caller vouches for): its loads go out without waiting for anything -- one memory round trip per
+        // iteration of a single frame's registration.  The other frames fetch their row range and layout first.
+        int b0 = 0, nrows, head, nbig, mlog, nslots;
+        if (VELO_SOLVE_SPEC && f == 0 && spec_rows > 0) {
+            head = lay0.x, nbig = lay0.y, mlog = lay0.z, nslots = lay0.w;
+            nrows = min(spec_rows, head + nbig + max(nslots - head - (nbig << mlog), 0));
+        } else {
+            b0 = fbs[f];
+            nrows = fbs[f + 1] - b0;
+            const int4 l = layout[f];
+            head = l.x, nbig = l.y, mlog = l.z, nslots = l.w;
         }
-        const int b0 = fbs[f], b1 = fbs[f + 1];
-        if (k < kAccN && b1 > b0) {
-            for (int b = b0 + g + first; b < b1; b += 16 * kSolveGroups) {
+        int B = 16;
+        while (B * kSolveGroups < nslots) B <<= 1;
+        const int trips = B >> 4;
+        double node = 0.0;
+        for (int c = 0; c < trips; ++c) {  // (uniform)
+            const int s0 = g * B + c * 16;
+            double t = 0.0;
+            if (k < kAccN && s0 < nslots) {
                 double v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    v[u] = partials[(size_t)min(b + u * kSolveGroups, b1 - 1) * kAccStride + k];
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (b + u * kSolveGroups >= b1) v[u] = 0.0;
-                a0 += (v[0] + v[4]) + (v[8] + v[12]);
-                a1 += (v[1] + v[5]) + (v[9] + v[13]);
-                a2 += (v[2] + v[6]) + (v[10] + v[14]);
-                a3 += (v[3] + v[7]) + (v[11] + v[15]);
+                for (int u = 0; u < 16; ++u) {
+                    const int r = slot_row(s0 + u, head, nbig, mlog, nrows);
+                    v[u] = r >= 0 ? partials[(size_t)(b0 + r) * kAccStride + k] : 0.0;
+                }
+                t = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                    (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
             }
+            int cc = c, lvl = 0;
+            while (cc & 1) {  // (uniform) carry: join with the waiting node of each completed level
+                t = s_stack[lvl][threadIdx.x] + t;
+                cc >>= 1;
+                ++lvl;
+            }
+            s_stack[lvl][threadIdx.x] = t;  // (own slot: no other thread reads it)
+            node = t;
         }
-        s_g[g][k] = (a0 + a1) + (a2 + a3);
+        s_g[g][k] = node;  // after the last trip (trips is a power of two) t is the group's node
     }
     if (threadIdx.x < 12) {
         s_pose[threadIdx.x] = pose_k;
@@ -1527,9 +1611,14 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     }
     __syncthreads();
     if (threadIdx.x < kAccN) {
-        double a = 0.0;
+        double w[kSolveGroups];
 #pragma unroll
-        for (int gg = 0; gg < kSolveGroups; ++gg) a += s_g[gg][threadIdx.x];
+        for (int gg = 0; gg < kSolveGroups; ++gg) w[gg] = s_g[gg][threadIdx.x];
+#pragma unroll
+        for (int span = 1; span < kSolveGroups; span <<= 1)
+#pragma unroll
+            for (int gg = 0; gg < kSolveGroups; gg += 2 * span) w[gg] = w[gg] + w[gg + span];
+        const double a = w[0];
         s_acc[threadIdx.x] = a;
         if (acc_out) acc_out[(size_t)f * kAccStride + threadIdx.x] = a;
     }
@@ -1573,16 +1662,23 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     if (stats) stats[(size_t)f * VELO_MAX_ITERS + iter] = st;
 }
 
-hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
+hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start, const RowLayout* layout,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, double* poses_prev,
-                               unsigned long long* pairs_total, hipStream_t s, int spec_rows)
+                               unsigned long long* pairs_total, hipStream_t s, int spec_rows,
+                               const RowLayout* layout0)
 {
     (void)iters_total;
     if (n_frames == 0) return hipSuccess;
+    static_assert(sizeof(RowLayout) == sizeof(int4), "RowLayout is read as an int4");
+    int4 l0 = make_int4(0, 0, 0, 0);
+    if (layout0 && spec_rows > 0)
+        l0 = make_int4(layout0->head, layout0->nbig, layout0->mlog, layout0->nslots);
+    else
+        spec_rows = 0;
     hipLaunchKernelGGL(k_reduce_solve, dim3(n_frames), dim3(kSolveThreads), 0, s, partials,
-                       frame_block_start, poses, stats, iter, acc_out, do_update, poses_prev,
-                       pairs_total, spec_rows);
+                       frame_block_start, reinterpret_cast<const int4*>(layout), poses, stats, iter, acc_out,
+                       do_update, poses_prev, pairs_total, spec_rows, l0);
     return hipGetLastError();
 }
 

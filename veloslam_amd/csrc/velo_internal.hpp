@@ -46,8 +46,11 @@ struct BlockItem {
     int32_t frame;
     int32_t q0;  // first query (global index into the concatenated arrays)
     int32_t q1;  // one past last
-    int32_t slot;  // row of the partials buffer this block writes (frame-major, fixed)
+    int32_t slot;  // bits 0..27: row of the partials buffer this block writes (frame-major, fixed);
+                   // bits 28..30: log2 of the rounds per wavefront the item is cut for (its NOMINAL size is
+                   // threads x rounds queries, an aligned block of the frame -- see linearize_body)
 };
+constexpr int kItemRowBits = 28;
 
 constexpr int kAccN = 29;      // 21 + 6 + 1 + 1
 constexpr int kAccStride = 32; // padded row of the partials buffer (doubles)
@@ -162,11 +165,19 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
                             int32_t* corr, float* d2, int32_t* hint, float* rho,
                             const double* poses_prev, bool stats, int force_kernel, hipStream_t s, int lat_lanes = 64);
 hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s);
-hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start,
+// How the rows of one frame tile its canonical summation tree (kernels/icp.hip, k_reduce_solve): `head` rows
+// of the small size, `nbig` rows 2^mlog times as large, small rows to the end; nslots = the frame's length in
+// small rows.  One per frame and decomposition, made by the planner.
+struct RowLayout {
+    int32_t head, nbig, mlog, nslots;
+};
+hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start, const RowLayout* layout,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, double* poses_prev,
-                               unsigned long long* pairs_total, hipStream_t s, int spec_rows = 0);
-// (spec_rows > 0: frame_block_start[0] == 0 and `partials` holds at least spec_rows rows)
+                               unsigned long long* pairs_total, hipStream_t s, int spec_rows = 0,
+                               const RowLayout* layout0 = nullptr);
+// (spec_rows > 0 with layout0 = HOST copy of frame 0's layout: frame_block_start[0] == 0 and `partials`
+//  holds at least spec_rows rows -- frame 0 then starts its loads without fetching anything first)
 hipError_t launch_frame_cellkeys(const FrameView& fv, const int64_t* d_frame_start, int n_frames,
                                  size_t n_total, const MapView& mv, const double* poses,
                                  uint32_t* keys, uint32_t* idx, hipStream_t s);
