@@ -2745,7 +2745,7 @@ int velo_knn(velo_ctx* c, int frame, const double T[12], float d_max, int k, int
     HIP_TRY(c, dT.reserve(12));
     HIP_TRY(c, hipMemcpyAsync(dT.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, dT.p, d_max * d_max, k, di.p,
-                          dd.p, dc.p, s));
+                          dd.p, dc.p, s, nullptr, c->cfg.force_kernel));
     HIP_TRY(c, hipMemcpyAsync(idx, di.p, n * (size_t)k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(d2, dd.p, n * (size_t)k * sizeof(float), hipMemcpyDeviceToHost, s));
     if (count) HIP_TRY(c, hipMemcpyAsync(count, dc.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -2775,7 +2775,7 @@ int velo_knn_dev(velo_ctx* c, int frame, const double T[12], float d_max, int k,
     HIP_TRY(c, hipMemcpyAsync(c->knn_T.p, c->h_knn_T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
     unsigned long long st[4] = {0, 0, 0, 0};
     HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, c->knn_T.p, d_max * d_max, k, d_idx, d_d2,
-                          d_count, s, stats ? st : nullptr));
+                          d_count, s, stats ? st : nullptr, c->cfg.force_kernel));
     if (stats)
         for (int i = 0; i < 4; ++i) stats[i] = st[i];
     return VELO_OK;
