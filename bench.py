@@ -947,6 +947,7 @@ def knn_record(args, d, dev, local):
     # slot per cell of the row through the hash), capped by what is resident (points + table: a byte of
     # the map does not have to cross the fabric twice in a launch)
     hashed = mi.table_kind == 1
+    wave_kernel = float(mi.n_points) >= 0.25 * float(mi.n_cells)   # (map_build.hip knn_use_wave; cfg.force_kernel = 0)
     q_bytes = n * (12 + 8 * k + 4) + 96
     tab_req = st["cells"] * 16 if hashed else st["rows"] * 8
     map_req = st["candidates"] * 16 + tab_req
@@ -971,7 +972,8 @@ def knn_record(args, d, dev, local):
            "search": {"candidates_per_query": st["candidates"] / max(st["queries"], 1),
                       "rows_per_query": st["rows"] / max(st["queries"], 1),
                       "cells_per_query": st["cells"] / max(st["queries"], 1)},
-           "roofline": {"bound": "hbm", "kernel": "k_knn<32>", "achieved": alg / (1e-6 * launch_us) / 1e9,
+           "roofline": {"bound": "hbm", "kernel": "k_knn_wave (one wavefront per query)" if wave_kernel else "k_knn<32> (one lane per query)",
+                        "achieved": alg / (1e-6 * launch_us) / 1e9,
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (1e-6 * launch_us) / 1e9 / HBM_PEAK_GBPS,
                         "algorithmic_bytes_per_launch": alg, "query_bytes_per_launch": q_bytes,
                         "map_requested_bytes_per_launch": map_req, "map_resident_bytes": resident,
@@ -980,9 +982,12 @@ def knn_record(args, d, dev, local):
                         "traffic_source": tr["source"] if tr else None,
                         "traffic_rocprof_avg_launch_us": tr.get("rocprof_avg_launch_us") if tr else None,
                         "traffic_GBps": (tr["hbm_bytes_per_launch"] / (1e-6 * launch_us) / 1e9) if tr else None,
-                        "note": "one thread per query, exact ball search with a k-best list in LDS: bound by "
-                                "dependent L2 / LDS round trips per lane, not by HBM -- 115 200 queries are 900 "
-                                "workgroups, less than 4 per CU; the fraction says how far from a stream it is"}}
+                        "note": ("one wavefront per query (the map is dense: points >= 0.25 x fine cells): the row walk is "
+                                 "wavefront-uniform, 64 candidates per coalesced request, the k-best list one entry per "
+                                 "lane; bound by the insertion chain and the per-row round trips, not by HBM"
+                                 if wave_kernel else
+                                 "one lane per query, exact ball search with a k-best list in LDS: bound by dependent "
+                                 "L2 / LDS round trips per lane, not by HBM -- 115 200 queries are 900 workgroups")}}
     # the registration of the same frame against the same 100 M-point map, for the record
     T0 = d["T0"][:1]
     for _ in range(3):

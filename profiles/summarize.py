@@ -164,7 +164,7 @@ def read_bytes(cs):
 
 krd, kwr, kdur = by_kernel("knn_rdreq"), by_kernel("knn_write"), trace_durations("knn_trace")
 for k in krd:
-    if "k_knn<32, false>" not in k:
+    if "k_knn<32, false>" not in k and "k_knn_wave<false>" not in k:   # (per-lane / wavefront-cooperative form)
         continue
     n = len(krd[k]["TCC_EA0_RDREQ_128B_sum"])
     nw = len(kwr.get(k, {}).get("WRITE_SIZE", []))

@@ -1528,3 +1528,37 @@ def test_pending_increments_equal_the_explicit_path(wl, comp):
     finally:
         a.close()
         b.close()
+
+
+def test_knn_dev_matches_knn_in_both_kernels_and_counts_its_bytes(wl, comp):
+    """velo_knn_dev (results left on the device; bench.py's configs[4] record) == velo_knn, through the
+    per-lane kernel and through the wavefront-cooperative one (cfg.force_kernel 1 / 2), and the counting
+    instantiation reports what it examined: every query, at least the k neighbours it returned."""
+    import torch
+    sub = tuple(a[::5].copy() for a in comp[0])
+    n, k = sub[0].size, 32
+    T = wl["frames"][0]["T0"]
+    ref = None
+    for fk in (capi.KERNEL_THROUGHPUT, capi.KERNEL_LATENCY, capi.KERNEL_AUTO):
+        c = capi.Context(0, max_batch=2, force_kernel=fk)
+        try:
+            c.map_reset(*wl["map"], 1.0, 16)
+            c.frames_upload([sub])
+            hi, hd, hc = c.knn(0, T, 0.8, k, n)
+            idx = torch.full((n, k), -5, dtype=torch.int32, device="cuda")
+            d2 = torch.zeros((n, k), dtype=torch.float32, device="cuda")
+            cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            assert c.knn_dev(0, T, 0.8, k, idx.data_ptr(), d2.data_ptr(), cnt.data_ptr()) is None
+            c.synchronize()
+            assert np.array_equal(idx.cpu().numpy(), hi) and np.array_equal(cnt.cpu().numpy(), hc)
+            assert np.array_equal(d2.cpu().numpy().view(np.uint32), hd.view(np.uint32))
+            st = c.knn_dev(0, T, 0.8, k, idx.data_ptr(), d2.data_ptr(), cnt.data_ptr(), stats=True)
+            assert st["queries"] == n and st["candidates"] >= int(hc.sum()) and st["rows"] >= 1
+            assert np.array_equal(idx.cpu().numpy(), hi)            # the counting instantiation returns the same
+            sig = (hi.tobytes(), hd.tobytes(), hc.tobytes())
+            if ref is None:
+                ref = sig
+            assert sig == ref
+        finally:
+            c.close()

@@ -1586,21 +1586,32 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
             double t = 0.0;
             if (k < kAccN && s0 < nslots) {
                 double v[16];
+                if (nbig == 0) {  // uniform rows (a single frame's items): row = slot, nothing to work out
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int r = slot_row(s0 + u, head, nbig, mlog, nrows);
-                    v[u] = r >= 0 ? partials[(size_t)(b0 + r) * kAccStride + k] : 0.0;
+                    for (int u = 0; u < 16; ++u)
+                        v[u] = partials[(size_t)(b0 + min(s0 + u, nrows - 1)) * kAccStride + k];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (s0 + u >= nrows) v[u] = 0.0;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int r = slot_row(s0 + u, head, nbig, mlog, nrows);
+                        v[u] = r >= 0 ? partials[(size_t)(b0 + r) * kAccStride + k] : 0.0;
+                    }
                 }
                 t = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
                     (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
             }
-            int cc = c, lvl = 0;
-            while (cc & 1) {  // (uniform) carry: join with the waiting node of each completed level
-                t = s_stack[lvl][threadIdx.x] + t;
-                cc >>= 1;
-                ++lvl;
+            if (trips > 1) {
+                int cc = c, lvl = 0;
+                while (cc & 1) {  // (uniform) carry: join with the waiting node of each completed level
+                    t = s_stack[lvl][threadIdx.x] + t;
+                    cc >>= 1;
+                    ++lvl;
+                }
+                s_stack[lvl][threadIdx.x] = t;  // (own slot: no other thread reads it)
             }
-            s_stack[lvl][threadIdx.x] = t;  // (own slot: no other thread reads it)
             node = t;
         }
         s_g[g][k] = node;  // after the last trip (trips is a power of two) t is the group's node
