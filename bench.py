@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true", help="skip dense / single_frame / stream / incl_h2d")
     ap.add_argument("--only", default="", help="comma list of sub-records to run (dense,single_frame,stream,incl_h2d,knn32_100m)")
-    ap.add_argument("--time-every", type=int, default=20,
+    ap.add_argument("--time-every", type=int, default=10,   # (two sampled steps in the driver's 20-step run: VERDICT r3 weak 9)
                     help="bracket the linearise launches with HIP events in every k-th timed step")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the increment exchange + map append path even with one rank")
