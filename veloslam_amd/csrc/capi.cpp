@@ -1079,6 +1079,10 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
             lay_h[(size_t)f] = RowLayout{0, 0, 0, nbig};
     }
     if (c->items_h.size() >= ((size_t)1 << kItemRowBits)) return c->fail(VELO_E_RANGE, "too many work items");
+    for (int f = 0; f < n_frames; ++f)
+        if (lay_h[(size_t)f].nslots > kMaxRowSlots)
+            return c->fail(VELO_E_RANGE, "frame %d has %lld points: more than %lld per frame", f,
+                           (long long)(frame_start[f + 1] - frame_start[f]), (long long)kMaxRowSlots * (planned ? kLinNT : per_block));
     c->lay0_h = lay_h[0];
     c->fbs_h[n_frames] = (int32_t)c->items_h.size();
     const size_t ni = c->items_h.size();

@@ -1610,7 +1610,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
                     cc >>= 1;
                     ++lvl;
                 }
-                s_stack[lvl][threadIdx.x] = t;  // (own slot: no other thread reads it)
+                if (c + 1 < trips) s_stack[lvl][threadIdx.x] = t;  // (own slot; the last trip's node is the result)
             }
             node = t;
         }

@@ -173,6 +173,8 @@ hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)
 struct RowLayout {
     int32_t head, nbig, mlog, nslots;
 };
+// k_reduce_solve joins a frame's slots in 32 groups of 16-slot trips through a carry stack of 8 levels
+constexpr int32_t kMaxRowSlots = 32 * 16 * 256;
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start, const RowLayout* layout,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, double* poses_prev,
