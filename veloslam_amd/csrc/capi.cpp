@@ -1341,7 +1341,8 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
                 if (e == hipSuccess)
                     e = launch_reduce_solve(c->partials.p, dc.fbs, dc.lay, c->n_frames, c->poses.p,
                                             c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
-                                            c->pairs_total.p, s, (int)(c->partials.cap / kAccStride), dc.lay0);
+                                            c->pairs_total.p, s, (int)(c->partials.cap / kAccStride), dc.lay0,
+                                            dc.lay0->nbig != 0 || c->n_frames > 1);
             }
             hipGraph_t g = nullptr;
             hipError_t e2 = hipStreamEndCapture(s, &g);
@@ -1380,7 +1381,8 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             Timed t(c, 1);
             HIP_TRY(c, launch_reduce_solve(c->partials.p, dc.fbs, dc.lay, c->n_frames, c->poses.p,
                                            c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
-                                           c->pairs_total.p, s, (int)(c->partials.cap / kAccStride), dc.lay0));
+                                           c->pairs_total.p, s, (int)(c->partials.cap / kAccStride), dc.lay0,
+                                           dc.lay0->nbig != 0 || c->n_frames > 1));
         }
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev_call1, s));

@@ -1549,6 +1549,9 @@ __device__ __forceinline__ int slot_row(int slot, int head, int nbig, int mlog, 
     return row < nrows ? row : -1;
 }
 
+// MIXED = false: every frame's rows are of one size (a single frame, the latency kernel's items): the
+// instantiation carries none of the two-size bookkeeping -- it is the kernel a single-frame iteration waits for
+template <bool MIXED>
 __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     const double* __restrict__ partials, const int32_t* __restrict__ fbs, const int4* __restrict__ layout,
     double* __restrict__ poses, velo_icp_iter* __restrict__ stats, int iter,
@@ -1579,29 +1582,79 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
         }
         int B = 16;
         while (B * kSolveGroups < nslots) B <<= 1;
-        const int trips = B >> 4;
-        double node = 0.0;
-        for (int c = 0; c < trips; ++c) {  // (uniform)
-            const int s0 = g * B + c * 16;
-            double t = 0.0;
-            if (k < kAccN && s0 < nslots) {
-                double v[16];
-                if (nbig == 0) {  // uniform rows (a single frame's items): row = slot, nothing to work out
+        // 16 slots = one fixed tree; with B >= 32 two of them (an aligned 32-slot node) per trip, ALL their loads
+        // in flight together: a batch's frames are 900 slots (B = 32) -- as two trips of 16 the solve of a
+        // 64-frame batch went from 6.5 to 9.8 us, two memory round trips in a row instead of one
+        auto load16 = [&](int s0, double (&v)[16]) {
+            if (!MIXED || nbig == 0) {  // uniform rows (a single frame's items): row = slot, nothing to work out
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    v[u] = partials[(size_t)(b0 + min(s0 + u, max(nrows - 1, 0))) * kAccStride + k];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (s0 + u >= nrows) v[u] = 0.0;
+            } else {
+                // (1 024 threads are 4 wavefronts per SIMD: 16 x slot_row per thread was 2 us of integer work.  A
+                // 16-slot span lies inside ONE region of the layout except at the two region borders: inside the
+                // large rows it is 16 >> mlog loads at a constant stride, inside the small ones 16 consecutive rows)
+                const int big0 = head, big1 = head + (nbig << mlog);
+                if (s0 >= big0 && s0 + 16 <= big1 && mlog >= 1 && mlog <= 2) {
+                    const int r0 = head + ((s0 - big0) >> mlog);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = 0.0;
+                    // (unconditional loads on clamped rows, masked afterwards: a load under a branch of its own
+                    // is waited for at the branch's end -- a chain of round trips instead of one)
+                    const int last = max(nrows - 1, 0);
+                    if (mlog == 2) {
+                        double w[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w[j] = partials[(size_t)(b0 + min(r0 + j, last)) * kAccStride + k];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[4 * j] = r0 + j < nrows ? w[j] : 0.0;
+                    } else {
+                        double w[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) w[j] = partials[(size_t)(b0 + min(r0 + j, last)) * kAccStride + k];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[2 * j] = r0 + j < nrows ? w[j] : 0.0;
+                    }
+                } else if (s0 + 16 <= big0 || s0 >= big1) {
+                    const int r0 = s0 < big0 ? s0 : s0 - (nbig << mlog) + nbig;
 #pragma unroll
                     for (int u = 0; u < 16; ++u)
-                        v[u] = partials[(size_t)(b0 + min(s0 + u, nrows - 1)) * kAccStride + k];
+                        v[u] = partials[(size_t)(b0 + min(r0 + u, max(nrows - 1, 0))) * kAccStride + k];
 #pragma unroll
                     for (int u = 0; u < 16; ++u)
-                        if (s0 + u >= nrows) v[u] = 0.0;
+                        if (r0 + u >= nrows) v[u] = 0.0;
                 } else {
+                    double w[16];
+                    int rr[16];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
-                        const int r = slot_row(s0 + u, head, nbig, mlog, nrows);
-                        v[u] = r >= 0 ? partials[(size_t)(b0 + r) * kAccStride + k] : 0.0;
+                        rr[u] = slot_row(s0 + u, head, nbig, mlog, nrows);
+                        w[u] = partials[(size_t)(b0 + max(rr[u], 0)) * kAccStride + k];
                     }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = rr[u] >= 0 ? w[u] : 0.0;
                 }
-                t = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
-                    (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+            }
+        };
+        auto tree16 = [](const double (&v)[16]) {
+            return (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                   (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+        };
+        const bool wide = B >= 32;
+        const int trips = wide ? B >> 5 : 1;
+        double node = 0.0;
+        for (int c = 0; c < trips; ++c) {  // (uniform)
+            const int s0 = g * B + c * (wide ? 32 : 16);
+            double t = 0.0;
+            if (k < kAccN && s0 < nslots && nrows > 0) {
+                double v0[16], v1[16];
+                load16(s0, v0);
+                if (wide) load16(s0 + 16, v1);
+                t = tree16(v0);
+                if (wide) t = t + tree16(v1);
             }
             if (trips > 1) {
                 int cc = c, lvl = 0;
@@ -1677,7 +1730,7 @@ hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_bloc
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, double* poses_prev,
                                unsigned long long* pairs_total, hipStream_t s, int spec_rows,
-                               const RowLayout* layout0)
+                               const RowLayout* layout0, bool mixed)
 {
     (void)iters_total;
     if (n_frames == 0) return hipSuccess;
@@ -1687,9 +1740,14 @@ hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_bloc
         l0 = make_int4(layout0->head, layout0->nbig, layout0->mlog, layout0->nslots);
     else
         spec_rows = 0;
-    hipLaunchKernelGGL(k_reduce_solve, dim3(n_frames), dim3(kSolveThreads), 0, s, partials,
-                       frame_block_start, reinterpret_cast<const int4*>(layout), poses, stats, iter, acc_out,
-                       do_update, poses_prev, pairs_total, spec_rows, l0);
+    if (mixed)
+        hipLaunchKernelGGL(k_reduce_solve<true>, dim3(n_frames), dim3(kSolveThreads), 0, s, partials,
+                           frame_block_start, reinterpret_cast<const int4*>(layout), poses, stats, iter, acc_out,
+                           do_update, poses_prev, pairs_total, spec_rows, l0);
+    else
+        hipLaunchKernelGGL(k_reduce_solve<false>, dim3(n_frames), dim3(kSolveThreads), 0, s, partials,
+                           frame_block_start, reinterpret_cast<const int4*>(layout), poses, stats, iter, acc_out,
+                           do_update, poses_prev, pairs_total, spec_rows, l0);
     return hipGetLastError();
 }
 

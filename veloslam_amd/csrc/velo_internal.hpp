@@ -174,12 +174,13 @@ struct RowLayout {
     int32_t head, nbig, mlog, nslots;
 };
 // k_reduce_solve joins a frame's slots in 32 groups of 16-slot trips through a carry stack of 8 levels
-constexpr int32_t kMaxRowSlots = 32 * 16 * 256;
+constexpr int32_t kMaxRowSlots = 32 * 32 * 256;
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start, const RowLayout* layout,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
                                int iters_total, double* acc_out, int do_update, double* poses_prev,
                                unsigned long long* pairs_total, hipStream_t s, int spec_rows = 0,
-                               const RowLayout* layout0 = nullptr);
+                               const RowLayout* layout0 = nullptr, bool mixed = true);
+// (mixed = false: the caller vouches that every frame's layout has nbig == 0 -- rows of one size)
 // (spec_rows > 0 with layout0 = HOST copy of frame 0's layout: frame_block_start[0] == 0 and `partials`
 //  holds at least spec_rows rows -- frame 0 then starts its loads without fetching anything first)
 hipError_t launch_frame_cellkeys(const FrameView& fv, const int64_t* d_frame_start, int n_frames,
