@@ -61,7 +61,7 @@ typedef enum { ncclInt32 = 2, ncclFloat32 = 7 } ncclDataType_t;
 #define VELO_CONV_FROM 5
 #endif
 #ifndef VELO_CONV_TAIL_PCT
-#define VELO_CONV_TAIL_PCT 10
+#define VELO_CONV_TAIL_PCT 0  // (round 4: rows of one size let k_reduce_solve take its short path in 15 of 20 iterations: 2.17 -> 2.15 ms per step; the tail still pays in iterations 1-4: 0 there costs 2.5 %)
 #endif
 #ifndef VELO_LATE_TAIL_PCT
 #define VELO_LATE_TAIL_PCT 10
@@ -945,7 +945,8 @@ int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, in
         const int64_t nqf = frame_start[f + 1] - frame_start[f];
         // (both regions start at multiples of their item size from the frame's first query: every item is an
         // aligned node of the frame's summation tree)
-        const int64_t big_end = frame_start[f] + (nqf * (100 - tail_pct) / 100) / per_big * per_big;
+        const int64_t big_end = tail_pct <= 0 ? frame_start[f + 1]   // (no tail: the last large item is a partial one)
+                                              : frame_start[f] + (nqf * (100 - tail_pct) / 100) / per_big * per_big;
         int nbig = 0;
         for (int64_t q = frame_start[f]; q < frame_start[f + 1];) {
             const int64_t step = q < big_end ? per_big : kLinNT;
@@ -958,7 +959,11 @@ int plan_decomposition(velo_ctx* c, const int64_t* frame_start, int n_frames, in
             (q < big_end ? big : tail).push_back(it);
             q += step;
         }
-        lay_h[(size_t)f] = RowLayout{0, nbig, log2i(rounds), (int32_t)((nqf + kLinNT - 1) / kLinNT)};
+        // (no one-round tail for this frame: its rows are of one size, one slot each -- the solve's short path)
+        if (big_end >= frame_start[f + 1] || rounds == 1)
+            lay_h[(size_t)f] = RowLayout{0, 0, 0, slot - fbl[f]};
+        else
+            lay_h[(size_t)f] = RowLayout{0, nbig, log2i(rounds), (int32_t)((nqf + kLinNT - 1) / kLinNT)};
     }
     fbl[n_frames] = slot;
     if (slot >= (1 << kItemRowBits)) return c->fail(VELO_E_RANGE, "too many work items");
