@@ -91,7 +91,11 @@ typedef struct velo_cfg {
                                iteration certified that correspondence as the unique nearest
                                point within a radius the query has not left (cfg == NULL: 2) */
     int32_t rounds_per_block; /* tuning: rounds of 256 queries per work item, in every iteration
-                               (0 = planned per iteration, see plan_wave_slots) */
+                               (0 = planned per iteration, see plan_wave_slots); rounded down to 1, 2 or 4
+                               rounds per wavefront: a work item is an aligned node of the frame's
+                               summation tree.  Whatever is chosen here, or by the planner, or by the
+                               batch a frame shares a launch with: the frame's sums, pose and statistics
+                               are the same bits ("Reduction") */
     int32_t map_margin;     /* rolling map: the grid is anchored this many voxels below the lowest
                                point and padded as many above, so appends/evictions inside the
                                slack update the sorted map incrementally (default 0 = tight) */
@@ -101,15 +105,17 @@ typedef struct velo_cfg {
                                < 2^31 entries, an open-addressing hash over the occupied cells
                                (load factor 0.5) beyond that; 5..90: always the hash, at that load
                                factor in percent.  Same sorted order, same results either way. */
-    int32_t force_kernel;   /* 0: the linearise kernel is chosen by the size of the registration
+    int32_t force_kernel;   /* (also pins velo_knn's kernel: 1 = one lane per query, 2 = one wavefront per
+                               query, 0 = by the map's density.)
+                               0: the linearise kernel is chosen by the size of the registration
                                (latency kernel below 2048 x 256 queries, ~4 frames; throughput kernel
                                above); 1: always the throughput kernel, 2: always the latency kernel
                                (tests hold both to the oracle) */
     int32_t plan_wave_slots; /* tuning / tests: wavefront slots the work-item planner assumes
                                (0 = the device's: CUs x 4 SIMDs x 7).  A batch is cut as coarse as
-                               4 / 3 / 6 rounds per wavefront (first / searching / converged
-                               iterations) while it keeps 2.5 wavefronts per slot; a small value
-                               makes a small batch take the decompositions of a large one */
+                               4 rounds per wavefront (1 / 2 / 4: powers of two) while it keeps 2.5
+                               wavefronts per slot; a small value makes a small batch take the
+                               decompositions of a large one.  Speed only: results do not depend on it */
     uint32_t abi_version;   /* = VELO_ABI_VERSION (the header the caller was compiled against) */
     int32_t reserved[2];
 } velo_cfg;
