@@ -91,3 +91,22 @@ def test_gpu_sums_equal_the_written_definition_bit_for_bit(n_q):
     assert int(want[28]) == int((corr >= 0).sum()) - sum(
         1 for i in range(n) if corr[i] >= 0 and g["nx"][corr[i]] == 0 and g["ny"][corr[i]] == 0 and g["nz"][corr[i]] == 0)
     assert want.tobytes() == acc.tobytes(), np.nonzero(want != acc)[0]
+
+
+def test_k1_equals_the_reference_expression_in_plain_numpy():
+    """K1 (a7) against `transformPoint` as the reference writes it (type_defs.h:160-166: Eigen's
+    `affine * point`, i.e. ((m0 x + m1 y) + m2 z) + m3 per row, every operation rounded on its own, then
+    PointXYZI's float) -- in plain numpy float64, no oracle: bit for bit."""
+    wl = make_workload(map_points=1000, n_frames=1)
+    f = wl["frames"][0]
+    s = f["sensor"]
+    c = capi.Context(0, max_batch=2)
+    try:
+        gx, gy, gz = c.compensate(s["x"], s["y"], s["z"], s["pkt"], f["table"])
+    finally:
+        c.close()
+    M = np.asarray(f["table"], np.float64).reshape(-1, 12)[s["pkt"].astype(np.int64)]
+    x, y, z = (np.asarray(s[k], np.float32).astype(np.float64) for k in ("x", "y", "z"))
+    for r, got in enumerate((gx, gy, gz)):
+        want = (((M[:, 4 * r] * x + M[:, 4 * r + 1] * y) + M[:, 4 * r + 2] * z) + M[:, 4 * r + 3]).astype(np.float32)
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), r
