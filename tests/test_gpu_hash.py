@@ -74,6 +74,27 @@ def test_hash_table_registration_knn_increment(oracle, wl, comp):
         c.close()
 
 
+@pytest.mark.parametrize("k", [8, 32])
+def test_hash_table_knn_wavefront_cooperative_kernel(oracle, wl, comp, k):
+    """k_knn_wave (one wavefront per query; chosen by density in production, pinned here with force_kernel = 2)
+    through the sparse fine-cell table: == oracle, at two load factors."""
+    om = oracle.Map(*wl["map"], 1.0, 16)
+    n = 3000
+    sub = tuple(a[5:5 + n].copy() for a in comp[0])
+    T = wl["frames"][0]["T0"]
+    oi, od, oc = om.knn(*sub, T, 0.9, k)
+    for load in (30, 75):
+        c = capi.Context(0, max_batch=2, map_hash_load=load, force_kernel=capi.KERNEL_LATENCY)
+        try:
+            c.map_reset(*wl["map"], 1.0, 16)
+            assert c.map_info().table_kind == 1
+            c.frames_upload([sub])
+            idx, d2, cnt = c.knn(0, T, 0.9, k, n)
+            assert np.array_equal(idx, oi) and np.array_equal(d2.view(np.uint32), od.view(np.uint32)) and np.array_equal(cnt, oc)
+        finally:
+            c.close()
+
+
 def test_hash_table_throughput_kernel_batch(oracle, wl, comp):
     """>= 2048 workgroups go to the throughput kernel: its sparse-table instantiation too."""
     om = oracle.Map(*wl["map"], 1.0, 16)
