@@ -145,7 +145,9 @@ struct velo_ctx {
     DevBuf<int32_t> cell_start_alt;
     DevBuf<uint8_t> vox_near_alt;
     bool overlap_update = false;        // inside velo_map_roll_overlapped
-    DevBuf<double> knn_T;               // velo_knn_dev: the pose on the device ...
+    DevBuf<double> knn_T;               // velo_knn / velo_knn_dev: the pose on the device ...
+    DevBuf<int32_t> knn_idx, knn_cnt;   // velo_knn: device-side results before the copy back
+    DevBuf<float> knn_d2;
     double* h_knn_T = nullptr;          // ... and its pinned source
     int overlap_done = 0;               // ... updates published so far in this call
     // a roll is TWO updates (evict, append): the second must not write the arrays the registration is
@@ -2747,12 +2749,13 @@ int velo_knn(velo_ctx* c, int frame, const double T[12], float d_max, int k, int
     hipStream_t s = c->stream;
     const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
     if (n == 0) return VELO_OK;
-    DevBuf<int32_t> di, dc;
-    DevBuf<float> dd;
-    DevBuf<double> dT;
-    HIP_TRY(c, di.reserve(n * (size_t)k));
-    HIP_TRY(c, dd.reserve(n * (size_t)k));
-    HIP_TRY(c, dc.reserve(n));
+    // (buffers of the ctx: a hipMalloc / hipFree pair per call is a device-wide synchronisation each)
+    DevBuf<int32_t>&di = c->knn_idx, &dc = c->knn_cnt;
+    DevBuf<float>& dd = c->knn_d2;
+    DevBuf<double>& dT = c->knn_T;
+    HIP_TRY(c, reserve_slack(di, n * (size_t)k));
+    HIP_TRY(c, reserve_slack(dd, n * (size_t)k));
+    HIP_TRY(c, reserve_slack(dc, n));
     HIP_TRY(c, dT.reserve(12));
     HIP_TRY(c, hipMemcpyAsync(dT.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, dT.p, d_max * d_max, k, di.p,
