@@ -518,7 +518,13 @@ int velo_matrix_from_pose(const double TRdeg[6], double T[12]);
 int velo_pose_from_matrix(const double T[12], double TRdeg[6]);
 /* TransformManager::interpolateTransform (TransformManager.cxx:149-177) over a
  * caller-held array sorted by t_us.  Returns 0 and fills *out on "true", VELO_E_NODATA on
- * "false" (empty store). out->seconds_pos keeps the reference's validity signal. */
+ * "false" (empty store). out->seconds_pos keeps the reference's validity signal.
+ * PRECONDITION of every entry point that takes a pose array (this one, velo_packet_transforms, velo_decode*,
+ * velo_decode_plan_fill): `sorted` is STRICTLY ascending in t_us over its whole length, as
+ * TransformManager's store is by construction (a map keyed by time).  The library spot-checks the ends and the
+ * samples around the bracket it uses (VELO_E_INVALID on a violation it sees); an unsorted or duplicated stretch
+ * elsewhere is NOT detected and yields the bracket a binary search happens to land on.  Sort and de-duplicate
+ * before the call (veloslam::TransformManager::snapshot() does). */
 int velo_interp_pose(const velo_pose* sorted, size_t n, int64_t t_us, velo_pose* out);
 /* What HDLParser::processHDLPacket does per packet before the firing loop
  * (HDLParser.cxx:988-1007): interpolate at each packet time, take packet 0's pose as

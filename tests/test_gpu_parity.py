@@ -1562,3 +1562,31 @@ def test_knn_dev_matches_knn_in_both_kernels_and_counts_its_bytes(wl, comp):
             assert sig == ref
         finally:
             c.close()
+
+
+@pytest.mark.parametrize("k", [5, 32])
+def test_knn_exact_ties_on_a_lattice_both_kernels(oracle, k):
+    """Equal distances everywhere (a lattice with duplicated points, queries on lattice sites and cell centres):
+    the k-NN order is decided by the sorted index alone -- the per-lane kernel, the wavefront-cooperative one
+    and the oracle must agree on every tie."""
+    g = np.arange(0, 6, 0.5, dtype=np.float32)
+    X, Y, Z = np.meshgrid(g, g, g[:6], indexing="ij")
+    base = np.stack([X.ravel(), Y.ravel(), Z.ravel()])
+    m = np.concatenate([base, base[:, ::3], base[:, 5::7]], axis=1).astype(np.float32)   # duplicates
+    rng = np.random.default_rng(5)
+    q = np.concatenate([base[:, rng.choice(base.shape[1], 300, replace=False)],
+                        base[:, rng.choice(base.shape[1], 300, replace=False)] + np.float32(0.25)], axis=1).astype(np.float32)
+    I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+    om = oracle.Map(*m, 1.0, 8, 3)
+    oi, od, oc = om.knn(*q, I, 1.0, k)
+    for fk in (capi.KERNEL_THROUGHPUT, capi.KERNEL_LATENCY):
+        c = capi.Context(0, max_batch=2, map_subdiv=3, force_kernel=fk)
+        try:
+            c.map_reset(*m, 1.0, 8)
+            c.frames_upload([tuple(q)])
+            gi, gd, gc = c.knn(0, I, 1.0, k, q.shape[1])
+            assert np.array_equal(gc, oc), fk
+            assert np.array_equal(gi, oi), fk
+            assert np.array_equal(gd.view(np.uint32), od.view(np.uint32)), fk
+        finally:
+            c.close()
