@@ -587,6 +587,12 @@ int velo_insmeta_read(const char* path, velo_pose* poses, size_t cap, size_t* n_
  * pose AND packet stamps; a replay adds them to the packet stamps of velo_pcap_read, which does not).
  * Poses come back sorted by time; poses may be NULL to count; VELO_E_RANGE beyond cap. */
 int velo_carposes_read(const char* path, velo_pose* poses, size_t cap, size_t* n_out);
+/* ptimeToWeekMilli (type_defs.cxx:74-79; time in microseconds, the reference's +8 h already in it):
+ * *week = ISO 8601 week number of the date (boost::gregorian::date::week_number), *milli =
+ * milliseconds since the preceding Sunday 00:00.  Either pointer may be NULL.  velo_carposes_read
+ * fills week_number, milliseconds, week_number_pos (= week) and seconds_pos (= milli / 1000.0f,
+ * divided in float) from it, as TransformManager.cxx:116-119 does. */
+void velo_time_to_week_milli(int64_t t_us, uint16_t* week, uint32_t* milli);
 /* Velodyne calibration file (db.xml) -> the 64 laser corrections velo_decode takes.  Replaces
  * HDLParser::vsInternal::loadCorrectionsFile (HDLParser.cxx:771-858): same element names, same
  * units (centimetres in the file, metres afterwards) and derived sin/cos fields; n_enabled

@@ -85,6 +85,8 @@ def lib():
     L.vo_timeline_add.argtypes = [C.c_void_p, pp]
     L.vo_timeline_boundary.argtypes = [C.c_void_p, C.c_int64, pp, pp]
     L.vo_interpolate_transform.argtypes = [C.c_void_p, C.c_int64, pp]
+    L.vo_time_to_week_milli.argtypes = [C.c_int64, C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)]
+    L.vo_time_to_week_milli.restype = None
     L.vo_compensate.argtypes = [fp, fp, fp, C.POINTER(C.c_uint16), C.c_size_t, dp, C.c_size_t,
                                 fp, fp, fp]
     L.vo_load_corrections.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -259,6 +261,12 @@ class Timeline:
         lib().vo_pose_init(C.byref(out))
         ok = lib().vo_interpolate_transform(self.h, int(t_us), C.byref(out))
         return bool(ok), out
+
+
+def time_to_week_milli(t_us):
+    w, m = C.c_uint16(0), C.c_uint32(0)
+    lib().vo_time_to_week_milli(int(t_us), C.byref(w), C.byref(m))
+    return w.value, m.value
 
 
 def compensate(x, y, z, pkt, table):

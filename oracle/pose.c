@@ -456,3 +456,60 @@ int vo_interpolate_transform(const vo_timeline* t, int64_t q, vo_pose* out)
     out->seconds_pos = 0; /* :174 */
     return 1;
 }
+
+/* ---- ptimeToWeekMilli, type_defs.cxx:74-79 --------------------------------------------------
+ *   week  = t.date().week_number();
+ *   beginOfWeek = date(t.date() - days(to_tm(t.date()).tm_wday));   (00:00 of the last Sunday)
+ *   milli = (t - beginOfWeek).total_milliseconds();                 (into a uint32)
+ * boost::gregorian::date::week_number lives in Boost.DateTime (a dependency the reference does not
+ * vendor or pin: CMakeLists.txt:98 `find_package(Boost ... date_time ...)`, absent from this image);
+ * its published algorithm (boost/date_time/gregorian_calendar.ipp, gregorian_calendar_base::
+ * week_number) is restated below on julian day numbers.  Unpinned to the reference's own object
+ * code; pinned to the ISO 8601 definition by tests/test_host_parity.py (== Python's
+ * date.isocalendar() on every day of 1970-2199). */
+static long vo_jdn(long y, long m, long d) /* gregorian_calendar.ipp: julian_day_number */
+{
+    const long a = (14 - m) / 12;
+    const long yy = y + 4800 - a;
+    const long mm = m + 12 * a - 3;
+    return d + (153 * mm + 2) / 5 + 365 * yy + yy / 4 - yy / 100 + yy / 400 - 32045;
+}
+static void vo_civil(long jdn, long* y, long* m, long* d) /* gregorian_calendar.ipp: from_day_number */
+{
+    const long a = jdn + 32044;
+    const long b = (4 * a + 3) / 146097;
+    const long c = a - (146097 * b) / 4;
+    const long dd = (4 * c + 3) / 1461;
+    const long e = c - (1461 * dd) / 4;
+    const long mm = (5 * e + 2) / 153;
+    *d = e - (153 * mm + 2) / 5 + 1;
+    *m = mm + 3 - 12 * (mm / 10);
+    *y = 100 * b + dd - 4800 + mm / 10;
+}
+void vo_time_to_week_milli(int64_t t_us, uint16_t* week, uint32_t* milli)
+{
+    const int64_t day_us = 86400LL * 1000000;
+    int64_t days = t_us / day_us;
+    if (t_us % day_us < 0) --days;
+    const long today = 2440588L + (long)days; /* JDN of 1970-01-01 */
+    const long wday = (today + 1) % 7;        /* tm_wday: 0 = Sunday */
+    *milli = (uint32_t)((t_us - (days - wday) * day_us) / 1000);
+    long y, m, d;
+    vo_civil(today, &y, &m, &d);
+    unsigned long begin = (unsigned long)vo_jdn(y, 1, 1);
+    unsigned long day = (begin + 3) % 7;
+    unsigned long w = ((unsigned long)today + day - begin + 4) / 7;
+    if (w >= 1 && w <= 52) {
+        *week = (uint16_t)w;
+        return;
+    }
+    if (w == 53) {
+        const int leap = (y % 4 == 0 && y % 100 != 0) || y % 400 == 0;
+        *week = (day == 6 || (day == 5 && leap)) ? 53 : 1;
+        return;
+    }
+    /* week 0: the date belongs to the last week of the previous year */
+    begin = (unsigned long)vo_jdn(y - 1, 1, 1);
+    day = (begin + 3) % 7;
+    *week = (uint16_t)(((unsigned long)today + day - begin + 4) / 7);
+}

@@ -79,6 +79,8 @@ void vo_timeline_add(vo_timeline*, const vo_pose* p);             /* TimeLine.h:
 int vo_timeline_boundary(const vo_timeline*, int64_t t_us, vo_pose* fore, vo_pose* back);
 /* TransformManager.cxx:149-177 ; returns 1 (true) / 0 (false) */
 int vo_interpolate_transform(const vo_timeline*, int64_t t_us, vo_pose* out);
+/* ptimeToWeekMilli, type_defs.cxx:74-79 (Boost.DateTime week_number restated) */
+void vo_time_to_week_milli(int64_t t_us, uint16_t* week, uint32_t* milli);
 
 /* a7: K1 restated.  Per point i: M = table[pkt[i]] ; out = (float)(M*p). */
 void vo_compensate(const float* x, const float* y, const float* z, const uint16_t* pkt,

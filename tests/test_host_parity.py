@@ -4,6 +4,7 @@ plus the C-ABI export check."""
 import ctypes as C
 import json
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -516,3 +517,156 @@ def test_host_parsers_under_address_and_ub_sanitizers(tmp_path):
     out = subprocess.run([exe, str(tmp_path), "300"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-3000:])
     assert "host fuzz: " in out.stdout and int(out.stdout.split("host fuzz: ")[1].split()[0]) > 1000
+
+
+_CXX_CALLER = r'''
+// A caller written the way the reference's translation units are: %(decls)s, no extern "C".
+// Its object file references the C++-mangled names (_Z7llh2xyzPdS_ ...), like INSSource.cxx:305-326.
+%(header)s
+#include <cstdio>
+#include <cstring>
+static void hex(const char* tag, const double* v, int n) {
+    std::printf("%%s", tag);
+    for (int i = 0; i < n; ++i) { unsigned long long b; std::memcpy(&b, &v[i], 8); std::printf(" %%016llx", b); }
+    std::printf("\n");
+}
+int main() {
+    double llh[3] = {0.6956357, 2.0276126, 89.09288895}, org_llh[3] = {0.6956182, 2.0275951, 88.0};
+    double eul[3] = {0.1, -0.2, 0.3};
+    double xyz[3], org[3], back[3], enu[3], x2[3], l2[3], e2[3], dcm[3][3];
+    llh2xyz(llh, xyz);        hex("llh2xyz", xyz, 3);
+    llh2xyz(org_llh, org);
+    xyz2llh(xyz, back);       hex("xyz2llh", back, 3);
+    xyz2enu(xyz, org, enu);   hex("xyz2enu", enu, 3);
+    enu2xyz(enu, org, x2);    hex("enu2xyz", x2, 3);
+    enu2llh(enu, org, l2);    hex("enu2llh", l2, 3);
+    llh2enu(llh, org, e2);    hex("llh2enu", e2, 3);
+    eulr2dcm(eul, dcm);       hex("eulr2dcm", &dcm[0][0], 9);
+    double m[3] = {MappingAngle(45.0), MappingAngle(180.0), MappingAngle(300.0)};
+    hex("MappingAngle", m, 3);
+    return 0;
+}
+'''
+
+_REF_STYLE_DECLS = '''
+void eulr2dcm(double eul_vect[3],double DCMbn[3][3]);
+void llh2xyz(double llh[3],double xyz[3]);
+void xyz2llh(double xyz [3],double llh [3]);
+void xyz2enu(double xyz[3],double orgxyz[3],double enu[3]);
+void enu2xyz(double enu[3],double orgxyz[3],double xyz[3]);
+void enu2llh(double enu[3],double orgxyz[3],double llh[3]);
+void llh2enu(double llh[3],double orgxyz[3],double enu[3]);
+double MappingAngle(double angle);
+'''
+
+
+def _cxx_caller_output(tmp_path, name, header, extra_flags=()):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "veloslam_amd", "csrc")
+    src = tmp_path / (name + ".cpp")
+    src.write_text(_CXX_CALLER % {"decls": name, "header": header})
+    obj, exe = tmp_path / (name + ".o"), tmp_path / name
+    subprocess.check_call(["g++", "-O2", "-c", str(src), "-o", str(obj), *extra_flags])
+    # what the caller's OBJECT file asks the linker for: the mangled names, not the C ones
+    und = subprocess.run(["nm", "-u", str(obj)], capture_output=True, text=True, check=True).stdout
+    assert "_Z7llh2xyzPdS_" in und and "_Z8eulr2dcmPdPA3_d" in und and "_Z12MappingAngled" in und
+    subprocess.check_call(["g++", str(obj), "-L", csrc, "-lveloslam_amd", "-Wl,-rpath," + csrc, "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True, timeout=60).stdout
+    return {l.split()[0]: [int(h, 16) for h in l.split()[1:]] for l in out.strip().splitlines()}
+
+
+def test_coorditran_cxx_linkage_links_reference_style_callers(tmp_path):
+    """VERDICT r4 item 1a: CoordiTran.h:7-15 declares the geodesy functions without extern "C", so a
+    reference translation unit references `_Z7llh2xyzPdS_`, not `llh2xyz`.  The library exports both;
+    here a caller with reference-style undecorated declarations (and one with include/veloslam/
+    CoordiTran.h, and -- where the tree is present -- one with the REFERENCE'S OWN header) is compiled,
+    linked with -lveloslam_amd alone, run, and held bit for bit to the C-linkage entry points."""
+    capi.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {"undecorated_declarations": _cxx_caller_output(tmp_path, "undecorated_declarations", _REF_STYLE_DECLS),
+            "veloslam_header": _cxx_caller_output(tmp_path, "veloslam_header", '#include "veloslam/CoordiTran.h"',
+                                                  ("-I", os.path.join(root, "include")))}
+    if os.path.exists("/root/reference/CoordiTran.h"):
+        runs["reference_header"] = _cxx_caller_output(tmp_path, "reference_header", '#include "CoordiTran.h"',
+                                                      ("-I", "/root/reference"))
+    llh, org_llh = [0.6956357, 2.0276126, 89.09288895], [0.6956182, 2.0275951, 88.0]
+    xyz, org = capi.llh2xyz(llh), capi.llh2xyz(org_llh)
+    enu = capi.xyz2enu(xyz, org)
+    want = {"llh2xyz": xyz, "xyz2llh": capi.xyz2llh(xyz), "xyz2enu": enu, "enu2xyz": capi.enu2xyz(enu, org),
+            "enu2llh": capi.enu2llh(enu, org), "llh2enu": capi.llh2enu(llh, org),
+            "eulr2dcm": capi.eulr2dcm([0.1, -0.2, 0.3]).ravel(),
+            "MappingAngle": [capi.mapping_angle(a) for a in (45.0, 180.0, 300.0)]}
+    for name, got in runs.items():
+        for fn, v in want.items():
+            bits = [int(b) for b in np.asarray(v, np.float64).view(np.uint64)]
+            assert got[fn] == bits, (name, fn)
+    # and the two linkages are exported side by side (nm -D), the implementation namespace is not
+    csrc = os.path.join(root, "veloslam_amd", "csrc", "libveloslam_amd.so")
+    dyn = subprocess.run(["nm", "-D", "--defined-only", csrc], capture_output=True, text=True, check=True).stdout
+    for sym in ("llh2xyz", "_Z7llh2xyzPdS_", "_Z7xyz2llhPdS_", "_Z7xyz2enuPdS_S_", "_Z7enu2xyzPdS_S_",
+                "_Z7enu2llhPdS_S_", "_Z7llh2enuPdS_S_", "_Z8eulr2dcmPdPA3_d", "_Z12MappingAngled"):
+        assert (" T " + sym + "\n") in dyn, sym
+    assert "velo_geodesy" not in dyn
+
+
+def test_time_to_week_milli_is_the_iso_week_and_ms_since_sunday(oracle):
+    """ptimeToWeekMilli (type_defs.cxx:74-79).  Product (ISO Thursday rule), oracle (Boost.DateTime's
+    julian-day algorithm restated) and Python's date.isocalendar() on every day of 1970-2199, with a
+    time of day; year ends (weeks 52/53/1) are in that range 230 times over."""
+    import datetime
+    epoch = datetime.date(1970, 1, 1)
+    day_us = 86400 * 10**6
+    for d in range(0, 84000):
+        tod = (d * 7919 * 10**6 + 123457) % day_us
+        t = d * day_us + tod
+        date = epoch + datetime.timedelta(days=d)
+        want_w = date.isocalendar()[1]
+        want_ms = (((date.weekday() + 1) % 7) * day_us + tod) // 1000
+        assert capi.time_to_week_milli(t) == (want_w, want_ms), date
+        assert oracle.time_to_week_milli(t) == (want_w, want_ms), date
+    # a time before the epoch belongs to the date that contains it (floor, not truncation)
+    assert capi.time_to_week_milli(-1) == oracle.time_to_week_milli(-1) == (1, 4 * 86400000 - 1)  # Wed 1969-12-31
+
+
+def test_txt_load_fills_the_gps_week_fields_and_they_survive_insmeta(tmp_path, oracle):
+    """TransformManager.cxx:116-119: a carposes.txt load fills week_number, milliseconds,
+    week_number_pos (= week) and seconds_pos (= milliseconds / 1000.0f, a FLOAT division) from the
+    +8 h time; the record written to .insmeta (type_defs.cxx:4-18) then carries them."""
+    from veloslam_amd import drive
+    rng = np.random.default_rng(5)
+    t0 = 1_475_000_000_000_000  # late September 2016
+    samples = [(rng.uniform(-50, 50, 3), rng.uniform(-3, 3, 3), np.zeros(3),
+                t0 + int(i * 86_400_000_000 * 0.37) + int(rng.integers(0, 10**6))) for i in range(40)]
+    path = str(tmp_path / "carposes.txt")
+    drive.write_carposes(path, samples)
+    L = capi.lib()
+    L.velo_carposes_read.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    n = C.c_size_t()
+    poses = (capi.Pose * len(samples))()
+    assert L.velo_carposes_read(path.encode(), poses, len(samples), C.byref(n)) == 0 and n.value == len(samples)
+    seen_weeks = set()
+    for p, (_, _, _, t) in zip(poses, samples):
+        assert p.t_us == t + drive.EIGHT_H_US
+        w, ms = oracle.time_to_week_milli(p.t_us)
+        assert (p.week_number, p.milliseconds, p.week_number_pos) == (w, ms, w)
+        want = float(np.float32(ms) / np.float32(1000.0))  # uint32 -> float (24 bits), float division
+        assert p.seconds_pos == want and p.seconds_pos != -1
+        seen_weeks.add(w)
+    assert len(seen_weeks) >= 2 and any(int(np.float32(p.milliseconds)) != p.milliseconds for p in poses)
+    # .insmeta round trip: 100-byte records, fields in the reference's order
+    meta = str(tmp_path / "drive.insmeta")
+    L.velo_insmeta_write(meta.encode(), poses, len(samples))
+    raw = open(meta, "rb").read()
+    rec = len(raw) // len(samples)
+    assert rec * len(samples) == len(raw)
+    for i, p in enumerate(poses):
+        r = raw[i * rec:(i + 1) * rec]
+        assert int.from_bytes(r[80:82], "little") == p.week_number
+        assert int.from_bytes(r[82:86], "little") == p.milliseconds
+        assert int.from_bytes(r[86:90], "little") == p.week_number_pos
+        assert np.frombuffer(r[90:98], np.float64)[0] == p.seconds_pos
+    back = (capi.Pose * len(samples))()
+    assert L.velo_insmeta_read(meta.encode(), back, len(samples), C.byref(n)) == 0
+    for a, b in zip(poses, back):
+        assert (a.week_number, a.milliseconds, a.week_number_pos, a.seconds_pos, a.t_us) == \
+            (b.week_number, b.milliseconds, b.week_number_pos, b.seconds_pos, b.t_us)

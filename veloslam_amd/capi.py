@@ -109,7 +109,7 @@ EXPORTS = [
     "velo_exchange_increments", "velo_exchange_plan", "velo_exchange_pack_dev", "velo_last_timing", "velo_last_linearize_us", "velo_set_timing", "velo_debug_search_stats", "velo_set_stats", "velo_pairs_total", "velo_search_stats",
     "velo_matrix_from_pose", "velo_pose_from_matrix", "velo_interp_pose",
     "velo_packet_transforms", "velo_pcap_write", "velo_pcap_read", "velo_pcap_index", "velo_ins_to_pose",
-    "velo_insmeta_write", "velo_insmeta_read", "velo_carposes_read", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
+    "velo_insmeta_write", "velo_insmeta_read", "velo_carposes_read", "velo_time_to_week_milli", "velo_load_corrections", "eulr2dcm", "llh2xyz", "xyz2llh", "xyz2enu", "enu2xyz", "enu2llh",
     "llh2enu", "MappingAngle",
 ]
 
@@ -317,6 +317,16 @@ def packet_transforms(poses, n, pkt_times):
     if rc:
         raise VeloError(rc, "velo_packet_transforms")
     return tab, valid, car
+
+
+def time_to_week_milli(t_us):
+    """ptimeToWeekMilli (type_defs.cxx:74-79): (ISO week of the date, ms since Sunday 00:00)."""
+    L = lib()
+    L.velo_time_to_week_milli.argtypes = [C.c_int64, C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)]
+    L.velo_time_to_week_milli.restype = None
+    w, m = C.c_uint16(0), C.c_uint32(0)
+    L.velo_time_to_week_milli(int(t_us), C.byref(w), C.byref(m))
+    return w.value, m.value
 
 
 def load_corrections(path):

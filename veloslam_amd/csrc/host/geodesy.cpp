@@ -1,9 +1,16 @@
-// geodesy.cpp -- product-side WGS-84 LLH <-> ECEF <-> local ENU and Euler -> DCM,
-// exported under the reference's names and signatures (CoordiTran.h:7-15) so the
-// reference's callers (INSSource.cxx:305-326 calcTransform,
-// TransformManager.cxx:179-185 setOriginLLH, TestINSSender.cxx:52-76) link
-// against this library unchanged.  Host-only, fp64: ~15 transcendental calls
-// per 100 Hz INS sample is not GPU work.
+// geodesy.cpp -- product-side WGS-84 LLH <-> ECEF <-> local ENU and Euler -> DCM
+// (CoordiTran.h:7-15).  Host-only, fp64: ~15 transcendental calls per 100 Hz INS sample is
+// not GPU work.
+//
+// Exported TWICE, from one set of bodies (namespace velo_geodesy below):
+//   * with C linkage (`llh2xyz`, ...; declared in include/velo.h) -- the C ABI that ctypes,
+//     cgo-style bindings and the tests call;
+//   * with C++ linkage (`_Z7llh2xyzPdS_`, ...; host/geodesy_cxx.cpp, declared in
+//     include/veloslam/CoordiTran.h) -- the reference's header declares these functions
+//     WITHOUT extern "C", so its translation units (INSSource.cxx:305-326 calcTransform,
+//     TransformManager.cxx:179-185 setOriginLLH, TestINSSender.cxx:52-76) reference the
+//     mangled names: those are the symbols such a caller links against unchanged
+//     (tests/test_host_parity.py::test_coorditran_cxx_linkage_links_reference_style_callers).
 //
 // The parity bar is bit-exact against vectors cut from the reference's own object
 // code (tests/golden/coorditran.json, and live against oracle/_ref), and a closed
@@ -13,8 +20,9 @@
 // this file's own is the structure around the formulas (Ellipsoid, EnuBasis, mul3).
 // Built with g++ -O2 -ffp-contract=off, the reference's compiler (csrc/Makefile).
 #include <cmath>
-#include "../../../include/velo.h"
+#include "geodesy_impl.hpp"
 
+namespace velo_geodesy {
 namespace {
 
 struct Ellipsoid {
@@ -55,8 +63,6 @@ void mul3(const double A[3][3], const double B[3][3], double O[3][3])
 }
 
 }  // namespace
-
-extern "C" {
 
 // CoordiTran.cpp:4-49 -- body->nav DCM = (C3(-phi) C2(-theta) C1(-psi))^T
 void eulr2dcm(double eul_vect[3], double DCMbn[3][3])
@@ -183,4 +189,17 @@ double MappingAngle(double angle)
     return (450.0 - angle) * kPi / 180.0;
 }
 
+}  // namespace velo_geodesy
+
+// ---- C linkage (include/velo.h) ----------------------------------------------------------
+#include "../../../include/velo.h"
+extern "C" {
+void eulr2dcm(double eul_vect[3], double DCMbn[3][3]) { velo_geodesy::eulr2dcm(eul_vect, DCMbn); }
+void llh2xyz(double llh[3], double xyz[3]) { velo_geodesy::llh2xyz(llh, xyz); }
+void xyz2llh(double xyz[3], double llh[3]) { velo_geodesy::xyz2llh(xyz, llh); }
+void xyz2enu(double xyz[3], double orgxyz[3], double enu[3]) { velo_geodesy::xyz2enu(xyz, orgxyz, enu); }
+void enu2xyz(double enu[3], double orgxyz[3], double xyz[3]) { velo_geodesy::enu2xyz(enu, orgxyz, xyz); }
+void enu2llh(double enu[3], double orgxyz[3], double llh[3]) { velo_geodesy::enu2llh(enu, orgxyz, llh); }
+void llh2enu(double llh[3], double orgxyz[3], double enu[3]) { velo_geodesy::llh2enu(llh, orgxyz, enu); }
+double MappingAngle(double angle) { return velo_geodesy::MappingAngle(angle); }
 }  // extern "C"

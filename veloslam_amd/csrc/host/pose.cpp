@@ -385,7 +385,12 @@ bool TransformManager::loadFromTxtFile(const std::string& filename, bool clearOl
         tr.R[1] = tr.R[1] * 180 / M_PI;
         tr.R[2] = -(tr.R[2] * 180 / M_PI);
         tr.timestamp = (int64_t)sec * 1000000 + usec + 8LL * 3600 * 1000000;
-        tr.seconds_pos = 0;
+        // TransformManager.cxx:116-119: the GPS-week fields are filled from the (+8 h) time, and
+        // seconds_pos is the millisecond count divided IN FLOAT (`milliseconds / 1000.0f`:
+        // the uint32 is first rounded to 24 bits), which also marks the sample valid (!= -1)
+        velo_time_to_week_milli(tr.timestamp, &tr.week_number, &tr.milliseconds);
+        tr.week_number_pos = tr.week_number;
+        tr.seconds_pos = (double)((float)tr.milliseconds / 1000.0f);
         addTransform(tr);
         tr = PoseTransform();
     }
@@ -572,6 +577,36 @@ int velo_interp_pose(const velo_pose* sorted, size_t n, int64_t t_us, velo_pose*
     if (!view.interpolate(t_us, &p)) return VELO_E_NODATA;
     *out = p.toC();
     return VELO_OK;
+}
+
+// ptimeToWeekMilli (type_defs.cxx:74-79): `week` = boost::gregorian::date::week_number() of the
+// date (the ISO 8601 week, 1..53), `milli` = milliseconds since the last Sunday 00:00
+// (`date - days(tm_wday)`), truncated into 32 bits.  Written here from the ISO rule itself -- the
+// week of a date is the ordinal week of the Thursday of its Monday-based week -- the oracle
+// (oracle/pose.c vo_time_to_week_milli) restates Boost.DateTime's julian-day formulation; the two
+// and Python's date.isocalendar() agree on every day of 1970-2199 (tests/test_host_parity.py).
+void velo_time_to_week_milli(int64_t t_us, uint16_t* week, uint32_t* milli)
+{
+    const int64_t kDayUs = 86400LL * 1000000;
+    int64_t days = t_us / kDayUs;
+    if (t_us % kDayUs < 0) --days;                 // floor: the date of a time before the epoch
+    const int64_t wd_sun = ((days % 7) + 7 + 4) % 7;   // 1970-01-01 was a Thursday; 0 = Sunday
+    if (milli) *milli = (uint32_t)((t_us - (days - wd_sun) * kDayUs) / 1000);
+    if (!week) return;
+    const int64_t wd_mon = (wd_sun + 6) % 7;           // 0 = Monday
+    const int64_t thursday = days - wd_mon + 3;        // the Thursday that names the ISO week
+    // civil year of `thursday` and its ordinal day (days-from-civil, proleptic Gregorian)
+    int64_t z = thursday + 719468;
+    const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+    const int64_t doe = z - era * 146097;
+    const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    const int64_t doy_mar = doe - (365 * yoe + yoe / 4 - yoe / 100);  // day of the March-based year
+    const int64_t month_mar = (5 * doy_mar + 2) / 153;
+    int64_t year = yoe + era * 400 + (month_mar >= 10 ? 1 : 0);
+    const bool leap = (year % 4 == 0 && year % 100 != 0) || year % 400 == 0;
+    // ordinal day in the January-based year
+    const int64_t doy = month_mar >= 10 ? doy_mar - 306 : doy_mar + 59 + (leap ? 1 : 0);
+    *week = (uint16_t)(doy / 7 + 1);
 }
 
 int velo_carposes_read(const char* path, velo_pose* poses, size_t cap, size_t* n_out)
