@@ -93,7 +93,7 @@ for h, S, load in [(h, S, l) for h in a.voxels for S in a.subdivs for l in a.has
             r = c.icp_batch([T0], 20, dm)
         t_icp = (time.perf_counter() - t0) / 3
         err = float(np.linalg.norm(np.array(list(r[0].T)).reshape(3, 4)[:, 3] - Tt.reshape(3, 4)[:, 3]))
-        print("h=%.2f S=%2d (used %2d) load %2d | build %.2f s | table %s | knn%d %.2f ms/frame (kernel), found %.1f, "
+        print("h=%.2f S=%2d (used %2d) load %2d | build %.3f s | table %s | knn%d %.3f ms/frame (kernel), found %.1f, "
               "%.0f candidates %.0f rows per query | 20-iter registration %.2f ms (pose err %.4f m, %d pairs)"
               % (h, S, mi.subdiv, load, t_build, table, a.k, t_knn, found, st["candidates"] / max(st["queries"], 1),
                  st["rows"] / max(st["queries"], 1), 1e3 * t_icp, err, int(r[0].total_pairs)), flush=True)

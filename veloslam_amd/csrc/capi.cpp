@@ -626,7 +626,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
         return txn.done(publish_map(c, mv, k_normals, invalid, 0, c->n_done_host));
     }
     if (k_normals > 0) {
-        HIP_TRY(c, launch_normals(mv, c->perm.p, k_normals, c->nrm.p, c->invalid_cnt.p, s));
+        HIP_TRY(c, launch_normals(mv, c->perm.p, k_normals, c->nrm.p, c->invalid_cnt.p, s, c->cfg.force_kernel));
         HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
     } else {
         HIP_TRY(c, hipMemsetAsync(c->nrm.p, 0, n * sizeof(float4), s));

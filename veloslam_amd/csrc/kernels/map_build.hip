@@ -4,6 +4,7 @@
 // (grid / normals), checked bit-for-bit against oracle/icp.c in tests/.
 // The stable key sort itself lives in sortscan.hip (rocPRIM radix sort).
 #include "device_math.hpp"
+#include "normal_math.hpp"
 
 namespace velo {
 
@@ -228,31 +229,6 @@ hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell
 #define VELO_NRM_THREADS 128
 #endif
 constexpr int kNrmThreads = VELO_NRM_THREADS;
-constexpr int kMinNb = 5;
-constexpr float kNormalRadius = 0.99f;
-
-__device__ __forceinline__ void jacobi_rot(double A[3][3], double V[3][3], int p, int q)
-{
-    if (A[p][q] == 0.0) return;
-    const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-    double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
-    if (theta < 0.0) t = -t;
-    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-    const int r = 3 - p - q;
-    const double app = A[p][p], aqq = A[q][q], apq = A[p][q];
-    const double arp = A[r][p], arq = A[r][q];
-    A[p][p] = app - t * apq;
-    A[q][q] = aqq + t * apq;
-    A[p][q] = A[q][p] = 0.0;
-    A[r][p] = A[p][r] = c * arp - s * arq;
-    A[r][q] = A[q][r] = s * arp + c * arq;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double vkp = V[k][p], vkq = V[k][q];
-        V[k][p] = c * vkp - s * vkq;
-        V[k][q] = s * vkp + c * vkq;
-    }
-}
 
 // The k smallest (d2, sorted index) among the points of the 27 voxels around q with
 // d2 <= r2, ascending, into the LDS lists s_d/s_i ([slot][thread]).  Returns how many.
@@ -378,54 +354,7 @@ __device__ __forceinline__ float4 point_normal(const MapView& mv, const uint32_t
     const float r2 = rn * rn;
     const int cnt = collect_knn<true>(mv, perm, q.x, q.y, q.z, r2, k, s_d, s_i, tid);
     const float rk2 = cnt == k ? s_d[k - 1][tid] : r2;
-    if (cnt < kMinNb) return make_float4(0.f, 0.f, 0.f, rk2);
-    double mx = 0, my = 0, mz = 0;
-    for (int i = 0; i < cnt; ++i) {
-        const float4 p = mv.pts[s_i[i][tid]];
-        mx += (double)p.x;
-        my += (double)p.y;
-        mz += (double)p.z;
-    }
-    const double invn = 1.0 / (double)cnt;
-    mx *= invn;
-    my *= invn;
-    mz *= invn;
-    double C0 = 0, C1 = 0, C2 = 0, C3 = 0, C4 = 0, C5 = 0;
-    for (int i = 0; i < cnt; ++i) {
-        const float4 p = mv.pts[s_i[i][tid]];
-        const double dx = (double)p.x - mx, dy = (double)p.y - my, dz = (double)p.z - mz;
-        C0 = fma(dx, dx, C0);
-        C1 = fma(dx, dy, C1);
-        C2 = fma(dx, dz, C2);
-        C3 = fma(dy, dy, C3);
-        C4 = fma(dy, dz, C4);
-        C5 = fma(dz, dz, C5);
-    }
-    double A[3][3] = {{C0, C1, C2}, {C1, C3, C4}, {C2, C4, C5}};
-    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 8; ++sweep) {
-        jacobi_rot(A, V, 0, 1);
-        jacobi_rot(A, V, 0, 2);
-        jacobi_rot(A, V, 1, 2);
-    }
-    int m = 0;
-    if (A[1][1] < A[m][m]) m = 1;
-    if (A[2][2] < A[m][m]) m = 2;
-    double vx = V[0][m], vy = V[1][m], vz = V[2][m];
-    const double inv = 1.0 / sqrt(vx * vx + vy * vy + vz * vz);
-    vx *= inv;
-    vy *= inv;
-    vz *= inv;
-    const bool flip = (vz < 0.0) || (vz == 0.0 && (vy < 0.0 || (vy == 0.0 && vx < 0.0)));
-    // The sign is flipped on the bits.  Written as `if (flip) { vx = -vx; ... }` this is
-    // miscompiled by the ROCm 7.2 compiler at -O3 for gfx950: the negation survives only on
-    // the `vz < 0` path and is dropped on the `vz == 0 && vy < 0` path (found by
-    // tools/fuzz_parity.py on a lattice map; tools/dbg/eig.hip reproduces it in 40 lines).
-    const long long sb = flip ? (long long)0x8000000000000000ull : 0ll;
-    vx = __longlong_as_double(__double_as_longlong(vx) ^ sb);
-    vy = __longlong_as_double(__double_as_longlong(vy) ^ sb);
-    vz = __longlong_as_double(__double_as_longlong(vz) ^ sb);
-    return make_float4((float)vx, (float)vy, (float)vz, rk2);
+    return pca_normal(cnt, rk2, [&](int i) { return mv.pts[s_i[i][tid]]; });
 }
 
 __device__ __forceinline__ bool is_zero3(const float4& v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f; }
@@ -520,7 +449,7 @@ __global__ __launch_bounds__(256) void k_removed_keys(const uint32_t* __restrict
 // a10 with k > 1: the k nearest map points of every (transformed) query within d_max,
 // ascending (d2, sorted index); rows of idx/d2 are padded with -1 / +inf.
 // [0] queries, [1] candidate points fetched, [2] fine rows looked up, [3] fine cells those rows span
-__device__ unsigned long long g_knn_stats[4];
+__device__ unsigned long long g_knn_lane_stats[4];
 
 template <int KMAX, bool STATS = false>
 __global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __restrict__ x,
@@ -547,164 +476,10 @@ __global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __
     }
     if (count) count[i] = cnt;
     if constexpr (STATS) {
-        atomicAdd(&g_knn_stats[0], 1ull);
-        atomicAdd(&g_knn_stats[1], (unsigned long long)nc);
-        atomicAdd(&g_knn_stats[2], (unsigned long long)nr);
-        atomicAdd(&g_knn_stats[3], (unsigned long long)ncell);
-    }
-}
-
-// ---- a10, k > 1, WAVEFRONT-COOPERATIVE form (round 4): one wavefront per query.
-// The per-lane kernel above walks its candidates four at a time and keeps its k-best list by insertion into
-// LDS: on a dense map (BASELINE configs[4]: 100 M points, ~590 candidates per query in rows of ~170) a lane
-// runs a chain of ~150 dependent memory round trips and ~125 insertions of up to 32 shifts, and a frame is only
-// 1 800 wavefronts -- 3.4 ms for 115 200 queries, 4 % of the HBM roofline.  Here the 64 lanes of a wavefront
-// serve ONE query: the same centre-out row walk (wavefront-uniform, no divergence), a row's candidates loaded 64
-// at a time -- consecutive sorted indices: one coalesced 1 KB request -- distances in parallel, and the k-best
-// list held ONE ENTRY PER LANE (lane m = m-th neighbour), a new entry placed by a ballot (how many entries
-// precede it) and one lane shift.  A frame is 115 200 wavefronts: the chip is full.
-// The result is the per-lane kernel's bit for bit: the k smallest candidates under the total order
-// (d2, index) within d_max do not depend on the order they are met in; every pruning test is the same
-// conservative one.
-constexpr int kKnnWaveThreads = 256;
-
-__device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
-__device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
-
-template <bool STATS>
-__global__ __launch_bounds__(kKnnWaveThreads) void k_knn_wave(MapView mv, const float* __restrict__ x,
-                                                              const float* __restrict__ y,
-                                                              const float* __restrict__ z, int n,
-                                                              const double* __restrict__ T, float r2, int k,
-                                                              int32_t* __restrict__ idx, float* __restrict__ d2o,
-                                                              int32_t* __restrict__ count)
-{
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (kKnnWaveThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (i >= n) return;  // (wavefront-uniform)
-    double px, py, pz;
-    xform(T, x[i], y[i], z[i], px, py, pz);
-    const float qx = (float)px, qy = (float)py, qz = (float)pz;
-    auto before = [](float d2, int j, float pd, int pi) -> bool { return d2 < pd || (d2 == pd && j < pi); };
-    // lane i <- lane i - 1 across the whole wavefront in ONE VALU instruction (DPP wave_shr:1, GFX9 family);
-    // through __shfl_up it was two ds_bpermute and an LDS wait in the dependent chain of every insertion
-    auto shift_up = [](int v) -> int { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); };
-    float my_d = INFINITY;  // lane m < cnt: the m-th best so far
-    int my_j = -1;
-    int cnt = 0;            // (uniform)
-    float kd = INFINITY;    // the k-th best once the list is full (uniform)
-    int kj = 0x7fffffff;
-    float bound = r2;
-    unsigned n_cand = 0, n_rows = 0, n_cells = 0;
-    const int cx = cell_coord(qx, mv.ox, mv.inv_h, mv.nx);
-    const int cy = cell_coord(qy, mv.oy, mv.inv_h, mv.ny);
-    const int cz = cell_coord(qz, mv.oz, mv.inv_h, mv.nz);
-    const int vx0 = max(cx - 1, 0), vx1 = min(cx + 1, mv.nx - 1);
-    const int vy0 = max(cy - 1, 0), vy1 = min(cy + 1, mv.ny - 1);
-    const int vz0 = max(cz - 1, 0), vz1 = min(cz + 1, mv.nz - 1);
-    if (!(vx0 > vx1 || vy0 > vy1 || vz0 > vz1)) {
-        const int S = mv.S;
-        const float hf = mv.h / (float)S;
-        const float inv_hf = mv.inv_h * (float)S;
-        const float ux = (qx - mv.ox) * inv_hf, uy = (qy - mv.oy) * inv_hf, uz = (qz - mv.oz) * inv_hf;
-        const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
-        const int x0 = vx0 * S, x1 = (vx1 + 1) * S - 1;  // inclusive fine ranges
-        const int y0 = vy0 * S, y1 = (vy1 + 1) * S - 1;
-        const int z0 = vz0 * S, z1 = (vz1 + 1) * S - 1;
-        const int hy = min(max((int)floorf(fminf(fmaxf(uy, -4.0f), 2.0e9f)), y0), y1);
-        const int hz = min(max((int)floorf(fminf(fmaxf(uz, -4.0f), 2.0e9f)), z0), z1);
-        for (int dz = 0; dz <= z1 - z0; ++dz) {
-            bool any_z = false;
-            for (int sz = 0; sz < 2; ++sz) {
-                if (dz == 0 && sz) continue;
-                const int fz = sz ? hz - dz : hz + dz;
-                if (fz < z0 || fz > z1) continue;
-                const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
-                if (gz * gz * 0.99999f > bound) continue;
-                any_z = true;
-                for (int dy = 0; dy <= y1 - y0; ++dy) {
-                    bool any_y = false;
-                    for (int sy = 0; sy < 2; ++sy) {
-                        if (dy == 0 && sy) continue;
-                        const int fy = sy ? hy - dy : hy + dy;
-                        if (fy < y0 || fy > y1) continue;
-                        const float gy = fmaxf(fmaxf((float)fy - uy, uy - (float)(fy + 1)) * hf - mg, 0.0f);
-                        const float g2 = gz * gz + gy * gy;
-                        if (g2 * 0.99999f > bound) continue;
-                        any_y = true;
-                        const float xr = (sqrtf(fmaxf(bound - g2 * 0.99999f, 0.0f)) * 1.00001f + 2.0f * mg) * inv_hf;
-                        const int fa = max(x0, (int)floorf(fmaxf(ux - xr, -4.0f)));
-                        const int fb = min(x1, (int)floorf(fminf(ux + xr, 2.0e9f)));
-                        if (fa > fb) continue;
-                        const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
-                        if constexpr (STATS) {
-                            n_rows += 1;
-                            n_cells += (unsigned)(fb - fa + 1);
-                        }
-                        // The row is walked from the query's own column OUTWARDS (right part ascending, left part
-                        // descending): in index order a 2 m row of a dense map approaches the query from one end,
-                        // every candidate of its first half beats the list so far and is inserted -- ~300
-                        // insertions per query instead of ~40.  (The result does not depend on the order.)
-                        const int hx = min(max((int)floorf(fminf(fmaxf(ux, -4.0f), 2.0e9f)), fa), fb + 1);
-                        for (int side = 0; side < 2; ++side) {
-                            const int ca = side == 0 ? hx : fa, cb = side == 0 ? fb : hx - 1;
-                            if (ca > cb) continue;
-                            int j0, j1;
-                            if (!row_range_rt(mv, row, ca, cb, j0, j1)) continue;
-                            j0 = __builtin_amdgcn_readfirstlane(j0);
-                            j1 = __builtin_amdgcn_readfirstlane(j1);
-                            for (int t = 0; t < j1 - j0; t += 64) {
-                                const int j = side == 0 ? j0 + t + lane : j1 - 1 - t - lane;
-                                const bool in = side == 0 ? j < j1 : j >= j0;
-                                if constexpr (STATS) n_cand += (unsigned)min(64, j1 - j0 - t);
-                                const float4 c = mv.pts[min(max(j, j0), j1 - 1)];
-                                const float d2 = dist2(c, qx, qy, qz);
-                                const bool ok = in && d2 <= r2 && (cnt < k || before(d2, j, kd, kj));
-                                unsigned long long m = __ballot(ok);
-                                while (m) {  // (uniform) one insertion per surviving candidate
-                                    const int src = __ffsll((long long)m) - 1;
-                                    m &= m - 1;
-                                    const float nd = lane_bcast(d2, src);
-                                    const int nj = lane_bcast(j, src);
-                                    if (cnt == k && !before(nd, nj, kd, kj)) continue;  // the list tightened meanwhile
-                                    const int pos = __popcll(__ballot(lane < cnt && before(my_d, my_j, nd, nj)));
-                                    const float up_d = __int_as_float(shift_up(__float_as_int(my_d)));
-                                    const int up_j = shift_up(my_j);
-                                    if (lane > pos) {
-                                        my_d = up_d;
-                                        my_j = up_j;
-                                    } else if (lane == pos) {
-                                        my_d = nd;
-                                        my_j = nj;
-                                    }
-                                    if (cnt < k) ++cnt;
-                                    if (cnt == k) {
-                                        kd = lane_bcast(my_d, k - 1);
-                                        kj = lane_bcast(my_j, k - 1);
-                                        bound = fminf(r2, kd);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    if (!any_y) break;  // gaps only grow with dy and the bound only shrinks
-                }
-            }
-            if (!any_z) break;
-        }
-    }
-    if (lane < k) {
-        idx[(size_t)i * k + lane] = lane < cnt ? my_j : -1;
-        d2o[(size_t)i * k + lane] = lane < cnt ? my_d : INFINITY;
-    }
-    if (lane == 0) {
-        if (count) count[i] = cnt;
-        if constexpr (STATS) {
-            atomicAdd(&g_knn_stats[0], 1ull);
-            atomicAdd(&g_knn_stats[1], (unsigned long long)n_cand);
-            atomicAdd(&g_knn_stats[2], (unsigned long long)n_rows);
-            atomicAdd(&g_knn_stats[3], (unsigned long long)n_cells);
-        }
+        atomicAdd(&g_knn_lane_stats[0], 1ull);
+        atomicAdd(&g_knn_lane_stats[1], (unsigned long long)nc);
+        atomicAdd(&g_knn_lane_stats[2], (unsigned long long)nr);
+        atomicAdd(&g_knn_lane_stats[3], (unsigned long long)ncell);
     }
 }
 
@@ -722,27 +497,18 @@ hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const f
                       hipStream_t s, unsigned long long* stats_out, int mode)
 {
     if (n == 0) return hipSuccess;
+    if (knn_use_wave(mv, mode))  // kernels/knn_wave.hip
+        return launch_knn_wave(mv, x, y, z, n, T, dmax2, k, idx, d2, count, s, stats_out);
     const int grid = (int)((n + kNrmThreads - 1) / kNrmThreads);
-    const bool wave = knn_use_wave(mv, mode);
-    const int wgrid = (int)((n + kKnnWaveThreads / 64 - 1) / (kKnnWaveThreads / 64));
     if (stats_out) {  // counting instantiation (widest list: the LDS footprint is not what is measured here)
         const unsigned long long z4[4] = {0, 0, 0, 0};
-        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z4, sizeof z4);
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_knn_lane_stats), z4, sizeof z4);
         if (e != hipSuccess) return e;
-        if (wave)
-            hipLaunchKernelGGL((k_knn_wave<true>), dim3(wgrid), dim3(kKnnWaveThreads), 0, s, mv, x, y, z, (int)n, T,
-                               dmax2, k, idx, d2, count);
-        else
-            hipLaunchKernelGGL((k_knn<VELO_MAX_KNORMALS, true>), dim3(grid), dim3(kNrmThreads), 0, s, mv, x, y, z,
-                               (int)n, T, dmax2, k, idx, d2, count);
+        hipLaunchKernelGGL((k_knn<VELO_MAX_KNORMALS, true>), dim3(grid), dim3(kNrmThreads), 0, s, mv, x, y, z,
+                           (int)n, T, dmax2, k, idx, d2, count);
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return e;
-        return hipMemcpyFromSymbol(stats_out, HIP_SYMBOL(g_knn_stats), sizeof z4);
-    }
-    if (wave) {
-        hipLaunchKernelGGL((k_knn_wave<false>), dim3(wgrid), dim3(kKnnWaveThreads), 0, s, mv, x, y, z, (int)n, T,
-                           dmax2, k, idx, d2, count);
-        return hipGetLastError();
+        return hipMemcpyFromSymbol(stats_out, HIP_SYMBOL(g_knn_lane_stats), sizeof z4);
     }
     if (k <= 8)
         hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(kNrmThreads), 0, s, mv, x, y, z, (int)n, T, dmax2,
@@ -757,8 +523,10 @@ hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const f
 }
 
 hipError_t launch_normals(const MapView& mv, const uint32_t* perm, int k, float4* nrm,
-                          unsigned long long* d_invalid, hipStream_t s)
+                          unsigned long long* d_invalid, hipStream_t s, int mode)
 {
+    // dense maps: one wavefront per point for the search, one lane per point for the PCA (kernels/knn_wave.hip)
+    if (knn_use_wave(mv, mode)) return launch_normals_wave(mv, perm, k, nrm, d_invalid, s);
     hipError_t e = hipMemsetAsync(d_invalid, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     const int grid = (mv.n + kNrmThreads - 1) / kNrmThreads;

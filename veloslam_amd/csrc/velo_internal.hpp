@@ -96,7 +96,13 @@ hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell
 hipError_t launch_count_runs(const uint32_t* sorted_keys, size_t n, unsigned long long* d_count, hipStream_t s);
 hipError_t launch_hash_build(const uint32_t* sorted_keys, size_t n, int4* hash, uint32_t cap, hipStream_t s);
 hipError_t launch_normals(const MapView& mv, const uint32_t* perm, int k, float4* nrm,
-                          unsigned long long* d_invalid, hipStream_t s);
+                          unsigned long long* d_invalid, hipStream_t s, int mode = 0);
+// (mode as launch_knn's: the full-map normals of a dense map go through the cooperative search)
+hipError_t launch_normals_wave(const MapView& mv, const uint32_t* perm, int k, float4* nrm,
+                               unsigned long long* d_invalid, hipStream_t s);
+hipError_t launch_knn_wave(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
+                           const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
+                           hipStream_t s, unsigned long long* stats_out);
 
 // incremental map update (f3): see kernels/map_build.hip
 hipError_t launch_keys4(const float4* pts, size_t n, const MapView& grid, uint32_t* keys,
