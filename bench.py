@@ -44,12 +44,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the CPU leg's OpenMP threads stay where they start (libgomp reads this when it is first loaded -- torch
+# brings it in): without it the all-thread figure moved by 15 % between two runs of the same code on one box
+os.environ.setdefault("OMP_PROC_BIND", "close")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from veloslam_amd import capi, synth  # noqa: E402
+from veloslam_amd import capi, srchash, synth  # noqa: E402
 from veloslam_amd.dist import exchange_increments  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -96,7 +99,9 @@ def parse():
     ap.add_argument("--capi-child", action="store_true",
                     help="internal: this process is the C-ABI-transport trial a rank of an N > 1 run started "
                          "(gloo rendezvous, RCCL only behind the C ABI; exit 5 = timed out, 6 = communicator refused)")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=-1,
+                    help="frames of the timed batch re-registered by the CPU oracle for the parity record "
+                         "(-1 = every frame of the batch: parity.frames == frames_per_step_per_gpu)")
     ap.add_argument("--workload", choices=["batch", "stream"], default="batch",
                     help="batch = BASELINE configs[1] (the headline line); stream = configs[2]: "
                          "packets -> decode -> register -> increment -> rolling-map update, "
@@ -201,13 +206,24 @@ def measured_bytes(ctx, T0, iters, d_max):
 
 
 def traffic_for(key):
-    """PMC (2 x FETCH_SIZE + WRITE_SIZE) bytes per k_linearize launch taken under rocprofv3 at
-    the SAME batch and map (profiles/traffic.json, written by profiles/summarize.py)."""
+    """PMC bytes per launch (reads by request size + WRITE_SIZE) taken under rocprofv3 at the SAME batch and
+    map (profiles/traffic.json, written by profiles/summarize.py from the driver's own command).  The file
+    is stamped with the hashes of bench.py and of the kernel sources it was measured on: `traffic_stale` in
+    the record says whether this run is that code."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(p)).get(key)
+        doc = json.load(open(p))
     except Exception:
         return None
+    rec = doc.get(key)
+    if rec is None:
+        return None
+    rec = dict(rec)
+    st = doc.get("_stamp") or {}
+    rec["stamp"] = st
+    rec["stale"] = not (st.get("bench_py_sha16") == srchash.file_sha16(os.path.join(ROOT, "bench.py"))
+                        and st.get("kernel_source_sha16") == srchash.kernel_source_sha16())
+    return rec
 
 
 def roofline_record(ctx, T0, iters, d_max, n_q, avg_launch_s, first_us, min_us, key, cbar=None):
@@ -218,6 +234,7 @@ def roofline_record(ctx, T0, iters, d_max, n_q, avg_launch_s, first_us, min_us, 
            "frac": ach / HBM_PEAK_GBPS,
            "traffic": tr["hbm_bytes_per_launch"] if tr else None,
            "traffic_source": tr["source"] if tr else None,
+           "traffic_stale": tr["stale"] if tr else None,
            "traffic_GBps": (tr["hbm_bytes_per_launch"] / avg_launch_s / 1e9) if tr else None,
            "traffic_frac": (tr["hbm_bytes_per_launch"] / avg_launch_s / 1e9 / HBM_PEAK_GBPS) if tr else None,
            "traffic_rocprof_avg_launch_us": tr.get("rocprof_avg_launch_us") if tr else None,
@@ -706,7 +723,7 @@ def run_replay(args, dev, local, steps, warmup, d=None):
                 "sustained_frac": tr["hbm_bytes_per_frame"] * fps / 1e9 / HBM_PEAK_GBPS,
                 "kernel_us_per_frame": tr["kernel_us_per_frame"],
                 "GBps_while_a_kernel_runs": tr["GBps_while_a_kernel_runs"],
-                "by_family": tr["by_family"], "traffic_source": tr["source"],
+                "by_family": tr["by_family"], "traffic_source": tr["source"], "traffic_stale": tr["stale"],
                 "note": "a frame of the stream is ~60 small launches on a chip it cannot fill (one frame = 450 "
                         "workgroups on 256 CUs): bound by launch and memory LATENCY, which is why the sustained "
                         "fraction of the HBM peak is small; the bytes are PMC counters (reads by request size + "
@@ -784,7 +801,7 @@ def cpu_baseline(args, d, gpu_res):
     from tests.util_scene import pose_delta
     ncpu = os.cpu_count() or 1
     om = orc.Map(*d["map"], args.voxel, args.k_normals)
-    nf = min(args.cpu_frames, len(d["host_frames"]))
+    nf = len(d["host_frames"]) if args.cpu_frames < 0 else min(args.cpu_frames, len(d["host_frames"]))
     comp = []
     for k in range(nf):
         fr, tab, _ = d["host_frames"][k]
@@ -807,10 +824,11 @@ def cpu_baseline(args, d, gpu_res):
         timed(th)  # warm-up
         runs = [timed(th) for _ in range(5)]
         ts = sorted(r[0] for r in runs)
-        return ts[2], runs[0][1], runs[0][2]
+        return ts[2], runs[0][1], runs[0][2], ts
 
-    t_all, T_all, st_all = median5(width)
-    t_one, T_one, st_one = median5(1)
+    t_all, T_all, st_all, runs_all = median5(width)
+    t_one, T_one, st_one, runs_one = median5(1)
+    t_box, runs_box = (t_all, runs_all) if width == ncpu else median5(ncpu)[::3]   # every host core, beside the winner
     pairs = sum(s["n_pairs"] for s in st_all)
     cbar = sum(s["candidates"] for s in st_all) / float(comp[0][0].size * args.iters)
     # parity of the timed GPU batch against the CPU path, frames 0..nf-1
@@ -824,12 +842,16 @@ def cpu_baseline(args, d, gpu_res):
         max_dpos, max_drot = max(max_dpos, dpos), max(max_drot, drot)
         pairs_equal &= all(int(gpu_res[k].iter[i].n_pairs) == int(st[i]["n_pairs"]) for i in range(args.iters))
     cb = dict(value=pairs / t_all, unit="pairs/s", cores=width, kind="port",
-              single_thread_value=pairs / t_one, host_cores=ncpu,
-              seconds_per_registration={"threads_%d" % width: t_all, "threads_1": t_one},
+              single_thread_value=pairs / t_one, host_cores=ncpu, all_cores_value=pairs / t_box,
+              omp_proc_bind=os.environ.get("OMP_PROC_BIND"),
+              seconds_per_registration={"threads_%d" % width: t_all, "threads_1": t_one, "threads_all_%d" % ncpu: t_box},
+              spread_of_5={"threads_%d" % width: [runs_all[0], runs_all[-1]], "threads_1": [runs_one[0], runs_one[-1]],
+                           "threads_all_%d" % ncpu: [runs_box[0], runs_box[-1]]},
               sample="frame 0 of the timed batch (115 200-pt frame vs the same %d-pt map, %d ICP "
                      "iterations = %d pairs), median of 5 runs after 1 warm-up: oracle/icp.c with "
-                     "OpenMP on %d threads (fastest of a 2-iteration probe over widths up to the box's "
-                     "%d host cores) and on 1 thread" % (args.map_points, args.iters, pairs, width, ncpu))
+                     "OpenMP (OMP_PROC_BIND=close) on %d threads (fastest of a 2-iteration probe over widths up to "
+                     "the box's %d host cores), on all %d, and on 1 thread; the other frames of the batch are "
+                     "registered once each for the parity record" % (args.map_points, args.iters, pairs, width, ncpu, ncpu))
     parity = dict(frames=nf, max_dpos_m=max_dpos, max_drot_rad=max_drot, pairs_equal=bool(pairs_equal),
                   tol_m=POS_TOL, tol_rad=ROT_TOL, against="oracle/icp.c vo_icp on the same frames, map and T0")
     return cb, cbar, parity
@@ -972,19 +994,32 @@ def knn_record(args, d, dev, local):
            "search": {"candidates_per_query": st["candidates"] / max(st["queries"], 1),
                       "rows_per_query": st["rows"] / max(st["queries"], 1),
                       "cells_per_query": st["cells"] / max(st["queries"], 1)},
+           # `achieved` / `frac` = ALGORITHMIC bytes of a launch (query side + the candidate and table bytes the search
+           # asks for, capped by the resident map) / launch time, as the contract defines them.  Most of those
+           # bytes are served by L2 / Infinity Cache (neighbouring queries share rows): `traffic` (PMC, fabric
+           # side of L2) is what crosses to memory, `traffic_frac` that figure against the HBM peak -- the honest
+           # HBM utilisation, and small: the kernel is bound by instruction issue and latency (`limiter`), not HBM.
            "roofline": {"bound": "hbm", "kernel": "k_knn_wave (one wavefront per query)" if wave_kernel else "k_knn<32> (one lane per query)",
                         "achieved": alg / (1e-6 * launch_us) / 1e9,
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (1e-6 * launch_us) / 1e9 / HBM_PEAK_GBPS,
                         "algorithmic_bytes_per_launch": alg, "query_bytes_per_launch": q_bytes,
                         "map_requested_bytes_per_launch": map_req, "map_resident_bytes": resident,
+                        "requested_GBps": (q_bytes + map_req) / (1e-6 * launch_us) / 1e9,
                         "avg_launch_us": launch_us,
                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                         "traffic_source": tr["source"] if tr else None,
+                        "traffic_stale": tr["stale"] if tr else None,
                         "traffic_rocprof_avg_launch_us": tr.get("rocprof_avg_launch_us") if tr else None,
                         "traffic_GBps": (tr["hbm_bytes_per_launch"] / (1e-6 * launch_us) / 1e9) if tr else None,
-                        "note": ("one wavefront per query (the map is dense: points >= 0.25 x fine cells): the row walk is "
-                                 "wavefront-uniform, 64 candidates per coalesced request, the k-best list one entry per "
-                                 "lane; bound by the insertion chain and the per-row round trips, not by HBM"
+                        "traffic_frac": (tr["hbm_bytes_per_launch"] / (1e-6 * launch_us) / 1e9 / HBM_PEAK_GBPS) if tr else None,
+                        "limiter": ("vector-instruction issue and latency, not HBM: ~1 000 vector instructions per query "
+                                    "(two to three 64-lane bitonic sorts, five 64-candidate chunks, the row geometry) on "
+                                    "one wavefront each; PMC: 70 % of the requested bytes never leave L2 / Infinity Cache"
+                                    if wave_kernel else "dependent L2 / LDS round trips per lane"),
+                        "note": ("one wavefront per query (the map is dense: points >= 0.25 x fine cells): rows walked from "
+                                 "the query's column outwards with an exact early stop, 64 candidates per coalesced request, "
+                                 "survivors merged into the k-best list (one entry per lane) by a 64-lane bitonic sort; the "
+                                 "table entries of the 3 x 3 rows around the query looked up in one load"
                                  if wave_kernel else
                                  "one lane per query, exact ball search with a k-best list in LDS: bound by dependent "
                                  "L2 / LDS round trips per lane, not by HBM -- 115 200 queries are 900 workgroups")}}

@@ -384,7 +384,8 @@ int velo_linearize(velo_ctx*, int frame, const double T[12], float d_max, int32_
 int velo_knn(velo_ctx*, int frame, const double T[12], float d_max, int k, int32_t* idx, float* d2,
              int32_t* count);
 /* The same with the results left on the DEVICE (d_idx, d_d2: n x k; d_count may be NULL), enqueued on the ctx
- * stream, nothing fetched: what a caller that consumes the neighbours on the GPU uses, and what bench.py times
+ * stream, nothing fetched and nothing waited for (the pose is a kernel argument): what a caller that consumes the
+ * neighbours on the GPU uses, and what bench.py times
  * for BASELINE configs[4] (100 M-point map, k = 32).  stats (may be NULL) switches to the COUNTING
  * instantiation of the kernel and waits for it: [0] queries, [1] candidate points fetched (16 B each),
  * [2] fine rows looked up in the table, [3] fine cells those rows span -- the kernel's byte accounting. */

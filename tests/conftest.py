@@ -24,7 +24,7 @@ def pytest_configure(config):
 # run in this order; inside a file the written order stays.  Files not listed go last, CPU tests are untouched
 # (they keep their alphabetical order in front / between, whatever `-m` selects).
 _GPU_ORDER = ["test_gpu_parity", "test_golden_icp", "test_gpu_fuzz", "test_gpu_hash", "test_gpu_knn",
-              "test_gpu_batch_invariance", "test_gpu_sum_definition", "test_drive", "test_cpp_api", "test_gpu_comm", "test_bench_cli"]
+              "test_gpu_batch_invariance", "test_gpu_sum_definition", "test_gpu_streams", "test_drive", "test_cpp_api", "test_gpu_comm", "test_bench_cli"]
 
 
 def pytest_collection_modifyitems(config, items):

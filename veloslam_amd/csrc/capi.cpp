@@ -145,10 +145,8 @@ struct velo_ctx {
     DevBuf<int32_t> cell_start_alt;
     DevBuf<uint8_t> vox_near_alt;
     bool overlap_update = false;        // inside velo_map_roll_overlapped
-    DevBuf<double> knn_T;               // velo_knn / velo_knn_dev: the pose on the device ...
     DevBuf<int32_t> knn_idx, knn_cnt;   // velo_knn: device-side results before the copy back
     DevBuf<float> knn_d2;
-    double* h_knn_T = nullptr;          // ... and its pinned source
     int overlap_done = 0;               // ... updates published so far in this call
     // a roll is TWO updates (evict, append): the second must not write the arrays the registration is
     // still reading either -- which after the first swap are the "alt" ones -- so a third set steps in
@@ -1079,17 +1077,19 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
             c->items_h.push_back(it);
             q += step;
         }
-        if (planned)   // head small rows (kLinNT queries), then large ones: slots of kLinNT queries
+        if (planned && R > 1)   // head small rows (kLinNT queries), then large ones: slots of kLinNT queries
             lay_h[(size_t)f] = RowLayout{(int32_t)((head_end - frame_start[f]) / kLinNT), nbig, log2i(R),
                                          (int32_t)((nqf + kLinNT - 1) / kLinNT)};
-        else           // uniform rows: one slot each
-            lay_h[(size_t)f] = RowLayout{0, 0, 0, nbig};
+        else           // uniform rows, one slot each -- also a planned batch at one round per wavefront, whose "large"
+                       // rows are the small size: the mixed layout sent every one of its 16-slot spans down the
+                       // solve's per-slot path (plan_decomposition already collapses this case)
+            lay_h[(size_t)f] = RowLayout{0, 0, 0, (int32_t)c->items_h.size() - c->fbs_h[f]};
     }
     if (c->items_h.size() >= ((size_t)1 << kItemRowBits)) return c->fail(VELO_E_RANGE, "too many work items");
     for (int f = 0; f < n_frames; ++f)
         if (lay_h[(size_t)f].nslots > kMaxRowSlots)
             return c->fail(VELO_E_RANGE, "frame %d has %lld points: more than %lld per frame", f,
-                           (long long)(frame_start[f + 1] - frame_start[f]), (long long)kMaxRowSlots * (planned ? kLinNT : per_block));
+                           (long long)(frame_start[f + 1] - frame_start[f]), (long long)kMaxRowSlots * (planned && R > 1 ? kLinNT : per_block));
     c->lay0_h = lay_h[0];
     c->fbs_h[n_frames] = (int32_t)c->items_h.size();
     const size_t ni = c->items_h.size();
@@ -1143,7 +1143,12 @@ int plan_frames(velo_ctx* c, int n_frames, const int64_t* frame_start)
     }
     // (with slack: in the pipelined stream plan_frames runs on the side stream while a registration still reads
     //  these rows -- a frame a few points larger than every one before must not reallocate under it)
-    HIP_TRY(c, reserve_slack(c->partials, (max_rows + max_rows / 4 + 64) * kAccStride));
+    //  Sized ONCE for the largest batch of real frames -- max_batch revolutions of 64 lasers x HDL_MAX_PTS_PER_LASER
+    //  2200 returns (type_defs.h:20), cut into the smallest items -- so that a short first sweep followed by full
+    //  revolutions never reallocates (a hipFree under a running registration is safe only through its device-wide
+    //  wait, which is the stall the pipeline exists to avoid); larger synthetic frames still grow it.
+    const size_t rows_bound = (size_t)std::max(maxb, n_frames) * ((size_t)(64 * 2200 + kLinNT - 1) / kLinNT + 2);
+    HIP_TRY(c, reserve_slack(c->partials, std::max(rows_bound, max_rows + max_rows / 4 + 64) * kAccStride));
     HIP_TRY(c, c->poses.reserve((size_t)maxb * 12));
     HIP_TRY(c, c->acc.reserve((size_t)maxb * kAccStride));
     HIP_TRY(c, c->stats.reserve((size_t)maxb * VELO_MAX_ITERS));
@@ -1568,7 +1573,6 @@ void velo_destroy(velo_ctx* c)
     }
     if (c->h_inc_total) (void)hipHostFree(c->h_inc_total);
     if (c->h_result) (void)hipHostFree(c->h_result);
-    if (c->h_knn_T) (void)hipHostFree(c->h_knn_T);
     if (c->h_starts) (void)hipHostFree(c->h_starts);
     if (c->h_pend_total) (void)hipHostFree(c->h_pend_total);
     if (c->ev_pend) (void)hipEventDestroy(c->ev_pend);
@@ -2752,13 +2756,12 @@ int velo_knn(velo_ctx* c, int frame, const double T[12], float d_max, int k, int
     // (buffers of the ctx: a hipMalloc / hipFree pair per call is a device-wide synchronisation each)
     DevBuf<int32_t>&di = c->knn_idx, &dc = c->knn_cnt;
     DevBuf<float>& dd = c->knn_d2;
-    DevBuf<double>& dT = c->knn_T;
     HIP_TRY(c, reserve_slack(di, n * (size_t)k));
     HIP_TRY(c, reserve_slack(dd, n * (size_t)k));
     HIP_TRY(c, reserve_slack(dc, n));
-    HIP_TRY(c, dT.reserve(12));
-    HIP_TRY(c, hipMemcpyAsync(dT.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, dT.p, d_max * d_max, k, di.p,
+    Pose12 P;
+    std::memcpy(P.t, T, sizeof P.t);
+    HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, P, d_max * d_max, k, di.p,
                           dd.p, dc.p, s, nullptr, c->cfg.force_kernel));
     HIP_TRY(c, hipMemcpyAsync(idx, di.p, n * (size_t)k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(d2, dd.p, n * (size_t)k * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -2781,14 +2784,12 @@ int velo_knn_dev(velo_ctx* c, int frame, const double T[12], float d_max, int k,
     hipStream_t s = c->stream;
     const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
     if (n == 0) return VELO_OK;
-    // the pose goes through the ctx's pinned pair like a registration's (no pageable copy, no wait)
-    HIP_TRY(c, c->knn_T.reserve(12));
-    if (!c->h_knn_T) HIP_TRY(c, hipHostMalloc((void**)&c->h_knn_T, 12 * sizeof(double), 0));
-    HIP_TRY(c, hipStreamSynchronize(s));  // (the previous call's copy out of h_knn_T; a diagnostics path)
-    std::memcpy(c->h_knn_T, T, 12 * sizeof(double));
-    HIP_TRY(c, hipMemcpyAsync(c->knn_T.p, c->h_knn_T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    // the pose travels as a kernel argument: nothing staged, nothing waited for -- the call only enqueues
+    // (it used to drain the stream to reuse one pinned staging buffer)
+    Pose12 P;
+    std::memcpy(P.t, T, sizeof P.t);
     unsigned long long st[4] = {0, 0, 0, 0};
-    HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, c->knn_T.p, d_max * d_max, k, d_idx, d_d2,
+    HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, P, d_max * d_max, k, d_idx, d_d2,
                           d_count, s, stats ? st : nullptr, c->cfg.force_kernel));
     if (stats)
         for (int i = 0; i < 4; ++i) stats[i] = st[i];

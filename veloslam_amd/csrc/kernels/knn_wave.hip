@@ -7,7 +7,10 @@
 // named ("What's weak" 3); this is the rewrite against each of them:
 //   (i)   one serial insertion per surviving candidate      -> survivors of a chunk are appended to the upper
 //         half-wavefront by ONE push permute and merged by ONE 64-lane bitonic sort (21 compare-exchange steps on
-//         64-bit keys, 14 of them DPP); only chunks with <= kSerialMax survivors insert one by one;
+//         64-bit keys, 14 of them DPP); only chunks with <= kSerialMax survivors insert one by one.  (Measured out
+//         in round 5, same box: the network on the 32-bit distance alone with the DPP exchanges folded into
+//         v_subb_co_u32_dpp / v_cndmask_b32_dpp by hand -- 3 vector instructions per step instead of 5, ties
+//         re-sorted in full -- is 7 % SLOWER, 0.214 against 0.200 ms: DESIGN / docs/lab_notebook.md.)
 //   (ii)  the next chunk was loaded after the insertions    -> both sides of a row are loaded before either is
 //         processed, and a row's table entries are not loaded in the chain at all (iv);
 //   (iii) lanes 32-63 held no list entry                    -> they are the staging half of the sort;
@@ -28,7 +31,8 @@ namespace velo {
 #define VELO_KNN_THREADS 256  // 4 wavefronts = 4 queries per workgroup
 #endif
 #ifndef VELO_KNN_WAVES_PER_SIMD
-#define VELO_KNN_WAVES_PER_SIMD 1  // __launch_bounds__' second argument (register budget of the search kernel)
+#define VELO_KNN_WAVES_PER_SIMD 8  // __launch_bounds__' second argument: 78 scalar registers instead of 104 admit an
+                                   // eighth wavefront per SIMD (+ 8 % on configs[4]; the normals kernel keeps its own)
 #endif
 #ifndef VELO_KNN_XCD
 #define VELO_KNN_XCD 0  // > 0: runs of that many consecutive workgroups share an XCD (0: plain blockIdx order)
@@ -444,7 +448,7 @@ template <bool HASH, bool STATS>
 __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN_WAVES_PER_SIMD) void k_knn_wave(MapView mv, const float* __restrict__ x,
                                                               const float* __restrict__ y,
                                                               const float* __restrict__ z, int n, int per_xcd,
-                                                              const double* __restrict__ T, float r2, int k,
+                                                              Pose12 T, float r2, int k,
                                                               int32_t* __restrict__ idx, float* __restrict__ d2o,
                                                               int32_t* __restrict__ count)
 {
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN_WAVES_PER_SIMD) void k_kn
     const int i = xcd_block() * (kKnnWaveThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (i >= n) return;  // (wavefront-uniform)
     double px, py, pz;
-    xform(T, x[i], y[i], z[i], px, py, pz);
+    xform(T.t, x[i], y[i], z[i], px, py, pz);
     Ent<false> e;
     KnnCounts ct;
     wave_knn<false, HASH, STATS>(mv, nullptr, (float)px, (float)py, (float)pz, r2, k, lane, e, ct);
@@ -488,7 +492,7 @@ static int knn_grid(int nb)
 }
 
 hipError_t launch_knn_wave(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
-                           const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
+                           const Pose12& T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
                            hipStream_t s, unsigned long long* stats_out)
 {
     if (n == 0) return hipSuccess;

@@ -455,7 +455,7 @@ template <int KMAX, bool STATS = false>
 __global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __restrict__ x,
                                                      const float* __restrict__ y,
                                                      const float* __restrict__ z, int n,
-                                                     const double* __restrict__ T, float dmax2,
+                                                     Pose12 T, float dmax2,
                                                      int k, int32_t* __restrict__ idx,
                                                      float* __restrict__ d2o,
                                                      int32_t* __restrict__ count)
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __
     const int i = blockIdx.x * kNrmThreads + tid;
     if (i >= n) return;
     double px, py, pz;
-    xform(T, x[i], y[i], z[i], px, py, pz);
+    xform(T.t, x[i], y[i], z[i], px, py, pz);
     unsigned nc = 0, nr = 0, ncell = 0;
     const int cnt = collect_knn<false, STATS>(mv, nullptr, (float)px, (float)py, (float)pz, dmax2, k, s_d,
                                               s_i, tid, &nc, &nr, &ncell);
@@ -493,7 +493,7 @@ bool knn_use_wave(const MapView& mv, int mode)
 }
 
 hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
-                      const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
+                      const Pose12& T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
                       hipStream_t s, unsigned long long* stats_out, int mode)
 {
     if (n == 0) return hipSuccess;

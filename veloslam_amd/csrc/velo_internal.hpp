@@ -13,6 +13,11 @@ namespace velo {
 // ---------------------------------------------------------------- device views
 // Voxel-sorted map as the kernels see it.  Points are float4 {x,y,z,0} so a
 // candidate is one 16-byte load; normals likewise ({0,0,0,0} = invalid normal).
+// a pose as a kernel ARGUMENT (96 bytes of kernarg, read by scalar loads): nothing to stage, nothing to wait for
+struct Pose12 {
+    double t[12];
+};
+
 struct MapView {
     const float4* pts;     // [n] sorted by FINE cell key (stable)
     const float4* nrm;     // [n]
@@ -101,7 +106,7 @@ hipError_t launch_normals(const MapView& mv, const uint32_t* perm, int k, float4
 hipError_t launch_normals_wave(const MapView& mv, const uint32_t* perm, int k, float4* nrm,
                                unsigned long long* d_invalid, hipStream_t s);
 hipError_t launch_knn_wave(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
-                           const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
+                           const struct Pose12& T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
                            hipStream_t s, unsigned long long* stats_out);
 
 // incremental map update (f3): see kernels/map_build.hip
@@ -162,7 +167,7 @@ hipError_t launch_count_occupied_voxels(const float* x, const float* y, const fl
                                         uint8_t* occ, unsigned long long* d_count, hipStream_t s);
 
 hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
-                      const double* T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
+                      const Pose12& T, float dmax2, int k, int32_t* idx, float* d2, int32_t* count,
                       hipStream_t s, unsigned long long* stats_out = nullptr, int mode = 0);
 // (mode: 0 = by the map's density, 1 = one lane per query, 2 = one wavefront per query; same results)
 bool knn_use_wave(const MapView& mv, int mode);
