@@ -488,7 +488,7 @@ def synthetic_drive(args, dev, src):
                 patch_range=pr, tile_of=tile_of, n_tiles=len(tile_of))
 
 
-def run_replay(args, dev, local, steps, warmup, d=None):
+def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
     """`--workload stream --drive DIR`: a recorded drive (veloslam_amd/drive.py layout: pcap +
     carposes.txt + db.xml + world.map) replayed against a rolling map, the same loop
     tools/stream_driver.cpp runs from C++ through veloslam::MapManager -- here through the C ABI:
@@ -496,8 +496,12 @@ def run_replay(args, dev, local, steps, warmup, d=None):
     skip per frame) -> velo_decode_to_frames -> roll the device map to the tiles in range of the prior
     (velo_map_evict_outside of the tile rectangle + velo_map_append of the entering tiles, host
     tiles as MapManager holds them) -> 20 ICP iterations -> accepted increment to the device-side
-    pending list (merged once --append-threshold points are pending)."""
+    pending list (merged once --append-threshold points are pending).
+    probe (tests only: tests/test_gpu_parity.py, the configs[2]-size test): {"mirror": a second ctx that is given every
+    map operation of the replay in its plain form (evict, then append), "poses": a list that receives every timed
+    frame's pose, "final": called with the replay's ctx before it is closed}."""
     from veloslam_amd import drive
+    mirror = probe.get("mirror") if probe else None
     if d is None:
         d = drive.load(args.drive)
         pr, tiles = drive.read_map_file(os.path.join(args.drive, "world.map"))
@@ -565,6 +569,8 @@ def run_replay(args, dev, local, steps, warmup, d=None):
         keep = (ti >= cur[0]) & (ti <= cur[1]) & (tj >= cur[2]) & (tj <= cur[3])
         if keep.any():
             ctx.map_append(x[keep], y[keep], z[keep])
+            if mirror:
+                mirror.map_append(x[keep], y[keep], z[keep])
 
     def roll_to(x, y, timed):
         rng = tile_range(x, y)
@@ -581,6 +587,8 @@ def run_replay(args, dev, local, steps, warmup, d=None):
                            np.nextafter(np.float32(rng[3] * pr + pr / 2), np.float32(-big)), big], np.float32)
             if rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]:
                 ctx.map_evict_outside(lo, hi)
+                if mirror:
+                    mirror.map_evict_outside(lo, hi)
             n1 = ctx.map_info().n_points
             ex, ey, ez = gather(rng, skip=cur)
             stays = ((pti >= max(rng[0], cur[0])) & (pti <= min(rng[1], cur[1])) &
@@ -588,6 +596,8 @@ def run_replay(args, dev, local, steps, warmup, d=None):
             ux, uy, uz = np.concatenate([ex, px[stays]]), np.concatenate([ey, py[stays]]), np.concatenate([ez, pz[stays]])
             if ux.size:
                 ctx.map_append(ux, uy, uz)
+                if mirror:
+                    mirror.map_append(ux, uy, uz)
             if timed:
                 state["rolls"] += 1
                 state["up"] += int(ex.size)
@@ -595,6 +605,8 @@ def run_replay(args, dev, local, steps, warmup, d=None):
         else:
             ex, ey, ez = gather(rng)
             ctx.map_reset(ex, ey, ez, args.voxel, args.k_normals)
+            if mirror:
+                mirror.map_reset(ex, ey, ez, args.voxel, args.k_normals)
             if timed:
                 state["full"] += 1
         state["res"] = rng
@@ -618,6 +630,13 @@ def run_replay(args, dev, local, steps, warmup, d=None):
             if ctx.map_info().n_points != n0:
                 state["res"] = None        # (an eviction went through, the append did not: rebuild from the tiles)
             return
+        if mirror:      # the same update in its plain form
+            if evicts:
+                mirror.map_evict_outside(lo, hi)
+            if ex.size:
+                mirror.map_append(ex, ey, ez)
+        if probe is not None:
+            probe["rolls_ahead"] = probe.get("rolls_ahead", 0) + 1
         if timed:
             state["rolls"] += 1
             state["up"] += int(ex.size)
@@ -684,6 +703,8 @@ def run_replay(args, dev, local, steps, warmup, d=None):
             flush()
         t.append(time.perf_counter())
         state["z"] = float(res.T[11])
+        if timed and probe is not None and "poses" in probe:
+            probe["poses"].append([float(v) for v in res.T])
         if timed:
             for name, a, b in zip(stage, t[:-1], t[1:]):
                 stage[name] += b - a
@@ -706,6 +727,8 @@ def run_replay(args, dev, local, steps, warmup, d=None):
     elapsed = time.perf_counter() - t0
     gc.enable()
     mi = ctx.map_info()
+    if probe is not None and probe.get("final"):
+        probe["final"](ctx)
     ctx.decode_plan_destroy(plan)
     ctx.close()
     if state["worst"] > 0.05:
@@ -969,7 +992,7 @@ def knn_record(args, d, dev, local):
     # slot per cell of the row through the hash), capped by what is resident (points + table: a byte of
     # the map does not have to cross the fabric twice in a launch)
     hashed = mi.table_kind == 1
-    wave_kernel = float(mi.n_points) >= 0.25 * float(mi.n_cells)   # (map_build.hip knn_use_wave; cfg.force_kernel = 0)
+    wave_kernel = float(mi.n_points) >= 1.5 * float(mi.dims[0]) * mi.dims[1] * mi.dims[2]   # (map_build.hip knn_use_wave; cfg.force_kernel = 0)
     q_bytes = n * (12 + 8 * k + 4) + 96
     tab_req = st["cells"] * 16 if hashed else st["rows"] * 8
     map_req = st["candidates"] * 16 + tab_req

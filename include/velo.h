@@ -105,8 +105,8 @@ typedef struct velo_cfg {
                                < 2^31 entries, an open-addressing hash over the occupied cells
                                (load factor 0.5) beyond that; 5..90: always the hash, at that load
                                factor in percent.  Same sorted order, same results either way. */
-    int32_t force_kernel;   /* (also pins velo_knn's kernel: 1 = one lane per query, 2 = one wavefront per
-                               query, 0 = by the map's density.)
+    int32_t force_kernel;   /* (also pins velo_knn's kernel and the full-build normals': 1 = one lane per
+                               query, 2 = one wavefront per query, 0 = by the map's density.)
                                0: the linearise kernel is chosen by the size of the registration
                                (latency kernel below 2048 x 256 queries, ~4 frames; throughput kernel
                                above); 1: always the throughput kernel, 2: always the latency kernel

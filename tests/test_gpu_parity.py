@@ -1590,3 +1590,74 @@ def test_knn_exact_ties_on_a_lattice_both_kernels(oracle, k):
             assert np.array_equal(gd.view(np.uint32), od.view(np.uint32)), fk
         finally:
             c.close()
+
+
+def test_config2_size_10m_rolling_map_pipelined_replay(monkeypatch):
+    """BASELINE configs[2] at its STATED size: the stream's replay loop (bench.run_replay: decode
+    of the indexed packets, MapManager-style rolls of the device map to the tile rectangle of the prior, 20 ICP
+    iterations, accepted increments on the device-side pending list) over a >= 10 M-point ROLLING map for 40 frames,
+    with the next frame decoded and the map rolled AHEAD beside the running registration.
+      * the final device map == the library's own full rebuild of the same operations (a second ctx with
+        cfg.map_full_rebuild = 1 that is given every map operation in its plain form), bit for bit: order, cell
+        table, points, normals;
+      * decoding ahead alone changes nothing: poses identical to the un-pipelined replay to the last bit;
+      * rolling ahead as well defers the pending increments past the roll (they join at the next flush): poses
+        within the north star's 1e-4 m / 1e-5 rad of the un-pipelined replay, same rolls, same points moved."""
+    import sys
+    import torch
+    import bench
+    from tests.util_scene import pose_delta
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--stream-frames", "24", "--stream-map-points", "12000000"])
+    args = bench.parse()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    base = bench.synthetic_drive(args, dev, None)
+    steps, warmup = 40, 3
+    out = {}
+    for mode in ("plain", "decode_ahead", "pipelined"):
+        d = dict(base)
+        d["tile_of"] = {k: list(v) for k, v in base["tile_of"].items()}   # (the replay files increments into its tiles)
+        args.no_decode_overlap = mode == "plain"
+        args.no_roll_ahead = mode != "pipelined"
+        mirror = None
+        if mode == "pipelined":
+            mirror = capi.Context(0, max_batch=2, map_margin=args.map_margin, map_subdiv=args.stream_subdiv,
+                                  map_full_rebuild=1)
+            mirror.map_set_margins(args.map_margin, args.map_margin, args.map_margin_z)
+        seen = {}
+
+        def final(ctx, mirror=mirror, seen=seen):
+            mi = ctx.map_info()
+            seen["n"] = int(mi.n_points)
+            if mirror is None:
+                return
+            a, b = ctx.map_download(), mirror.map_download()
+            mb = mirror.map_info()
+            assert mi.n_points == mb.n_points and list(mi.dims) == list(mb.dims) and list(mi.origin) == list(mb.origin)
+            assert mi.subdiv == mb.subdiv and mi.n_invalid_normals == mb.n_invalid_normals
+            assert mi.last_update == 1 and mb.last_update == 0          # (incremental here, rebuilt there)
+            for k in ("cell_start", "perm", "x", "y", "z"):
+                assert np.array_equal(a[k], b[k]), k
+            for k in ("nx", "ny", "nz"):
+                assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+        probe = {"mirror": mirror, "poses": [], "final": final}
+        try:
+            rec = bench.run_replay(args, dev, 0, steps, warmup, d=d, probe=probe)
+        finally:
+            if mirror is not None:
+                mirror.close()
+        out[mode] = (rec, probe, seen)
+    plain, ahead, pipe = out["plain"], out["decode_ahead"], out["pipelined"]
+    assert pipe[2]["n"] >= 10_000_000 and plain[2]["n"] >= 10_000_000
+    assert len(plain[1]["poses"]) == steps
+    assert plain[1]["poses"] == ahead[1]["poses"]                          # to the last bit
+    assert plain[0]["map"] == ahead[0]["map"] and plain[2]["n"] == ahead[2]["n"]
+    deltas = [pose_delta(np.array(p), np.array(q)) for p, q in zip(plain[1]["poses"], pipe[1]["poses"])]
+    worst = (max(d[0] for d in deltas), max(d[1] for d in deltas))
+    assert worst[0] <= 1e-4 and worst[1] <= 1e-5, worst
+    assert pipe[0]["map"]["rolls"] == plain[0]["map"]["rolls"] >= 3 and pipe[0]["map"]["full_builds"] == 0
+    assert pipe[0]["map"]["points_evicted"] == plain[0]["map"]["points_evicted"] > 100_000
+    assert pipe[0]["map"]["points_uploaded"] == plain[0]["map"]["points_uploaded"] > 100_000
+    assert pipe[1].get("rolls_ahead", 0) >= 3 and pipe[0]["map"]["increment_flushes"] >= 1
+    assert pipe[0]["worst_pose_error_m"] < 0.02

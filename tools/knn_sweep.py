@@ -30,6 +30,7 @@ ap.add_argument("--hash-loads", type=int, nargs="+", default=[0, 25, 50, 75],
                 help="fine-cell table: 0 = dense prefix table, 25 / 50 / 75 = hash at that load factor (%%)")
 ap.add_argument("--occupancy", action="store_true", help="download the dense table and count its occupied cells")
 ap.add_argument("--tag", default="")
+ap.add_argument("--force-kernel", type=int, default=0, help="cfg.force_kernel: 0 = by density, 1 = one lane per query, 2 = one wavefront per query (k-NN and full-map normals)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -45,7 +46,7 @@ T0 = synth.perturbed_guess(Tt)
 print("%smap points %d (sampled on the GPU), frame points %d, k = %d, normals k = %d"
       % (a.tag + " " if a.tag else "", a.points, fr["x"].size, a.k, a.k_normals))
 for h, S, load in [(h, S, l) for h in a.voxels for S in a.subdivs for l in a.hash_loads]:
-    c = capi.Context(0, max_batch=2, map_subdiv=S, map_hash_load=load, use_graph=0)
+    c = capi.Context(0, max_batch=2, map_subdiv=S, map_hash_load=load, use_graph=0, force_kernel=a.force_kernel)
     try:
         c.set_stream(torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()

@@ -483,13 +483,28 @@ __global__ __launch_bounds__(kNrmThreads) void k_knn(MapView mv, const float* __
     }
 }
 
-// which k-NN kernel: the cooperative one pays where rows hold many points (dense maps)
+// which k-NN kernel.  The cooperative one (one wavefront per query) spends a fixed ~600 vector instructions per
+// query on its row geometry and its first sort whatever the map holds; the per-lane one runs a chain of dependent
+// round trips per candidate row.  Measured on the scene at k = 32 (profiles/r05/knn_density_ab.txt, ms per
+// 115 200-query frame, per-lane / cooperative): 50 k points 0.08 / 0.33, 200 k 0.31 / 0.43, 1 M 0.85 / 0.51,
+// 10 M 1.31 / 0.34, 30 M 1.61 / 0.26, 100 M 3.4 / 0.19 -- and 100 M at h = 0.5 m 1.75 / 0.40, at h = 0.25 m
+// (hashed) 1.66 / 0.68: the crossover follows the points per VOXEL (0.6 -> 2.8 between 200 k and 1 M), not the points
+// per fine cell round 4 used.
 bool knn_use_wave(const MapView& mv, int mode)
 {
     if (mode == 1) return false;
     if (mode == 2) return true;
+    return (double)mv.n >= 1.5 * (double)mv.nx * mv.ny * mv.nz;
+}
+// ... and which normals kernel for a full build: there every point of the map is a query, neighbours in the sorted
+// order share their rows in L1 / L2 and the per-lane kernel holds up longer (full build incl. sorts, per-lane /
+// cooperative: 1 M 12 / 16 ms, 10 M 25 / 35 ms, 30 M 70 / 69 ms, 100 M 1 600 / 200 ms)
+bool normals_use_wave(const MapView& mv, int mode)
+{
+    if (mode == 1) return false;
+    if (mode == 2) return true;
     const double fine_cells = (double)mv.fx * mv.fy * mv.fz;
-    return (double)mv.n >= 0.25 * fine_cells;  // (100 M points on 186 M fine cells: 0.54; the 1 M-point map: 0.03)
+    return (double)mv.n >= 0.25 * fine_cells;  // (100 M points on 186 M fine cells: 0.54; 30 M: 0.16)
 }
 
 hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const float* z, size_t n,
@@ -526,7 +541,7 @@ hipError_t launch_normals(const MapView& mv, const uint32_t* perm, int k, float4
                           unsigned long long* d_invalid, hipStream_t s, int mode)
 {
     // dense maps: one wavefront per point for the search, one lane per point for the PCA (kernels/knn_wave.hip)
-    if (knn_use_wave(mv, mode)) return launch_normals_wave(mv, perm, k, nrm, d_invalid, s);
+    if (normals_use_wave(mv, mode)) return launch_normals_wave(mv, perm, k, nrm, d_invalid, s);
     hipError_t e = hipMemsetAsync(d_invalid, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     const int grid = (mv.n + kNrmThreads - 1) / kNrmThreads;

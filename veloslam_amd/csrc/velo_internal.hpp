@@ -171,6 +171,7 @@ hipError_t launch_knn(const MapView& mv, const float* x, const float* y, const f
                       hipStream_t s, unsigned long long* stats_out = nullptr, int mode = 0);
 // (mode: 0 = by the map's density, 1 = one lane per query, 2 = one wavefront per query; same results)
 bool knn_use_wave(const MapView& mv, int mode);
+bool normals_use_wave(const MapView& mv, int mode);
 // (stats_out != nullptr: the counting instantiation; waits for the stream; [0] queries, [1] candidate points
 //  fetched, [2] fine rows looked up, [3] fine cells those rows span)
 hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, const FrameView& fv,
