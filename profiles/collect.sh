@@ -1,13 +1,13 @@
 #!/bin/bash
 # How the files under profiles/rNN/ are produced (run on the GPU box through gpurun):
-#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r03'
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r05'
 # Raw rocprofv3 output goes to gpurun_out/prof_<round>/ (scratch); profiles/summarize.py turns
 # it into the small committed summaries and profiles/traffic.json (what bench.py's
 # roofline.traffic reads, keyed by batch size and map size).  Counter passes are separate runs
 # with --kernel-trace only (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md,
 # rocprofv3 PMC slots); the program itself follows `--`.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
@@ -35,6 +35,8 @@ rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_E
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/stream_write -- $SD > $OUT/stream_write.json 2> $OUT/stream_write.err
 $SD > $OUT/stream_plain.json 2> $OUT/stream_plain.err
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+# the driver's exact command under the kernel trace (what the judge re-derives the launch times from)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err
 
 # the raw CSVs are > 64 MiB (more than gpurun carries back): summarise HERE, keep the summaries
 python3 profiles/summarize.py $R > $OUT/summarize.log 2>&1

@@ -22,7 +22,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + R)
 DST = os.path.join(ROOT, "profiles", R)
@@ -32,7 +32,7 @@ os.makedirs(DST, exist_ok=True)
 R_SRC = R
 CONFIGS = {"F64_M1000000": 1, "F16_M10000000": 2}
 PROD = "k_linearize<false, 1, false"  # the production instantiation (any table kind)
-MAPBUILD = "k_normals<"
+MAPBUILD = "k_normals<"  # (a full build; dense maps: k_normals_wave<, matched below as well)
 ITERS = 20  # linearise launches per registration in the collection runs (bench.py --iters default)
 
 
@@ -51,7 +51,7 @@ def counters(sub):
         builds, seen = 0, set()
         for r in rows_in_order(f, "Dispatch_Id"):
             k = r["Kernel_Name"].split("(")[0]
-            if MAPBUILD in k and r["Dispatch_Id"] not in seen:
+            if (MAPBUILD in k or "k_normals_wave<" in k) and r["Dispatch_Id"] not in seen:
                 seen.add(r["Dispatch_Id"])  # (one row per counter and dispatch)
                 builds += 1
             if "velo::" in k:
@@ -75,7 +75,7 @@ dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_trace.csv")):
     builds = 0
     for r in rows_in_order(f, "Dispatch_Id"):
-        if MAPBUILD in r["Kernel_Name"]:
+        if MAPBUILD in r["Kernel_Name"] or "k_normals_wave<" in r["Kernel_Name"]:
             builds += 1
         if PROD in r["Kernel_Name"]:
             dur[builds].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -164,7 +164,8 @@ def read_bytes(cs):
 
 krd, kwr, kdur = by_kernel("knn_rdreq"), by_kernel("knn_write"), trace_durations("knn_trace")
 for k in krd:
-    if "k_knn<32, false>" not in k and "k_knn_wave<false>" not in k:   # (per-lane / wavefront-cooperative form)
+    # (per-lane / wavefront-cooperative form; the cooperative kernel's parameters are <sparse table, counting>)
+    if "k_knn<32, false>" not in k and "k_knn_wave<false, false>" not in k and "k_knn_wave<true, false>" not in k:
         continue
     n = len(krd[k]["TCC_EA0_RDREQ_128B_sum"])
     nw = len(kwr.get(k, {}).get("WRITE_SIZE", []))
@@ -244,9 +245,19 @@ if srd and swr:
 st = sorted(glob.glob(os.path.join(SRC, "knn_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if st:
     shutil.copy(st[-1], os.path.join(DST, "kernel_stats_knn.csv"))
+st = sorted(glob.glob(os.path.join(SRC, "trace_driver", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+if st:
+    shutil.copy(st[-1], os.path.join(DST, "kernel_stats_driver_cmd.csv"))
+# which code these bytes were measured on: bench.py compares the hashes and prints `traffic_stale`
+sys.path.insert(0, ROOT)
+from veloslam_amd import srchash  # noqa: E402
+traffic["_stamp"] = srchash.stamp(command="profiles/collect.sh %s: rocprofv3 --kernel-trace --pmc <reads by size class | WRITE_SIZE> -- "
+                                          "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --only dense (headline batch + "
+                                          "dense record); ... --only knn32_100m; tools/stream_driver <drive> --steps 200 --warmup 20" % R,
+                                  round_name=R)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
-for nm in ("bench_default.json", "bench_stream.json", "bench_trace.json"):
+for nm in ("bench_default.json", "bench_stream.json", "bench_trace.json", "bench_driver_cmd.json"):
     b = os.path.join(SRC, nm)
     if os.path.exists(b) and os.path.getsize(b):
         shutil.copy(b, os.path.join(DST, nm))
