@@ -230,6 +230,19 @@ int velo_map_evict_radius(velo_ctx*, const float center_xy[2], float radius);
  * table -- do it with the plain calls after velo_icp_batch_finish.  The call waits for the side stream. */
 int velo_map_roll_overlapped(velo_ctx*, const float lo[3], const float hi[3], const float* x, const float* y,
                              const float* z, size_t n);
+/* The same roll BEGUN AHEAD of the frame that needs it.  The tile rectangle of a frame comes from the pose track
+ * (ROI_RANGE, MapManager.h:13,43), so the host knows it frames before: velo_map_roll_begin -- called, like
+ * velo_map_roll_overlapped, between velo_icp_batch_start and _finish -- waits once for the first count (points
+ * kept and their bounds, ~0.2 ms) and enqueues the rest of the eviction and the append on a stream of its own
+ * without waiting; the registrations that follow keep reading the map AS IT WAS.  velo_map_roll_publish, called at
+ * the frame the new rectangle is due (outside a registration or inside one: the main stream waits on the
+ * device), switches them to the rolled map -- bit for bit what velo_map_evict_outside + velo_map_append
+ * leave.  One roll may be begun at a time; any other map operation (append, evict, reset, download) publishes a
+ * begun roll first; velo_map_info_get reports the rolled map at once (its normal counts once the roll is
+ * through).  Refusals as for velo_map_roll_overlapped (VELO_E_AGAIN before anything changed). */
+int velo_map_roll_begin(velo_ctx*, const float lo[3], const float hi[3], const float* x, const float* y,
+                        const float* z, size_t n);
+int velo_map_roll_publish(velo_ctx*);
 /* Per-axis grid slack in voxels (cfg.map_margin sets all three): a vehicle wants tens of
  * voxels in x/y and one or two in z -- the dense fine-cell table grows with the product.
  * Takes effect at the next (re-)anchoring: velo_map_reset, or the rules above. */

@@ -1592,6 +1592,101 @@ def test_knn_exact_ties_on_a_lattice_both_kernels(oracle, k):
             c.close()
 
 
+def test_map_roll_begun_ahead_and_published_later_equals_the_plain_roll():
+    """velo_map_roll_begin / velo_map_roll_publish: the roll enqueued on a stream of its own while a
+    registration runs, published THREE registrations later.  Four such rolls in a row (all three sets of sorted arrays,
+    both tables, both near-voxel maps come round): (a) the registration it was begun beside and the ones up to the
+    publish give the results they have on the map BEFORE the roll -- bit for bit those of a ctx that has not rolled
+    yet; (b) after the publish the map is what the plain velo_map_evict_outside + velo_map_append leave, bit for
+    bit, counts included, and the next registration agrees; (c) a second begin before the publish is refused, a
+    plain map operation publishes first, a roll that needs a re-anchor is refused and changes nothing."""
+    from veloslam_amd import synth
+    sc = synth.Scene()
+    wx, wy, wz = sc.sample_map(900_000)
+    wl = make_workload(map_points=1000, n_frames=1)
+    f = wl["frames"][0]
+    s = f["sensor"]
+    big = 3.0e38
+    A = capi.Context(0, max_batch=2, map_margin=16)
+    B = capi.Context(0, max_batch=2, map_margin=16)
+    try:
+        for c in (A, B):
+            c.map_set_margins(16, 16, 2)
+        cx, cy, cz = A.compensate(s["x"], s["y"], s["z"], s["pkt"], f["table"])
+        px, py = float(f["T_true"][3]), float(f["T_true"][7])
+        half = 60.0
+
+        def box(x0):
+            return (wx >= x0 - half) & (wx < x0 + half) & (wy >= py - half) & (wy < py + half)
+
+        res = box(px)
+        for c in (A, B):
+            c.map_reset(wx[res], wy[res], wz[res], 1.0, 16)
+            c.frames_upload([(cx, cy, cz)])
+        T0 = f["T0"].reshape(1, 12)
+        T1 = T0.copy()
+        T1[0, 3] += 0.05
+
+        def same():
+            a, b = A.map_download(), B.map_download()
+            ia, ib = A.map_info(), B.map_info()
+            assert ia.n_points == ib.n_points and list(ia.dims) == list(ib.dims) and list(ia.origin) == list(ib.origin)
+            assert ia.n_invalid_normals == ib.n_invalid_normals and ia.last_update == ib.last_update == 1
+            assert ia.n_normals_recomputed == ib.n_normals_recomputed
+            for k in ("cell_start", "perm", "x", "y", "z"):
+                assert np.array_equal(a[k], b[k]), k
+            for k in ("nx", "ny", "nz"):
+                assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+        def sig(r):
+            return list(r.T), [r.iter[i].n_pairs for i in range(8)], [r.iter[i].rmse for i in range(8)]
+
+        x0 = px
+        for step in range(4):
+            x1 = x0 + 3.5          # (14 m in all: inside the 16-voxel slack, no grid change on the way)
+            new = box(x1)
+            entering = new & ~res
+            lo = np.array([x1 - half, py - half, -big], np.float32)
+            hi = np.array([np.nextafter(np.float32(x1 + half), np.float32(-big)),
+                           np.nextafter(np.float32(py + half), np.float32(-big)), big], np.float32)
+            n_old = A.map_info().n_points
+            A.icp_batch_start(T0, 8, 1.0)
+            assert A.map_roll_begin(lo, hi, wx[entering], wy[entering], wz[entering])
+            with pytest.raises(capi.VeloError):                               # one roll at a time
+                A.map_roll_begin(None, None, wx[:3], wy[:3], wz[:3])
+            ra = [A.icp_batch_finish()[0]]
+            for T in (T1, T0, T1):                                           # three more registrations: still the old map
+                A.icp_batch_start(T, 8, 1.0)
+                ra.append(A.icp_batch_finish()[0])
+            rb = [B.icp_batch(T, 8, 1.0)[0] for T in (T0, T1, T0, T1)]       # B has not rolled yet
+            for a, b in zip(ra, rb):
+                assert sig(a) == sig(b)
+            assert B.map_info().n_points == n_old
+            if step % 2 == 0:
+                A.map_roll_publish()
+            # (odd steps: no explicit publish -- the download below, a whole-map operation, publishes first)
+            B.map_evict_outside(lo, hi)
+            B.map_append(wx[entering], wy[entering], wz[entering])
+            same()
+            na, nb = A.icp_batch(T0, 8, 1.0)[0], B.icp_batch(T0, 8, 1.0)[0]   # on the rolled map
+            assert sig(na) == sig(nb)
+            res, x0 = (res & new) | entering, x1
+        # a roll that needs a re-anchor: refused, nothing changed, nothing left to publish
+        mi = A.map_info()
+        low = (np.full(5, mi.origin[0] - 40.0, np.float32), np.full(5, mi.origin[1] - 40.0, np.float32), np.zeros(5, np.float32))
+        before = A.map_download()
+        A.icp_batch_start(T0, 3, 1.0)
+        assert A.map_roll_begin(None, None, *low) is False
+        A.icp_batch_finish()
+        A.map_roll_publish()
+        after = A.map_download()
+        for k in before:
+            assert np.array_equal(before[k].view(np.uint8), after[k].view(np.uint8)), k
+    finally:
+        A.close()
+        B.close()
+
+
 def test_config2_size_10m_rolling_map_pipelined_replay(monkeypatch):
     """BASELINE configs[2] at its STATED size: the stream's replay loop (bench.run_replay: decode
     of the indexed packets, MapManager-style rolls of the device map to the tile rectangle of the prior, 20 ICP

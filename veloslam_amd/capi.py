@@ -102,7 +102,7 @@ class MapInfo(C.Structure):
 EXPORTS = [
     "velo_create", "velo_destroy", "velo_last_error", "velo_abi_version", "velo_cfg_get", "velo_set_stream",
     "velo_synchronize", "velo_map_reset", "velo_map_reset_dev", "velo_map_append",
-    "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_roll_overlapped", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
+    "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_roll_overlapped", "velo_map_roll_begin", "velo_map_roll_publish", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_icp_batch_start", "velo_icp_batch_finish", "velo_linearize",
     "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_knn_dev", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_decode_plan_create", "velo_decode_plan_destroy", "velo_decode_plan_fill", "velo_decode_submit", "velo_decode_submit_overlapped", "velo_decode_plan_error", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_increment_pending", "velo_pending_count", "velo_pending_fetch", "velo_map_append_pending", "velo_pending_clear", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
@@ -157,6 +157,8 @@ def lib():
     L.velo_map_append_sparse_dev.argtypes = L.velo_map_append_sparse.argtypes
     L.velo_map_evict_outside.argtypes = [vp, vp, vp]
     L.velo_map_roll_overlapped.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t]
+    L.velo_map_roll_begin.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t]
+    L.velo_map_roll_publish.argtypes = [vp]
     L.velo_map_evict_radius.argtypes = [vp, vp, C.c_float]
     L.velo_map_set_margins.argtypes = [vp, vp]
     L.velo_debug_search_stats.argtypes = [vp, vp, C.c_int]
@@ -537,6 +539,21 @@ class Context:
             return False
         self._chk(rc)
         return True
+
+    def map_roll_begin(self, lo, hi, x, y, z):
+        """the same roll begun ahead (velo_map_roll_begin): enqueued on a stream of its own, readers keep the map
+        as it was until map_roll_publish(); -> False when the library refuses (VELO_E_AGAIN)"""
+        x, y, z = (np.ascontiguousarray(a, np.float32) for a in (x, y, z))
+        plo = None if lo is None else _p(np.ascontiguousarray(lo, np.float32))
+        phi = None if hi is None else _p(np.ascontiguousarray(hi, np.float32))
+        rc = lib().velo_map_roll_begin(self.h, plo, phi, _p(x), _p(y), _p(z), x.size)
+        if rc == -7:
+            return False
+        self._chk(rc)
+        return True
+
+    def map_roll_publish(self):
+        self._chk(lib().velo_map_roll_publish(self.h))
 
     def map_evict_outside(self, lo, hi):
         lo = np.ascontiguousarray(lo, np.float32)

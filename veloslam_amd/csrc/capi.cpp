@@ -161,7 +161,25 @@ struct velo_ctx {
     int map_S = 3;                // sub-division of the current map: cfg.map_subdiv, or chosen from
                                   // the density when that is 0; resolved at velo_map_reset
     DevBuf<char> temp;
-    MapView mv{};
+    MapView mv{};          // the map as of the last update (what the next update starts from)
+    MapView mv_read{};     // the map registrations / increments / k-NN READ: == mv, except between
+                           // velo_map_roll_begin and velo_map_roll_publish, when it is still the map before the roll
+    // ---- a roll begun ahead of the frame that needs it (velo_map_roll_begin .. velo_map_roll_publish)
+    hipStream_t roll_stream = nullptr;  // a stream of its own: a decode on the side stream must not queue behind 2 ms of roll
+    hipEvent_t ev_roll = nullptr;       // the roll's last kernel
+    bool roll_staged = false;           // begun, not yet published
+    bool defer_counts = false;          // inside velo_map_roll_begin: nothing waits for the device after the first count
+    struct RollResults {                // pinned: what the device reports when the roll is through
+        unsigned long long invalid;
+        unsigned n_done;
+    }* h_roll = nullptr;
+    bool roll_counts_pending = false;   // info.n_invalid_normals / n_normals_recomputed still to be read from h_roll
+    float* h_enter = nullptr;           // pinned staging of the entering points (x | y | z)
+    size_t h_enter_cap = 0;
+    bool have_enter_mm = false;         // bounds of the entering points, known on the host (no device min/max, no wait)
+    float enter_mn[3] = {0, 0, 0}, enter_mx[3] = {0, 0, 0};
+    size_t roll_extra = 0;              // points the roll's append will add: the eviction sizes the raw arrays for both
+    DevBuf<char> roll_temp;             // sort / scan scratch of a roll on roll_stream
     bool has_map = false;
     velo_map_info info{};
 
@@ -405,6 +423,15 @@ int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, const uint32_t*
     HIP_TRY(c, hipMemsetAsync(c->work_cnt.p, 0, 2 * sizeof(unsigned), s));
     HIP_TRY(c, launch_select_dirty(c->keys_sorted.p, (uint32_t)mv.n, mv, c->dirty.p, c->work.p,
                                    c->work_cnt.p, s));
+    if (c->defer_counts) {
+        // a roll begun ahead: the length of the work list stays on the device -- the launch covers its upper
+        // bound (every point), the surplus workgroups leave at once -- and the count of normals re-estimated
+        // goes to pinned memory for whoever asks after the roll (velo_map_info_get)
+        HIP_TRY(c, launch_normals_subset(mv, c->perm.p, k, c->work.p, mv.n, chg_keys, n_chg, c->nrm.p,
+                                         c->invalid_cnt.p, c->work_cnt.p + 1, s, c->work_cnt.p));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_roll->n_done, c->work_cnt.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        return VELO_OK;
+    }
     unsigned n_work = 0;
     HIP_TRY(c, hipMemcpyAsync(&n_work, c->work_cnt.p, sizeof n_work, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -416,6 +443,39 @@ int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, const uint32_t*
 }
 
 // make `mv` the ctx's map: bookkeeping shared by the full build and the incremental updates
+// A roll begun ahead and not yet published is published now: every entry point that changes or reads the map
+// as a whole starts here.  (The registrations do not: they keep reading the map before the roll -- mv_read.)
+static int resolve_roll_counts(velo_ctx* c);
+static int settle_roll(velo_ctx* c)
+{
+    // (the counts too: a plain update that follows publishes its own, and must not be overwritten by a late read)
+    if (int rc = resolve_roll_counts(c)) return rc;
+    if (!c->roll_staged) return VELO_OK;
+    return velo_map_roll_publish(c);
+}
+// info.n_invalid_normals / n_normals_recomputed of a roll begun ahead: known when its last kernel is through
+static int resolve_roll_counts(velo_ctx* c)
+{
+    if (!c->roll_counts_pending) return VELO_OK;
+    HIP_TRY(c, hipEventSynchronize(c->ev_roll));
+    c->info.n_invalid_normals = c->h_roll->invalid;
+    c->info.n_normals_recomputed = c->h_roll->n_done;
+    c->n_done_host = c->h_roll->n_done;
+    c->roll_counts_pending = false;
+    return VELO_OK;
+}
+
+// hints / certificates are indices and radii in the OLD map: forget them (overlapped update: the
+// running registration is using them -- the reset queues behind it on the main stream)
+static int reset_hints(velo_ctx* c, hipStream_t hs)
+{
+    if (c->hint.p && c->hint.cap)
+        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), hs));
+    if (c->rho.p && c->rho.cap)  // 0 = no certificate (negative values certify "no match")
+        HIP_TRY(c, hipMemsetAsync(c->rho.p, 0, c->rho.cap * sizeof(float), hs));
+    return VELO_OK;
+}
+
 int publish_map(velo_ctx* c, MapView mv, int k_normals, unsigned long long invalid,
                 int last_update, uint64_t n_recomputed)
 {
@@ -433,13 +493,10 @@ int publish_map(velo_ctx* c, MapView mv, int k_normals, unsigned long long inval
     c->mv = mv;
     c->has_map = true;
     ++c->map_gen;
-    // hints / certificates are indices and radii in the OLD map: forget them (overlapped update: the
-    // running registration is using them -- the reset queues behind it on the main stream)
-    hipStream_t hs = c->overlap_update ? c->overlap_main : s;
-    if (c->hint.p && c->hint.cap)
-        HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), hs));
-    if (c->rho.p && c->rho.cap)  // 0 = no certificate (negative values certify "no match")
-        HIP_TRY(c, hipMemsetAsync(c->rho.p, 0, c->rho.cap * sizeof(float), hs));
+    if (!c->defer_counts) {   // (a roll begun ahead: readers keep the old map until velo_map_roll_publish)
+        c->mv_read = mv;
+        if (int rc = reset_hints(c, c->overlap_update ? c->overlap_main : s)) return rc;
+    }
     c->info.n_points = (uint64_t)mv.n;
     c->info.n_cells = (uint64_t)mv.fx * mv.fy * mv.fz;
     c->info.origin[0] = mv.ox;
@@ -705,8 +762,15 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     if (n_old + m >= (size_t)INT32_MAX) return c->fail(VELO_E_RANGE, "map larger than 2^31-1 points");
     HIP_TRY(c, c->mm_scratch.reserve(8));
     MinMax mm;
-    HIP_TRY(c, launch_minmax(c->raw_x.p + n_old, c->raw_y.p + n_old, c->raw_z.p + n_old, m,
-                             c->mm_scratch.p, &mm, s));
+    if (c->defer_counts && c->have_enter_mm) {  // (host arrays: their bounds were taken on the host, no device pass, no wait)
+        for (int a = 0; a < 3; ++a) {
+            mm.mn[a] = c->enter_mn[a];
+            mm.mx[a] = c->enter_mx[a];
+        }
+    } else {
+        HIP_TRY(c, launch_minmax(c->raw_x.p + n_old, c->raw_y.p + n_old, c->raw_z.p + n_old, m,
+                                 c->mm_scratch.p, &mm, s));
+    }
     const float org[3] = {old.ox, old.oy, old.oz};
     int dims[3] = {old.nx, old.ny, old.nz};
     bool grew = false;
@@ -804,11 +868,15 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
         HIP_TRY(c, hipMemsetAsync(c->dirty.p, 0, nvox, s));
         HIP_TRY(c, launch_mark_dirty(c->nk_sorted.p, (uint32_t)m, nullptr, g, c->dirty.p, s));
         if (int rc = refresh_dirty_normals(c, g, k, c->nk_sorted.p, (uint32_t)m)) return rc;
-        HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
+        if (c->defer_counts)
+            HIP_TRY(c, hipMemcpyAsync(&c->h_roll->invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
+        else
+            HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(c, hipStreamSynchronize(s));
+    if (!c->defer_counts) HIP_TRY(c, hipStreamSynchronize(s));
     for (int a = 0; a < 3; ++a) c->map_mx[a] = mx[a];
     *done = 1;
+    if (c->defer_counts) c->roll_counts_pending = k > 0;
     return txn.done(publish_map(c, g, k, invalid, 1, c->n_done_host));
 }
 
@@ -1000,7 +1068,7 @@ Decomposition decomposition_for(velo_ctx* c, int it, bool hinted, bool sorted_qu
     // full of points (S >= 4: first launch 304 -> 132 us on a 9 M-point map); on a light map (S = 3,
     // 1 M points) the 13 us it saves are less than the eight times as many partial rows cost the
     // solve: there the 256-query items serve every iteration
-    if (c->plan_lat && c->lat_first_lanes < 64 && c->ni_late > 0 && c->mv.S < VELO_LAT_SPARSE_MIN_S)
+    if (c->plan_lat && c->lat_first_lanes < 64 && c->ni_late > 0 && c->mv_read.S < VELO_LAT_SPARSE_MIN_S)
         return {c->items_late.p, c->fbs_late.p, c->ni_late, 64, c->lay_late.p, &c->lay0_late_h};
     return {c->items_first.p, c->fbs.p, (int)c->items_h.size(), c->lat_first_lanes, c->lay.p, &c->lay0_h};
 }
@@ -1218,13 +1286,13 @@ int maybe_sort_frames(velo_ctx* c, FrameView& fv)
     fv.order = nullptr;
     if (!c->cfg.sort_frames) return VELO_OK;
     const size_t n = (size_t)c->frame_start[c->n_frames];
-    const double span = (double)c->n_frames * ((double)c->mv.nx * c->mv.ny * c->mv.nz + 1.0);
+    const double span = (double)c->n_frames * ((double)c->mv_read.nx * c->mv_read.ny * c->mv_read.nz + 1.0);
     if (n == 0 || span >= 4294967296.0) return VELO_OK;  // composite key would not fit 32 bits
     HIP_TRY(c, c->order_keys.reserve(n));
     HIP_TRY(c, c->order_keys2.reserve(n));
     HIP_TRY(c, c->order_idx.reserve(n));
     HIP_TRY(c, c->order.reserve(n));
-    HIP_TRY(c, launch_frame_cellkeys(fv, c->d_frame_start.p, c->n_frames, n, c->mv, c->poses.p,
+    HIP_TRY(c, launch_frame_cellkeys(fv, c->d_frame_start.p, c->n_frames, n, c->mv_read, c->poses.p,
                                      c->order_keys.p, c->order_idx.p, c->stream));
     int bits = 1;
     while (bits < 32 && (double)((uint64_t)1 << bits) < span) ++bits;
@@ -1279,8 +1347,8 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     if (!T0) return c->fail(VELO_E_INVALID, "T0 is null");
     if (iters < 1 || iters > VELO_MAX_ITERS)
         return c->fail(VELO_E_INVALID, "iters must be in [1,%d]", VELO_MAX_ITERS);
-    if (!(d_max > 0.0f) || !(d_max <= c->mv.h))
-        return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv.h);
+    if (!(d_max > 0.0f) || !(d_max <= c->mv_read.h))
+        return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv_read.h);
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->ev_used = 0;
@@ -1346,7 +1414,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             FrameView fv{c->ax, c->ay, c->az, nullptr};
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
                 const Decomposition dc = decomposition_for(c, it, hint != nullptr, false);
-                e = launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv, c->poses.p,
+                e = launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv_read, c->poses.p,
                                      dmax2, c->partials.p, nullptr, nullptr, hint, rho,
                                      it == 0 ? nullptr : c->poses_prev.p,  // (first iteration: stale hints)
                                      false, c->plan_lat ? 2 : 1, s, dc.lat_lanes);
@@ -1384,7 +1452,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         const Decomposition dc = decomposition_for(c, it, hint != nullptr, fv.order != nullptr);
         {
             Timed t(c, 0);
-            HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv,
+            HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv_read,
                                         c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, rho,
                                         it == 0 ? nullptr : c->poses_prev.p,  // (first iteration: stale hints)
                                         c->stats_on, c->plan_lat ? 2 : 1, s, dc.lat_lanes));
@@ -1565,6 +1633,11 @@ void velo_destroy(velo_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);  // (pinned buffers below may still be its sources)
+    if (c->roll_stream) (void)hipStreamSynchronize(c->roll_stream);
+    if (c->ev_roll) (void)hipEventDestroy(c->ev_roll);
+    if (c->roll_stream) (void)hipStreamDestroy(c->roll_stream);
+    if (c->h_roll) (void)hipHostFree(c->h_roll);
+    if (c->h_enter) (void)hipHostFree(c->h_enter);
     (void)velo_comm_destroy(c);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     for (int b = 0; b < 2; ++b) {
@@ -1611,6 +1684,7 @@ int velo_synchronize(velo_ctx* c)
     if (!c) return VELO_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->roll_stream) HIP_TRY(c, hipStreamSynchronize(c->roll_stream));  // (a roll begun ahead runs on its own stream)
     return VELO_OK;
 }
 
@@ -1694,6 +1768,7 @@ static int map_reset_impl(velo_ctx* c, const float* x, const float* y, const flo
 {
     if (!c) return VELO_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = settle_roll(c)) return rc;
     c->has_map = false;
     if (n == 0) return c->fail(VELO_E_INVALID, "map needs at least one point");
     if (int rc = stage_raw(c, x, y, z, n, dev, false)) return rc;
@@ -1717,6 +1792,8 @@ static int map_append_impl(velo_ctx* c, const float* x, const float* y, const fl
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "velo_map_append before velo_map_reset");
     if (n == 0) return VELO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->overlap_update)
+        if (int rc = settle_roll(c)) return rc;
     const size_t n_old = c->raw_n;
     if (int rc = stage_raw(c, x, y, z, n, dev, true)) return rc;
     int done = 0;
@@ -1763,6 +1840,7 @@ static int map_append_sparse_impl(velo_ctx* c, const float* x, const float* y, c
     if (min_count < 1) return c->fail(VELO_E_INVALID, "min_count must be >= 1");
     if (n >= (size_t)INT32_MAX) return c->fail(VELO_E_RANGE, "too many points");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = settle_roll(c)) return rc;
     hipStream_t s = c->stream;
     HIP_TRY(c, c->sp_x.reserve(2 * n));  // [0,n): staged input (host entry), [n,2n): survivors
     HIP_TRY(c, c->sp_y.reserve(2 * n));
@@ -1821,6 +1899,7 @@ int velo_map_evict_outside(velo_ctx* c, const float lo[3], const float hi[3])
 {
     if (!c) return VELO_E_INVALID;
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "velo_map_evict_outside before velo_map_reset");
+    if (int rc = settle_roll(c)) return rc;
     if (!lo || !hi) return c->fail(VELO_E_INVALID, "null box");
     KeepRegion g{};
     for (int a = 0; a < 3; ++a) {
@@ -1834,6 +1913,7 @@ int velo_map_evict_radius(velo_ctx* c, const float center_xy[2], float radius)
 {
     if (!c) return VELO_E_INVALID;
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "velo_map_evict_radius before velo_map_reset");
+    if (int rc = settle_roll(c)) return rc;
     if (!center_xy || !(radius >= 0.0f)) return c->fail(VELO_E_INVALID, "null centre or negative radius");
     KeepRegion g{};
     for (int a = 0; a < 3; ++a) {
@@ -1877,9 +1957,10 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     if (kept == 0) return c->fail(VELO_E_INVALID, "eviction region would remove every map point");
     if (kept == n) return VELO_OK;
     // append-order arrays first: they decide whether the grid keeps
-    HIP_TRY(c, reserve_slack(c->raw_x2, kept));
-    HIP_TRY(c, reserve_slack(c->raw_y2, kept));
-    HIP_TRY(c, reserve_slack(c->raw_z2, kept));
+    // (a roll: room for the points its append will add, so that staging them does not reallocate -- and wait)
+    HIP_TRY(c, reserve_slack(c->raw_x2, kept + c->roll_extra));
+    HIP_TRY(c, reserve_slack(c->raw_y2, kept + c->roll_extra));
+    HIP_TRY(c, reserve_slack(c->raw_z2, kept + c->roll_extra));
     HIP_TRY(c, launch_compact_raw(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, c->rflags.p, c->roffs.p,
                                   c->raw_x2.p, c->raw_y2.p, c->raw_z2.p, s));
     MinMax mm;  // of the kept points: came back with the counts above
@@ -1977,10 +2058,14 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     if (k > 0) {
         if (int rc = refresh_dirty_normals(c, g, k, c->nk_sorted.p, n - kept)) return rc;
         // (the running count: compact_sorted took the leavers off, the re-estimation adjusted the rest)
-        HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
+        if (c->defer_counts)
+            HIP_TRY(c, hipMemcpyAsync(&c->h_roll->invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
+        else
+            HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(c, hipStreamSynchronize(s));
+    if (!c->defer_counts) HIP_TRY(c, hipStreamSynchronize(s));
     for (int a = 0; a < 3; ++a) c->map_mx[a] = mm.mx[a];
+    if (c->defer_counts) c->roll_counts_pending = k > 0;
     return txn.done(publish_map(c, g, k, invalid, 1, c->n_done_host));
 }
 
@@ -1990,14 +2075,13 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
 // update of the call), scratch of their own (the increment got its own flags / offsets), and wait on
 // the device for everything older than the registration.  What cannot be done that way -- a
 // re-anchor, a grown or hashed table -- is refused with VELO_E_AGAIN before anything changed.
-int velo_map_roll_overlapped(velo_ctx* c, const float lo[3], const float hi[3], const float* x, const float* y,
-                             const float* z, size_t n)
+// what both forms of the roll check before anything changes, and the bounds of the entering points
+static int roll_precheck(velo_ctx* c, const char* who, const float lo[3], const float hi[3], const float* x,
+                         const float* y, const float* z, size_t n, float mn[3], float mx[3])
 {
-    if (!c) return VELO_E_INVALID;
-    if (!c->has_map) return c->fail(VELO_E_NOMAP, "velo_map_roll_overlapped before velo_map_reset");
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "%s before velo_map_reset", who);
     if (!c->res_pending)
-        return c->fail(VELO_E_INVALID, "velo_map_roll_overlapped needs a registration started with velo_icp_batch_start "
-                                       "and not yet finished");
+        return c->fail(VELO_E_INVALID, "%s needs a registration started with velo_icp_batch_start and not yet finished", who);
     if (c->roll_overlapped_done) return c->fail(VELO_E_INVALID, "one overlapped roll per registration");
     if ((lo == nullptr) != (hi == nullptr)) return c->fail(VELO_E_INVALID, "lo and hi go together");
     if (n && (!x || !y || !z)) return c->fail(VELO_E_INVALID, "null point array");
@@ -2010,7 +2094,6 @@ int velo_map_roll_overlapped(velo_ctx* c, const float lo[3], const float hi[3], 
     if (c->use_hash || c->cfg.map_full_rebuild)
         return c->fail(VELO_E_AGAIN, "this update needs the map rebuilt: not beside a registration");
     if (n) {
-        float mn[3] = {x[0], y[0], z[0]}, mx[3] = {x[0], y[0], z[0]};
         const float* src[3] = {x, y, z};
         for (int a = 0; a < 3; ++a) {
             float lo_a = src[a][0], hi_a = src[a][0];
@@ -2034,15 +2117,19 @@ int velo_map_roll_overlapped(velo_ctx* c, const float lo[3], const float hi[3], 
                 return c->fail(VELO_E_AGAIN, "the entering points need the grid re-anchored or grown: not beside a registration");
         }
     }
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->side_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    if (!c->ev_side) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
-    HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_mark, 0));
-    c->roll_overlapped_done = true;
+    return VELO_OK;
+}
+
+// evict + append on stream `rs` with the ctx's update machinery pointed at it
+static int roll_run(velo_ctx* c, hipStream_t rs, DevBuf<char>& scratch, const float lo[3], const float hi[3],
+                    const float* x, const float* y, const float* z, size_t n)
+{
     hipStream_t main_stream = c->stream;
-    c->stream = c->side_stream;
-    std::swap(c->temp.p, c->dk_temp.p);
-    std::swap(c->temp.cap, c->dk_temp.cap);
+    c->stream = rs;
+    // (sort / scan scratch of its own: `temp` belongs to the main stream's work, and a roll on its own stream may run
+    //  beside a decode on the side stream, whose scratch dk_temp is)
+    std::swap(c->temp.p, scratch.p);
+    std::swap(c->temp.cap, scratch.cap);
     c->overlap_update = true;
     c->overlap_done = 0;
     c->overlap_main = main_stream;
@@ -2057,15 +2144,121 @@ int velo_map_roll_overlapped(velo_ctx* c, const float lo[3], const float hi[3], 
     }
     if (rc == VELO_OK && n) rc = map_append_impl(c, x, y, z, n, false);
     c->overlap_update = false;
-    std::swap(c->temp.p, c->dk_temp.p);
-    std::swap(c->temp.cap, c->dk_temp.cap);
+    std::swap(c->temp.p, scratch.p);
+    std::swap(c->temp.cap, scratch.cap);
     c->stream = main_stream;
+    return rc;
+}
+
+int velo_map_roll_overlapped(velo_ctx* c, const float lo[3], const float hi[3], const float* x, const float* y,
+                             const float* z, size_t n)
+{
+    if (!c) return VELO_E_INVALID;
+    if (int rc = settle_roll(c)) return rc;
+    float mn[3], mx[3];
+    if (int rc = roll_precheck(c, "velo_map_roll_overlapped", lo, hi, x, y, z, n, mn, mx)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->side_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    if (!c->ev_side) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_mark, 0));
+    c->roll_overlapped_done = true;
+    const int rc = roll_run(c, c->side_stream, c->dk_temp, lo, hi, x, y, z, n);
     hipError_t e = hipEventRecord(c->ev_side, c->side_stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, c->ev_side, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_side, 0);
     if (rc == VELO_E_AGAIN) return c->fail(VELO_E_AGAIN, "this update needs the map rebuilt: not beside a registration");
     if (rc) return rc;
     if (e != hipSuccess) return c->fail(VELO_E_DEVICE, "side stream: %s", hipGetErrorString(e));
     return VELO_OK;
+}
+
+// The same roll BEGUN AHEAD of the frame that needs it.  The tile rectangle of a frame comes
+// from the pose track, so it is known frames before; the roll is 2 ms of GPU work against 0.5 ms of registration,
+// and velo_map_roll_overlapped holds the host until it is through (its stages hand counts over through the
+// host) while the main stream idles behind the one registration it overlaps.  Here:
+//   * one wait, for the first count (points kept, their bounds: what decides whether the grid keeps -- ~0.2 ms
+//     of flags and scans); everything after it is enqueued on a stream of its own without waiting: buffer
+//     sizes are host arithmetic from that count, the one length that stays on the device (the work list of the
+//     normals) is read there, the counts the host only reports (invalid normals, normals re-estimated) land in
+//     pinned memory;
+//   * the registrations that follow keep reading the map as it was (mv_read) until velo_map_roll_publish --
+//     called by the host at the frame the new rectangle is due -- makes the main stream wait for the roll's last
+//     kernel (a device-side wait) and switches the readers over.  Any other map operation publishes first.
+// The map that results is the plain evict + append, bit for bit (tests/test_gpu_parity.py).
+int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const float* x, const float* y,
+                        const float* z, size_t n)
+{
+    if (!c) return VELO_E_INVALID;
+    if (c->roll_staged) return c->fail(VELO_E_INVALID, "a roll is begun already: velo_map_roll_publish first");
+    float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    if (int rc = roll_precheck(c, "velo_map_roll_begin", lo, hi, x, y, z, n, mn, mx)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->roll_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->roll_stream, hipStreamNonBlocking));
+    if (!c->ev_roll) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_roll, hipEventDisableTiming));
+    if (!c->h_roll) HIP_TRY(c, hipHostMalloc((void**)&c->h_roll, sizeof *c->h_roll, 0));
+    if (int rc = resolve_roll_counts(c)) return rc;  // (the previous roll's, before its pinned slots are reused)
+    // the entering points through pinned memory: a copy from pageable memory would hold the host
+    const float* px = x;
+    const float* py = y;
+    const float* pz = z;
+    if (n) {
+        if (c->h_enter_cap < 3 * n) {
+            if (c->h_enter) {
+                HIP_TRY(c, hipStreamSynchronize(c->roll_stream));
+                (void)hipHostFree(c->h_enter);
+                c->h_enter = nullptr;
+                c->h_enter_cap = 0;
+            }
+            const size_t want = 3 * n + 3 * n / 4 + 4096;
+            HIP_TRY(c, hipHostMalloc((void**)&c->h_enter, want * sizeof(float), 0));
+            c->h_enter_cap = want;
+        } else {
+            HIP_TRY(c, hipStreamSynchronize(c->roll_stream));  // (the previous roll's copy out of this buffer: long done)
+        }
+        std::memcpy(c->h_enter, x, n * sizeof(float));
+        std::memcpy(c->h_enter + n, y, n * sizeof(float));
+        std::memcpy(c->h_enter + 2 * n, z, n * sizeof(float));
+        px = c->h_enter;
+        py = c->h_enter + n;
+        pz = c->h_enter + 2 * n;
+    }
+    HIP_TRY(c, hipStreamWaitEvent(c->roll_stream, c->ev_mark, 0));
+    c->roll_overlapped_done = true;
+    const uint64_t n_before = c->info.n_points;
+    c->defer_counts = true;
+    c->have_enter_mm = n > 0;
+    for (int a = 0; a < 3; ++a) {
+        c->enter_mn[a] = mn[a];
+        c->enter_mx[a] = mx[a];
+    }
+    c->roll_extra = n;
+    c->h_roll->invalid = c->info.n_invalid_normals;
+    c->h_roll->n_done = 0;
+    c->roll_counts_pending = false;
+    const uint64_t gen0 = c->map_gen;
+    const int rc = roll_run(c, c->roll_stream, c->roll_temp, lo, hi, px, py, pz, n);
+    c->defer_counts = false;
+    c->have_enter_mm = false;
+    c->roll_extra = 0;
+    const hipError_t e = hipEventRecord(c->ev_roll, c->roll_stream);
+    if (c->map_gen != gen0) c->roll_staged = true;  // (something was published into mv: the readers are behind it now)
+    (void)n_before;
+    if (rc == VELO_E_AGAIN) return c->fail(VELO_E_AGAIN, "this update needs the map rebuilt: not beside a registration");
+    if (rc) return rc;
+    if (e != hipSuccess) return c->fail(VELO_E_DEVICE, "roll stream: %s", hipGetErrorString(e));
+    return VELO_OK;
+}
+
+int velo_map_roll_publish(velo_ctx* c)
+{
+    if (!c) return VELO_E_INVALID;
+    if (!c->roll_staged) return VELO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the main stream waits ON THE DEVICE for the roll's last kernel; what it runs from here on reads the new map
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_roll, 0));
+    c->mv_read = c->mv;
+    c->roll_staged = false;
+    ++c->map_gen;  // (captured graphs and hints of the old map are stale)
+    return reset_hints(c, c->stream);
 }
 
 int velo_map_set_margins(velo_ctx* c, const int32_t margin[3])
@@ -2083,6 +2276,7 @@ int velo_map_info_get(velo_ctx* c, velo_map_info* out)
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
     // the caller says how large ITS velo_map_info is; never write past that (the struct has grown
     // before and will again)
+    if (int rc = resolve_roll_counts(c)) return rc;
     const uint32_t have = out->struct_size;
     if (have < offsetof(velo_map_info, n_points) + sizeof(uint64_t))
         return c->fail(VELO_E_INVALID, "velo_map_info.struct_size must be set to sizeof(velo_map_info) by the caller");
@@ -2099,6 +2293,7 @@ int velo_map_download(velo_ctx* c, float* x, float* y, float* z, float* nx, floa
     if (!c) return VELO_E_INVALID;
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = settle_roll(c)) return rc;
     const size_t n = c->info.n_points;
     std::vector<float4> h;
     if (x || y || z || nx || ny || nz) h.resize(n);
@@ -2292,8 +2487,8 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
     if (frame < 0 || frame >= c->n_frames) return c->fail(VELO_E_INVALID, "frame index out of range");
     if (!T) return c->fail(VELO_E_INVALID, "T is null");
-    if (!(d_max > 0.0f) || !(d_max <= c->mv.h))
-        return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv.h);
+    if (!(d_max > 0.0f) || !(d_max <= c->mv_read.h))
+        return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv_read.h);
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const size_t n_all = (size_t)c->frame_start[c->n_frames];
@@ -2319,7 +2514,7 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
                               hipMemcpyHostToDevice, s));
     FrameView fv{c->ax, c->ay, c->az, nullptr};
     const int b0 = c->fbs_h[frame], b1 = c->fbs_h[frame + 1];
-    HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, c->items.p + b0, b1 - b0, fv, c->mv,
+    HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, c->items.p + b0, b1 - b0, fv, c->mv_read,
                                 c->poses.p, d_max * d_max, c->partials.p, c->corr.p, c->d2.p,
                                 c->lin_hints ? c->hint.p : nullptr,
                                 (c->lin_hints && c->cfg.use_hints >= 2) ? c->rho.p : nullptr,
@@ -2747,8 +2942,8 @@ int velo_knn(velo_ctx* c, int frame, const double T[12], float d_max, int k, int
     if (frame < 0 || frame >= c->n_frames) return c->fail(VELO_E_INVALID, "frame index out of range");
     if (!T || !idx || !d2) return c->fail(VELO_E_INVALID, "null argument");
     if (k < 1 || k > VELO_MAX_KNORMALS) return c->fail(VELO_E_INVALID, "k must be in [1,%d]", VELO_MAX_KNORMALS);
-    if (!(d_max > 0.0f) || !(d_max <= c->mv.h))
-        return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv.h);
+    if (!(d_max > 0.0f) || !(d_max <= c->mv_read.h))
+        return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv_read.h);
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
@@ -2761,7 +2956,7 @@ int velo_knn(velo_ctx* c, int frame, const double T[12], float d_max, int k, int
     HIP_TRY(c, reserve_slack(dc, n));
     Pose12 P;
     std::memcpy(P.t, T, sizeof P.t);
-    HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, P, d_max * d_max, k, di.p,
+    HIP_TRY(c, launch_knn(c->mv_read, c->ax + q0, c->ay + q0, c->az + q0, n, P, d_max * d_max, k, di.p,
                           dd.p, dc.p, s, nullptr, c->cfg.force_kernel));
     HIP_TRY(c, hipMemcpyAsync(idx, di.p, n * (size_t)k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(d2, dd.p, n * (size_t)k * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -2778,8 +2973,8 @@ int velo_knn_dev(velo_ctx* c, int frame, const double T[12], float d_max, int k,
     if (frame < 0 || frame >= c->n_frames) return c->fail(VELO_E_INVALID, "frame index out of range");
     if (!T || !d_idx || !d_d2) return c->fail(VELO_E_INVALID, "null argument");
     if (k < 1 || k > VELO_MAX_KNORMALS) return c->fail(VELO_E_INVALID, "k must be in [1,%d]", VELO_MAX_KNORMALS);
-    if (!(d_max > 0.0f) || !(d_max <= c->mv.h))
-        return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv.h);
+    if (!(d_max > 0.0f) || !(d_max <= c->mv_read.h))
+        return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv_read.h);
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const size_t q0 = (size_t)c->frame_start[frame], n = (size_t)c->frame_start[frame + 1] - q0;
@@ -2789,7 +2984,7 @@ int velo_knn_dev(velo_ctx* c, int frame, const double T[12], float d_max, int k,
     Pose12 P;
     std::memcpy(P.t, T, sizeof P.t);
     unsigned long long st[4] = {0, 0, 0, 0};
-    HIP_TRY(c, launch_knn(c->mv, c->ax + q0, c->ay + q0, c->az + q0, n, P, d_max * d_max, k, d_idx, d_d2,
+    HIP_TRY(c, launch_knn(c->mv_read, c->ax + q0, c->ay + q0, c->az + q0, n, P, d_max * d_max, k, d_idx, d_d2,
                           d_count, s, stats ? st : nullptr, c->cfg.force_kernel));
     if (stats)
         for (int i = 0; i < 4; ++i) stats[i] = st[i];
@@ -2814,12 +3009,12 @@ static int enqueue_increment(velo_ctx* c, int frame, const double* d_pose, int m
         // a frame: two launches (flags + per-tile counts; bases + scatter) and the count's copy, instead of
         // flags, memset, two scan launches, count copy and scatter; offs doubles as [tile counts | total]
         HIP_TRY(c, c->inc_offs.reserve(tiles + 1));
-        HIP_TRY(c, launch_increment_fused(c->ax + q0, c->ay + q0, c->az + q0, (uint32_t)n, c->mv, d_pose, min_count,
+        HIP_TRY(c, launch_increment_fused(c->ax + q0, c->ay + q0, c->az + q0, (uint32_t)n, c->mv_read, d_pose, min_count,
                                           c->inc_flags.p, c->inc_offs.p, tx, ty, tz, c->inc_offs.p + tiles, s));
         HIP_TRY(c, hipMemcpyAsync(h_total, c->inc_offs.p + tiles, sizeof *h_total, hipMemcpyDeviceToHost, s));
         return VELO_OK;
     }
-    HIP_TRY(c, launch_increment_flags(c->ax + q0, c->ay + q0, c->az + q0, n, c->mv, d_pose, min_count,
+    HIP_TRY(c, launch_increment_flags(c->ax + q0, c->ay + q0, c->az + q0, n, c->mv_read, d_pose, min_count,
                                       c->inc_flags.p, s));
     HIP_TRY(c, hipMemsetAsync(c->inc_flags.p + n, 0, sizeof(uint32_t), s));
     size_t tb = 0;
@@ -3012,7 +3207,7 @@ int velo_increment_all_registered_async(velo_ctx* c, int min_count, float* dox, 
         HIP_TRY(c, c->inc_flags.reserve(n + 1));
         HIP_TRY(c, c->inc_offs.reserve(n + 1));
         FrameView fv{c->ax, c->ay, c->az, nullptr};
-        HIP_TRY(c, launch_increment_flags_items(c->items.p, ni, fv, c->mv, c->poses.p, min_count, c->inc_flags.p, s));
+        HIP_TRY(c, launch_increment_flags_items(c->items.p, ni, fv, c->mv_read, c->poses.p, min_count, c->inc_flags.p, s));
         HIP_TRY(c, hipMemsetAsync(c->inc_flags.p + n, 0, sizeof(uint32_t), s));
         size_t tb = 0;
         HIP_TRY(c, exclusive_scan_u32(nullptr, tb, c->inc_flags.p, c->inc_offs.p, n + 1, s));

@@ -416,14 +416,16 @@ __device__ __forceinline__ bool near_changed(const MapView& mv, const float4& p,
 template <int KMAX>
 __global__ __launch_bounds__(kNrmThreads) void k_normals_subset(
     MapView mv, const uint32_t* __restrict__ perm, int k, const int32_t* __restrict__ work,
-    int n_work, const uint32_t* __restrict__ chg, uint32_t n_chg, float4* __restrict__ nrm,
-    unsigned long long* __restrict__ invalid, unsigned* __restrict__ n_done)
+    int n_work, const unsigned* __restrict__ n_work_dev, const uint32_t* __restrict__ chg, uint32_t n_chg,
+    float4* __restrict__ nrm, unsigned long long* __restrict__ invalid, unsigned* __restrict__ n_done)
 {
     __shared__ float s_d[KMAX][kNrmThreads];
     __shared__ int s_i[KMAX][kNrmThreads];
     const int tid = threadIdx.x;
     const int w = blockIdx.x * kNrmThreads + tid;
-    if (w >= n_work) return;
+    // (n_work_dev: the length of the work list is still on the device -- a roll enqueued without a host wait;
+    //  the grid then covers the upper bound n_work and the surplus workgroups leave at once)
+    if (w >= (n_work_dev ? (int)min(*n_work_dev, (unsigned)n_work) : n_work)) return;
     const int s = work[w];
     const float4 old = nrm[s];
     if (chg && old.w >= 0.0f && !near_changed(mv, mv.pts[s], old.w, chg, n_chg)) return;
@@ -978,18 +980,18 @@ hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& 
 hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
                                  const int32_t* work, int n_work, const uint32_t* chg_keys,
                                  uint32_t n_chg, float4* nrm, unsigned long long* d_invalid,
-                                 unsigned* d_done, hipStream_t s)
+                                 unsigned* d_done, hipStream_t s, const unsigned* n_work_dev)
 {
     if (n_work <= 0) return hipSuccess;
     const dim3 g((n_work + kNrmThreads - 1) / kNrmThreads), b(kNrmThreads);
     if (k <= 8)
-        hipLaunchKernelGGL(k_normals_subset<8>, g, b, 0, s, mv, perm, k, work, n_work, chg_keys, n_chg,
+        hipLaunchKernelGGL(k_normals_subset<8>, g, b, 0, s, mv, perm, k, work, n_work, n_work_dev, chg_keys, n_chg,
                            nrm, d_invalid, d_done);
     else if (k <= 16)
-        hipLaunchKernelGGL(k_normals_subset<16>, g, b, 0, s, mv, perm, k, work, n_work, chg_keys, n_chg,
+        hipLaunchKernelGGL(k_normals_subset<16>, g, b, 0, s, mv, perm, k, work, n_work, n_work_dev, chg_keys, n_chg,
                            nrm, d_invalid, d_done);
     else
-        hipLaunchKernelGGL(k_normals_subset<VELO_MAX_KNORMALS>, g, b, 0, s, mv, perm, k, work, n_work,
+        hipLaunchKernelGGL(k_normals_subset<VELO_MAX_KNORMALS>, g, b, 0, s, mv, perm, k, work, n_work, n_work_dev,
                            chg_keys, n_chg, nrm, d_invalid, d_done);
     return hipGetLastError();
 }

@@ -126,7 +126,8 @@ hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& 
 hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
                                  const int32_t* work, int n_work, const uint32_t* chg_keys,
                                  uint32_t n_chg, float4* nrm, unsigned long long* d_invalid,
-                                 unsigned* d_done, hipStream_t s);
+                                 unsigned* d_done, hipStream_t s, const unsigned* n_work_dev = nullptr);
+// (n_work_dev != nullptr: n_work is an upper bound, the length of the list is read on the device)
 hipError_t launch_removed_keys(const uint32_t* keys, const uint32_t* keep, const uint32_t* offs,
                                uint32_t n, uint32_t* out, hipStream_t s);
 hipError_t launch_count_invalid(const float4* nrm, uint32_t n, unsigned long long* d_invalid,
