@@ -135,6 +135,9 @@ def parse():
     ap.add_argument("--no-decode-overlap", action="store_true",
                     help="stream: plan every frame's decode on the host when it is due instead of a frame ahead, "
                          "while the GPU registers the previous one")
+    ap.add_argument("--roll-lead", type=int, default=4,
+                    help="stream: frames ahead a roll of the device map is begun (velo_map_roll_begin; published when "
+                         "the frame is due); 0 = beside the previous frame's registration only (velo_map_roll_overlapped)")
     ap.add_argument("--map-margin", type=int, default=16, help="stream: grid slack in x/y, voxels")
     ap.add_argument("--map-margin-z", type=int, default=2, help="stream: grid slack in z, voxels")
     ap.add_argument("--full-rebuild", action="store_true", help="stream: re-sort the whole map on every update (A/B)")
@@ -523,7 +526,8 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
     nfr = len(idx)
     truth = meta.get("true_positions")
     period = max(2 * nfr - 2, 1)
-    state = dict(res=None, z=float(meta.get("z0", 0.0)), worst=0.0, pairs=0, rolls=0, full=0, up=0, ev=0, flush=0)
+    state = dict(res=None, z=float(meta.get("z0", 0.0)), worst=0.0, pairs=0, rolls=0, full=0, up=0, ev=0, flush=0,
+                 staged=None, begun=0)
     stage = dict(decode=0.0, roll=0.0, icp=0.0, increment=0.0)
     big = 3.0e38
 
@@ -572,11 +576,29 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
             if mirror:
                 mirror.map_append(x[keep], y[keep], z[keep])
 
+    def publish_begun(timed):
+        """a roll begun ahead (roll_begin) becomes the resident rectangle: velo_map_roll_publish"""
+        rng, n_before, n_in = state["staged"]
+        t_p = time.perf_counter()
+        ctx.map_roll_publish()
+        state.setdefault("t_publish", []).append(time.perf_counter() - t_p)
+        if timed:
+            state["rolls"] += 1
+            state["up"] += n_in
+            state["ev"] += int(n_before + n_in - ctx.map_info().n_points)
+        state["res"] = rng
+        state["staged"] = None
+
     def roll_to(x, y, timed):
         rng = tile_range(x, y)
         cur = state["res"]
         if cur == rng:
-            return
+            return                      # (a roll begun ahead is not due yet)
+        if state["staged"] is not None:  # this prior leaves the resident rectangle: the begun roll is due now
+            publish_begun(timed)         # (or went elsewhere: published all the same, the plain roll goes on from it)
+            cur = state["res"]
+            if cur == rng:
+                return
         # increments accepted so far: to the host tiles now, and -- those in tiles that stay resident --
         # back up with the entering tiles in the roll's ONE append (MapManager::rollTo)
         px, py, pz, pti, ptj = take() if cur is not None else ((np.empty(0, np.float32),) * 3 + (np.empty(0, np.int64),) * 2)
@@ -643,6 +665,41 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
             state["ev"] += int(n0 + ex.size - ctx.map_info().n_points)
         state["res"] = rng
 
+    def roll_begin(x, y, timed):
+        """the roll to a LATER frame's rectangle begun now (MapManager::rollBegin): enqueued on a stream of its
+        own, the frames in between keep the map as it was, roll_to publishes it when that frame is due"""
+        rng = tile_range(x, y)
+        cur = state["res"]
+        if cur is None or cur == rng or state["staged"] is not None:
+            return
+        if not (rng[0] <= cur[1] and rng[1] >= cur[0] and rng[2] <= cur[3] and rng[3] >= cur[2]):
+            return
+        ex, ey, ez = gather(rng, skip=cur)
+        evicts = rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]
+        lo = np.array([rng[0] * pr - pr / 2, rng[2] * pr - pr / 2, -big], np.float32)
+        hi = np.array([np.nextafter(np.float32(rng[1] * pr + pr / 2), np.float32(-big)),
+                       np.nextafter(np.float32(rng[3] * pr + pr / 2), np.float32(-big)), big], np.float32)
+        n0 = int(ctx.map_info().n_points)      # (before the begin: afterwards the call waits for the roll's counts)
+        t_b = time.perf_counter()
+        ok_b = ctx.map_roll_begin(lo if evicts else None, hi if evicts else None, ex, ey, ez)
+        state.setdefault("t_begin", []).append(time.perf_counter() - t_b)
+        if not ok_b:
+            return                             # refused before anything changed: the plain roll does it when due
+        if mirror:      # the same update in its plain form
+            if evicts:
+                mirror.map_evict_outside(lo, hi)
+            if ex.size:
+                mirror.map_append(ex, ey, ez)
+        if probe is not None:
+            probe["rolls_ahead"] = probe.get("rolls_ahead", 0) + 1
+        state["staged"] = (rng, n0, int(ex.size))
+        state["begun"] += 1
+
+    def prior_of(f):
+        ok2, car2 = capi.interp_pose(d["poses"], d["n_poses"], int(times[int(idx[f].first_packet)]))
+        return synth.perturbed_guess(np.array([1, 0, 0, car2.T[0], 0, 1, 0, car2.T[1], 0, 0, 1, 0.0], np.float64),
+                                     dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))
+
     plan = ctx.decode_plan_create()
     planned = dict(f=None)
 
@@ -670,7 +727,7 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
         assert nf >= 1
         ctx.decode_to_frames()
 
-    def one(f, f_next, timed):
+    def one(f, f_next, timed, k=0):
         e = idx[f]
         p0 = int(e.first_packet)
         t = [time.perf_counter()]
@@ -692,14 +749,24 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
         if f_next is not None and not args.no_decode_overlap:
             decode_frame(f_next, overlapped=True)   # (second stream: concurrent with the registration; the
             state["resident"] = f_next              #  `icp` stage below is both)
-            if not args.no_roll_ahead:              # ... and so is the roll of the map to the next frame's ROI
-                ok2, car2 = capi.interp_pose(d["poses"], d["n_poses"], int(times[int(idx[f_next].first_packet)]))
-                Tn = synth.perturbed_guess(np.array([1, 0, 0, car2.T[0], 0, 1, 0, car2.T[1], 0, 0, 1, 0.0], np.float64),
-                                           dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))
+            if not args.no_roll_ahead and args.roll_lead > 0:
+                # ... and so is the roll of the map: begun as soon as one of the next roll_lead frames names another
+                # tile rectangle (the priors come from the pose track), published when that frame is due
+                if state["staged"] is None and state["res"] is not None:
+                    for dd in range(1, args.roll_lead + 1):
+                        if k + dd > k_last:     # (no frame of this run will need it)
+                            break
+                        Tn = prior_of(frame_at(k + dd))
+                        if tile_range(float(Tn[3]), float(Tn[7])) != state["res"]:
+                            roll_begin(float(Tn[3]), float(Tn[7]), timed)
+                            break
+            elif not args.no_roll_ahead:            # ... beside this registration only, for the next frame
+                Tn = prior_of(f_next)
                 roll_ahead(float(Tn[3]), float(Tn[7]), timed)
         res = ctx.icp_batch_finish()[0]
         t.append(time.perf_counter())
-        if ctx.pending_count(False) >= max(args.append_threshold, 1):
+        # (while a roll is begun the increments stay pending: a flush would publish it early)
+        if state["staged"] is None and ctx.pending_count(False) >= max(args.append_threshold, 1):
             flush()
         t.append(time.perf_counter())
         state["z"] = float(res.T[11])
@@ -714,14 +781,17 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
                 state["worst"] = max(state["worst"], err)
 
     frame_at = lambda k: (k % period) if (k % period) < nfr else period - (k % period)  # noqa: E731
+    k_last = warmup + steps - 1
     for k in range(warmup):
-        one(frame_at(k), frame_at(k + 1), False)
+        one(frame_at(k), frame_at(k + 1), False, k)
     torch.cuda.synchronize()
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
     for k in range(steps):
-        one(frame_at(warmup + k), frame_at(warmup + k + 1) if k + 1 < steps else None, True)
+        one(frame_at(warmup + k), frame_at(warmup + k + 1) if k + 1 < steps else None, True, warmup + k)
+    if state["staged"] is not None:
+        publish_begun(True)
     flush()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -766,7 +836,11 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
                         points_evicted=state["ev"], increment_flushes=state["flush"]),
             "last_update": int(mi.last_update), "worst_pose_error_m": state["worst"],
             "decode_planned_ahead": not args.no_decode_overlap,
-            "roll_ahead": not (args.no_decode_overlap or args.no_roll_ahead)}
+            "roll_ahead": not (args.no_decode_overlap or args.no_roll_ahead),
+            "roll_lead": 0 if (args.no_decode_overlap or args.no_roll_ahead) else int(args.roll_lead),
+            "rolls_begun_ahead": state["begun"],
+            "roll_begin_host_ms": (1e3 * float(np.mean(state["t_begin"]))) if state.get("t_begin") else None,
+            "roll_publish_host_ms": (1e3 * float(np.mean(state["t_publish"]))) if state.get("t_publish") else None}
 
 
 # ------------------------------------------------------------------------- inputs

@@ -44,6 +44,7 @@ struct MapStats {
     uint64_t rolls = 0;              // ROI changes applied incrementally (evict + append entering tiles)
     uint64_t rolls_ahead = 0;        // ... of which beside the previous frame's registration (rollAhead)
     uint64_t rolls_refused = 0;      // rollAhead attempts the library refused (re-anchor needed): done by the plain roll
+    uint64_t rolls_begun = 0;        // ... begun several frames ahead (rollBegin) and published when due
     uint64_t tiles_entered = 0, tiles_left = 0;
     uint64_t points_uploaded = 0;    // host tile points sent to the device by rolls
     uint64_t points_evicted = 0;
@@ -86,6 +87,17 @@ public:
     // false without having changed anything when the roll cannot be done that way (first ROI, a jump,
     // a re-anchor ...): the rollTo inside the next registerFrame / registerResident then does it.
     bool rollAhead(double x, double y, const RegisterOptions& opts);
+    // The roll BEGUN SEVERAL FRAMES AHEAD (velo_map_roll_begin): call it from while_registering with the prior
+    // of a LATER frame -- the first of the next few whose tile rectangle differs (needsRoll tells).  The roll is
+    // enqueued on a stream of its own and holds the host for its first count only; the frames registered
+    // meanwhile keep reading the map as it was; the rollTo of the frame whose prior names the begun rectangle
+    // publishes it (velo_map_roll_publish: a device-side wait).  While a roll is begun the pending increments
+    // stay pending (a flush would publish it early); a prior that asks for any other rectangle publishes it and
+    // rolls on from there.  Returns false without having changed anything when it cannot be done that way.
+    bool rollBegin(double x, double y, const RegisterOptions& opts);
+    // does the prior (x, y) name another tile rectangle than the resident one -- and no roll is begun yet?
+    bool needsRoll(double x, double y) const;
+    bool rollBegun() const { return staged_; }
     // The pending increments (device-side list) -> the host tiles, and -> the device map for those
     // that lie in resident tiles (one velo_map_append).  A roll does not call this: it takes the list
     // and folds the points into the ONE append that brings the entering tiles up (rollTo).
@@ -116,6 +128,10 @@ private:
     bool dirty_;                   // host tiles changed behind the device map's back: rebuild
     bool haveDevice_;
     int res_i0_, res_i1_, res_j0_, res_j1_;  // resident tile index range (inclusive)
+    bool staged_ = false;                    // a roll is begun (rollBegin), to the rectangle below
+    int st_i0_ = 0, st_i1_ = 0, st_j0_ = 0, st_j1_ = 0;
+    uint64_t st_n_before_ = 0, st_n_in_ = 0;  // device points before it / entering points (for points_evicted)
+    bool publishBegun();                     // the begun roll becomes the resident rectangle
     float residentVoxel_;
     int residentK_;
     MapStats stats_;

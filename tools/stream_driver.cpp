@@ -20,7 +20,7 @@
 //
 //   hipcc -std=c++17 -O2 -x c++ tools/stream_driver.cpp -Iinclude -Lveloslam_amd/csrc -lveloslam_amd \
 //         -Wl,-rpath,$PWD/veloslam_amd/csrc -o tools/stream_driver
-//   tools/stream_driver DIR [--steps 100] [--warmup 10] [--threshold 512] [--no-integrate] [--no-overlap] [--no-roll-ahead]
+//   tools/stream_driver DIR [--steps 100] [--warmup 10] [--threshold 512] [--roll-lead 4] [--no-integrate] [--no-overlap] [--no-roll-ahead]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -44,13 +44,14 @@ int main(int argc, char** argv)
         return 2;
     }
     const std::string dir = argv[1];
-    int steps = 100, warmup = 10, threshold = 512;
+    int steps = 100, warmup = 10, threshold = 512, roll_lead = 4;
     bool integrate = true, overlap = true, roll_ahead = true;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
         else if (a == "--warmup" && i + 1 < argc) warmup = std::atoi(argv[++i]);
         else if (a == "--threshold" && i + 1 < argc) threshold = std::atoi(argv[++i]);
+        else if (a == "--roll-lead" && i + 1 < argc) roll_lead = std::atoi(argv[++i]);  // frames a roll is begun ahead (0: beside the previous frame only)
         else if (a == "--no-integrate") integrate = false;
         else if (a == "--no-overlap") overlap = false;
         else if (a == "--no-roll-ahead") roll_ahead = false;  // roll the map when the frame is due, not beside the previous registration  // decode every frame when it is due, not during the previous registration
@@ -95,6 +96,10 @@ int main(int argc, char** argv)
     double z_prev = z0, worst = 0, t_decode = 0, t_register = 0;
     int prepared = -1;  // the frame resident in HBM already (decoded during the previous registration)
     uint64_t pairs = 0;
+    const int period = std::max(2 * n_frames - 2, 1);
+    auto frame_at = [&](int k) { const int j = k % period; return j < n_frames ? j : period - j; };
+    int k_now = 0;   // play position of the frame being registered
+    const int k_last = warmup + steps - 1;
     auto one = [&](int f, int f_next, bool timed) -> bool {
         const std::shared_ptr<HDLFrame>& fr = frames[(size_t)f];
         // the NEXT frame is decoded while the GPU registers this one: its packets go up and through the
@@ -103,12 +108,21 @@ int main(int argc, char** argv)
         double t_next = 0;
         opt.while_registering = nullptr;
         if (overlap && f_next >= 0)
-            opt.while_registering = [&hdl, &mgr, &opt, &frames, f_next, &next_ok, &t_next, roll_ahead] {
+            opt.while_registering = [&hdl, &mgr, &opt, &frames, f_next, &next_ok, &t_next, roll_ahead, roll_lead, &frame_at, &k_now, k_last] {
                 const auto a0 = clk::now();
                 next_ok = hdl.prepareResidentDuringRegistration(frames[(size_t)f_next]);
-                // ... and the map is rolled to the next frame's ROI beside the registration as well (the
-                // prior's x, y come from the pose track, not from this registration's result)
-                if (next_ok && roll_ahead) {
+                // ... and the map is rolled towards the ROI of a frame to come beside the registration as well (the
+                // prior's x, y come from the pose track, not from this registration's result): begun as soon as one
+                // of the next roll_lead frames names another tile rectangle, published when that frame is due
+                if (next_ok && roll_ahead && roll_lead > 0) {
+                    for (int d = 1; d <= roll_lead && k_now + d <= k_last; ++d) {   // (no later frame of this run needs it)
+                        const PoseTransform& cd = *frames[(size_t)frame_at(k_now + d)]->carpose;
+                        if (mgr.needsRoll(cd.T[0] + 0.15, cd.T[1] - 0.10)) {
+                            mgr.rollBegin(cd.T[0] + 0.15, cd.T[1] - 0.10, opt);
+                            break;
+                        }
+                    }
+                } else if (next_ok && roll_ahead) {
                     const PoseTransform& c2 = *frames[(size_t)f_next]->carpose;
                     mgr.rollAhead(c2.T[0] + 0.15, c2.T[1] - 0.10, opt);
                 }
@@ -153,15 +167,17 @@ int main(int argc, char** argv)
         }
         return true;
     };
-    const int period = std::max(2 * n_frames - 2, 1);
-    auto frame_at = [&](int k) { const int j = k % period; return j < n_frames ? j : period - j; };
-    for (int k = 0; k < warmup; ++k)
+    for (int k = 0; k < warmup; ++k) {
+        k_now = k;
         if (!one(frame_at(k), frame_at(k + 1), false)) return 5;
+    }
     velo_synchronize(ctx);
     const MapStats s0 = mgr.stats();
     const auto t0 = clk::now();
-    for (int k = 0; k < steps; ++k)
+    for (int k = 0; k < steps; ++k) {
+        k_now = warmup + k;
         if (!one(frame_at(warmup + k), k + 1 < steps ? frame_at(warmup + k + 1) : -1, true)) return 5;
+    }
     mgr.flushIncrements();
     velo_synchronize(ctx);
     const double total_ms = ms_since(t0);
@@ -173,12 +189,14 @@ int main(int argc, char** argv)
                 "\"stage_ms_per_frame\": {\"decode\": %.4f, \"register_roll_icp_increment\": %.4f}, "
                 "\"pairs_per_s\": %.4g, \"worst_pose_error_m\": %.15g, \"map_points\": %llu, \"map_subdiv\": %d, "
                 "\"last_update\": %d, \"tile_edge_m\": %g, \"decode_planned_ahead\": %s, \"roll_ahead\": %s, "
-                "\"map\": {\"full_builds\": %llu, \"rolls\": %llu, \"rolls_ahead\": %llu, \"rolls_refused\": %llu, \"tiles_entered\": %llu, \"tiles_left\": %llu, "
+                "\"roll_lead\": %d, \"map\": {\"full_builds\": %llu, \"rolls\": %llu, \"rolls_ahead\": %llu, \"rolls_begun\": %llu, \"rolls_refused\": %llu, \"tiles_entered\": %llu, \"tiles_left\": %llu, "
                 "\"points_uploaded\": %llu, \"points_evicted\": %llu, \"increment_flushes\": %llu, \"increment_points\": %llu}}\n",
                 steps, 1e3 * steps / total_ms, total_ms / steps, t_decode / steps, t_register / steps,
                 (double)pairs / (total_ms * 1e-3), worst, (unsigned long long)mi.n_points, mi.subdiv, mi.last_update, patch, overlap ? "true" : "false", (overlap && roll_ahead) ? "true" : "false",
+                (overlap && roll_ahead) ? roll_lead : 0,
                 (unsigned long long)(s1.full_builds - s0.full_builds), (unsigned long long)(s1.rolls - s0.rolls),
-                (unsigned long long)(s1.rolls_ahead - s0.rolls_ahead), (unsigned long long)(s1.rolls_refused - s0.rolls_refused),
+                (unsigned long long)(s1.rolls_ahead - s0.rolls_ahead), (unsigned long long)(s1.rolls_begun - s0.rolls_begun),
+                (unsigned long long)(s1.rolls_refused - s0.rolls_refused),
                 (unsigned long long)(s1.tiles_entered - s0.tiles_entered), (unsigned long long)(s1.tiles_left - s0.tiles_left),
                 (unsigned long long)(s1.points_uploaded - s0.points_uploaded),
                 (unsigned long long)(s1.points_evicted - s0.points_evicted),

@@ -2096,15 +2096,19 @@ static int roll_precheck(velo_ctx* c, const char* who, const float lo[3], const 
     if (n) {
         const float* src[3] = {x, y, z};
         for (int a = 0; a < 3; ++a) {
-            float lo_a = src[a][0], hi_a = src[a][0];
-            bool finite = true;
+            // (branch-free, so that the compiler vectorises it: this pass is on the host's critical path once per
+            //  roll -- 235 k points took 0.3 ms as a scalar loop with isfinite per element.  A NaN makes lo > hi or
+            //  survives in the sum below; an infinity shows in the bounds.)
+            const float* p = src[a];
+            float lo_a = p[0], hi_a = p[0], acc = 0.0f;
             for (size_t i = 0; i < n; ++i) {
-                const float v = src[a][i];
-                finite &= std::isfinite(v);
-                lo_a = std::min(lo_a, v);
-                hi_a = std::max(hi_a, v);
+                const float v = p[i];
+                lo_a = v < lo_a ? v : lo_a;
+                hi_a = v > hi_a ? v : hi_a;
+                acc += v * 0.0f;   // 0 for finite values, NaN for NaN / infinity
             }
-            if (!finite) return c->fail(VELO_E_INVALID, "map points must be finite");
+            if (!(acc == 0.0f) || !std::isfinite(lo_a) || !std::isfinite(hi_a))
+                return c->fail(VELO_E_INVALID, "map points must be finite");
             mn[a] = lo_a;
             mx[a] = hi_a;
         }
@@ -2192,7 +2196,32 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
     float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     if (int rc = roll_precheck(c, "velo_map_roll_begin", lo, hi, x, y, z, n, mn, mx)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->roll_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->roll_stream, hipStreamNonBlocking));
+    if (!c->roll_stream) {
+        // A stream that may use THREE QUARTERS of the CUs (8 of every XCD's 32 are masked out).  The roll's kernels
+        // fill whatever they may run on for 2 ms; the registration on the main stream is a chain of small dependent
+        // kernels, one of them (k_reduce_solve) a single 1 024-thread workgroup that needs a nearly empty CU -- beside
+        // an unmasked roll it waited 0.9 - 4.7 ms for one, whatever the stream priorities and however the roll's
+        // grids were cut (profiles/r05/roll_begin_trace_*.txt).  The masked quarter is always free of roll work.
+        // Which bits: measured with tools/cu_mask_probe (profiles/r05/cu_mask_probe.txt) -- bit i is XCD i % 8, shader
+        // engine (i / 8) % 4, CU (i / 32) of that engine.  The free CUs must be spread over ALL shader engines: a
+        // workgroup is handed to an engine before anyone asks whether that engine has room (with engine 3 of every
+        // XCD masked out instead, the solve still waited for 1.3 ms three times out of four).  So: the last two CUs
+        // of every engine, i.e. bits 3/4 x n_CUs and up.  No such stream (older runtime): a plain one, still correct.
+        hipDeviceProp_t prop;
+        HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        int roll_cus = ncu - ncu / 4;
+        if (const char* e = getenv("VELO_ROLL_CUS")) {   // (measurement aid: how many CUs the roll may use)
+            const int v = atoi(e);
+            if (v >= 32 && v <= ncu) roll_cus = v / 32 * 32;
+        }
+        for (int i = 0; i < roll_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+        if (getenv("VELO_ROLL_NO_CU_MASK") || hipExtStreamCreateWithCUMask(&c->roll_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->roll_stream, hipStreamNonBlocking));
+        }
+    }
     if (!c->ev_roll) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_roll, hipEventDisableTiming));
     if (!c->h_roll) HIP_TRY(c, hipHostMalloc((void**)&c->h_roll, sizeof *c->h_roll, 0));
     if (int rc = resolve_roll_counts(c)) return rc;  // (the previous roll's, before its pinned slots are reused)

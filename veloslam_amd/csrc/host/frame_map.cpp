@@ -441,7 +441,14 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
     tileRange(x, y, i0, i1, j0, j1);
     const bool same_cfg = o.voxel == residentVoxel_ && o.k_normals == residentK_;
     if (haveDevice_ && !dirty_ && same_cfg && i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_)
-        return true;
+        return true;   // (a roll begun ahead is not due yet: the readers keep the resident rectangle)
+    // this prior leaves the resident rectangle: a roll begun ahead is due now -- or, if it went elsewhere,
+    // is published all the same and the plain roll below goes on from its rectangle
+    if (staged_) {
+        if (!publishBegun()) return false;
+        if (haveDevice_ && !dirty_ && same_cfg && i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_)
+            return true;
+    }
     auto gather = [&](int a0, int a1, int b0, int b1, bool only_new, size_t* tiles) {
         stage_x_.clear(), stage_y_.clear(), stage_z_.clear();
         for (int j = b0; j <= b1; ++j)
@@ -596,6 +603,87 @@ bool MapManager::rollAhead(double x, double y, const RegisterOptions& o)
     return true;
 }
 
+bool MapManager::needsRoll(double x, double y) const
+{
+    if (!ctx_ || !haveDevice_ || dirty_ || staged_) return false;
+    int i0, i1, j0, j1;
+    tileRange(x, y, i0, i1, j0, j1);
+    return !(i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_);
+}
+
+bool MapManager::rollBegin(double x, double y, const RegisterOptions& o)
+{
+    if (!ctx_ || !haveDevice_ || dirty_ || staged_) return false;
+    int i0, i1, j0, j1;
+    tileRange(x, y, i0, i1, j0, j1);
+    if (o.voxel != residentVoxel_ || o.k_normals != residentK_) return false;
+    if (i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_) return true;  // nothing to do
+    if (!(i0 <= res_i1_ && i1 >= res_i0_ && j0 <= res_j1_ && j1 >= res_j0_)) return false;  // a jump: plain rebuild
+    stage_x_.clear(), stage_y_.clear(), stage_z_.clear();
+    size_t tiles = 0;
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            if (i >= res_i0_ && i <= res_i1_ && j >= res_j0_ && j <= res_j1_) continue;
+            auto it = patches_.find({i, j});
+            if (it == patches_.end() || it->second->size() == 0) continue;
+            const MapPatch& p = *it->second;
+            stage_x_.insert(stage_x_.end(), p.x.begin(), p.x.end());
+            stage_y_.insert(stage_y_.end(), p.y.begin(), p.y.end());
+            stage_z_.insert(stage_z_.end(), p.z.begin(), p.z.end());
+            ++tiles;
+        }
+    const bool evicts = i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_;
+    const float big = 3.0e38f;
+    const float lo[3] = {(float)(i0 * (double)patchRange_ - patchRange_ / 2.0),
+                         (float)(j0 * (double)patchRange_ - patchRange_ / 2.0), -big};
+    const float hi[3] = {std::nextafter((float)(i1 * (double)patchRange_ + patchRange_ / 2.0), -big),
+                         std::nextafter((float)(j1 * (double)patchRange_ + patchRange_ / 2.0), -big), big};
+    velo_map_info mi;
+    mi.struct_size = sizeof mi;
+    velo_map_info_get(ctx_, &mi);   // (before the begin: afterwards the call would wait for the roll's counts)
+    const int rc = velo_map_roll_begin(ctx_, evicts ? lo : nullptr, evicts ? hi : nullptr, stage_x_.data(),
+                                       stage_y_.data(), stage_z_.data(), stage_x_.size());
+    if (rc == VELO_E_AGAIN || rc == VELO_E_INVALID) {  // refused before anything changed: the plain roll does it when due
+        ++stats_.rolls_refused;
+        return false;
+    }
+    if (rc) {
+        err_ = velo_last_error(ctx_);
+        dirty_ = true;
+        return false;
+    }
+    staged_ = true;
+    st_i0_ = i0, st_i1_ = i1, st_j0_ = j0, st_j1_ = j1;
+    st_n_before_ = mi.n_points;
+    st_n_in_ = stage_x_.size();
+    stats_.points_uploaded += stage_x_.size();
+    stats_.tiles_entered += tiles;
+    stats_.tiles_left += (uint64_t)std::max(0, (res_i1_ - res_i0_ + 1) * (res_j1_ - res_j0_ + 1) -
+                                                   (std::min(i1, res_i1_) - std::max(i0, res_i0_) + 1) *
+                                                       (std::min(j1, res_j1_) - std::max(j0, res_j0_) + 1));
+    return true;
+}
+
+bool MapManager::publishBegun()
+{
+    if (!staged_) return true;
+    if (velo_map_roll_publish(ctx_)) {
+        err_ = velo_last_error(ctx_);
+        dirty_ = true;
+        return false;
+    }
+    velo_map_info mi;
+    mi.struct_size = sizeof mi;
+    velo_map_info_get(ctx_, &mi);   // (n_points is host arithmetic; the normal counts wait for the roll -- begun frames ago)
+    stats_.points_evicted += st_n_before_ + st_n_in_ - mi.n_points;
+    ++stats_.rolls;
+    ++stats_.rolls_ahead;
+    ++stats_.rolls_begun;
+    res_i0_ = st_i0_, res_i1_ = st_i1_, res_j0_ = st_j0_, res_j1_ = st_j1_;
+    staged_ = false;
+    return true;
+}
+
 bool MapManager::takeIncrements()
 {
     size_t n = 0;
@@ -621,6 +709,9 @@ bool MapManager::takeIncrements()
 bool MapManager::flushIncrements()
 {
     if (!ctx_) return false;
+    // (an explicit flush while a roll is begun: the append below would publish it inside the library -- keep the
+    //  resident rectangle in step)
+    if (staged_ && !publishBegun()) return false;
     if (!takeIncrements()) return false;
     if (pend_x_.empty() || !haveDevice_) return true;
     // back up: the points in resident tiles (anything else waits in its host tile until that tile enters)
@@ -682,11 +773,12 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
     *out = p;
     if (o.integrate) {
         if (o.append_threshold <= 1) {  // "after every frame": wait for this one
-            if (!flushIncrements()) return false;
+            if (!staged_ && !flushIncrements()) return false;
         } else {
             size_t pending = 0;
             velo_pending_count(ctx_, &pending, 0);  // without waiting: the frame in flight counts next time
-            if (pending >= (size_t)o.append_threshold && !flushIncrements()) return false;
+            // (while a roll is begun the increments stay pending: they join the map at the first flush after it)
+            if (pending >= (size_t)o.append_threshold && !staged_ && !flushIncrements()) return false;
         }
     }
     return true;

@@ -8,6 +8,7 @@
 // reference has no counterpart.  Bandwidth/latency-bound integer
 // and fp32 work: no MFMA anywhere.
 #include "device_math.hpp"
+#include <cstdlib>
 
 namespace velo {
 
@@ -1530,9 +1531,17 @@ __device__ void se3_exp_apply(const double* xi, double* T)
 #ifndef VELO_SOLVE_SPEC
 #define VELO_SOLVE_SPEC 1
 #endif
-constexpr int kSolveThreads = 1024;
-constexpr int kSolveGroups = kSolveThreads / 32;
-constexpr int kSolveStack = 8;  // trips per group <= 2^8: 32 x 16 x 256 slots per frame
+constexpr int kSolveStack = 8;  // trips per group <= 2^8: 8 .. 32 groups x 16 x 256 slots per frame
+// (measurement aid: VELO_SOLVE_THREADS = 256 / 512 / 1024 pins the workgroup size of k_reduce_solve)
+static int solve_threads_override()
+{
+    static const int v = [] {
+        const char* e = getenv("VELO_SOLVE_THREADS");
+        const int t = e ? atoi(e) : 0;
+        return (t == 256 || t == 512 || t == 1024) ? t : 0;
+    }();
+    return v;
+}
 
 __device__ __forceinline__ int slot_row(int slot, int head, int nbig, int mlog, int nrows)
 {
@@ -1551,13 +1560,14 @@ __device__ __forceinline__ int slot_row(int slot, int head, int nbig, int mlog, 
 
 // MIXED = false: every frame's rows are of one size (a single frame, the latency kernel's items): the
 // instantiation carries none of the two-size bookkeeping -- it is the kernel a single-frame iteration waits for
-template <bool MIXED>
+template <bool MIXED, int kSolveThreads>
 __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
     const double* __restrict__ partials, const int32_t* __restrict__ fbs, const int4* __restrict__ layout,
     double* __restrict__ poses, velo_icp_iter* __restrict__ stats, int iter,
     double* __restrict__ acc_out, int do_update, double* __restrict__ poses_prev,
     unsigned long long* __restrict__ pairs_total, int spec_rows, int4 lay0)
 {
+    constexpr int kSolveGroups = kSolveThreads / 32;
     __shared__ double s_g[kSolveGroups][32];
     __shared__ double s_acc[32];
     __shared__ double s_pose[12];
@@ -1740,14 +1750,27 @@ hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_bloc
         l0 = make_int4(layout0->head, layout0->nbig, layout0->mlog, layout0->nslots);
     else
         spec_rows = 0;
-    if (mixed)
-        hipLaunchKernelGGL(k_reduce_solve<true>, dim3(n_frames), dim3(kSolveThreads), 0, s, partials,
-                           frame_block_start, reinterpret_cast<const int4*>(layout), poses, stats, iter, acc_out,
-                           do_update, poses_prev, pairs_total, spec_rows, l0);
-    else
-        hipLaunchKernelGGL(k_reduce_solve<false>, dim3(n_frames), dim3(kSolveThreads), 0, s, partials,
-                           frame_block_start, reinterpret_cast<const int4*>(layout), poses, stats, iter, acc_out,
-                           do_update, poses_prev, pairs_total, spec_rows, l0);
+    // 1 024 threads (32 groups: a frame's 450 rows in ONE trip of loads) for a batch; a workgroup that size needs a
+    // nearly empty CU, though -- 4 wavefronts of 112 registers on every SIMD -- and waits for one while another
+    // stream's kernels hold registers everywhere (the map roll begun ahead of a frame of the stream: 0.9 - 4.7 ms
+    // behind its k_normals_subset, profiles/r05/roll_begin_trace_*.txt).  The registration of one or two frames
+    // therefore runs the 8-group form: the same aligned tree over the slots (B x groups >= slots either way), four
+    // trips of loads instead of one.
+    const int threads = solve_threads_override() ? solve_threads_override() : (n_frames <= 2 ? 256 : 1024);
+#define VELO_LAUNCH_SOLVE(MX, TT)                                                                                      \
+    hipLaunchKernelGGL((k_reduce_solve<MX, TT>), dim3(n_frames), dim3(TT), 0, s, partials, frame_block_start,          \
+                       reinterpret_cast<const int4*>(layout), poses, stats, iter, acc_out, do_update, poses_prev,       \
+                       pairs_total, spec_rows, l0)
+    if (mixed) {
+        if (threads == 256) VELO_LAUNCH_SOLVE(true, 256);
+        else if (threads == 512) VELO_LAUNCH_SOLVE(true, 512);
+        else VELO_LAUNCH_SOLVE(true, 1024);
+    } else {
+        if (threads == 256) VELO_LAUNCH_SOLVE(false, 256);
+        else if (threads == 512) VELO_LAUNCH_SOLVE(false, 512);
+        else VELO_LAUNCH_SOLVE(false, 1024);
+    }
+#undef VELO_LAUNCH_SOLVE
     return hipGetLastError();
 }
 

@@ -422,19 +422,22 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals_subset(
     __shared__ float s_d[KMAX][kNrmThreads];
     __shared__ int s_i[KMAX][kNrmThreads];
     const int tid = threadIdx.x;
-    const int w = blockIdx.x * kNrmThreads + tid;
-    // (n_work_dev: the length of the work list is still on the device -- a roll enqueued without a host wait;
-    //  the grid then covers the upper bound n_work and the surplus workgroups leave at once)
-    if (w >= (n_work_dev ? (int)min(*n_work_dev, (unsigned)n_work) : n_work)) return;
-    const int s = work[w];
-    const float4 old = nrm[s];
-    if (chg && old.w >= 0.0f && !near_changed(mv, mv.pts[s], old.w, chg, n_chg)) return;
-    const float4 nv = point_normal(mv, perm, s, k, s_d, s_i, tid);
-    nrm[s] = nv;
-    const int was = (old.w >= 0.0f && is_zero3(old)) ? 1 : 0;
-    const int now = is_zero3(nv) ? 1 : 0;
-    if (now != was) atomicAdd(invalid, (unsigned long long)(long long)(now - was));
-    if (n_done) atomicAdd(n_done, 1u);
+    // (n_work_dev: the length of the work list is still on the device -- a roll enqueued without a host wait.  The
+    //  grid is then a bounded one and strides over the list: a grid sized for the upper bound, every point of the
+    //  map, was 91 000 workgroups of which 90 000 left at once -- and held the dispatcher for 0.8 ms while a
+    //  registration on the other stream waited for slots, profiles/r05)
+    const int nw = n_work_dev ? (int)min(*n_work_dev, (unsigned)n_work) : n_work;
+    for (int w = blockIdx.x * kNrmThreads + tid; w < nw; w += gridDim.x * kNrmThreads) {
+        const int s = work[w];
+        const float4 old = nrm[s];
+        if (chg && old.w >= 0.0f && !near_changed(mv, mv.pts[s], old.w, chg, n_chg)) continue;
+        const float4 nv = point_normal(mv, perm, s, k, s_d, s_i, tid);
+        nrm[s] = nv;
+        const int was = (old.w >= 0.0f && is_zero3(old)) ? 1 : 0;
+        const int now = is_zero3(nv) ? 1 : 0;
+        if (now != was) atomicAdd(invalid, (unsigned long long)(long long)(now - was));
+        if (n_done) atomicAdd(n_done, 1u);
+    }
 }
 
 // sorted fine keys of the points an eviction removes (keep == 0), compacted in order
@@ -983,7 +986,10 @@ hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
                                  unsigned* d_done, hipStream_t s, const unsigned* n_work_dev)
 {
     if (n_work <= 0) return hipSuccess;
-    const dim3 g((n_work + kNrmThreads - 1) / kNrmThreads), b(kNrmThreads);
+    // (length on the device: a bounded grid that strides over the list -- 4 096 workgroups cover 524 288 points in one
+    //  pass, more than a roll of the stream marks; the roll's stream keeps a quarter of the CUs free, capi.cpp)
+    const int blocks = (n_work + kNrmThreads - 1) / kNrmThreads;
+    const dim3 g(n_work_dev ? min(blocks, 4096) : blocks), b(kNrmThreads);
     if (k <= 8)
         hipLaunchKernelGGL(k_normals_subset<8>, g, b, 0, s, mv, perm, k, work, n_work, n_work_dev, chg_keys, n_chg,
                            nrm, d_invalid, d_done);
