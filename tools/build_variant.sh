@@ -8,4 +8,4 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -c ${SRC
 echo
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -x hip -c capi.cpp -o build/variants/capi_$name.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -c kernels/map_build.hip -o build/variants/map_build_$name.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libveloslam_amd_$name.so build/variants/icp_$name.o build/variants/map_build_$name.o build/sortscan.o build/decode.o build/exchange.o build/variants/capi_$name.o build/geodesy.o build/pose.o build/frame_map.o build/hdl_manager.o build/decode_plan.o build/packet_file.o build/io.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libveloslam_amd_$name.so build/variants/icp_$name.o build/variants/map_build_$name.o build/knn_wave.o build/sortscan.o build/decode.o build/exchange.o build/variants/capi_$name.o build/geodesy.o build/geodesy_cxx.o build/pose.o build/frame_map.o build/hdl_manager.o build/decode_plan.o build/packet_file.o build/io.o

@@ -383,6 +383,9 @@ constexpr float kCertSlack = VELO_CERT_SLACK;  // metres searched beyond the hin
 #ifndef VELO_WALK_W
 #define VELO_WALK_W 4
 #endif
+#ifndef VELO_SEED_BOUND
+#define VELO_SEED_BOUND 0  // 1: block-less stragglers take a first bound from the sorted-order neighbours of their cell (A/B)
+#endif
 #ifndef VELO_WALK_W_LAT
 #define VELO_WALK_W_LAT 8  // latency kernel: twice the candidate loads in flight per trip
 #endif
@@ -661,6 +664,23 @@ __device__ void search_ball(const MapView& mv, float qx, float qy, float qz, flo
     // map point within sqrt(cov) at the end has been looked at and `sd` (second-smallest
     // distance seen) bounds everything but the winner -- a certificate, as in the cooperative
     // form.  (Without it a straggler of this path came back as a straggler at every iteration.)
+#if VELO_SEED_BOUND
+    // A/B of round 5: a SEED for the block-less straggler out of the table itself -- the entry of
+    // the query's own (empty) fine cell is the index of the first map point at or beyond it in the sorted order, so
+    // that point and the one before it are the nearest along the query's fine row (or, where the row is empty, on a
+    // neighbouring row): two candidates, one table entry, and a bound for the probe and the ball below.  A bound only.
+    if (probe && !HASH && (unsigned)g.Fx < (unsigned)mv.fx && (unsigned)g.Fy < (unsigned)mv.fy &&
+        (unsigned)g.Fz < (unsigned)mv.fz) {
+        const uint32_t key = ((uint32_t)g.Fz * (uint32_t)mv.fy + (uint32_t)g.Fy) * (uint32_t)mv.fx + (uint32_t)g.Fx;
+        const int js = mv.cell_start[key];
+        tl.table(1, 4);
+        tl.candidates(2);
+        float sb = ub;
+        if (js < mv.n) sb = fminf(sb, dist2(mv.pts[(unsigned)js], qx, qy, qz));
+        if (js > 0) sb = fminf(sb, dist2(mv.pts[(unsigned)(js - 1)], qx, qy, qz));
+        ub = fminf(ub, sb);
+    }
+#endif
 #if VELO_BALL_PROBE
     // A straggler whose 3x3x3 block held NOTHING has no bound but d_max: its ball is a whole voxel
     // wide, all (2S+1)^2 rows, and the wavefront runs for it (a third of the stragglers of an
@@ -1750,13 +1770,14 @@ hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_bloc
         l0 = make_int4(layout0->head, layout0->nbig, layout0->mlog, layout0->nslots);
     else
         spec_rows = 0;
-    // 1 024 threads (32 groups: a frame's 450 rows in ONE trip of loads) for a batch; a workgroup that size needs a
-    // nearly empty CU, though -- 4 wavefronts of 112 registers on every SIMD -- and waits for one while another
-    // stream's kernels hold registers everywhere (the map roll begun ahead of a frame of the stream: 0.9 - 4.7 ms
-    // behind its k_normals_subset, profiles/r05/roll_begin_trace_*.txt).  The registration of one or two frames
-    // therefore runs the 8-group form: the same aligned tree over the slots (B x groups >= slots either way), four
-    // trips of loads instead of one.
-    const int threads = solve_threads_override() ? solve_threads_override() : (n_frames <= 2 ? 256 : 1024);
+    // 1 024 threads (32 groups): a frame's 450 rows in ONE trip of loads.  The workgroup size is a template parameter
+    // since round 5 -- the tree over the slots is the same aligned one for 8, 16 or 32 groups (B x groups >= slots),
+    // the whole GPU suite passes bit for bit with 256 threads for single frames -- because a workgroup of 1 024 threads
+    // x 112 registers needs a nearly empty CU, and beside a map roll on another stream it waited 0.9 - 4.7 ms for
+    // one.  What cured that was not a smaller solve (256 threads still waited 0.2 - 0.35 ms per launch and cost the
+    // stream 7 % by its four trips) but keeping two CUs of every shader engine free of the roll (capi.cpp,
+    // velo_map_roll_begin; profiles/r05/roll_begin_trace_*.txt).  VELO_SOLVE_THREADS pins another size (measurement).
+    const int threads = solve_threads_override() ? solve_threads_override() : 1024;
 #define VELO_LAUNCH_SOLVE(MX, TT)                                                                                      \
     hipLaunchKernelGGL((k_reduce_solve<MX, TT>), dim3(n_frames), dim3(TT), 0, s, partials, frame_block_start,          \
                        reinterpret_cast<const int4*>(layout), poses, stats, iter, acc_out, do_update, poses_prev,       \
