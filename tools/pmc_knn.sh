@@ -7,12 +7,14 @@ export TMPDIR=/tmp
 tag=$1; shift
 args=${@:---voxels 1.0 --hash-loads 0 --k-normals 32}
 i=0
+# (PASSES="1 2 4": only those passes -- each is ~100 s on the 100 M-point map)
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" \
             "SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_WAVES_EQ_64 SQ_LEVEL_WAVES" \
             "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum" \
             "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum WRITE_SIZE"; do
   i=$((i+1))
+  if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $i "; then continue; fi
   rocprofv3 --kernel-trace --kernel-include-regex "k_knn|k_normals" --pmc $pass --output-format csv -d gpurun_out/pmcknn_${tag}_$i -- python3 tools/knn_sweep.py $args > gpurun_out/pmcknn_${tag}_$i.log 2>&1
 done
 python3 - "$tag" <<'PY' > gpurun_out/pmc_knn_$tag.txt
