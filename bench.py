@@ -124,7 +124,7 @@ def parse():
     ap.add_argument("--stream-map-points", type=int, default=12_000_000,
                     help="points of the whole scene the rolling map is cut from")
     ap.add_argument("--stream-subdiv", type=int, default=0)
-    ap.add_argument("--stream-hash-load", type=int, default=0, help="stream map: 0 = dense fine table, else hash load (%)")
+    ap.add_argument("--stream-hash-load", type=int, default=0, help="stream map: 0 = dense fine table, else hash load (%%)")
     ap.add_argument("--roi-range", type=float, default=ROI_RANGE, help="rolling map: kept radius around the pose (m)")
     ap.add_argument("--evict-every", type=int, default=5)
     ap.add_argument("--append-threshold", type=int, default=512,
@@ -135,9 +135,12 @@ def parse():
     ap.add_argument("--no-decode-overlap", action="store_true",
                     help="stream: plan every frame's decode on the host when it is due instead of a frame ahead, "
                          "while the GPU registers the previous one")
-    ap.add_argument("--roll-lead", type=int, default=4,
+    ap.add_argument("--roll-lead", type=int, default=0,
                     help="stream: frames ahead a roll of the device map is begun (velo_map_roll_begin; published when "
-                         "the frame is due); 0 = beside the previous frame's registration only (velo_map_roll_overlapped)")
+                         "the frame is due); 0 = beside the previous frame's registration only (velo_map_roll_overlapped). "
+                         "Measured on one box (profiles/r05/roll_ahead_ab.txt, roll_lead_python_ab.txt): the C++ driver "
+                         "gains 3.8 %% at 4 (1 235 vs 1 190 frames/s, its default), this Python loop LOSES 8 %% (1 073 vs "
+                         "1 165) -- hence 0 here")
     ap.add_argument("--map-margin", type=int, default=16, help="stream: grid slack in x/y, voxels")
     ap.add_argument("--map-margin-z", type=int, default=2, help="stream: grid slack in z, voxels")
     ap.add_argument("--full-rebuild", action="store_true", help="stream: re-sort the whole map on every update (A/B)")
@@ -695,10 +698,17 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
         state["staged"] = (rng, n0, int(ex.size))
         state["begun"] += 1
 
+    prior_cache = {}
+
     def prior_of(f):
-        ok2, car2 = capi.interp_pose(d["poses"], d["n_poses"], int(times[int(idx[f].first_packet)]))
-        return synth.perturbed_guess(np.array([1, 0, 0, car2.T[0], 0, 1, 0, car2.T[1], 0, 0, 1, 0.0], np.float64),
-                                     dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))
+        """the prior of frame f (pose track + the bench's perturbation) -- a function of the drive alone: computed
+        once per distinct frame (the look-ahead asks for the next few frames' priors at every frame)"""
+        if f not in prior_cache:
+            ok2, car2 = capi.interp_pose(d["poses"], d["n_poses"], int(times[int(idx[f].first_packet)]))
+            Tn = synth.perturbed_guess(np.array([1, 0, 0, car2.T[0], 0, 1, 0, car2.T[1], 0, 0, 1, 0.0], np.float64),
+                                       dt=(0.15, -0.1, 0.03), drot_deg=(0.2, -0.1, 0.4))
+            prior_cache[f] = (Tn, tile_range(float(Tn[3]), float(Tn[7])))
+        return prior_cache[f]
 
     plan = ctx.decode_plan_create()
     planned = dict(f=None)
@@ -756,12 +766,12 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
                     for dd in range(1, args.roll_lead + 1):
                         if k + dd > k_last:     # (no frame of this run will need it)
                             break
-                        Tn = prior_of(frame_at(k + dd))
-                        if tile_range(float(Tn[3]), float(Tn[7])) != state["res"]:
+                        Tn, rect = prior_of(frame_at(k + dd))
+                        if rect != state["res"]:
                             roll_begin(float(Tn[3]), float(Tn[7]), timed)
                             break
             elif not args.no_roll_ahead:            # ... beside this registration only, for the next frame
-                Tn = prior_of(f_next)
+                Tn, _ = prior_of(f_next)
                 roll_ahead(float(Tn[3]), float(Tn[7]), timed)
         res = ctx.icp_batch_finish()[0]
         t.append(time.perf_counter())
