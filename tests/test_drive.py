@@ -266,8 +266,8 @@ def test_cpp_stream_driver_rolls_the_device_map_and_matches_python(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     py = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stream", "--drive", str(tmp_path),
-                         "--steps", "12", "--warmup", "1", "--append-threshold", "64"],
-                        capture_output=True, text=True, timeout=600, env=env)
+                         "--steps", "12", "--warmup", "1", "--append-threshold", "64", "--roll-lead", "4"],
+                        capture_output=True, text=True, timeout=600, env=env)   # (the C++ driver's default lead)
     assert py.returncode == 0, py.stderr[-2000:]
     rec = json.loads(py.stdout.strip().splitlines()[-1])
     assert rec["worst_pose_error_m"] < 0.02 and rec["map"]["full_builds"] == 0 and rec["map"]["rolls"] == cpp["map"]["rolls"]

@@ -1714,6 +1714,7 @@ def test_config2_size_10m_rolling_map_pipelined_replay(monkeypatch):
         d["tile_of"] = {k: list(v) for k, v in base["tile_of"].items()}   # (the replay files increments into its tiles)
         args.no_decode_overlap = mode == "plain"
         args.no_roll_ahead = mode != "pipelined"
+        args.roll_lead = 4      # the roll BEGUN AHEAD (velo_map_roll_begin / _publish); bench.py's own default is 0
         mirror = None
         if mode == "pipelined":
             mirror = capi.Context(0, max_batch=2, map_margin=args.map_margin, map_subdiv=args.stream_subdiv,
