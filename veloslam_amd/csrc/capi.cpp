@@ -421,8 +421,12 @@ int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, const uint32_t*
     HIP_TRY(c, reserve_slack(c->work, (size_t)mv.n));
     HIP_TRY(c, c->work_cnt.reserve(2));
     HIP_TRY(c, hipMemsetAsync(c->work_cnt.p, 0, 2 * sizeof(unsigned), s));
-    HIP_TRY(c, launch_select_dirty(c->keys_sorted.p, (uint32_t)mv.n, mv, c->dirty.p, c->work.p,
-                                   c->work_cnt.p, s));
+    // (the work list holds only the points a changed point can reach: the test is part of the selection -- the
+    //  normals kernel below is given no changed keys and re-estimates everything it is handed)
+    HIP_TRY(c, launch_select_dirty(c->keys_sorted.p, (uint32_t)mv.n, mv, c->dirty.p, c->nrm.p, chg_keys, n_chg,
+                                   c->work.p, c->work_cnt.p, s));
+    chg_keys = nullptr;
+    n_chg = 0;
     if (c->defer_counts) {
         // a roll begun ahead: the length of the work list stays on the device -- the launch covers its upper
         // bound (every point), the surplus workgroups leave at once -- and the count of normals re-estimated

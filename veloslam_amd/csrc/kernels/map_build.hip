@@ -733,10 +733,18 @@ __global__ __launch_bounds__(256) void k_mark_dirty(const uint32_t* __restrict__
     }
 }
 
-// work list of the sorted points that live in a dirty voxel (order irrelevant)
+// work list of the sorted points that live in a dirty voxel (order irrelevant) -- and, where the changed points are
+// given (chg: their sorted fine keys), only those of them a changed point can actually reach: a surviving normal
+// carries the squared reach of its neighbour list in w, and a point is listed only if a changed point's fine cell
+// intersects that ball (near_changed; new points, w < 0, always).  Round 5: the test used to sit at the top of
+// k_normals_subset, where one lane that passed it kept its 63 neighbours waiting through a whole k-NN + PCA -- after an
+// eviction 8 k of 100 k listed points pass, scattered over nearly every wavefront: 0.66 ms per call.  Filtered HERE,
+// the normals kernel gets a list of points that all have work to do.
 __global__ __launch_bounds__(256) void k_select_dirty(const uint32_t* __restrict__ keys,
-                                                      uint32_t n, int S, int fx, int fy, int nx,
-                                                      int ny, const uint8_t* __restrict__ dirty,
+                                                      uint32_t n, MapView mv,
+                                                      const uint8_t* __restrict__ dirty,
+                                                      const float4* __restrict__ nrm,
+                                                      const uint32_t* __restrict__ chg, uint32_t n_chg,
                                                       int32_t* __restrict__ work,
                                                       unsigned* __restrict__ count)
 {
@@ -744,10 +752,14 @@ __global__ __launch_bounds__(256) void k_select_dirty(const uint32_t* __restrict
     bool hit = false;
     if (i < n) {
         const uint32_t key = keys[i];
-        const int Fx = (int)(key % (uint32_t)fx);
-        const uint32_t t = key / (uint32_t)fx;
-        const int Fy = (int)(t % (uint32_t)fy), Fz = (int)(t / (uint32_t)fy);
-        hit = dirty[((size_t)(Fz / S) * ny + (Fy / S)) * nx + (Fx / S)] != 0;
+        const int Fx = (int)(key % (uint32_t)mv.fx);
+        const uint32_t t = key / (uint32_t)mv.fx;
+        const int Fy = (int)(t % (uint32_t)mv.fy), Fz = (int)(t / (uint32_t)mv.fy);
+        hit = dirty[((size_t)(Fz / mv.S) * mv.ny + (Fy / mv.S)) * mv.nx + (Fx / mv.S)] != 0;
+        if (hit && chg) {
+            const float w = nrm[i].w;
+            if (w >= 0.0f && !near_changed(mv, mv.pts[i], w, chg, n_chg)) hit = false;
+        }
     }
     const unsigned long long mask = __ballot(hit);
     if (mask == 0ull) return;
@@ -969,14 +981,13 @@ hipError_t launch_mark_dirty(const uint32_t* keys, uint32_t m, const uint32_t* s
     return hipGetLastError();
 }
 
-hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& g,
-                               const uint8_t* dirty, int32_t* work, unsigned* count, hipStream_t s)
+hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& g, const uint8_t* dirty,
+                               const float4* nrm, const uint32_t* chg_keys, uint32_t n_chg, int32_t* work,
+                               unsigned* count, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned), s);
-    if (e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_select_dirty, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, g.S, g.fx,
-                       g.fy, g.nx, g.ny, dirty, work, count);
+    hipLaunchKernelGGL(k_select_dirty, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, g, dirty, nrm, chg_keys, n_chg,
+                       work, count);
     return hipGetLastError();
 }
 

@@ -121,8 +121,10 @@ hipError_t launch_table_shift(const int32_t* src, int32_t* dst, size_t n_entries
                               hipStream_t s);
 hipError_t launch_mark_dirty(const uint32_t* keys, uint32_t m, const uint32_t* sel,
                              const MapView& grid, uint8_t* dirty, hipStream_t s);
-hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& grid,
-                               const uint8_t* dirty, int32_t* work, unsigned* count, hipStream_t s);
+hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& grid, const uint8_t* dirty,
+                               const float4* nrm, const uint32_t* chg_keys, uint32_t n_chg, int32_t* work,
+                               unsigned* count, hipStream_t s);
+// (grid = the map AFTER the update: its pts / nrm are read for the reach test when chg_keys != nullptr)
 hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
                                  const int32_t* work, int n_work, const uint32_t* chg_keys,
                                  uint32_t n_chg, float4* nrm, unsigned long long* d_invalid,
