@@ -552,6 +552,19 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
             return (np.empty(0, np.float32),) * 3
         return np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)
 
+    def holds(rng, outside):
+        """does a tile of rectangle rng that lies outside rectangle `outside` hold points?  (MapManager::
+        leavingTilesHoldPoints / enteringTilesHoldPoints: the device map holds what the host tiles of its rectangle
+        hold, so empty leaving tiles need no eviction pass and empty entering tiles no append)"""
+        for j in range(rng[2], rng[3] + 1):
+            for i in range(rng[0], rng[1] + 1):
+                if outside[0] <= i <= outside[1] and outside[2] <= j <= outside[3]:
+                    continue
+                t = tile_of.get((i, j))
+                if t is not None and t[0].size:
+                    return True
+        return False
+
     def take():
         """the pending increments off the device (list emptied) into the host tiles; -> (x, y, z, ti, tj)"""
         n = ctx.pending_count(True)
@@ -604,13 +617,16 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
                 return
         # increments accepted so far: to the host tiles now, and -- those in tiles that stay resident --
         # back up with the entering tiles in the roll's ONE append (MapManager::rollTo)
-        px, py, pz, pti, ptj = take() if cur is not None else ((np.empty(0, np.float32),) * 3 + (np.empty(0, np.int64),) * 2)
-        if cur is not None and rng[0] <= cur[1] and rng[1] >= cur[0] and rng[2] <= cur[3] and rng[3] >= cur[2]:
+        # (a roll that only evicts leaves the list pending, MapManager::rollTo)
+        lap = cur is not None and rng[0] <= cur[1] and rng[1] >= cur[0] and rng[2] <= cur[3] and rng[3] >= cur[2]
+        px, py, pz, pti, ptj = (take() if cur is not None and (not lap or holds(rng, cur))
+                                else ((np.empty(0, np.float32),) * 3 + (np.empty(0, np.int64),) * 2))
+        if lap:
             n0 = ctx.map_info().n_points
             lo = np.array([rng[0] * pr - pr / 2, rng[2] * pr - pr / 2, -big], np.float32)
             hi = np.array([np.nextafter(np.float32(rng[1] * pr + pr / 2), np.float32(-big)),
                            np.nextafter(np.float32(rng[3] * pr + pr / 2), np.float32(-big)), big], np.float32)
-            if rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]:
+            if (rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]) and holds(cur, rng):
                 ctx.map_evict_outside(lo, hi)
                 if mirror:
                     mirror.map_evict_outside(lo, hi)
@@ -646,7 +662,7 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
         if not (rng[0] <= cur[1] and rng[1] >= cur[0] and rng[2] <= cur[3] and rng[3] >= cur[2]):
             return
         ex, ey, ez = gather(rng, skip=cur)
-        evicts = rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]
+        evicts = (rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]) and holds(cur, rng)
         lo = np.array([rng[0] * pr - pr / 2, rng[2] * pr - pr / 2, -big], np.float32)
         hi = np.array([np.nextafter(np.float32(rng[1] * pr + pr / 2), np.float32(-big)),
                        np.nextafter(np.float32(rng[3] * pr + pr / 2), np.float32(-big)), big], np.float32)
@@ -678,7 +694,7 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
         if not (rng[0] <= cur[1] and rng[1] >= cur[0] and rng[2] <= cur[3] and rng[3] >= cur[2]):
             return
         ex, ey, ez = gather(rng, skip=cur)
-        evicts = rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]
+        evicts = (rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]) and holds(cur, rng)
         lo = np.array([rng[0] * pr - pr / 2, rng[2] * pr - pr / 2, -big], np.float32)
         hi = np.array([np.nextafter(np.float32(rng[1] * pr + pr / 2), np.float32(-big)),
                        np.nextafter(np.float32(rng[3] * pr + pr / 2), np.float32(-big)), big], np.float32)

@@ -46,12 +46,14 @@ int main(int argc, char** argv)
     const std::string dir = argv[1];
     int steps = 100, warmup = 10, threshold = 512, roll_lead = 4;
     bool integrate = true, overlap = true, roll_ahead = true;
+    std::string per_frame;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
         else if (a == "--warmup" && i + 1 < argc) warmup = std::atoi(argv[++i]);
         else if (a == "--threshold" && i + 1 < argc) threshold = std::atoi(argv[++i]);
         else if (a == "--roll-lead" && i + 1 < argc) roll_lead = std::atoi(argv[++i]);  // frames a roll is begun ahead (0: beside the previous frame only)
+        else if (a == "--per-frame" && i + 1 < argc) per_frame = argv[++i];  // per-frame wall time + what the map did, one line each
         else if (a == "--no-integrate") integrate = false;
         else if (a == "--no-overlap") overlap = false;
         else if (a == "--no-roll-ahead") roll_ahead = false;  // roll the map when the frame is due, not beside the previous registration  // decode every frame when it is due, not during the previous registration
@@ -174,12 +176,34 @@ int main(int argc, char** argv)
     velo_synchronize(ctx);
     const MapStats s0 = mgr.stats();
     const auto t0 = clk::now();
+    std::FILE* pf = per_frame.empty() ? nullptr : std::fopen(per_frame.c_str(), "w");
+    MapStats sp = s0;
     for (int k = 0; k < steps; ++k) {
         k_now = warmup + k;
+        const auto tk = clk::now();
         if (!one(frame_at(warmup + k), k + 1 < steps ? frame_at(warmup + k + 1) : -1, true)) return 5;
+        if (pf) {
+            const MapStats sn = mgr.stats();
+            velo_map_info m2;
+            m2.struct_size = sizeof m2;
+            velo_map_info_get(ctx, &m2);
+            std::fprintf(pf, "%d frame %d ms %.4f rolls %llu ahead %llu begun %llu refused %llu full %llu flush %llu up %llu ev %llu last_update %d dims %d %d %d n %llu\n",
+                         k, frame_at(warmup + k), ms_since(tk), (unsigned long long)(sn.rolls - sp.rolls),
+                         (unsigned long long)(sn.rolls_ahead - sp.rolls_ahead), (unsigned long long)(sn.rolls_begun - sp.rolls_begun),
+                         (unsigned long long)(sn.rolls_refused - sp.rolls_refused), (unsigned long long)(sn.full_builds - sp.full_builds),
+                         (unsigned long long)(sn.increment_flushes - sp.increment_flushes),
+                         (unsigned long long)(sn.points_uploaded - sp.points_uploaded), (unsigned long long)(sn.points_evicted - sp.points_evicted),
+                         m2.last_update, m2.dims[0], m2.dims[1], m2.dims[2], (unsigned long long)m2.n_points);
+            sp = sn;
+        }
     }
+    if (pf) std::fclose(pf);
+    const bool dbg_end = std::getenv("VELO_TRACE_END") != nullptr;
+    if (dbg_end) std::fprintf(stderr, "loop done\n");
     mgr.flushIncrements();
+    if (dbg_end) std::fprintf(stderr, "flushed\n");
     velo_synchronize(ctx);
+    if (dbg_end) std::fprintf(stderr, "synchronized\n");
     const double total_ms = ms_since(t0);
     const MapStats s1 = mgr.stats();
     velo_map_info mi;

@@ -18,7 +18,10 @@ lat = [i for i, n in enumerate(names) if "k_linearize_lat" in n]
 starts = [i for i, n in enumerate(names) if "k_decode_keys" in n]
 print("frames seen:", len(starts))
 roll = [i for i, n in enumerate(names) if "k_compact_sorted" in n]
-if len(sys.argv) > 2 and sys.argv[2] == "roll" and roll:
+pick = {"append": "k_merge_old", "reanchor": "k_cell_start", "gather": "k_gather"}.get(sys.argv[2] if len(sys.argv) > 2 else "", None)
+if pick:
+    roll = [i for i, n in enumerate(names) if pick in n]
+if len(sys.argv) > 2 and sys.argv[2] in ("roll", "append", "reanchor", "gather") and roll:
     k = max(j for j, st in enumerate(starts) if st < roll[-1])
     starts_w = (starts[k], starts[k + 1] if k + 1 < len(starts) else len(ev) - 1)
 else:

@@ -143,6 +143,7 @@ struct velo_ctx {
     // second copies of what a registration reads and a rolling update would rewrite in place: with
     // them an update writes the copy the running registration does not read (overlap_update)
     DevBuf<int32_t> cell_start_alt;
+    DevBuf<uint32_t> tile_bounds;   // per 1 024-entry tile of the table: launch_table_shift / _remap
     DevBuf<uint8_t> vox_near_alt;
     bool overlap_update = false;        // inside velo_map_roll_overlapped
     DevBuf<int32_t> knn_idx, knn_cnt;   // velo_knn: device-side results before the copy back
@@ -846,11 +847,13 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
         HIP_TRY(c, launch_cell_start(c->keys_alt.p, total, ncell, c->cell_start.p, s));
     } else if (c->overlap_update && c->overlap_done == 0) {  // the running registration reads cell_start: write the other copy
         HIP_TRY(c, reserve_slack(c->cell_start_alt, ncell + 8));
-        HIP_TRY(c, launch_table_shift(c->cell_start.p, c->cell_start_alt.p, ncell + 1, c->nk_sorted.p, (uint32_t)m, s));
+        HIP_TRY(c, reserve_slack(c->tile_bounds, table_tile_bounds(ncell + 1)));
+        HIP_TRY(c, launch_table_shift(c->cell_start.p, c->cell_start_alt.p, ncell + 1, c->nk_sorted.p, (uint32_t)m, c->tile_bounds.p, s));
         std::swap(c->cell_start.p, c->cell_start_alt.p);
         std::swap(c->cell_start.cap, c->cell_start_alt.cap);
     } else {
-        HIP_TRY(c, launch_table_shift(c->cell_start.p, c->cell_start.p, ncell + 1, c->nk_sorted.p, (uint32_t)m, s));
+        HIP_TRY(c, reserve_slack(c->tile_bounds, table_tile_bounds(ncell + 1)));
+        HIP_TRY(c, launch_table_shift(c->cell_start.p, c->cell_start.p, ncell + 1, c->nk_sorted.p, (uint32_t)m, c->tile_bounds.p, s));
     }
     std::swap(c->pts.p, c->pts_alt.p);
     std::swap(c->pts.cap, c->pts_alt.cap);
@@ -2037,11 +2040,13 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
         if (int rc = build_table(c, g, c->keys_alt.p, kept, ncell)) return rc;
     } else if (c->overlap_update && c->overlap_done == 0) {
         HIP_TRY(c, reserve_slack(c->cell_start_alt, ncell + 8));
-        HIP_TRY(c, launch_table_remap(c->cell_start.p, c->cell_start_alt.p, ncell + 1, c->offs.p, n, kept, s));
+        HIP_TRY(c, reserve_slack(c->tile_bounds, table_tile_bounds(ncell + 1)));
+        HIP_TRY(c, launch_table_remap(c->cell_start.p, c->cell_start_alt.p, ncell + 1, c->offs.p, n, kept, c->tile_bounds.p, s));
         std::swap(c->cell_start.p, c->cell_start_alt.p);
         std::swap(c->cell_start.cap, c->cell_start_alt.cap);
     } else {
-        HIP_TRY(c, launch_table_remap(c->cell_start.p, c->cell_start.p, ncell + 1, c->offs.p, n, kept, s));
+        HIP_TRY(c, reserve_slack(c->tile_bounds, table_tile_bounds(ncell + 1)));
+        HIP_TRY(c, launch_table_remap(c->cell_start.p, c->cell_start.p, ncell + 1, c->offs.p, n, kept, c->tile_bounds.p, s));
     }
     swap_raw();
     c->raw_n = kept;

@@ -4,6 +4,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include "../../../include/veloslam/MapManager.hpp"
@@ -434,6 +437,28 @@ bool MapManager::load(const std::string& filename)
 // and the C ABI's box eviction applies it exactly; entering tiles go up in ONE append (row-major
 // tile order, each tile's points in their stored order): the device map then equals a fresh build of
 // [survivors in their old order, entering points] on the kept grid, by velo_map_append's definition.
+bool MapManager::leavingTilesHoldPoints(int i0, int i1, int j0, int j1) const
+{
+    for (int j = res_j0_; j <= res_j1_; ++j)
+        for (int i = res_i0_; i <= res_i1_; ++i) {
+            if (i >= i0 && i <= i1 && j >= j0 && j <= j1) continue;
+            const auto it = patches_.find({i, j});
+            if (it != patches_.end() && it->second->size() != 0) return true;
+        }
+    return false;
+}
+
+bool MapManager::enteringTilesHoldPoints(int i0, int i1, int j0, int j1) const
+{
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            if (i >= res_i0_ && i <= res_i1_ && j >= res_j0_ && j <= res_j1_) continue;
+            const auto it = patches_.find({i, j});
+            if (it != patches_.end() && it->second->size() != 0) return true;
+        }
+    return false;
+}
+
 bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
 {
     if (!ctx_) return false;
@@ -468,8 +493,16 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
     // increments accepted so far go to the host tiles now; what of them lies in tiles that stay
     // resident goes back up with the entering tiles, in the roll's ONE append (a flush of its own
     // would be a second pass over the whole sorted map for a few dozen points)
+    static const bool trace_host = std::getenv("VELO_TRACE_REGISTER") != nullptr;
+    using tclk = std::chrono::steady_clock;
+    const auto tt0 = tclk::now();
+    auto us_since = [&](tclk::time_point a) { return std::chrono::duration<double, std::micro>(tclk::now() - a).count(); };
+    // (a roll that only evicts leaves the list pending: folding a dozen points into the map is a pass over all of
+    //  it -- 0.85 ms on the stream's 11 M points -- that the next flush or the next entering column does anyway)
     pend_x_.clear(), pend_y_.clear(), pend_z_.clear();
-    if (haveDevice_ && !takeIncrements()) return false;
+    const bool enters = !overlap || enteringTilesHoldPoints(i0, i1, j0, j1);
+    if (haveDevice_ && enters && !takeIncrements()) return false;
+    const double t_take = us_since(tt0);
     if (overlap) {
         velo_map_info mi;
         mi.struct_size = sizeof mi;
@@ -483,7 +516,7 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
         const float hi[3] = {std::nextafter((float)(i1 * (double)patchRange_ + patchRange_ / 2.0), -big),
                              std::nextafter((float)(j1 * (double)patchRange_ + patchRange_ / 2.0), -big), big};
         bool kept_something = true;
-        if (i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_) {
+        if ((i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_) && leavingTilesHoldPoints(i0, i1, j0, j1)) {
             const int rc = velo_map_evict_outside(ctx_, lo, hi);
             if (rc == VELO_E_INVALID) {
                 kept_something = false;  // nothing of the device map lies in the new rectangle: rebuild
@@ -493,10 +526,12 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
             }
         }
         if (kept_something) {
+            const double t_evict = us_since(tt0);
             velo_map_info_get(ctx_, &mi);
             stats_.points_evicted += n_before - mi.n_points;
             size_t tiles = 0;
             gather(i0, i1, j0, j1, true, &tiles);
+            const double t_gather = us_since(tt0);
             const size_t n_tile_points = stage_x_.size();
             for (size_t k = 0; k < pend_x_.size(); ++k) {
                 // (entering tiles already hold their share: takeIncrements put it into the host tiles)
@@ -511,6 +546,9 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
                 err_ = velo_last_error(ctx_);
                 return false;
             }
+            if (trace_host)
+                std::fprintf(stderr, "rollTo: take %.0f us, evict %.0f, gather %.0f (%zu points), append %.0f\n", t_take, t_evict - t_take,
+                             t_gather - t_evict, stage_x_.size(), us_since(tt0) - t_gather);
             stats_.points_uploaded += n_tile_points;
             stats_.tiles_entered += tiles;
             stats_.tiles_left += (uint64_t)std::max(0, (res_i1_ - res_i0_ + 1) * (res_j1_ - res_j0_ + 1) -
@@ -566,7 +604,7 @@ bool MapManager::rollAhead(double x, double y, const RegisterOptions& o)
             stage_z_.insert(stage_z_.end(), p.z.begin(), p.z.end());
             ++tiles;
         }
-    const bool evicts = i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_;
+    const bool evicts = (i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_) && leavingTilesHoldPoints(i0, i1, j0, j1);
     const float big = 3.0e38f;
     const float lo[3] = {(float)(i0 * (double)patchRange_ - patchRange_ / 2.0),
                          (float)(j0 * (double)patchRange_ - patchRange_ / 2.0), -big};
@@ -632,7 +670,7 @@ bool MapManager::rollBegin(double x, double y, const RegisterOptions& o)
             stage_z_.insert(stage_z_.end(), p.z.begin(), p.z.end());
             ++tiles;
         }
-    const bool evicts = i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_;
+    const bool evicts = (i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_) && leavingTilesHoldPoints(i0, i1, j0, j1);
     const float big = 3.0e38f;
     const float lo[3] = {(float)(i0 * (double)patchRange_ - patchRange_ / 2.0),
                          (float)(j0 * (double)patchRange_ - patchRange_ / 2.0), -big};
@@ -732,7 +770,12 @@ bool MapManager::flushIncrements()
 bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform& init, const RegisterOptions& o,
                               PoseTransform* out, velo_icp_result* result)
 {
+    static const bool trace_host = std::getenv("VELO_TRACE_REGISTER") != nullptr;   // (debugging aid: where a frame's host time goes)
+    using tclk = std::chrono::steady_clock;
+    const auto tt0 = tclk::now();
+    auto us_since = [&](tclk::time_point a) { return std::chrono::duration<double, std::micro>(tclk::now() - a).count(); };
     if (!rollTo(init.T[0], init.T[1], o)) return false;
+    const double t_roll = us_since(tt0);
     const Affine3x4 T0 = init.getMatrix();
     // one registration of the resident frames; the other frames of a multi-frame decode keep the
     // prior they are given here only if they are registered by their own call
@@ -758,11 +801,16 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
     // the GPU is busy for ~0.5 ms: the caller's work goes here -- host work, or the NEXT frame's decode
     // on this very context (HDLManager::prepareResident: it queues behind the registration, and the
     // result below belongs to the frames that were resident when it started)
+    const double t_start = us_since(tt0);
     if (o.while_registering) o.while_registering();
+    const double t_while = us_since(tt0);
     if (velo_icp_batch_finish(ctx_, local)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
+    if (trace_host && us_since(tt0) > 900.0)
+        std::fprintf(stderr, "registerCore: rollTo %.0f us, start+increment %.0f, while_registering %.0f, finish %.0f\n", t_roll,
+                     t_start - t_roll, t_while - t_start, us_since(tt0) - t_while);
     const velo_icp_result& r = local[frame];
     if (result) *result = r;
     Affine3x4 M;

@@ -138,20 +138,63 @@ hipError_t launch_gather(const float* x, const float* y, const float* z, const u
 
 // -------------------------------------------------------------- cell table
 // cell_start[c] = number of sorted keys < c  (lower bound), c in [0, ncell]
+// One workgroup per tile of kCsTile consecutive entries: the first key at or beyond both ends of the tile is found
+// by a 256-ary search the whole workgroup takes part in (three rounds over 16 M keys), the tile's keys -- a few
+// hundred -- are staged in LDS, and every entry is a short binary search there.  (The per-entry binary search over
+// the whole key array this replaces ran 23 dependent global loads per entry: 1.5 ms on the stream's 78 M-entry
+// table, 0.2 TB/s; a re-anchoring roll pays it.)
+constexpr int kCsTile = 4096;
+constexpr int kCsCap = 4096;
+// number of keys < c, every thread of the 256-thread workgroup calling with the same c
+__device__ __forceinline__ size_t lower_bound_wg(const uint32_t* __restrict__ keys, size_t n, size_t c)
+{
+    size_t lo = 0, hi = n;  // the answer lies in [lo, hi]: keys[i] < c below lo, >= c from hi on
+    while (hi > lo) {
+        const size_t step = (hi - lo + 255) / 256;
+        const size_t idx = lo + (size_t)threadIdx.x * step;
+        const int below = __syncthreads_count(idx < hi && (size_t)keys[idx] < c);  // the probes are monotone
+        if (below == 0) {
+            hi = lo;
+        } else {
+            const size_t top = lo + (size_t)below * step;
+            lo = lo + (size_t)(below - 1) * step + 1;
+            hi = top < hi ? top : hi;
+        }
+    }
+    return lo;
+}
 __global__ __launch_bounds__(256) void k_cell_start(const uint32_t* __restrict__ keys, size_t n,
                                                     size_t ncell, int32_t* __restrict__ cell_start)
 {
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c <= ncell;
-         c += (size_t)gridDim.x * blockDim.x) {
-        size_t lo = 0, hi = n;
-        while (lo < hi) {
-            const size_t mid = (lo + hi) >> 1;
-            if ((size_t)keys[mid] < c)
-                lo = mid + 1;
-            else
-                hi = mid;
+    __shared__ uint32_t s_keys[kCsCap];
+    const size_t n_entries = ncell + 1;
+    const size_t ntile = (n_entries + kCsTile - 1) / kCsTile;
+    for (size_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const size_t c0 = tile * kCsTile;
+        const size_t c1 = c0 + kCsTile < n_entries ? c0 + kCsTile : n_entries;
+        const size_t a = lower_bound_wg(keys, n, c0);
+        const size_t b = lower_bound_wg(keys, n, c1);  // keys [a, b) are the tile's
+        const size_t cnt = b - a;
+        const bool staged = cnt <= (size_t)kCsCap;
+        if (staged)
+            for (size_t i = threadIdx.x; i < cnt; i += 256) s_keys[i] = keys[a + i];
+        __syncthreads();
+        for (size_t c = c0 + threadIdx.x; c < c1; c += 256) {
+            size_t lo = 0, hi = cnt;
+            if (staged) {
+                while (lo < hi) {
+                    const size_t mid = (lo + hi) >> 1;
+                    if ((size_t)s_keys[mid] < c) lo = mid + 1; else hi = mid;
+                }
+            } else {
+                while (lo < hi) {
+                    const size_t mid = (lo + hi) >> 1;
+                    if ((size_t)keys[a + mid] < c) lo = mid + 1; else hi = mid;
+                }
+            }
+            cell_start[c] = (int32_t)(a + lo);
         }
-        cell_start[c] = (int32_t)lo;
+        __syncthreads();  // (the next tile's keys overwrite the stage)
     }
 }
 
@@ -211,8 +254,8 @@ hipError_t launch_hash_build(const uint32_t* sorted_keys, size_t n, int4* hash, 
 hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell,
                              int32_t* cell_start, hipStream_t s)
 {
-    size_t g = (ncell + 1 + 255) / 256;
-    int grid = (int)(g > 8192 ? 8192 : g);
+    size_t g = (ncell + 1 + kCsTile - 1) / kCsTile;
+    int grid = (int)(g > 16384 ? 16384 : g);
     hipLaunchKernelGGL(k_cell_start, dim3(grid), dim3(256), 0, s, sorted_keys, n, ncell,
                        cell_start);
     return hipGetLastError();
@@ -652,20 +695,28 @@ __global__ __launch_bounds__(256) void k_merge_new(
 constexpr int kTableTile = 1024;  // entries per workgroup step: 256 threads x 4
 // (src == dst: in place; src != dst: the shifted table is written to dst and src stays as it was --
 // a registration still running on the other stream keeps reading src)
+// (round 5: the two searches per tile -- 20 dependent loads in front of 8 KB of streaming, 362 us on the 78 M-entry
+//  table where the bytes take 150 -- are made for all tiles at once by k_tile_bounds, one thread per tile boundary;
+//  a tile then starts with one 8-byte load.  tb[t] = number of new keys below entry t * kTableTile.)
+__global__ __launch_bounds__(256) void k_tile_bounds(const uint32_t* __restrict__ nk, uint32_t m, size_t n_entries,
+                                                     uint32_t* __restrict__ tb, size_t n_bounds)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_bounds) return;
+    const size_t c = min(t * (size_t)kTableTile, n_entries);
+    tb[t] = lower_bound_u32(nk, m, (uint32_t)min(c, (size_t)0xffffffffu));
+}
 __global__ __launch_bounds__(256) void k_table_shift(const int32_t* src, int32_t* dst,
                                                      size_t n_entries,
-                                                     const uint32_t* __restrict__ nk, uint32_t m)
+                                                     const uint32_t* __restrict__ nk, uint32_t m,
+                                                     const uint32_t* __restrict__ tb)
 {
     const bool oop = src != dst;
-    __shared__ uint32_t s_j[2];
     const size_t n_tiles = (n_entries + kTableTile - 1) / kTableTile;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t t0 = tile * kTableTile, t1 = min(t0 + (size_t)kTableTile, n_entries);
-        if (threadIdx.x < 2)
-            s_j[threadIdx.x] = lower_bound_u32(nk, m, (uint32_t)(threadIdx.x ? t1 - 1 : t0));
-        __syncthreads();
-        const uint32_t jlo = s_j[0], jhi = s_j[1];
-        __syncthreads();
+        // new keys below the tile's first entry / below the NEXT tile's first entry (an upper limit for this tile's)
+        const uint32_t jlo = tb[tile], jhi = tb[tile + 1];
         const size_t c0 = t0 + (size_t)threadIdx.x * 4;
         if (c0 >= t1) continue;
         if (jhi == 0) {  // every entry of the tile lies at or below the first new key: unchanged
@@ -888,23 +939,28 @@ __global__ __launch_bounds__(256) void k_compact_raw(const float* __restrict__ x
 // removes points in a few per cent of the table's key range; everywhere else "removed before this
 // position" is one number for a whole 1 024-entry tile (positions ascend with c), so the tile
 // streams (v - removed) instead of gathering offs[v] per entry.
+// (tr[t] = points removed before the position entry t * kTableTile holds, made for all tiles at once by
+//  k_tile_removed: as k_tile_bounds)
+__global__ __launch_bounds__(256) void k_tile_removed(const int32_t* __restrict__ src, size_t n_entries,
+                                                      const uint32_t* __restrict__ offs, uint32_t n, uint32_t kept,
+                                                      uint32_t* __restrict__ tr, size_t n_bounds)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_bounds) return;
+    const uint32_t v = (uint32_t)src[min(t * (size_t)kTableTile, n_entries - 1)];
+    tr[t] = v < n ? v - offs[v] : n - kept;  // points removed before position v
+}
 __global__ __launch_bounds__(256) void k_table_remap(const int32_t* src, int32_t* dst,
                                                      size_t n_entries,
                                                      const uint32_t* __restrict__ offs, uint32_t n,
-                                                     uint32_t kept)
+                                                     uint32_t kept, const uint32_t* __restrict__ tr)
 {
     const bool oop = src != dst;  // (as k_table_shift)
-    __shared__ uint32_t s_r[2];
     const size_t n_tiles = (n_entries + kTableTile - 1) / kTableTile;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const size_t t0 = tile * kTableTile, t1 = min(t0 + (size_t)kTableTile, n_entries);
-        if (threadIdx.x < 2) {
-            const uint32_t v = (uint32_t)src[threadIdx.x ? t1 - 1 : t0];
-            s_r[threadIdx.x] = v < n ? v - offs[v] : n - kept;  // points removed before position v
-        }
-        __syncthreads();
-        const uint32_t r0 = s_r[0], r1 = s_r[1];
-        __syncthreads();
+        // removed before the tile's first entry / before the next tile's first (positions ascend: the tile's lie between)
+        const uint32_t r0 = tr[tile], r1 = tr[tile + 1];
         const size_t c0 = t0 + (size_t)threadIdx.x * 4;
         if (c0 >= t1) continue;
         if (r0 == r1) {
@@ -964,11 +1020,15 @@ hipError_t launch_merge(const float4* pts, const float4* nrm, const uint32_t* pe
     return hipGetLastError();
 }
 
+size_t table_tile_bounds(size_t n_entries) { return (n_entries + kTableTile - 1) / kTableTile + 1; }
+
 hipError_t launch_table_shift(const int32_t* src, int32_t* dst, size_t n_entries, const uint32_t* nk, uint32_t m,
-                              hipStream_t s)
+                              uint32_t* tile_scratch, hipStream_t s)
 {
+    const size_t nb = table_tile_bounds(n_entries);
+    hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, nk, m, n_entries, tile_scratch, nb);
     hipLaunchKernelGGL(k_table_shift, dim3(grid_for((n_entries + kTableTile - 1) / kTableTile, 1, 16384)), dim3(256), 0,
-                       s, src, dst, n_entries, nk, m);
+                       s, src, dst, n_entries, nk, m, tile_scratch);
     return hipGetLastError();
 }
 
@@ -1079,10 +1139,13 @@ hipError_t launch_compact_raw(const float* x, const float* y, const float* z, ui
 }
 
 hipError_t launch_table_remap(const int32_t* src, int32_t* dst, size_t n_entries, const uint32_t* offs, uint32_t n,
-                              uint32_t kept, hipStream_t s)
+                              uint32_t kept, uint32_t* tile_scratch, hipStream_t s)
 {
+    const size_t nb = table_tile_bounds(n_entries);
+    hipLaunchKernelGGL(k_tile_removed, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, src, n_entries, offs, n, kept,
+                       tile_scratch, nb);
     hipLaunchKernelGGL(k_table_remap, dim3(grid_for((n_entries + kTableTile - 1) / kTableTile, 1, 16384)), dim3(256), 0, s,
-                       src, dst, n_entries, offs, n, kept);
+                       src, dst, n_entries, offs, n, kept, tile_scratch);
     return hipGetLastError();
 }
 

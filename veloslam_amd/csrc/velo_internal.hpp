@@ -117,8 +117,10 @@ hipError_t launch_merge(const float4* pts, const float4* nrm, const uint32_t* pe
                         const float* rz, uint32_t raw_base, const uint32_t* nk,
                         const uint32_t* nidx, uint32_t m, float4* pts2, float4* nrm2,
                         uint32_t* perm2, uint32_t* keys2, hipStream_t s);
+// (tile_scratch: table_tile_bounds(n_entries) words, filled by the call)
+size_t table_tile_bounds(size_t n_entries);
 hipError_t launch_table_shift(const int32_t* src, int32_t* dst, size_t n_entries, const uint32_t* nk, uint32_t m,
-                              hipStream_t s);
+                              uint32_t* tile_scratch, hipStream_t s);
 hipError_t launch_mark_dirty(const uint32_t* keys, uint32_t m, const uint32_t* sel,
                              const MapView& grid, uint8_t* dirty, hipStream_t s);
 hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& grid, const uint8_t* dirty,
@@ -152,7 +154,7 @@ hipError_t launch_compact_raw(const float* x, const float* y, const float* z, ui
                               const uint32_t* flags, const uint32_t* offs, float* x2, float* y2,
                               float* z2, hipStream_t s);
 hipError_t launch_table_remap(const int32_t* src, int32_t* dst, size_t n_entries, const uint32_t* offs, uint32_t n,
-                              uint32_t kept, hipStream_t s);
+                              uint32_t kept, uint32_t* tile_scratch, hipStream_t s);
 
 hipError_t launch_scatter_nrm_raw(const float4* nrm, const uint32_t* perm, uint32_t n,
                                   const uint32_t* keep, const uint32_t* raw_offs, float4* nrm_raw,
