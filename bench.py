@@ -124,6 +124,9 @@ def parse():
     ap.add_argument("--stream-map-points", type=int, default=12_000_000,
                     help="points of the whole scene the rolling map is cut from")
     ap.add_argument("--stream-subdiv", type=int, default=0)
+    ap.add_argument("--stream-in-process", action="store_true",
+                    help="stream sub-record: replay the in-memory drive inside this process (the form until round 5) instead "
+                         "of exporting it and replaying it from the C++ host and the Python loop in processes of their own")
     ap.add_argument("--stream-hash-load", type=int, default=0, help="stream map: 0 = dense fine table, else hash load (%%)")
     ap.add_argument("--roi-range", type=float, default=ROI_RANGE, help="rolling map: kept radius around the pose (m)")
     ap.add_argument("--evict-every", type=int, default=5)
@@ -135,12 +138,11 @@ def parse():
     ap.add_argument("--no-decode-overlap", action="store_true",
                     help="stream: plan every frame's decode on the host when it is due instead of a frame ahead, "
                          "while the GPU registers the previous one")
-    ap.add_argument("--roll-lead", type=int, default=0,
+    ap.add_argument("--roll-lead", type=int, default=4,
                     help="stream: frames ahead a roll of the device map is begun (velo_map_roll_begin; published when "
                          "the frame is due); 0 = beside the previous frame's registration only (velo_map_roll_overlapped). "
-                         "Measured on one box (profiles/r05/roll_ahead_ab.txt, roll_lead_python_ab.txt): the C++ driver "
-                         "gains 3.8 %% at 4 (1 235 vs 1 190 frames/s, its default), this Python loop LOSES 8 %% (1 073 vs "
-                         "1 165) -- hence 0 here")
+                         "Measured after the roll itself got cheaper (profiles/r05/roll_lead_ab_final.txt): the C++ driver "
+                         "1 255 frames/s at 0, 1 385 at 4 and 6; this Python loop 1 100 - 1 220 at 0, 1 290 - 1 345 at 4")
     ap.add_argument("--map-margin", type=int, default=16, help="stream: grid slack in x/y, voxels")
     ap.add_argument("--map-margin-z", type=int, default=2, help="stream: grid slack in z, voxels")
     ap.add_argument("--full-rebuild", action="store_true", help="stream: re-sort the whole map on every update (A/B)")
@@ -494,6 +496,91 @@ def synthetic_drive(args, dev, src):
                 patch_range=pr, tile_of=tile_of, n_tiles=len(tile_of))
 
 
+def stream_roofline(fps):
+    """BASELINE configs[2] "sustained frames/s + rocprof HBM GB/s": the fabric-side bytes every kernel of a frame moves
+    (PMC, per dispatch, summed: profiles/collect.sh on the C++ replay of the same drive) x the frames per second of
+    THIS run = the sustained rate; beside it the rate while a kernel runs"""
+    tr = traffic_for("stream")
+    if not tr:
+        return None
+    return {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "traffic_bytes_per_frame": tr["hbm_bytes_per_frame"],
+            "sustained_GBps": tr["hbm_bytes_per_frame"] * fps / 1e9,
+            "sustained_frac": tr["hbm_bytes_per_frame"] * fps / 1e9 / HBM_PEAK_GBPS,
+            "kernel_us_per_frame": tr["kernel_us_per_frame"],
+            "GBps_while_a_kernel_runs": tr["GBps_while_a_kernel_runs"],
+            "by_family": tr["by_family"], "traffic_source": tr["source"], "traffic_stale": tr["stale"],
+            "note": "a frame of the stream is ~60 small launches on a chip it cannot fill (one frame = 450 "
+                    "workgroups on 256 CUs): bound by launch and memory LATENCY, which is why the sustained "
+                    "fraction of the HBM peak is small; the bytes are PMC counters (reads by request size + "
+                    "WRITE_SIZE), not a model"}
+
+
+def stream_children(args, local):
+    """configs[2] measured the way it is deployed: the drive exported to disk (pcap + frame index + pose track + tiled
+    world map), then replayed by the C++ host (tools/stream_driver: veloslam::HDLManager + MapManager over the C ABI) in
+    a PROCESS OF ITS OWN, and once more by this file's Python loop (--workload stream --drive), also in its own process.
+    Why not in this process (as until round 5): the replay overlaps three queues -- registrations, the next frame's
+    decode, the roll begun ahead on a CU-masked queue -- and how well they overlap depends on which hardware queues
+    the process already holds: beside the headline context (and torch's streams) the same replay ran at 1 050 - 1 190
+    frames/s where a fresh process runs 1 300 - 1 390 (tools/ab_stream_modes.sh, docs/lab_notebook.md round 5 section 6)."""
+    import subprocess
+    import tempfile
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    if local:   # (the children see one device: this rank's)
+        vis = [v for v in env.get("HIP_VISIBLE_DEVICES", "").split(",") if v]
+        env["HIP_VISIBLE_DEVICES"] = vis[local] if local < len(vis) else str(local)
+    me = os.path.abspath(__file__)
+    root = os.path.dirname(me)
+    common = ["--stream-frames", str(args.stream_frames), "--stream-map-points", str(args.stream_map_points),
+              "--tile", str(args.tile), "--voxel", str(args.voxel), "--k-normals", str(args.k_normals)]
+    with tempfile.TemporaryDirectory() as td:
+        ex = subprocess.run([sys.executable, me, "--export-drive", td] + common, capture_output=True, text=True,
+                            timeout=600, env=env)
+        if ex.returncode != 0:
+            raise RuntimeError("drive export failed: " + ex.stderr[-1500:])
+        py = subprocess.run([sys.executable, me, "--workload", "stream", "--drive", td, "--steps", str(args.stream_steps),
+                             "--warmup", str(args.stream_warmup), "--no-cpu-baseline", "--roll-lead", str(args.roll_lead),
+                             "--iters", str(args.iters), "--append-threshold", str(args.append_threshold)],
+                            capture_output=True, text=True, timeout=900, env=env)
+        if py.returncode != 0:
+            raise RuntimeError("python replay failed: " + py.stderr[-1500:])
+        prec = json.loads(py.stdout.strip().splitlines()[-1])
+        rec = {k: v for k, v in prec.items() if k in (
+            "frames", "roofline", "host", "map_points_mean", "map_subdiv", "map_update", "pairs_per_s", "stage_ms_per_frame",
+            "map", "last_update", "worst_pose_error_m", "decode_planned_ahead", "roll_ahead", "roll_lead",
+            "rolls_begun_ahead", "roll_begin_host_ms", "roll_publish_host_ms")}
+        rec["frames_per_s"] = prec["value"]
+        rec["ms_per_frame"] = prec["ms_per_step"]
+        rec["workload"] = prec["config"]["workload"]
+        rec["frames"] = prec.get("frames", args.stream_steps)
+        rec["process"] = "own (child of bench.py)"
+        drv = os.path.join(root, "tools", "stream_driver")
+        if os.path.exists(drv):
+            cp = subprocess.run([drv, td, "--steps", str(args.stream_steps), "--warmup", str(args.stream_warmup),
+                                 "--roll-lead", str(args.roll_lead), "--threshold", str(args.append_threshold)],
+                                capture_output=True, text=True, timeout=600, env=env)
+            if cp.returncode != 0:
+                raise RuntimeError("tools/stream_driver failed (%d): %s" % (cp.returncode, cp.stderr[-1500:]))
+            crec = json.loads(cp.stdout.strip().splitlines()[-1])
+            # the C++ host is the product's (north star: "host code stays C++"): its rate is the record's, the Python
+            # loop's rides beside it
+            py_side = {"frames_per_s": rec["frames_per_s"], "ms_per_frame": rec["ms_per_frame"],
+                       "stage_ms_per_frame": rec.get("stage_ms_per_frame"), "host": rec.get("host")}
+            rec.update({"frames_per_s": crec["frames_per_s"], "ms_per_frame": crec["ms_per_frame"], "frames": crec["frames"],
+                        "host": crec["host"], "stage_ms_per_frame": crec["stage_ms_per_frame"],
+                        "pairs_per_s": crec["pairs_per_s"], "worst_pose_error_m": crec["worst_pose_error_m"],
+                        "map_points_mean": crec["map_points"], "map_subdiv": crec["map_subdiv"], "map": crec["map"],
+                        "last_update": crec["last_update"], "roll_lead": crec["roll_lead"]})
+            for k in ("rolls_begun_ahead", "roll_begin_host_ms", "roll_publish_host_ms"):
+                rec.pop(k, None)
+            rec["python_host"] = py_side
+        rec["roofline"] = stream_roofline(rec["frames_per_s"])
+    return rec
+
+
 def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
     """`--workload stream --drive DIR`: a recorded drive (veloslam_amd/drive.py layout: pcap +
     carposes.txt + db.xml + world.map) replayed against a rolling map, the same loop
@@ -522,7 +609,12 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
     meta = d["meta"]
     ctx = capi.Context(local, max_batch=4, map_margin=args.map_margin, use_hints=0 if args.no_hints else args.hints,
                        use_graph=0 if args.no_graph else 1, map_subdiv=args.stream_subdiv)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # (the ctx keeps its OWN stream, as under the C++ host: nothing of the replay is a torch tensor.  On torch's stream --
+    #  the first queue this process made -- the roll begun ahead (its own CU-masked queue) and the registrations took
+    #  turns instead of overlapping whenever the world had been sampled on the GPU first: 1 190 vs 1 300 frames/s,
+    #  same drive, tools/ab_stream_modes.sh)
+    if os.environ.get("VELO_REPLAY_TORCH_STREAM"):
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.map_set_margins(args.map_margin, args.map_margin, args.map_margin_z)
     R = float(args.roi_range)
     idx, times, pk = d["index"], d["times"], d["packets"]
@@ -661,6 +753,8 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
             return
         if not (rng[0] <= cur[1] and rng[1] >= cur[0] and rng[2] <= cur[3] and rng[3] >= cur[2]):
             return
+        if state.get("refused") == (rng, cur):   # (MapManager::refusedBefore: the same question, the same answer)
+            return
         ex, ey, ez = gather(rng, skip=cur)
         evicts = (rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]) and holds(cur, rng)
         lo = np.array([rng[0] * pr - pr / 2, rng[2] * pr - pr / 2, -big], np.float32)
@@ -670,6 +764,7 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
         if not ctx.map_roll_overlapped(lo if evicts else None, hi if evicts else None, ex, ey, ez):
             if ctx.map_info().n_points != n0:
                 state["res"] = None        # (an eviction went through, the append did not: rebuild from the tiles)
+            state["refused"] = (rng, cur)
             return
         if mirror:      # the same update in its plain form
             if evicts:
@@ -693,6 +788,8 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
             return
         if not (rng[0] <= cur[1] and rng[1] >= cur[0] and rng[2] <= cur[3] and rng[3] >= cur[2]):
             return
+        if state.get("refused") == (rng, cur):   # (MapManager::refusedBefore)
+            return
         ex, ey, ez = gather(rng, skip=cur)
         evicts = (rng[0] > cur[0] or rng[1] < cur[1] or rng[2] > cur[2] or rng[3] < cur[3]) and holds(cur, rng)
         lo = np.array([rng[0] * pr - pr / 2, rng[2] * pr - pr / 2, -big], np.float32)
@@ -703,6 +800,7 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
         ok_b = ctx.map_roll_begin(lo if evicts else None, hi if evicts else None, ex, ey, ez)
         state.setdefault("t_begin", []).append(time.perf_counter() - t_b)
         if not ok_b:
+            state["refused"] = (rng, cur)
             return                             # refused before anything changed: the plain roll does it when due
         if mirror:      # the same update in its plain form
             if evicts:
@@ -772,9 +870,11 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
         # registration only and returns the result of the frames that were resident at the start
         ctx.icp_batch_start(np.tile(T0, (ctx.n_frames, 1)), args.iters, args.d_max)
         ctx.increment_pending(0, None, 3)
+        state["sub"] = [time.perf_counter()]        # (diagnosis: start -> decode submitted -> roll begun -> finished)
         if f_next is not None and not args.no_decode_overlap:
             decode_frame(f_next, overlapped=True)   # (second stream: concurrent with the registration; the
             state["resident"] = f_next              #  `icp` stage below is both)
+            state["sub"].append(time.perf_counter())
             if not args.no_roll_ahead and args.roll_lead > 0:
                 # ... and so is the roll of the map: begun as soon as one of the next roll_lead frames names another
                 # tile rectangle (the priors come from the pose track), published when that frame is due
@@ -789,8 +889,10 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
             elif not args.no_roll_ahead:            # ... beside this registration only, for the next frame
                 Tn, _ = prior_of(f_next)
                 roll_ahead(float(Tn[3]), float(Tn[7]), timed)
+        state["sub"].append(time.perf_counter())
         res = ctx.icp_batch_finish()[0]
         t.append(time.perf_counter())
+        state["sub"].append(t[-1])
         # (while a roll is begun the increments stay pending: a flush would publish it early)
         if state["staged"] is None and ctx.pending_count(False) >= max(args.append_threshold, 1):
             flush()
@@ -814,14 +916,24 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
+    per_frame = [] if os.environ.get("VELO_PER_FRAME") else None   # (diagnosis: wall time of every timed frame)
     for k in range(steps):
+        t_f = time.perf_counter()
         one(frame_at(warmup + k), frame_at(warmup + k + 1) if k + 1 < steps else None, True, warmup + k)
+        if per_frame is not None:
+            sb = state.get("sub", [])
+            per_frame.append((frame_at(warmup + k), time.perf_counter() - t_f, state["rolls"], state["begun"], state["flush"],
+                              " ".join("%.3f" % (1e3 * (b - a)) for a, b in zip(sb[:-1], sb[1:]))))
     if state["staged"] is not None:
         publish_begun(True)
     flush()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if per_frame is not None:
+        with open(os.environ["VELO_PER_FRAME"], "w") as fh:
+            for i, (f, dt, r, b, fl, sub) in enumerate(per_frame):
+                fh.write("%d frame %d ms %.4f rolls %d begun %d flush %d sub %s\n" % (i, f, 1e3 * dt, r, b, fl, sub))
     mi = ctx.map_info()
     if probe is not None and probe.get("final"):
         probe["final"](ctx)
@@ -830,23 +942,7 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
     if state["worst"] > 0.05:
         raise SystemExit("bench replay: registration diverged (%.3f m)" % state["worst"])
     fps = steps / elapsed
-    tr = traffic_for("stream")
-    roof = None
-    if tr:
-        # BASELINE configs[2] "sustained frames/s + rocprof HBM GB/s": the fabric-side bytes every kernel of a
-        # frame moves (PMC, per dispatch, summed: profiles/collect.sh on the C++ replay of the same drive) x
-        # the frames per second of THIS run = the sustained rate; beside it the rate while a kernel runs
-        roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "traffic_bytes_per_frame": tr["hbm_bytes_per_frame"],
-                "sustained_GBps": tr["hbm_bytes_per_frame"] * fps / 1e9,
-                "sustained_frac": tr["hbm_bytes_per_frame"] * fps / 1e9 / HBM_PEAK_GBPS,
-                "kernel_us_per_frame": tr["kernel_us_per_frame"],
-                "GBps_while_a_kernel_runs": tr["GBps_while_a_kernel_runs"],
-                "by_family": tr["by_family"], "traffic_source": tr["source"], "traffic_stale": tr["stale"],
-                "note": "a frame of the stream is ~60 small launches on a chip it cannot fill (one frame = 450 "
-                        "workgroups on 256 CUs): bound by launch and memory LATENCY, which is why the sustained "
-                        "fraction of the HBM peak is small; the bytes are PMC counters (reads by request size + "
-                        "WRITE_SIZE), not a model"}
+    roof = stream_roofline(fps)
     return {"frames_per_s": fps, "ms_per_frame": 1e3 * elapsed / steps, "frames": steps, "roofline": roof,
             "host": "Python (C ABI through ctypes)",
             "workload": "BASELINE configs[2], %s: %d frames 1 m apart (pcap + frame index + pose track), played "
@@ -1795,7 +1891,9 @@ def main():
             sub("dense", lambda: dense_record(args, d, dev, local))
             sub("knn32_100m", lambda: knn_record(args, d, dev, local))
             src = d["stream_src"] if rank == 0 and F >= 24 else None
-            if args.stream_policy == "tiles":
+            if args.stream_policy == "tiles" and not args.stream_in_process:
+                sub("stream", lambda: stream_children(args, local))
+            elif args.stream_policy == "tiles":
                 sub("stream", lambda: run_replay(args, dev, local, args.stream_steps, args.stream_warmup,
                                                  d=synthetic_drive(args, dev, src)))
             else:

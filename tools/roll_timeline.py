@@ -9,7 +9,12 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"].split("(")[0][-48:]))
 ev.sort()
-rolls = [i for i, e in enumerate(ev) if "k_keep4" in e[3] or "k_keep_flags" in e[3]]
+for f in glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy", "COPY " + r.get("Direction", "")[12:]))
+ev.sort()
+pick = os.environ.get("PICK", "")
+rolls = [i for i, e in enumerate(ev) if (pick in e[3] if pick else ("k_keep4" in e[3] or "k_keep_flags" in e[3]))]
 print(len(ev), "kernels,", len(rolls), "roll starts; queues:", sorted({e[2] for e in ev}))
 if not rolls:
     sys.exit(0)
@@ -19,7 +24,7 @@ t0 = ev[i0][0]
 lin_q = next((e[2] for e in ev if "k_linearize" in e[3]), None)
 last_end = {}
 for s, e, q, n in ev:
-    if s < t0 - 300_000 or s > t0 + 4_000_000:
+    if s < t0 - int(os.environ.get('BEFORE_US', '300')) * 1000 or s > t0 + int(os.environ.get('AFTER_US', '4000')) * 1000:
         continue
     gap = (s - last_end.get(q, s)) / 1e3
     last_end[q] = e

@@ -47,12 +47,14 @@ int main(int argc, char** argv)
     int steps = 100, warmup = 10, threshold = 512, roll_lead = 4;
     bool integrate = true, overlap = true, roll_ahead = true;
     std::string per_frame;
+    int margin = -1;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
         else if (a == "--warmup" && i + 1 < argc) warmup = std::atoi(argv[++i]);
         else if (a == "--threshold" && i + 1 < argc) threshold = std::atoi(argv[++i]);
         else if (a == "--roll-lead" && i + 1 < argc) roll_lead = std::atoi(argv[++i]);  // frames a roll is begun ahead (0: beside the previous frame only)
+        else if (a == "--margin" && i + 1 < argc) margin = std::atoi(argv[++i]);  // grid slack in x / y, voxels (MapManager's default: 16)
         else if (a == "--per-frame" && i + 1 < argc) per_frame = argv[++i];  // per-frame wall time + what the map did, one line each
         else if (a == "--no-integrate") integrate = false;
         else if (a == "--no-overlap") overlap = false;
@@ -78,6 +80,10 @@ int main(int argc, char** argv)
         return 3;
     }
     velo_ctx* ctx = mgr.context();
+    if (margin >= 0) {
+        const int32_t mg[3] = {margin, margin, 2};
+        velo_map_set_margins(ctx, mg);
+    }
     // ---- the drive: one stub per revolution, points decoded on the GPU when asked for
     HDLManager hdl(ctx);
     if (!hdl.setCalibFile(dir + "/db.xml") || !hdl.loadOffline(dir + "/carposes.txt", dir + "/drive.pcap") ||
@@ -184,9 +190,9 @@ int main(int argc, char** argv)
         if (!one(frame_at(warmup + k), k + 1 < steps ? frame_at(warmup + k + 1) : -1, true)) return 5;
         if (pf) {
             const MapStats sn = mgr.stats();
-            velo_map_info m2;
+            velo_map_info m2{};      // (velo_map_info_get waits for a roll begun ahead: only on request)
             m2.struct_size = sizeof m2;
-            velo_map_info_get(ctx, &m2);
+            if (std::getenv("VELO_PER_FRAME_INFO")) velo_map_info_get(ctx, &m2);
             std::fprintf(pf, "%d frame %d ms %.4f rolls %llu ahead %llu begun %llu refused %llu full %llu flush %llu up %llu ev %llu last_update %d dims %d %d %d n %llu\n",
                          k, frame_at(warmup + k), ms_since(tk), (unsigned long long)(sn.rolls - sp.rolls),
                          (unsigned long long)(sn.rolls_ahead - sp.rolls_ahead), (unsigned long long)(sn.rolls_begun - sp.rolls_begun),

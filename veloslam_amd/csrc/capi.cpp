@@ -620,16 +620,18 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     c->use_hash = c->cfg.map_hash_load > 0 || ncell_d >= 2147483648.0;
     const int fdims[3] = {dims[0] * S, dims[1] * S, dims[2] * S};
     const size_t ncell = (size_t)fdims[0] * fdims[1] * fdims[2];
-    HIP_TRY(c, c->keys.reserve(n));
-    HIP_TRY(c, c->keys_sorted.reserve(n));
-    HIP_TRY(c, c->idx.reserve(n));
-    HIP_TRY(c, c->perm.reserve(n));
+    // (with slack: a rolling map re-anchors with a few more points every time -- exact sizes were four to six
+    //  hipFree + hipMalloc pairs, 0.8 ms of host time, per re-anchoring roll)
+    HIP_TRY(c, reserve_slack(c->keys, n));
+    HIP_TRY(c, reserve_slack(c->keys_sorted, n));
+    HIP_TRY(c, reserve_slack(c->idx, n));
+    HIP_TRY(c, reserve_slack(c->perm, n));
     if (carry) {  // build into the second set of arrays: the old points are still needed
         HIP_TRY(c, reserve_slack(c->pts_alt, n));
         HIP_TRY(c, reserve_slack(c->nrm_alt, n));
     } else {
-        HIP_TRY(c, c->pts.reserve(n));
-        HIP_TRY(c, c->nrm.reserve(n));
+        HIP_TRY(c, reserve_slack(c->pts, n));
+        HIP_TRY(c, reserve_slack(c->nrm, n));
     }
     HIP_TRY(c, c->invalid_cnt.reserve(1));
     HIP_TRY(c, launch_keys(c->raw_x.p, c->raw_y.p, c->raw_z.p, n, org[0], org[1], org[2],
@@ -2228,6 +2230,7 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
         for (int i = 0; i < roll_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
         if (getenv("VELO_ROLL_NO_CU_MASK") || hipExtStreamCreateWithCUMask(&c->roll_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
             (void)hipGetLastError();
+            if (getenv("VELO_TRACE_ROLL")) std::fprintf(stderr, "velo: the roll's stream has no CU mask\n");
             HIP_TRY(c, hipStreamCreateWithFlags(&c->roll_stream, hipStreamNonBlocking));
         }
     }

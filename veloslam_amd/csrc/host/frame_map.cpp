@@ -590,6 +590,7 @@ bool MapManager::rollAhead(double x, double y, const RegisterOptions& o)
     if (o.voxel != residentVoxel_ || o.k_normals != residentK_) return false;
     if (i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_) return true;  // nothing to do
     if (!(i0 <= res_i1_ && i1 >= res_i0_ && j0 <= res_j1_ && j1 >= res_j0_)) return false;  // a jump: plain rebuild
+    if (refusedBefore(i0, i1, j0, j1)) return false;   // (the same question from the same rectangle: the same answer)
     // entering tiles (as rollTo gathers them; the pending increments are not taken here)
     stage_x_.clear(), stage_y_.clear(), stage_z_.clear();
     size_t tiles = 0;
@@ -622,6 +623,7 @@ bool MapManager::rollAhead(double x, double y, const RegisterOptions& o)
         // have gone through) -- the plain roll rebuilds from the tiles
         if (mi.n_points != n_before) dirty_ = true;
         ++stats_.rolls_refused;
+        noteRefused(i0, i1, j0, j1);
         return false;
     }
     if (rc) {
@@ -657,6 +659,7 @@ bool MapManager::rollBegin(double x, double y, const RegisterOptions& o)
     if (o.voxel != residentVoxel_ || o.k_normals != residentK_) return false;
     if (i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_) return true;  // nothing to do
     if (!(i0 <= res_i1_ && i1 >= res_i0_ && j0 <= res_j1_ && j1 >= res_j0_)) return false;  // a jump: plain rebuild
+    if (refusedBefore(i0, i1, j0, j1)) return false;   // (the same question from the same rectangle: the same answer)
     stage_x_.clear(), stage_y_.clear(), stage_z_.clear();
     size_t tiles = 0;
     for (int j = j0; j <= j1; ++j)
@@ -683,6 +686,7 @@ bool MapManager::rollBegin(double x, double y, const RegisterOptions& o)
                                        stage_y_.data(), stage_z_.data(), stage_x_.size());
     if (rc == VELO_E_AGAIN || rc == VELO_E_INVALID) {  // refused before anything changed: the plain roll does it when due
         ++stats_.rolls_refused;
+        noteRefused(i0, i1, j0, j1);
         return false;
     }
     if (rc) {
