@@ -5,9 +5,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <dlfcn.h>
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#endif
 #include "velo_internal.hpp"
 #include "host/decode_plan.hpp"
 #include "../../include/veloslam/TransformManager.hpp"
@@ -1961,7 +1965,12 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     HIP_TRY(c, hipMemcpyAsync(&last[0], c->offs.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&last[1], c->flags.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(mm6, c->mm_scratch.p, sizeof mm6, hipMemcpyDeviceToHost, s));
+    static const bool trace_roll = getenv("VELO_TRACE_ROLL") != nullptr;
+    const auto te0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (trace_roll)
+        std::fprintf(stderr, "evict: waited %.0f us for the keep counts\n",
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - te0).count());
     const uint32_t kept = last[0] + last[1];
     if (kept == 0) return c->fail(VELO_E_INVALID, "eviction region would remove every map point");
     if (kept == n) return VELO_OK;
@@ -2087,6 +2096,45 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
 // the device for everything older than the registration.  What cannot be done that way -- a
 // re-anchor, a grown or hashed table -- is refused with VELO_E_AGAIN before anything changed.
 // what both forms of the roll check before anything changes, and the bounds of the entering points
+// min / max of p[0..n) (n >= 1); false if a value is NaN or infinite
+static bool bounds_finite(const float* p, size_t n, float& lo_a, float& hi_a)
+{
+    size_t i = 0;
+    bool bad = false;
+    lo_a = hi_a = p[0];
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+    {
+        __m128 lo0 = _mm_set1_ps(p[0]), hi0 = lo0, lo1 = lo0, hi1 = lo0;
+        const __m128i ex = _mm_set1_epi32(0x7f800000);
+        __m128i b4 = _mm_setzero_si128();
+        for (; i + 8 <= n; i += 8) {
+            const __m128 a = _mm_loadu_ps(p + i), b = _mm_loadu_ps(p + i + 4);
+            lo0 = _mm_min_ps(lo0, a), hi0 = _mm_max_ps(hi0, a);
+            lo1 = _mm_min_ps(lo1, b), hi1 = _mm_max_ps(hi1, b);
+            b4 = _mm_or_si128(b4, _mm_cmpeq_epi32(_mm_and_si128(_mm_castps_si128(a), ex), ex));  // exponent all ones
+            b4 = _mm_or_si128(b4, _mm_cmpeq_epi32(_mm_and_si128(_mm_castps_si128(b), ex), ex));
+        }
+        float l4[4], h4[4];
+        _mm_storeu_ps(l4, _mm_min_ps(lo0, lo1));
+        _mm_storeu_ps(h4, _mm_max_ps(hi0, hi1));
+        for (int k = 0; k < 4; ++k) {
+            lo_a = l4[k] < lo_a ? l4[k] : lo_a;
+            hi_a = h4[k] > hi_a ? h4[k] : hi_a;
+        }
+        bad = _mm_movemask_epi8(b4) != 0;
+    }
+#endif
+    for (; i < n; ++i) {
+        const float v = p[i];
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        bad |= (u & 0x7f800000u) == 0x7f800000u;
+        lo_a = v < lo_a ? v : lo_a;
+        hi_a = v > hi_a ? v : hi_a;
+    }
+    return !bad;
+}
+
 static int roll_precheck(velo_ctx* c, const char* who, const float lo[3], const float hi[3], const float* x,
                          const float* y, const float* z, size_t n, float mn[3], float mx[3])
 {
@@ -2107,17 +2155,12 @@ static int roll_precheck(velo_ctx* c, const char* who, const float lo[3], const 
     if (n) {
         const float* src[3] = {x, y, z};
         for (int a = 0; a < 3; ++a) {
-            // (branch-free, so that the compiler vectorises it: this pass is on the host's critical path once per
-            //  roll -- 235 k points took 0.3 ms as a scalar loop with isfinite per element.  A NaN makes lo > hi or
-            //  survives in the sum below; an infinity shows in the bounds.)
-            const float* p = src[a];
-            float lo_a = p[0], hi_a = p[0], acc = 0.0f;
-            for (size_t i = 0; i < n; ++i) {
-                const float v = p[i];
-                lo_a = v < lo_a ? v : lo_a;
-                hi_a = v > hi_a ? v : hi_a;
-                acc += v * 0.0f;   // 0 for finite values, NaN for NaN / infinity
-            }
+            // (on the host's critical path once per roll: 0.85 - 1.05 ms for the 547 k points of a tile column as a scalar
+            //  loop -- neither clang nor gcc vectorises the min / max / finiteness pass whichever way it is written --
+            //  0.25 ms with SSE2, profiles/r05/roll_begin_host.txt)
+            float lo_a, hi_a;
+            const bool bad = !bounds_finite(src[a], n, lo_a, hi_a);
+            const float acc = bad ? 1.0f : 0.0f;
             if (!(acc == 0.0f) || !std::isfinite(lo_a) || !std::isfinite(hi_a))
                 return c->fail(VELO_E_INVALID, "map points must be finite");
             mn[a] = lo_a;
@@ -2204,8 +2247,12 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
 {
     if (!c) return VELO_E_INVALID;
     if (c->roll_staged) return c->fail(VELO_E_INVALID, "a roll is begun already: velo_map_roll_publish first");
+    static const bool trace_roll = getenv("VELO_TRACE_ROLL") != nullptr;   // (where the host's time in this call goes)
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); };
     float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     if (int rc = roll_precheck(c, "velo_map_roll_begin", lo, hi, x, y, z, n, mn, mx)) return rc;
+    const double t_pre = tr_us();
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->roll_stream) {
         // A stream that may use THREE QUARTERS of the CUs (8 of every XCD's 32 are masked out).  The roll's kernels
@@ -2262,6 +2309,7 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
         py = c->h_enter + n;
         pz = c->h_enter + 2 * n;
     }
+    const double t_copy = tr_us();
     HIP_TRY(c, hipStreamWaitEvent(c->roll_stream, c->ev_mark, 0));
     c->roll_overlapped_done = true;
     const uint64_t n_before = c->info.n_points;
@@ -2277,6 +2325,9 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
     c->roll_counts_pending = false;
     const uint64_t gen0 = c->map_gen;
     const int rc = roll_run(c, c->roll_stream, c->roll_temp, lo, hi, px, py, pz, n);
+    if (trace_roll)
+        std::fprintf(stderr, "roll_begin: precheck %.0f us, pinned copy %.0f, evict%s + append of %zu enqueued %.0f (rc %d)\n", t_pre,
+                     t_copy - t_pre, lo ? "" : " (none)", n, tr_us() - t_copy, rc);
     c->defer_counts = false;
     c->have_enter_mm = false;
     c->roll_extra = 0;

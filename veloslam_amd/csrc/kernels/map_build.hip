@@ -456,8 +456,11 @@ __device__ __forceinline__ bool near_changed(const MapView& mv, const float4& p,
 // w < 0 for points that are new.  A listed point whose reach no changed point can touch keeps
 // its normal untouched (chg == nullptr: no such test).  The invalid-normal count is
 // maintained by difference (two's complement add).
+#ifndef VELO_NRM_SUBSET_WAVES
+#define VELO_NRM_SUBSET_WAVES 4  // wavefronts per SIMD the register allocation aims at (3 = 133 VGPRs as the compiler chooses freely)
+#endif
 template <int KMAX>
-__global__ __launch_bounds__(kNrmThreads) void k_normals_subset(
+__global__ __launch_bounds__(kNrmThreads) __attribute__((amdgpu_waves_per_eu(VELO_NRM_SUBSET_WAVES, VELO_NRM_SUBSET_WAVES))) void k_normals_subset(
     MapView mv, const uint32_t* __restrict__ perm, int k, const int32_t* __restrict__ work,
     int n_work, const unsigned* __restrict__ n_work_dev, const uint32_t* __restrict__ chg, uint32_t n_chg,
     float4* __restrict__ nrm, unsigned long long* __restrict__ invalid, unsigned* __restrict__ n_done)
