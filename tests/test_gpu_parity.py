@@ -132,6 +132,35 @@ def test_map_build_and_search_other_grids(oracle, voxel, k, subdiv):
             c.close()
 
 
+def test_cell_table_of_clustered_and_empty_tiles(oracle):
+    """k_cell_start works tile by tile (4 096 table entries, their keys staged in LDS): a tile that holds more keys
+    than the stage (a heap of points in a few fine cells -> the global-memory search inside the tile's key range),
+    long runs of tiles without any key, and keys in the very first and very last cell."""
+    rng = np.random.default_rng(77)
+    heap = rng.normal(0.0, 0.02, (3, 12_000)).astype(np.float32) + np.array([[7.3], [-3.1], [0.4]], np.float32)
+    far = np.array([[-60.0, 60.0, -60.0, 60.0], [-40.0, 40.0, 40.0, -40.0], [-1.0, 1.0, 1.0, -1.0]], np.float32)
+    thin = rng.uniform(-50, 50, (3, 2_000)).astype(np.float32)
+    thin[2] *= 0.01
+    x, y, z = (np.concatenate([heap[a], far[a], thin[a]]) for a in range(3))
+    for subdiv in (3, 8):
+        om = oracle.Map(x, y, z, 1.0, 8, subdiv)
+        c = capi.Context(0, max_batch=1, map_subdiv=subdiv)
+        try:
+            c.map_reset(x, y, z, 1.0, 8)
+            g = c.map_download()
+            assert np.array_equal(g["cell_start"], om.cell_start())
+            assert np.array_equal(g["perm"], om.perm())
+            # (and the same table after a re-anchoring append: the rebuild path of a rolling map)
+            c.map_append(np.array([-90.0], np.float32), np.array([-70.0], np.float32), np.array([-2.0], np.float32))
+            om2 = oracle.Map(np.append(x, np.float32(-90.0)), np.append(y, np.float32(-70.0)), np.append(z, np.float32(-2.0)),
+                             1.0, 8, subdiv)
+            g2 = c.map_download()
+            assert c.map_info().last_update == 0
+            assert np.array_equal(g2["cell_start"], om2.cell_start())
+        finally:
+            c.close()
+
+
 def test_map_append_equals_rebuild(ctx, oracle):
     rng = np.random.default_rng(9)
     pts = rng.uniform(-10, 10, (3, 5000)).astype(np.float32)
