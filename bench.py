@@ -529,6 +529,14 @@ def stream_children(args, local):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
+    # (under rocprofv3 the children would be traced into the same output directory, and counted into the parent's
+    #  kernel statistics: they run unprofiled -- the stream has its own trace, profiles/collect.sh)
+    if "rocprof" in env.get("LD_PRELOAD", ""):
+        env["LD_PRELOAD"] = ":".join(v for v in env["LD_PRELOAD"].split(":") if v and "rocprof" not in v)
+        if not env["LD_PRELOAD"]:
+            env.pop("LD_PRELOAD")
+        for k in [k for k in env if k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER"))]:
+            env.pop(k)
     if local:   # (the children see one device: this rank's)
         vis = [v for v in env.get("HIP_VISIBLE_DEVICES", "").split(",") if v]
         env["HIP_VISIBLE_DEVICES"] = vis[local] if local < len(vis) else str(local)

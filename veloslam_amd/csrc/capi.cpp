@@ -148,6 +148,10 @@ struct velo_ctx {
     // them an update writes the copy the running registration does not read (overlap_update)
     DevBuf<int32_t> cell_start_alt;
     DevBuf<uint32_t> tile_bounds;   // per 1 024-entry tile of the table: launch_table_shift / _remap
+    DevBuf<int4> sq;                // the split iteration's straggler queue (one slot per query) ...
+    DevBuf<unsigned> sq_count;      // ... and its length, one counter per iteration of a registration
+    int split_iters = 1;            // iterations 0 .. split_iters - 1 run as three launches (VELO_SPLIT_ITERS)
+    unsigned split_per_wave_max = 24576;  // stragglers up to which phase B gives each a wavefront of its own
     DevBuf<uint8_t> vox_near_alt;
     bool overlap_update = false;        // inside velo_map_roll_overlapped
     DevBuf<int32_t> knn_idx, knn_cnt;   // velo_knn: device-side results before the copy back
@@ -276,13 +280,14 @@ struct velo_ctx {
     struct GraphKey {
         int iters = 0, ni = 0, n_frames = 0, variant = 0;
         float dmax2 = 0;
-        const void *hint = nullptr, *rho = nullptr, *items = nullptr, *stream = nullptr;
+        const void *hint = nullptr, *rho = nullptr, *items = nullptr, *stream = nullptr, *sq = nullptr;
         uint64_t map_gen = 0, frames_gen = 0;
+        int n_split = 0;
         bool operator==(const GraphKey& o) const
         {
             return iters == o.iters && ni == o.ni && n_frames == o.n_frames && variant == o.variant &&
                    dmax2 == o.dmax2 && hint == o.hint && rho == o.rho && items == o.items && stream == o.stream &&
-                   map_gen == o.map_gen && frames_gen == o.frames_gen;
+                   map_gen == o.map_gen && frames_gen == o.frames_gen && n_split == o.n_split && sq == o.sq;
         }
     } graph_key;
     uint64_t map_gen = 0, frames_gen = 0;
@@ -548,7 +553,8 @@ int build_table(velo_ctx* c, MapView& mv, const uint32_t* keys_sorted, size_t n,
         // +1 entry, padded: rows are read 4 entries at a time; with slack, because a rolling map's
         // grid grows a margin at a time and a fresh 0.3-0.6 GB allocation costs milliseconds
         HIP_TRY(c, reserve_slack(c->cell_start, ncell + 8));
-        HIP_TRY(c, launch_cell_start(keys_sorted, n, ncell, c->cell_start.p, s));
+        HIP_TRY(c, reserve_slack(c->tile_bounds, cell_start_bounds(ncell)));
+        HIP_TRY(c, launch_cell_start(keys_sorted, n, ncell, c->cell_start.p, c->tile_bounds.p, s));
         mv.cell_start = c->cell_start.p;
         mv.hash = nullptr;
         mv.hash_cap = 0;
@@ -850,7 +856,8 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     } else if (grew) {
         HIP_TRY(c, hipStreamSynchronize(s));  // the old table may still be read by queued work
         HIP_TRY(c, reserve_slack(c->cell_start, ncell + 8));
-        HIP_TRY(c, launch_cell_start(c->keys_alt.p, total, ncell, c->cell_start.p, s));
+        HIP_TRY(c, reserve_slack(c->tile_bounds, cell_start_bounds(ncell)));
+        HIP_TRY(c, launch_cell_start(c->keys_alt.p, total, ncell, c->cell_start.p, c->tile_bounds.p, s));
     } else if (c->overlap_update && c->overlap_done == 0) {  // the running registration reads cell_start: write the other copy
         HIP_TRY(c, reserve_slack(c->cell_start_alt, ncell + 8));
         HIP_TRY(c, reserve_slack(c->tile_bounds, table_tile_bounds(ncell + 1)));
@@ -1353,6 +1360,28 @@ int forget_hints_for_linearize(velo_ctx* c, int32_t* hint, size_t n_all, hipStre
     return VELO_OK;
 }
 
+// One iteration's linearise launch(es).  Split (round 5): the searching iterations -- unhinted, or hinted from a pose
+// still far off -- spend most of their time on the stragglers of stage A, a fifth of the queries on a dense map, each
+// searched inside the wavefront it happens to sit in.  Cut in three launches the stragglers of the WHOLE launch are
+// searched together (launch_search_split) and the sums are made by the ordinary kernel from certified hints.
+// Same correspondences bit for bit (the search functions are the same); the sums are canonical.
+static hipError_t launch_iteration(velo_ctx* c, int it, bool split, const FrameView& fv, float dmax2, int32_t* hint, float* rho,
+                                   bool stats, bool sorted, hipStream_t s)
+{
+    const Decomposition dc = decomposition_for(c, split ? std::max(it, 1) : it, hint != nullptr, sorted);
+    const double* prev = it == 0 ? nullptr : c->poses_prev.p;  // (first iteration: stale hints)
+    if (split) {
+        hipError_t e = launch_search_split(dc.items, dc.n, fv, c->mv_read, c->poses.p, dmax2, hint, rho, prev,
+                                           c->plan_lat ? 2 : 1, dc.lat_lanes, c->sq.p, c->sq_count.p + it,
+                                           c->split_per_wave_max, c->wave_slots > 0 ? std::max(256, c->wave_slots / 4) : 2048, s);
+        if (e != hipSuccess) return e;
+        prev = c->poses.p;   // the third launch: every query holds its certified result at THIS pose
+    }
+    static const bool split_debug = getenv("VELO_SPLIT_DEBUG") != nullptr;   // (count the third launch's searches: velo_search_stats)
+    return launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv_read, c->poses.p, dmax2, c->partials.p, nullptr,
+                            nullptr, hint, rho, prev, stats || (split && split_debug), c->plan_lat ? 2 : 1, s, dc.lat_lanes);
+}
+
 int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
 {
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map: call velo_map_reset first");
@@ -1388,6 +1417,20 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         }
     }
     HIP_TRY(c, c->poses_prev.reserve((size_t)c->cfg.max_batch * 12));
+    // the split iterations need hints AND certificates (the third launch lives on them), the pruned search, plain
+    // query order; the counting instantiation keeps the one-launch form (its byte model is per launch)
+    // ... and it pays on the LATENCY path only (a frame or two: a wavefront's stragglers wait for each other while the
+    // chip idles -- first launch of a single frame 70 -> 40 us); a batch fills the chip either way, and its stragglers
+    // packed 64 to a wavefront walk for as long as the slowest of them (headline 339 -> 630 us, dense 363 -> 320:
+    // profiles/r05/split_iteration_ab.txt).  VELO_SPLIT_BATCH=1 forces it there for measurements.
+    static const bool split_batch = getenv("VELO_SPLIT_BATCH") != nullptr;
+    const int n_split = (hint && rho && c->cfg.linearize_variant == VELO_VARIANT_BALL && !c->stats_on && !c->cfg.sort_frames && n_all &&
+                         (c->plan_lat || split_batch))
+                            ? std::min(c->split_iters, iters) : 0;
+    if (n_split > 0) {
+        HIP_TRY(c, reserve_slack(c->sq, n_all));
+        HIP_TRY(c, c->sq_count.reserve(VELO_MAX_ITERS));
+    }
     if (!c->pairs_total.p) {
         HIP_TRY(c, c->pairs_total.reserve(1));
         HIP_TRY(c, hipMemsetAsync(c->pairs_total.p, 0, sizeof(unsigned long long), s));
@@ -1416,6 +1459,8 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         key.stream = s;
         key.map_gen = c->map_gen;
         key.frames_gen = c->frames_gen;
+        key.n_split = n_split;
+        key.sq = c->sq.p;
         if (!c->graph_exec || !(key == c->graph_key)) {
             if (c->graph_exec) {
                 (void)hipGraphExecDestroy(c->graph_exec);
@@ -1425,12 +1470,11 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             HIP_TRY(c, hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
             hipError_t e = hipSuccess;  // (the pose upload stays outside the graph: its source alternates)
             FrameView fv{c->ax, c->ay, c->az, nullptr};
+            if (n_split > 0) e = hipMemsetAsync(c->sq_count.p, 0, VELO_MAX_ITERS * sizeof(unsigned), s);
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
-                const Decomposition dc = decomposition_for(c, it, hint != nullptr, false);
-                e = launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv_read, c->poses.p,
-                                     dmax2, c->partials.p, nullptr, nullptr, hint, rho,
-                                     it == 0 ? nullptr : c->poses_prev.p,  // (first iteration: stale hints)
-                                     false, c->plan_lat ? 2 : 1, s, dc.lat_lanes);
+                const bool split = it < n_split;
+                const Decomposition dc = decomposition_for(c, split ? std::max(it, 1) : it, hint != nullptr, false);
+                e = launch_iteration(c, it, split, fv, dmax2, hint, rho, false, false, s);
                 if (e == hipSuccess)
                     e = launch_reduce_solve(c->partials.p, dc.fbs, dc.lay, c->n_frames, c->poses.p,
                                             c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
@@ -1461,14 +1505,13 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     FrameView fv{c->ax, c->ay, c->az, nullptr};
     if (int rc = maybe_sort_frames(c, fv)) return rc;
     // hints never outlive a registration: results do not depend on earlier calls
+    if (n_split > 0) HIP_TRY(c, hipMemsetAsync(c->sq_count.p, 0, VELO_MAX_ITERS * sizeof(unsigned), s));
     for (int it = 0; it < iters; ++it) {
-        const Decomposition dc = decomposition_for(c, it, hint != nullptr, fv.order != nullptr);
+        const bool split = it < n_split && fv.order == nullptr;
+        const Decomposition dc = decomposition_for(c, split ? std::max(it, 1) : it, hint != nullptr, fv.order != nullptr);
         {
-            Timed t(c, 0);
-            HIP_TRY(c, launch_linearize(c->cfg.linearize_variant, dc.items, dc.n, fv, c->mv_read,
-                                        c->poses.p, dmax2, c->partials.p, nullptr, nullptr, hint, rho,
-                                        it == 0 ? nullptr : c->poses_prev.p,  // (first iteration: stale hints)
-                                        c->stats_on, c->plan_lat ? 2 : 1, s, dc.lat_lanes));
+            Timed t(c, 0);   // (a split iteration's three launches are ONE linearise step of the timing record)
+            HIP_TRY(c, launch_iteration(c, it, split, fv, dmax2, hint, rho, c->stats_on, fv.order != nullptr, s));
         }
         {
             Timed t(c, 1);
@@ -1608,6 +1651,8 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     c->cfg.struct_size = sizeof(velo_cfg);
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 64;
     if (c->cfg.plan_wave_slots > 0) c->wave_slots = c->cfg.plan_wave_slots;
+    if (const char* e = getenv("VELO_SPLIT_ITERS")) c->split_iters = std::max(0, std::min(atoi(e), VELO_MAX_ITERS));   // (A/B: 0 = never split)
+    if (const char* e = getenv("VELO_SPLIT_PER_WAVE_MAX")) c->split_per_wave_max = (unsigned)std::max(0, atoi(e));
     // 0 = the default (fast, pruned) kernel for every consumer -- C, C++ MapManager and Python
     // alike; the exhaustive validation kernel has to be asked for by name
     if (c->cfg.linearize_variant == 0) c->cfg.linearize_variant = VELO_VARIANT_BALL;
@@ -2413,7 +2458,8 @@ int velo_map_download(velo_ctx* c, float* x, float* y, float* z, float* nx, floa
             if (c->info.n_cells + 8 >= 2147483648ull)
                 return c->fail(VELO_E_RANGE, "the dense cell table of this map has more than 2^31 entries");
             HIP_TRY(c, c->cell_start.reserve(c->info.n_cells + 8));
-            HIP_TRY(c, launch_cell_start(c->keys_sorted.p, n, c->info.n_cells, c->cell_start.p, c->stream));
+            HIP_TRY(c, reserve_slack(c->tile_bounds, cell_start_bounds(c->info.n_cells)));
+            HIP_TRY(c, launch_cell_start(c->keys_sorted.p, n, c->info.n_cells, c->cell_start.p, c->tile_bounds.p, c->stream));
         }
         HIP_TRY(c, hipMemcpyAsync(cell_start, c->cell_start.p, (c->info.n_cells + 1) * sizeof(int32_t),
                                   hipMemcpyDeviceToHost, c->stream));

@@ -1024,13 +1024,18 @@ union LinLds {  // the search ranges and the reduction tile are never live toget
 // issue and occupancy: 72 registers, 7 waves per SIMD).  LAT = true: the latency kernel (a
 // single frame: < 2 workgroups per CU, bound by dependent memory round trips: registers are
 // free, stage B is the packed / probed form above).  Same results bit for bit.
-template <bool WRITE_CORR, int VARIANT, bool STATS, bool LAT, bool HASH, int NT>
+// SEARCH_ONLY (round 5, the split iteration): phase A of an iteration cut in three launches -- certificate test and
+// stage A exactly as below, the outcome of every query that is final written to hint / rho (what the full kernel
+// would store), every straggler appended to the launch-wide queue sq (k_search_b searches those: one wavefront
+// each, or packed 64 to a wavefront), no residual, no sums.  The third launch is this kernel in its ordinary form
+// with poses_prev == poses: every query then finds its own certified result and only gathers.
+template <bool WRITE_CORR, int VARIANT, bool STATS, bool LAT, bool HASH, int NT, bool SEARCH_ONLY = false>
 __device__ __forceinline__ void linearize_body(
     const BlockItem* __restrict__ items, const FrameView& fv, const MapView& mv,
     const double* __restrict__ poses, float dmax2, double* __restrict__ partials,
     int32_t* __restrict__ corr, float* __restrict__ d2out, int32_t* __restrict__ hint,
     float* __restrict__ rho, const double* __restrict__ poses_prev, LinLds* s_uw, double (*s_run)[2][64],
-    int lat_lanes = 64)
+    int lat_lanes = 64, int4* __restrict__ sq = nullptr, unsigned* __restrict__ sq_count = nullptr)
 {
     const BlockItem it = items[blockIdx.x];
     const double* __restrict__ T = poses + 12 * (size_t)it.frame;
@@ -1140,6 +1145,24 @@ __device__ __forceinline__ void linearize_body(
                     const float rs = d1 + kCertSlack;
                     ub0 = fminf(ub0, rs * rs * 1.00001f);
                 }
+                // A query found WITHOUT a match at exactly this position (rho < 0: written by the search that found
+                // nothing within d_max among its candidates) is without one still: the split iteration's third launch
+                // meets every such query again at the very pose it was searched at -- they are the costliest searches
+                // of a launch (a ball one voxel wide) and come in runs along a scan line, one wavefront's worth.
+                // Only for an unmoved query: with d_max = h the radius such a search covers is no larger than d_max.
+                if (hj < 0 && rho && hint && poses_prev) {
+                    const float rho_in = rho[uq];
+                    tl.addq(4);
+                    if (rho_in < 0.0f) {
+                        double cx, cy, cz;
+                        xform(poses_prev + 12 * (size_t)it.frame, sxq, syq, szq, cx, cy, cz);
+                        if (qx == (float)cx && qy == (float)cy && qz == (float)cz) {
+                            certified = true;  // (bd = INFINITY, bj = -1: no pair)
+                            rho_new_out = rho_in;
+                            state_same = true;
+                        }
+                    }
+                }
                 VELO_COUNT(1, certified);
                 if (!certified) {
                     const QueryCell g = locate(mv, qx, qy, qz);
@@ -1160,6 +1183,26 @@ __device__ __forceinline__ void linearize_body(
             VELO_COUNT(4, live && st == kFinal);
             queued = st == kStraggler;
             if (queued) rho_new_out = 0.0f;
+            if constexpr (SEARCH_ONLY) {
+                if (live && !queued) {
+                    const bool ok = (bj >= 0) && (bd <= dmax2);
+                    if (!(state_same && (ok || bj < 0))) {
+                        hint[uq] = ok ? bj : -1;
+                        rho[uq] = rho_new_out;
+                    }
+                }
+                const unsigned long long qm = __ballot(queued);
+                if (qm) {  // one atomic per wavefront-round; the order of the queue does not matter (one slot per query)
+                    const int leader = __ffsll((long long)qm) - 1;
+                    unsigned base = 0;
+                    if (lane == leader) base = atomicAdd(sq_count, (unsigned)__popcll(qm));
+                    base = __shfl(base, leader, 64);
+                    if (queued)
+                        sq[base + (unsigned)__popcll(qm & ((1ull << lane) - 1ull))] =
+                            make_int4((int)uq, it.frame | (bj < 0 ? (int)0x40000000 : 0), __float_as_int(bd), 0);
+                }
+                continue;  // (next round of this wavefront)
+            }
             unsigned long long need = __ballot(queued);
             VELO_COUNT(0, live);
             VELO_COUNT(6, queued);
@@ -1221,8 +1264,8 @@ __device__ __forceinline__ void linearize_body(
         bool contributes = false;
         if (live) {
             const bool ok = (bj >= 0) && (bd <= dmax2);
-            // (a certified, unmoved query with a still-valid match keeps its state: no stores)
-            if (!(state_same && ok)) {
+            // (a certified, unmoved query with a still-valid match -- or still without one -- keeps its state: no stores)
+            if (!(state_same && (ok || bj < 0))) {
                 if (hint) hint[uq] = ok ? bj : -1;
                 if (VARIANT >= 1 && rho) rho[uq] = rho_new_out;
                 tl.addq((hint ? 4 : 0) + ((VARIANT >= 1 && rho) ? 4 : 0));
@@ -1313,6 +1356,7 @@ __device__ __forceinline__ void linearize_body(
         rounds_done = rr + 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    if constexpr (SEARCH_ONLY) return;
     double colsum = 0.0;
     if (col < kAccN && rounds_done > 0) {
         colsum = s_run[wave][0][lane];
@@ -1362,6 +1406,130 @@ __global__ __launch_bounds__(kLinThreads, 4) void k_linearize_lat(
     __shared__ double s_run[kLinThreads / 64][2][64];
     linearize_body<WRITE_CORR, 1, STATS, true, HASH, kLinThreads>(items, fv, mv, poses, dmax2, partials, corr,
                                                                   d2out, hint, rho, poses_prev, s_uw, s_run, lat_lanes);
+}
+
+// ---- the split iteration (round 5): phase A = the search of every query up to and including stage A, phase B = the
+// stragglers of the whole launch, phase C = the ordinary kernel on certified hints (launch_linearize, poses_prev = poses)
+template <bool HASH>
+__global__ __launch_bounds__(kLinNT, VELO_LIN_WAVES) void k_search_a(
+    const BlockItem* __restrict__ items, FrameView fv, MapView mv, const double* __restrict__ poses, float dmax2,
+    int32_t* __restrict__ hint, float* __restrict__ rho, const double* __restrict__ poses_prev,
+    int4* __restrict__ sq, unsigned* __restrict__ sq_count)
+{
+    __shared__ LinLds s_uw[kLinNT / 64];
+    linearize_body<false, 1, false, false, HASH, kLinNT, true>(items, fv, mv, poses, dmax2, nullptr, nullptr, nullptr, hint,
+                                                                rho, poses_prev, s_uw, nullptr, 64, sq, sq_count);
+}
+template <bool HASH>
+__global__ __launch_bounds__(kLinThreads, 4) void k_search_a_lat(
+    const BlockItem* __restrict__ items, FrameView fv, MapView mv, const double* __restrict__ poses, float dmax2,
+    int32_t* __restrict__ hint, float* __restrict__ rho, const double* __restrict__ poses_prev, int lat_lanes,
+    int4* __restrict__ sq, unsigned* __restrict__ sq_count)
+{
+    __shared__ LinLds s_uw[kLinThreads / 64];
+    linearize_body<false, 1, false, true, HASH, kLinThreads, true>(items, fv, mv, poses, dmax2, nullptr, nullptr, nullptr,
+                                                                    hint, rho, poses_prev, s_uw, nullptr, lat_lanes, sq,
+                                                                    sq_count);
+}
+
+// phase B.  Few stragglers (a single frame: the chip is idle): ONE WAVEFRONT PER STRAGGLER, rows of its ball in
+// parallel over the lanes (search_ball_wave_lat) -- inside the full kernel a wavefront works its own stragglers off
+// one after the other while four fifths of the machine wait.  Many (a batch): 64 to a wavefront, per lane
+// (search_ball_lat) -- inside the full kernel a fifth of the lanes of every wavefront walk while the others idle.
+// Either way exact, either way a certificate is left behind (the forms differ in the radius they certify, never in
+// the winner).
+constexpr int kSearchBThreads = 256;
+template <bool HASH>
+__global__ __launch_bounds__(kSearchBThreads, 4) void k_search_b(
+    const int4* __restrict__ sq, const unsigned* __restrict__ sq_count, FrameView fv, MapView mv,
+    const double* __restrict__ poses, float dmax2, int32_t* __restrict__ hint, float* __restrict__ rho,
+    unsigned per_wave_max)
+{
+    __shared__ SearchLds s_l[kSearchBThreads / 64];
+    const unsigned n = *sq_count;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned wg = blockIdx.x * (kSearchBThreads / 64) + (unsigned)wave, nw = gridDim.x * (kSearchBThreads / 64);
+    Tally<false> tl;
+    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+    if (n <= per_wave_max) {
+        for (unsigned e = wg; e < n; e += nw) {
+            const int4 en = sq[e];
+            const unsigned uq = (unsigned)en.x;
+            const double* __restrict__ T = poses + 12 * (size_t)(en.y & 0x3fffffff);
+            double px, py, pz;
+            xform(T, fv.x[uq], fv.y[uq], fv.z[uq], px, py, pz);
+            const float qx = (float)px, qy = (float)py, qz = (float)pz;
+            // (as the cooperative branch of linearize_body: a little beyond the bound, never past one voxel)
+            const float rsq = bsqrt(__int_as_float(en.z)) + kCertSlack;
+            const float sub = fminf(rsq * rsq, mv.h * mv.h);
+            float rbd, rsd;
+            int rbj;
+            search_ball_wave_lat<false, HASH>(mv, qx, qy, qz, sub, lane, rbd, rbj, rsd, tl);
+            if (lane == 0) {
+                const bool ok = (rbj >= 0) && (rbd <= dmax2);
+                hint[uq] = ok ? rbj : -1;
+                // (nothing within the ball, and the ball was the whole d_max: "no match at this position", see linearize_body)
+                rho[uq] = rbj >= 0 ? fmaxf(fminf(bsqrt(rsd) * 0.999999f, mv.h - 2.0f * mg) - 1e-6f, 0.0f)
+                                   : (__int_as_float(en.z) >= dmax2 ? -1.0f : 0.0f);
+            }
+        }
+    } else {
+        for (unsigned b0 = wg * 64u; b0 < n; b0 += nw * 64u) {  // (uniform per wavefront)
+            const unsigned e = b0 + (unsigned)lane;
+            const bool active = e < n;
+            const int4 en = active ? sq[e] : make_int4(0, 0, 0, 0);
+            const unsigned uq = (unsigned)en.x;
+            float qx = 0.f, qy = 0.f, qz = 0.f;
+            if (active) {
+                const double* __restrict__ T = poses + 12 * (size_t)(en.y & 0x3fffffff);
+                double px, py, pz;
+                xform(T, fv.x[uq], fv.y[uq], fv.z[uq], px, py, pz);
+                qx = (float)px, qy = (float)py, qz = (float)pz;
+            }
+            float rbd = 0.0f, rcert = 0.0f;
+            int rbj = -1;
+            search_ball_lat<false, HASH>(mv, qx, qy, qz, active ? __int_as_float(en.z) : 0.0f, active,
+                                         active && (en.y & 0x40000000) != 0, s_l[wave], lane, rbd, rbj, rcert, tl);
+            if (active) {
+                const bool ok = (rbj >= 0) && (rbd <= dmax2);
+                hint[uq] = ok ? rbj : -1;
+                rho[uq] = rbj >= 0 ? rcert : (__int_as_float(en.z) >= dmax2 ? -1.0f : 0.0f);
+            }
+        }
+    }
+}
+
+hipError_t launch_search_split(const BlockItem* items, int n_items, const FrameView& fv, const MapView& mv,
+                               const double* poses, float dmax2, int32_t* hint, float* rho, const double* poses_prev,
+                               int force_kernel, int lat_lanes, int4* sq, unsigned* sq_count, unsigned per_wave_max,
+                               int grid_b, hipStream_t s)
+{
+    if (n_items == 0) return hipSuccess;
+    if (lat_lanes < 1 || lat_lanes > 64) lat_lanes = 64;
+    const bool lat = force_kernel == 2 || (force_kernel != 1 && n_items < kLatItems);
+    const bool hash = !mv.cell_start;
+    if (lat) {
+        if (hash)
+            hipLaunchKernelGGL((k_search_a_lat<true>), dim3(n_items), dim3(kLinThreads), 0, s, items, fv, mv, poses, dmax2,
+                               hint, rho, poses_prev, lat_lanes, sq, sq_count);
+        else
+            hipLaunchKernelGGL((k_search_a_lat<false>), dim3(n_items), dim3(kLinThreads), 0, s, items, fv, mv, poses, dmax2,
+                               hint, rho, poses_prev, lat_lanes, sq, sq_count);
+    } else {
+        if (hash)
+            hipLaunchKernelGGL((k_search_a<true>), dim3(n_items), dim3(kLinNT), 0, s, items, fv, mv, poses, dmax2, hint,
+                               rho, poses_prev, sq, sq_count);
+        else
+            hipLaunchKernelGGL((k_search_a<false>), dim3(n_items), dim3(kLinNT), 0, s, items, fv, mv, poses, dmax2, hint,
+                               rho, poses_prev, sq, sq_count);
+    }
+    if (hash)
+        hipLaunchKernelGGL((k_search_b<true>), dim3(grid_b), dim3(kSearchBThreads), 0, s, sq, sq_count, fv, mv, poses, dmax2,
+                           hint, rho, per_wave_max);
+    else
+        hipLaunchKernelGGL((k_search_b<false>), dim3(grid_b), dim3(kSearchBThreads), 0, s, sq, sq_count, fv, mv, poses, dmax2,
+                           hint, rho, per_wave_max);
+    return hipGetLastError();
 }
 
 hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s)

@@ -138,33 +138,30 @@ hipError_t launch_gather(const float* x, const float* y, const float* z, const u
 
 // -------------------------------------------------------------- cell table
 // cell_start[c] = number of sorted keys < c  (lower bound), c in [0, ncell]
-// One workgroup per tile of kCsTile consecutive entries: the first key at or beyond both ends of the tile is found
-// by a 256-ary search the whole workgroup takes part in (three rounds over 16 M keys), the tile's keys -- a few
-// hundred -- are staged in LDS, and every entry is a short binary search there.  (The per-entry binary search over
+// One workgroup per tile of kCsTile consecutive entries: the first key at or beyond every tile boundary comes from a
+// small kernel of its own (one thread per boundary), the tile's keys -- a few hundred -- are staged in LDS, and every
+// entry is a short binary search there.  (The per-entry binary search over
 // the whole key array this replaces ran 23 dependent global loads per entry: 1.5 ms on the stream's 78 M-entry
 // table, 0.2 TB/s; a re-anchoring roll pays it.)
 constexpr int kCsTile = 4096;
 constexpr int kCsCap = 4096;
-// number of keys < c, every thread of the 256-thread workgroup calling with the same c
-__device__ __forceinline__ size_t lower_bound_wg(const uint32_t* __restrict__ keys, size_t n, size_t c)
+// tb[t] = number of keys below entry t * kCsTile (t = 0 .. number of tiles): one thread per tile boundary
+__global__ __launch_bounds__(256) void k_cs_bounds(const uint32_t* __restrict__ keys, size_t n, size_t n_entries,
+                                                   uint32_t* __restrict__ tb, size_t n_bounds)
 {
-    size_t lo = 0, hi = n;  // the answer lies in [lo, hi]: keys[i] < c below lo, >= c from hi on
-    while (hi > lo) {
-        const size_t step = (hi - lo + 255) / 256;
-        const size_t idx = lo + (size_t)threadIdx.x * step;
-        const int below = __syncthreads_count(idx < hi && (size_t)keys[idx] < c);  // the probes are monotone
-        if (below == 0) {
-            hi = lo;
-        } else {
-            const size_t top = lo + (size_t)below * step;
-            lo = lo + (size_t)(below - 1) * step + 1;
-            hi = top < hi ? top : hi;
-        }
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_bounds) return;
+    const size_t c = min(t * (size_t)kCsTile, n_entries);
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) >> 1;
+        if ((size_t)keys[mid] < c) lo = mid + 1; else hi = mid;
     }
-    return lo;
+    tb[t] = (uint32_t)lo;
 }
 __global__ __launch_bounds__(256) void k_cell_start(const uint32_t* __restrict__ keys, size_t n,
-                                                    size_t ncell, int32_t* __restrict__ cell_start)
+                                                    size_t ncell, int32_t* __restrict__ cell_start,
+                                                    const uint32_t* __restrict__ tb)
 {
     __shared__ uint32_t s_keys[kCsCap];
     const size_t n_entries = ncell + 1;
@@ -172,8 +169,7 @@ __global__ __launch_bounds__(256) void k_cell_start(const uint32_t* __restrict__
     for (size_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const size_t c0 = tile * kCsTile;
         const size_t c1 = c0 + kCsTile < n_entries ? c0 + kCsTile : n_entries;
-        const size_t a = lower_bound_wg(keys, n, c0);
-        const size_t b = lower_bound_wg(keys, n, c1);  // keys [a, b) are the tile's
+        const size_t a = tb[tile], b = tb[tile + 1];  // keys [a, b) are the tile's
         const size_t cnt = b - a;
         const bool staged = cnt <= (size_t)kCsCap;
         if (staged)
@@ -251,13 +247,18 @@ hipError_t launch_hash_build(const uint32_t* sorted_keys, size_t n, int4* hash, 
     return hipGetLastError();
 }
 
+size_t cell_start_bounds(size_t ncell) { return (ncell + 1 + kCsTile - 1) / kCsTile + 1; }
+
 hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell,
-                             int32_t* cell_start, hipStream_t s)
+                             int32_t* cell_start, uint32_t* tile_scratch, hipStream_t s)
 {
-    size_t g = (ncell + 1 + kCsTile - 1) / kCsTile;
+    const size_t nb = cell_start_bounds(ncell);
+    hipLaunchKernelGGL(k_cs_bounds, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, sorted_keys, n, ncell + 1,
+                       tile_scratch, nb);
+    size_t g = nb - 1;
     int grid = (int)(g > 16384 ? 16384 : g);
     hipLaunchKernelGGL(k_cell_start, dim3(grid), dim3(256), 0, s, sorted_keys, n, ncell,
-                       cell_start);
+                       cell_start, tile_scratch);
     return hipGetLastError();
 }
 
@@ -460,7 +461,7 @@ __device__ __forceinline__ bool near_changed(const MapView& mv, const float4& p,
 #define VELO_NRM_SUBSET_WAVES 4  // wavefronts per SIMD the register allocation aims at (3 = 133 VGPRs as the compiler chooses freely)
 #endif
 template <int KMAX>
-__global__ __launch_bounds__(kNrmThreads) __attribute__((amdgpu_waves_per_eu(VELO_NRM_SUBSET_WAVES, VELO_NRM_SUBSET_WAVES))) void k_normals_subset(
+__global__ __launch_bounds__(kNrmThreads) __attribute__((amdgpu_waves_per_eu(KMAX <= 16 ? VELO_NRM_SUBSET_WAVES : 2, KMAX <= 16 ? VELO_NRM_SUBSET_WAVES : 3))) void k_normals_subset(
     MapView mv, const uint32_t* __restrict__ perm, int k, const int32_t* __restrict__ work,
     int n_work, const unsigned* __restrict__ n_work_dev, const uint32_t* __restrict__ chg, uint32_t n_chg,
     float4* __restrict__ nrm, unsigned long long* __restrict__ invalid, unsigned* __restrict__ n_done)

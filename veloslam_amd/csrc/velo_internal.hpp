@@ -95,8 +95,10 @@ hipError_t sort_pairs64(void* temp, size_t& temp_bytes, const uint64_t* k_in, ui
                         const uint32_t* v_in, uint32_t* v_out, size_t n, hipStream_t s);
 hipError_t launch_gather(const float* x, const float* y, const float* z, const uint32_t* perm,
                          size_t n, float4* pts, hipStream_t s);
+// (tile_scratch: cell_start_bounds(ncell) words, filled by the call)
+size_t cell_start_bounds(size_t ncell);
 hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell,
-                             int32_t* cell_start, hipStream_t s);
+                             int32_t* cell_start, uint32_t* tile_scratch, hipStream_t s);
 // sparse table: number of occupied fine cells, then the hash itself (cap slots)
 hipError_t launch_count_runs(const uint32_t* sorted_keys, size_t n, unsigned long long* d_count, hipStream_t s);
 hipError_t launch_hash_build(const uint32_t* sorted_keys, size_t n, int4* hash, uint32_t cap, hipStream_t s);
@@ -183,6 +185,13 @@ hipError_t launch_linearize(int variant, const BlockItem* items, int n_items, co
                             const MapView& mv, const double* poses, float dmax2, double* partials,
                             int32_t* corr, float* d2, int32_t* hint, float* rho,
                             const double* poses_prev, bool stats, int force_kernel, hipStream_t s, int lat_lanes = 64);
+// the split iteration (kernels/icp.hip): phase A (certificate test + stage A of every query, stragglers to the queue
+// sq, *sq_count of them) and phase B (the queue: one wavefront per straggler up to per_wave_max of them, 64 per
+// wavefront beyond) of an iteration whose third launch is launch_linearize with poses_prev == poses
+hipError_t launch_search_split(const BlockItem* items, int n_items, const FrameView& fv, const MapView& mv,
+                               const double* poses, float dmax2, int32_t* hint, float* rho, const double* poses_prev,
+                               int force_kernel, int lat_lanes, int4* sq, unsigned* sq_count, unsigned per_wave_max,
+                               int grid_b, hipStream_t s);
 hipError_t read_lin_stats(unsigned long long out[16], bool reset, hipStream_t s);
 // How the rows of one frame tile its canonical summation tree (kernels/icp.hip, k_reduce_solve): `head` rows
 // of the small size, `nbig` rows 2^mlog times as large, small rows to the end; nslots = the frame's length in
