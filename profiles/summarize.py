@@ -189,7 +189,9 @@ srd, swr, sdur = by_kernel("stream_rdreq"), by_kernel("stream_write"), trace_dur
 
 
 def family(k):
-    for pat, fam in (("k_linearize", "registration (k_linearize_lat)"), ("k_reduce_solve", "registration (k_reduce_solve)"),
+    for pat, fam in (("k_linearize", "registration (k_linearize_lat)"), ("k_search_a", "registration (split first iteration: k_search_a / _b)"),
+                     ("k_search_b", "registration (split first iteration: k_search_a / _b)"), ("k_reduce_solve", "registration (k_reduce_solve)"),
+                     ("k_tile_", "roll: fine table"), ("k_cs_bounds", "roll: fine table"), ("k_cell_start", "roll: fine table"),
                      ("k_decode", "decode"), ("k_key_starts", "decode"), ("k_compensate", "decode"),
                      ("k_increment", "increment"), ("k_normals", "roll: normals"),
                      ("k_merge", "roll: merge / compact"), ("k_compact", "roll: merge / compact"), ("k_keep", "roll: merge / compact"),

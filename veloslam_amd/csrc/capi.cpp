@@ -151,7 +151,7 @@ struct velo_ctx {
     DevBuf<int4> sq;                // the split iteration's straggler queue (one slot per query) ...
     DevBuf<unsigned> sq_count;      // ... and its length, one counter per iteration of a registration
     int split_iters = 1;            // iterations 0 .. split_iters - 1 run as three launches (VELO_SPLIT_ITERS)
-    unsigned split_per_wave_max = 24576;  // stragglers up to which phase B gives each a wavefront of its own
+    unsigned split_per_wave_max = 131072;  // stragglers up to which phase B gives each a wavefront of its own (a latency-path launch: two or three frames at most)
     DevBuf<uint8_t> vox_near_alt;
     bool overlap_update = false;        // inside velo_map_roll_overlapped
     DevBuf<int32_t> knn_idx, knn_cnt;   // velo_knn: device-side results before the copy back
