@@ -42,6 +42,18 @@ cp gpurun_out/pmc_knn_$R.txt profiles/$R/pmc_knn_sq.txt 2>/dev/null
 # the driver's exact command under the kernel trace (what the judge re-derives the launch times from)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err
 
+# round 5, second session: what a roll costs and where (the numbers DESIGN 4 / the notebook quote)
+mkdir -p profiles/$R
+{ echo "== C++ host (tools/stream_driver), 400 timed frames, 3 runs per lead"; LEADS="0 2 4 6 8" bash tools/lead_ab.sh 2>&1 | grep "^lead" | cut -c1-200;
+  echo "== Python host (bench.py --workload stream --drive), 300 timed frames, 2 runs per lead"; LEADS="0 4 6" bash tools/lead_ab_py.sh 2>&1 | grep "^py lead"; } > profiles/$R/roll_lead_ab_final.txt
+bash tools/margin_ab.sh 2>&1 | grep "^margin" > profiles/$R/margin_ab.txt
+bash tools/split_ab.sh 2>&1 | grep "VELO_SPLIT" > profiles/$R/split_iteration_ab.txt
+LEADS="4 0" STEPS=300 DRV_TIMEOUT=60 bash tools/per_frame.sh 2>&1 | cut -c1-260 > profiles/$R/per_frame_summary.txt
+cp gpurun_out/per_frame_lead4.txt profiles/$R/per_frame_lead4.txt 2>/dev/null
+VELO_TRACE_ROLL=1 timeout 60 tools/stream_driver $D --steps 130 --warmup 20 2>&1 | grep "roll_begin\|evict:" > profiles/$R/roll_begin_host.txt
+bash tools/ab_stream_modes.sh 2>&1 | grep "stream\|median" > profiles/$R/stream_in_process_vs_own.txt
+timeout 900 python3 -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > profiles/$R/gpu_suite.txt
+
 # the raw CSVs are > 64 MiB (more than gpurun carries back): summarise HERE, keep the summaries
 python3 profiles/summarize.py $R > $OUT/summarize.log 2>&1
 mkdir -p gpurun_out/summary_$R
