@@ -43,7 +43,7 @@ struct MapStats {
     uint64_t full_builds = 0;        // velo_map_reset: first ROI, or voxel / k changed, or nothing could be kept
     uint64_t rolls = 0;              // ROI changes applied incrementally (evict + append entering tiles)
     uint64_t rolls_ahead = 0;        // ... of which beside the previous frame's registration (rollAhead)
-    uint64_t rolls_refused = 0;      // rollAhead attempts the library refused (re-anchor needed): done by the plain roll
+    uint64_t rolls_refused = 0;      // rollAhead / rollBegin attempts the library refused (a hashed table, a map without normals: since round 5 a re-anchor is not one): done by the plain roll
     uint64_t rolls_begun = 0;        // ... begun several frames ahead (rollBegin) and published when due
     uint64_t tiles_entered = 0, tiles_left = 0;
     uint64_t points_uploaded = 0;    // host tile points sent to the device by rolls
@@ -134,7 +134,7 @@ private:
     bool dirty_;                   // host tiles changed behind the device map's back: rebuild
     bool haveDevice_;
     int res_i0_, res_i1_, res_j0_, res_j1_;  // resident tile index range (inclusive)
-    // the rectangle the library last refused to roll to ahead of time (a re-anchor: only the plain roll does it), from
+    // the rectangle the library last refused to roll to ahead of time (until round 5: every re-anchor), from
     // the resident rectangle it was refused at -- asked again at every frame until it is due, each attempt gathered
     // the entering tiles and walked their points before hearing the same answer (0.2 - 0.8 ms, four times per re-anchor)
     bool refused_ = false;

@@ -1332,7 +1332,7 @@ def test_map_rolled_beside_a_registration_equals_the_plain_roll():
     one it has with nothing beside it -- it saw the map as it was; (b) the map afterwards is the map
     the plain velo_map_evict_outside + velo_map_append leave, bit for bit (sorted points, normals,
     permutation, fine table, counts); (c) the next registration, on the new map, agrees too; (d) an
-    update that needs a re-anchor (or a larger table) is refused with VELO_E_AGAIN and changes nothing."""
+    update that needs a re-anchor (or a larger table) goes through as well (round 5: rebuilt into the other copies)."""
     from veloslam_amd import synth
     sc = synth.Scene()
     wx, wy, wz = sc.sample_map(900_000)
@@ -1358,11 +1358,14 @@ def test_map_rolled_beside_a_registration_equals_the_plain_roll():
             c.frames_upload([(cx, cy, cz)])
         T0 = f["T0"].reshape(1, 12)
 
-        def same():
+        def same(update=1):
             a, b = A.map_download(), B.map_download()
             ia, ib = A.map_info(), B.map_info()
             assert ia.n_points == ib.n_points and list(ia.dims) == list(ib.dims) and list(ia.origin) == list(ib.origin)
-            assert ia.n_invalid_normals == ib.n_invalid_normals and ia.last_update == ib.last_update == 1
+            assert ia.n_invalid_normals == ib.n_invalid_normals
+            # (last_update says HOW the update was applied: a grid grown beside a registration is a rebuild on the same
+            #  grid, 0, where the plain call re-encodes in place, 1 -- the maps are the same)
+            assert update is None or ia.last_update == ib.last_update == update
             for k in ("cell_start", "perm", "x", "y", "z"):
                 assert np.array_equal(a[k], b[k]), k
             for k in ("nx", "ny", "nz"):
@@ -1393,30 +1396,41 @@ def test_map_rolled_beside_a_registration_equals_the_plain_roll():
             res, x0 = (res & new) | entering, x1
             with pytest.raises(capi.VeloError):
                 A.map_roll_overlapped(lo, hi, wx[:3], wy[:3], wz[:3])          # no registration in flight
-        # (d) points far below the origin need a re-anchor: refused, nothing changed
+        # (d) round 5: an update that needs the grid RE-ANCHORED (points below the origin), GROWN (points beyond the
+        # dims) or re-anchored by the eviction itself (the lowest survivor far above the origin) goes through beside a
+        # registration too -- rebuilt into the other copies of the arrays and of the table -- and leaves what the plain
+        # calls leave, bit for bit; the registration in flight reads the map as it was
+        def beside(lo_, hi_, pts, update):
+            A.icp_batch_start(T0, 6, 1.0)
+            assert A.map_roll_overlapped(lo_, hi_, *pts)
+            ra = A.icp_batch_finish()[0]
+            rb = B.icp_batch(T0, 6, 1.0)[0]
+            if lo_ is not None:
+                B.map_evict_outside(lo_, hi_)
+            if pts[0].size:
+                B.map_append(*pts)
+            assert list(ra.T) == list(rb.T) and [ra.iter[i].n_pairs for i in range(6)] == [rb.iter[i].n_pairs for i in range(6)]
+            same(update)
+            na, nb = A.icp_batch(T0, 6, 1.0)[0], B.icp_batch(T0, 6, 1.0)[0]   # on the updated map
+            assert list(na.T) == list(nb.T)
+
         mi = A.map_info()
         low = (np.full(5, mi.origin[0] - 40.0, np.float32), np.full(5, mi.origin[1] - 40.0, np.float32), np.zeros(5, np.float32))
-        before = A.map_download()
-        A.icp_batch_start(T0, 3, 1.0)
-        assert A.map_roll_overlapped(None, None, *low) is False
-        A.icp_batch_finish()
-        after = A.map_download()
-        assert A.map_info().n_points == mi.n_points and all(np.array_equal(before[k], after[k]) for k in ("x", "cell_start", "perm"))
-        # (e) ADVICE r3: the refusal holds for the PAIR -- an eviction that would go through together with
-        # entering points that need a re-anchor (or a larger table) must leave the map as it was (the
-        # eviction used to publish its map before the append found out)
-        lo_e = np.array([x0 - half + 7.0, py - half, -big], np.float32)         # would evict a 7 m strip
-        hi_e = np.array([x0 + half, py + half, big], np.float32)
+        beside(None, None, low, 0)                                              # below the origin: re-anchor
+        mi = A.map_info()
         far = (np.full(5, mi.origin[0] + (mi.dims[0] + 3) * 1.0, np.float32), np.full(5, py, np.float32), np.zeros(5, np.float32))
-        for pts in (low, far):                                                  # below the origin / beyond the dims
-            A.icp_batch_start(T0, 3, 1.0)
-            assert A.map_roll_overlapped(lo_e, hi_e, *pts) is False
-            A.icp_batch_finish()
-            assert A.map_info().n_points == mi.n_points
-            again = A.map_download()
-            assert all(np.array_equal(before[k], again[k]) for k in ("x", "cell_start", "perm"))
-        A.map_append(*low)                                                      # the plain call does it
-        assert A.map_info().n_points == mi.n_points + 5 and A.map_info().last_update == 0
+        beside(None, None, far, None)                                           # beyond the dims: the grid grows in place
+        # ADVICE r3's pair, now the other way round: an eviction together with entering points that need a re-anchor
+        lo_e = np.array([x0 - half + 7.0, py - half, -big], np.float32)         # evicts a 7 m strip (and the five low / far points)
+        hi_e = np.array([x0 + half, py + half, big], np.float32)
+        mi = A.map_info()
+        low2 = (np.full(5, x0 - half + 7.5, np.float32), np.full(5, py, np.float32), np.full(5, mi.origin[2] - 30.0, np.float32))
+        beside(lo_e, hi_e, low2, None)
+        # ... and an eviction that re-anchors by itself: everything below x0 + 10 goes, the lowest survivor is then
+        # some 50 voxels above the origin (2 * margin + 2 = 34)
+        lo_f = np.array([x0 + 10.0, py - half, -big], np.float32)
+        empty = (np.empty(0, np.float32),) * 3
+        beside(lo_f, hi_e, empty, 0)
     finally:
         A.close()
         B.close()
@@ -1628,7 +1642,7 @@ def test_map_roll_begun_ahead_and_published_later_equals_the_plain_roll():
     publish give the results they have on the map BEFORE the roll -- bit for bit those of a ctx that has not rolled
     yet; (b) after the publish the map is what the plain velo_map_evict_outside + velo_map_append leave, bit for
     bit, counts included, and the next registration agrees; (c) a second begin before the publish is refused, a
-    plain map operation publishes first, a roll that needs a re-anchor is refused and changes nothing."""
+    plain map operation publishes first, a roll that needs a re-anchor is begun ahead like any other."""
     from veloslam_amd import synth
     sc = synth.Scene()
     wx, wy, wz = sc.sample_map(900_000)
@@ -1700,17 +1714,40 @@ def test_map_roll_begun_ahead_and_published_later_equals_the_plain_roll():
             na, nb = A.icp_batch(T0, 8, 1.0)[0], B.icp_batch(T0, 8, 1.0)[0]   # on the rolled map
             assert sig(na) == sig(nb)
             res, x0 = (res & new) | entering, x1
-        # a roll that needs a re-anchor: refused, nothing changed, nothing left to publish
+        # round 5: a roll that needs a RE-ANCHOR is begun ahead like any other (rebuilt into the other copies): the
+        # registrations in between read the map as it was, the published map is the plain calls' bit for bit
         mi = A.map_info()
         low = (np.full(5, mi.origin[0] - 40.0, np.float32), np.full(5, mi.origin[1] - 40.0, np.float32), np.zeros(5, np.float32))
-        before = A.map_download()
-        A.icp_batch_start(T0, 3, 1.0)
-        assert A.map_roll_begin(None, None, *low) is False
-        A.icp_batch_finish()
-        A.map_roll_publish()
-        after = A.map_download()
-        for k in before:
-            assert np.array_equal(before[k].view(np.uint8), after[k].view(np.uint8)), k
+        lo_f = np.array([x0 + 10.0, py - half, -big], np.float32)               # an eviction that re-anchors by itself
+        hi_f = np.array([x0 + half, py + half, big], np.float32)
+        empty = (np.empty(0, np.float32),) * 3
+        for lo_, hi_, pts in ((None, None, low), (lo_f, hi_f, empty)):
+            n_old = A.map_info().n_points
+            A.icp_batch_start(T0, 8, 1.0)
+            assert A.map_roll_begin(lo_, hi_, *pts)
+            ra = [A.icp_batch_finish()[0]]
+            for T in (T1, T0):
+                A.icp_batch_start(T, 8, 1.0)
+                ra.append(A.icp_batch_finish()[0])
+            rb = [B.icp_batch(T, 8, 1.0)[0] for T in (T0, T1, T0)]
+            for a, b in zip(ra, rb):
+                assert sig(a) == sig(b)
+            assert B.map_info().n_points == n_old
+            A.map_roll_publish()
+            if lo_ is not None:
+                B.map_evict_outside(lo_, hi_)
+            if pts[0].size:
+                B.map_append(*pts)
+            a, b = A.map_download(), B.map_download()
+            ia, ib = A.map_info(), B.map_info()
+            assert ia.n_points == ib.n_points and list(ia.dims) == list(ib.dims) and list(ia.origin) == list(ib.origin)
+            assert ia.n_invalid_normals == ib.n_invalid_normals and ia.last_update == ib.last_update == 0
+            for k in ("cell_start", "perm", "x", "y", "z"):
+                assert np.array_equal(a[k], b[k]), k
+            for k in ("nx", "ny", "nz"):
+                assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+            na, nb = A.icp_batch(T0, 8, 1.0)[0], B.icp_batch(T0, 8, 1.0)[0]
+            assert sig(na) == sig(nb)
     finally:
         A.close()
         B.close()

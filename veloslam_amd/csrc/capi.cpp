@@ -549,7 +549,14 @@ int build_table(velo_ctx* c, MapView& mv, const uint32_t* keys_sorted, size_t n,
 {
     hipStream_t s = c->stream;
     if (!c->use_hash) {
-        if (ncell + 8 > c->cell_start.cap) HIP_TRY(c, hipStreamSynchronize(s));  // queued readers
+        if (c->overlap_update && c->overlap_done == 0) {
+            // a rebuild beside a registration (a re-anchoring roll begun ahead): the registration reads cell_start --
+            // the new table goes into the other copy, as the incremental updates' shift / remap do
+            std::swap(c->cell_start.p, c->cell_start_alt.p);
+            std::swap(c->cell_start.cap, c->cell_start_alt.cap);
+        } else if (ncell + 8 > c->cell_start.cap) {
+            HIP_TRY(c, hipStreamSynchronize(s));  // queued readers
+        }
         // +1 entry, padded: rows are read 4 entries at a time; with slack, because a rolling map's
         // grid grows a margin at a time and a fresh 0.3-0.6 GB allocation costs milliseconds
         HIP_TRY(c, reserve_slack(c->cell_start, ncell + 8));
@@ -637,6 +644,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
     HIP_TRY(c, reserve_slack(c->idx, n));
     HIP_TRY(c, reserve_slack(c->perm, n));
     if (carry) {  // build into the second set of arrays: the old points are still needed
+        overlap_rotate_alt(c);  // (beside a registration, second update of the call: the third set)
         HIP_TRY(c, reserve_slack(c->pts_alt, n));
         HIP_TRY(c, reserve_slack(c->nrm_alt, n));
     } else {
@@ -693,8 +701,13 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
                                              mv, c->dirty.p, s));
         if (int rc = refresh_dirty_normals(c, mv, k_normals, nullptr, 0)) return rc;
         HIP_TRY(c, launch_count_invalid(c->nrm.p, (uint32_t)n, c->invalid_cnt.p, s));
-        HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        if (c->defer_counts) {   // (a roll begun ahead: the counts arrive in pinned memory, nobody waits here)
+            HIP_TRY(c, hipMemcpyAsync(&c->h_roll->invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
+            c->roll_counts_pending = true;
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(&invalid, c->invalid_cnt.p, sizeof invalid, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+        }
         return txn.done(publish_map(c, mv, k_normals, invalid, 0, c->n_done_host));
     }
     if (k_normals > 0) {
@@ -770,9 +783,10 @@ int stage_raw(velo_ctx* c, const float* x, const float* y, const float* z, size_
 
 // Append raw points [n_old, n_old+m) (already staged) without re-sorting the map.  Returns
 // 1 if the grid cannot be kept (caller does the full, re-anchoring rebuild), 0 when done.
-int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
+int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done, int* grown_dims = nullptr)
 {
     *done = 0;
+    if (grown_dims) grown_dims[0] = grown_dims[1] = grown_dims[2] = 0;
     hipStream_t s = c->stream;
     const MapView old = c->mv;
     const int k = c->info.k_normals;
@@ -818,9 +832,13 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done)
     g.fz = dims[2] * S;
     const size_t ncell = (size_t)g.fx * g.fy * g.fz;
     const size_t total = n_old + m;
-    if (c->overlap_update && (grew || c->use_hash || c->cfg.map_full_rebuild))
-        return VELO_OK;  // (done == 0.  A grown table could be built into the other copy -- tried: both copies
-                         //  then outgrow their allocations in turn, and the replay loses 20 %; refused instead)
+    if (c->overlap_update && (grew || c->use_hash || c->cfg.map_full_rebuild)) {
+        // (done == 0.  A grown grid beside a registration: the caller rebuilds on THIS grid -- same origin, grown dims --
+        //  into the other copies, which is what the in-place re-encoding below leaves, bit for bit)
+        if (grew && grown_dims)
+            for (int a = 0; a < 3; ++a) grown_dims[a] = dims[a];
+        return VELO_OK;
+    }
     if (c->cfg.map_full_rebuild) {  // A/B switch: same grid, everything recomputed
         *done = 1;
         return rebuild_map(c, old.h, k, org, dims);
@@ -1854,18 +1872,20 @@ static int map_append_impl(velo_ctx* c, const float* x, const float* y, const fl
         if (int rc = settle_roll(c)) return rc;
     const size_t n_old = c->raw_n;
     if (int rc = stage_raw(c, x, y, z, n, dev, true)) return rc;
-    int done = 0;
-    if (int rc = append_incremental(c, n_old, n, &done)) {
+    int done = 0, grown[3] = {0, 0, 0};
+    if (int rc = append_incremental(c, n_old, n, &done, grown)) {
         c->raw_n = n_old;  // refused: the map is unchanged
         return rc;
     }
     if (done) return VELO_OK;
-    if (c->overlap_update) {  // a re-anchor rewrites what the running registration reads: not here
+    const int k = c->info.k_normals;
+    // beside a registration the rebuild needs the carried normals (it then writes the other copies of everything the
+    // registration reads); without them, with the A/B switch or a hashed table it is refused, nothing changed
+    if (c->overlap_update && (k <= 0 || c->cfg.map_full_rebuild || c->use_hash)) {
         c->raw_n = n_old;
         return VELO_E_AGAIN;
     }
     // re-anchor: new origin, full re-sort; the normals of the old points travel with them
-    const int k = c->info.k_normals;
     if (k > 0 && !c->cfg.map_full_rebuild) {
         hipStream_t s = c->stream;
         HIP_TRY(c, reserve_slack(c->nrm_raw, n_old + n));
@@ -1873,7 +1893,13 @@ static int map_append_impl(velo_ctx* c, const float* x, const float* y, const fl
                                           c->nrm_raw.p, s));
         HIP_TRY(c, launch_fill_fresh(c->nrm_raw.p + n_old, (uint32_t)n, s));
         CarryNormals cr;
-        int rc = rebuild_map(c, c->info.voxel, k, nullptr, nullptr, &cr);
+        int rc;
+        if (grown[0] > 0) {  // (beside a registration only: the grid keeps its origin and grows, see append_incremental)
+            const float org[3] = {c->mv.ox, c->mv.oy, c->mv.oz};
+            rc = rebuild_map(c, c->info.voxel, k, org, grown, &cr);
+        } else {
+            rc = rebuild_map(c, c->info.voxel, k, nullptr, nullptr, &cr);
+        }
         if (rc) c->raw_n = n_old;
         return rc;
     }
@@ -2049,8 +2075,11 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
         std::swap(c->raw_z.p, c->raw_z2.p);
         std::swap(c->raw_z.cap, c->raw_z2.cap);
     };
-    if (c->overlap_update && (anchor || c->cfg.map_full_rebuild || c->use_hash))
-        return VELO_E_AGAIN;  // a rebuild rewrites what the running registration reads: not here (nothing changed yet)
+    // beside a registration: the re-anchoring rebuild goes into the other copies of the arrays and of the table (round 5:
+    // rebuild_map / build_table), like an incremental update; what is still refused -- before anything changed -- is a
+    // rebuild in place (A/B switch), a hashed table, a map without normals (its rebuild rewrites pts / nrm in place)
+    if (c->overlap_update && (c->cfg.map_full_rebuild || c->use_hash || (anchor && k <= 0)))
+        return VELO_E_AGAIN;
     if (anchor || c->cfg.map_full_rebuild) {
         CarryNormals cr;
         const bool carry = anchor && k > 0 && !c->cfg.map_full_rebuild;
@@ -2214,9 +2243,11 @@ static int roll_precheck(velo_ctx* c, const char* who, const float lo[3], const 
         const float org[3] = {c->mv.ox, c->mv.oy, c->mv.oz};
         const int dims[3] = {c->mv.nx, c->mv.ny, c->mv.nz};
         for (int a = 0; a < 3; ++a) {
-            // (the same float expressions append_incremental decides with)
+            // (the same float expressions append_incremental decides with.  With normals to carry a re-anchor or a
+            //  grown grid is built into the other copies beside the registration; without them it is refused here)
             const float ext = floorf((mx[a] - org[a]) * c->mv.inv_h);
-            if (mn[a] < org[a] || !(ext < 2.0e9f) || (int)ext + 1 > dims[a])
+            if (!(ext < 2.0e9f)) return c->fail(VELO_E_RANGE, "map extent / voxel too large");
+            if ((mn[a] < org[a] || (int)ext + 1 > dims[a]) && c->info.k_normals <= 0)
                 return c->fail(VELO_E_AGAIN, "the entering points need the grid re-anchored or grown: not beside a registration");
         }
     }
