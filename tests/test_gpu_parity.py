@@ -609,6 +609,48 @@ def test_icp_pose_matches_oracle(ctx, omap, wl, comp):
     assert np.allclose(tr, list(res.TRdeg))
 
 
+def test_split_first_iteration_changes_nothing(omap, wl, comp, monkeypatch):
+    """Round 5: on the latency path the searching iterations run as three launches (k_search_a: certificate test +
+    stage A of every query; k_search_b: the launch's stragglers, one wavefront each; the ordinary kernel on certified
+    hints at the same pose).  Off, one, two or all iterations split -- and forced on the throughput kernel, with the
+    stragglers packed 64 to a wavefront: the same poses, pair counts and residuals to the last bit (and the
+    oracle's pose).  The frame is also registered against a map with a hole under a third of it: queries without
+    any match (the no-match certificate of the third launch)."""
+    def run(split, force, batch, pts, per_wave_max=None):
+        monkeypatch.setenv("VELO_SPLIT_ITERS", str(split))
+        if batch:
+            monkeypatch.setenv("VELO_SPLIT_BATCH", "1")
+        else:
+            monkeypatch.delenv("VELO_SPLIT_BATCH", raising=False)
+        if per_wave_max is None:
+            monkeypatch.delenv("VELO_SPLIT_PER_WAVE_MAX", raising=False)
+        else:
+            monkeypatch.setenv("VELO_SPLIT_PER_WAVE_MAX", str(per_wave_max))
+        c = capi.Context(0, max_batch=2, force_kernel=force)
+        try:
+            c.map_reset(*pts, 1.0, 16)
+            c.frames_upload([tuple(comp[0])])
+            r = c.icp_batch(wl["frames"][0]["T0"].reshape(1, 12), 12, 1.0)[0]
+            return list(r.T), [r.iter[i].n_pairs for i in range(12)], [r.iter[i].rmse for i in range(12)]
+        finally:
+            c.close()
+
+    mx, my, mz = wl["map"]
+    px = float(wl["frames"][0]["T_true"][3])
+    holed = tuple(a[(mx < px - 5.0) | (mx > px + 25.0)] for a in (mx, my, mz))
+    for pts in (wl["map"], holed):
+        base = run(0, capi.KERNEL_LATENCY, False, pts)
+        assert base == run(0, capi.KERNEL_THROUGHPUT, False, pts)
+        for split in (1, 2, 12):
+            assert run(split, capi.KERNEL_LATENCY, False, pts) == base
+        assert run(1, capi.KERNEL_LATENCY, False, pts, per_wave_max=0) == base      # phase B packed 64 to a wavefront
+        assert run(2, capi.KERNEL_THROUGHPUT, True, pts) == base                  # forced on the throughput kernel
+        assert run(1, capi.KERNEL_THROUGHPUT, True, pts, per_wave_max=0) == base
+    T_o, _, _ = omap.icp(*comp[0], wl["frames"][0]["T0"], 12, 1.0)
+    dp, dr = pose_delta(run(1, capi.KERNEL_LATENCY, False, wl["map"])[0], T_o)
+    assert dp <= POS_TOL and dr <= ROT_TOL
+
+
 def test_icp_batch_equals_single_and_is_deterministic(ctx, omap, wl, comp):
     ctx.map_reset(*wl["map"], 1.0, 16)
     T0 = np.stack([f["T0"] for f in wl["frames"]])

@@ -151,6 +151,7 @@ struct velo_ctx {
     DevBuf<int4> sq;                // the split iteration's straggler queue (one slot per query) ...
     DevBuf<unsigned> sq_count;      // ... and its length, one counter per iteration of a registration
     int split_iters = 1;            // iterations 0 .. split_iters - 1 run as three launches (VELO_SPLIT_ITERS)
+    bool split_batch = false;       // ... on the throughput path too (VELO_SPLIT_BATCH: measurements and tests)
     unsigned split_per_wave_max = 131072;  // stragglers up to which phase B gives each a wavefront of its own (a latency-path launch: two or three frames at most)
     DevBuf<uint8_t> vox_near_alt;
     bool overlap_update = false;        // inside velo_map_roll_overlapped
@@ -1441,7 +1442,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     // chip idles -- first launch of a single frame 70 -> 40 us); a batch fills the chip either way, and its stragglers
     // packed 64 to a wavefront walk for as long as the slowest of them (headline 339 -> 630 us, dense 363 -> 320:
     // profiles/r05/split_iteration_ab.txt).  VELO_SPLIT_BATCH=1 forces it there for measurements.
-    static const bool split_batch = getenv("VELO_SPLIT_BATCH") != nullptr;
+    const bool split_batch = c->split_batch;
     const int n_split = (hint && rho && c->cfg.linearize_variant == VELO_VARIANT_BALL && !c->stats_on && !c->cfg.sort_frames && n_all &&
                          (c->plan_lat || split_batch))
                             ? std::min(c->split_iters, iters) : 0;
@@ -1670,6 +1671,7 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 64;
     if (c->cfg.plan_wave_slots > 0) c->wave_slots = c->cfg.plan_wave_slots;
     if (const char* e = getenv("VELO_SPLIT_ITERS")) c->split_iters = std::max(0, std::min(atoi(e), VELO_MAX_ITERS));   // (A/B: 0 = never split)
+    c->split_batch = getenv("VELO_SPLIT_BATCH") != nullptr;
     if (const char* e = getenv("VELO_SPLIT_PER_WAVE_MAX")) c->split_per_wave_max = (unsigned)std::max(0, atoi(e));
     // 0 = the default (fast, pruned) kernel for every consumer -- C, C++ MapManager and Python
     // alike; the exhaustive validation kernel has to be asked for by name
