@@ -1900,7 +1900,15 @@ def main():
             sub("knn32_100m", lambda: knn_record(args, d, dev, local))
             src = d["stream_src"] if rank == 0 and F >= 24 else None
             if args.stream_policy == "tiles" and not args.stream_in_process:
-                sub("stream", lambda: stream_children(args, local))
+                def stream_own_process():
+                    try:
+                        return stream_children(args, local)
+                    except Exception as e:  # noqa: BLE001  (no child processes on this box: the in-process form, marked)
+                        sys.stderr.write("bench: stream in processes of its own failed (%r): replaying in-process\n" % (e,))
+                        rec = run_replay(args, dev, local, args.stream_steps, args.stream_warmup, d=synthetic_drive(args, dev, src))
+                        rec["process"] = "bench.py's own (the child processes failed: %s)" % (str(e)[:300],)
+                        return rec
+                sub("stream", stream_own_process)
             elif args.stream_policy == "tiles":
                 sub("stream", lambda: run_replay(args, dev, local, args.stream_steps, args.stream_warmup,
                                                  d=synthetic_drive(args, dev, src)))
