@@ -2,9 +2,8 @@
 // frames to the registration kernels through the C ABI.  Host-only
 // plumbing: no arithmetic beyond tile indexing lives here.
 #include <algorithm>
-#include <cmath>
-#include <cstdio>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
