@@ -83,7 +83,7 @@ def parse():
                     help="pending increment points that trigger a map append (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true", help="skip dense / single_frame / stream / incl_h2d")
-    ap.add_argument("--only", default="", help="comma list of sub-records to run (dense,single_frame,stream,incl_h2d,knn32_100m)")
+    ap.add_argument("--only", default="", help="comma list of sub-records to run (dense,single_frame,stream,stream_mapping,incl_h2d,knn32_100m)")
     ap.add_argument("--time-every", type=int, default=10,   # (two sampled steps in the driver's 20-step run: VERDICT r3 weak 9)
                     help="bracket the linearise launches with HIP events in every k-th timed step")
     ap.add_argument("--force-exchange", action="store_true",
@@ -110,6 +110,14 @@ def parse():
                     "drive.pcap, carposes.txt, db.xml, world.map) instead of the synthetic generator")
     ap.add_argument("--export-drive", default="", help="write the synthetic drive of the stream workload to this directory "
                     "(--stream-frames frames, --stream-map-points world points, --tile metres per tile) and exit")
+    ap.add_argument("--export-mapping-drive", default="", help="write a synthetic drive TO BE MAPPED (veloslam_amd/drive.py "
+                    "export_mapping_drive: --mapping-frames revolutions 1 m apart down synth.LongScene, no world.map) to this "
+                    "directory and exit")
+    ap.add_argument("--mapping-frames", type=int, default=648, help="stream_mapping: distinct frames of the drive (frame 0 seeds the map)")
+    ap.add_argument("--mapping-steps", type=int, default=600, help="stream_mapping: timed frames (SURVEY 8d config 3: 600)")
+    ap.add_argument("--mapping-warmup", type=int, default=40,
+                    help="stream_mapping: untimed frames first (the seed's neighbourhood fills up: the first frames accept "
+                         "10 000 points each, the steady state 2 000 - 3 000)")
     ap.add_argument("--tile", type=float, default=10.0, help="tile edge of the world map (m): --export-drive, stream record")
     ap.add_argument("--stream-policy", choices=["tiles", "radius"], default="tiles",
                     help="stream record: how the map rolls.  tiles (default) = what veloslam::MapManager does: the "
@@ -589,6 +597,67 @@ def stream_children(args, local):
     return rec
 
 
+def child_env(local):
+    """environment of a child process that measures on this rank's device: no launcher variables, no profiler"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    if "rocprof" in env.get("LD_PRELOAD", ""):
+        env["LD_PRELOAD"] = ":".join(v for v in env["LD_PRELOAD"].split(":") if v and "rocprof" not in v)
+        if not env["LD_PRELOAD"]:
+            env.pop("LD_PRELOAD")
+        for k in [k for k in env if k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER"))]:
+            env.pop(k)
+    if local:
+        vis = [v for v in env.get("HIP_VISIBLE_DEVICES", "").split(",") if v]
+        env["HIP_VISIBLE_DEVICES"] = vis[local] if local < len(vis) else str(local)
+    return env
+
+
+def stream_mapping_children(args, local):
+    """BASELINE configs[2] AS SLAM (README.md:25, MapManager.h:13,43): the device map starts from the
+    first frame of a drive and GROWS ONLY FROM ACCEPTED INCREMENTS -- every frame's increment (points that land in a map
+    cell with fewer than 3 points, inside the resident tile rectangle) goes into the host tiles and the device map; tiles
+    further than ROI_RANGE behind the car leave the device.  The drive (--mapping-frames revolutions 1 m apart down a
+    street longer than the drive, synth.LongScene) is exported by a child of this file and replayed by the C++ host
+    (tools/stream_driver --mapping: veloslam::HDLManager + MapManager over the C ABI) in a process of its own, once with
+    the increments integrated in pipeline (RegisterOptions::pipeline_increments) and once host-synchronously."""
+    import subprocess
+    import tempfile
+    env = child_env(local)
+    me = os.path.abspath(__file__)
+    drv = os.path.join(os.path.dirname(me), "tools", "stream_driver")
+    if not os.path.exists(drv):
+        raise RuntimeError("tools/stream_driver is not built (__graft_entry__.build())")
+    with tempfile.TemporaryDirectory() as td:
+        t0 = time.perf_counter()
+        ex = subprocess.run([sys.executable, me, "--export-mapping-drive", td, "--mapping-frames", str(args.mapping_frames),
+                             "--tile", str(args.tile), "--voxel", str(args.voxel), "--k-normals", str(args.k_normals)],
+                            capture_output=True, text=True, timeout=900, env=env)
+        if ex.returncode != 0:
+            raise RuntimeError("mapping drive export failed: " + ex.stderr[-1500:])
+        t_export = time.perf_counter() - t0
+        recs = {}
+        for name, extra in (("pipelined", []), ("synchronous", ["--no-pipeline"])):
+            cp = subprocess.run([drv, td, "--mapping", "--steps", str(args.mapping_steps), "--warmup", str(args.mapping_warmup),
+                                 "--threshold", "1"] + extra, capture_output=True, text=True, timeout=900, env=env)
+            if cp.returncode != 0:
+                raise RuntimeError("tools/stream_driver --mapping %s failed (%d): %s" % (name, cp.returncode, cp.stderr[-1500:]))
+            recs[name] = json.loads(cp.stdout.strip().splitlines()[-1])
+    rec = dict(recs["pipelined"])
+    rec["workload"] = ("BASELINE configs[2] as SLAM: HDL-64E packet stream of %d distinct frames 1 m apart down a %d m street "
+                       "(synth.LongScene), map seeded with frame 0 and grown ONLY from accepted increments (min_count 3, inside "
+                       "the resident tiles), tiles beyond ROI_RANGE %.0f m evicted to the host; per frame: decode + compensate + "
+                       "%d ICP iterations + increment + map update" % (args.mapping_frames, int(0.1 * 10 * args.mapping_frames + 150),
+                                                                        ROI_RANGE, args.iters))
+    rec["process"] = "own (child of bench.py)"
+    rec["export_s"] = t_export
+    rec["synchronous_integration"] = {k: recs["synchronous"][k] for k in (
+        "frames_per_s", "ms_per_frame", "increment_points_per_frame", "map_updates", "worst_pose_error_m",
+        "mean_pose_error_m", "map_points")}
+    return rec
+
+
 def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
     """`--workload stream --drive DIR`: a recorded drive (veloslam_amd/drive.py layout: pcap +
     carposes.txt + db.xml + world.map) replayed against a rolling map, the same loop
@@ -680,8 +749,10 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
         state["flush"] += 1
         return x, y, z, ti, tj
 
-    def flush():
+    def flush(timed=False):
         """... and back up for the points in resident tiles (MapManager::flushIncrements)"""
+        if state["staged"] is not None:   # (the append would publish the begun roll inside the library: keep the rectangle in step)
+            publish_begun(timed)
         x, y, z, ti, tj = take()
         cur = state["res"]
         if not x.size or cur is None:
@@ -714,6 +785,11 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
             publish_begun(timed)         # (or went elsewhere: published all the same, the plain roll goes on from it)
             cur = state["res"]
             if cur == rng:
+                # while a roll is begun the increments stay pending; the due frame is where none is begun: what has been
+                # collected meanwhile goes in now (MapManager::rollTo; ADVICE r5: a driver that begins the next roll in
+                # every frame would otherwise never flush)
+                if ctx.pending_count(False) >= max(args.append_threshold, 1):
+                    flush(timed)
                 return
         # increments accepted so far: to the host tiles now, and -- those in tiles that stay resident --
         # back up with the entering tiles in the roll's ONE append (MapManager::rollTo)
@@ -901,9 +977,10 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
         res = ctx.icp_batch_finish()[0]
         t.append(time.perf_counter())
         state["sub"].append(t[-1])
-        # (while a roll is begun the increments stay pending: a flush would publish it early)
+        # (while a roll is begun the increments stay pending: a flush would publish it early; they join the map in the
+        #  roll_to of the frame the roll is due at, MapManager::rollTo)
         if state["staged"] is None and ctx.pending_count(False) >= max(args.append_threshold, 1):
-            flush()
+            flush(timed)
         t.append(time.perf_counter())
         state["z"] = float(res.T[11])
         if timed and probe is not None and "poses" in probe:
@@ -934,7 +1011,7 @@ def run_replay(args, dev, local, steps, warmup, d=None, probe=None):
                               " ".join("%.3f" % (1e3 * (b - a)) for a, b in zip(sb[:-1], sb[1:]))))
     if state["staged"] is not None:
         publish_begun(True)
-    flush()
+    flush(True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -1497,6 +1574,12 @@ def main():
         emit({"exported": args.export_drive, "frames": meta["n_frames"], "world_points": meta["world_points"],
               "tiles": meta["tiles"]})
         return
+    if args.export_mapping_drive:
+        from veloslam_amd import drive
+        meta = drive.export_mapping_drive(args.export_mapping_drive, n_frames=args.mapping_frames, device=dev,
+                                          patch_range=args.tile, voxel=args.voxel, k_normals=args.k_normals)
+        emit({"exported": args.export_mapping_drive, "frames": meta["n_frames"], "scene_length_m": meta["scene_length"]})
+        return
     if args.workload == "stream":
         if world > 1:
             raise SystemExit("the stream workload is one sequence on one GPU (run N replicas for N GPUs)")
@@ -1915,6 +1998,7 @@ def main():
             else:
                 sub("stream", lambda: run_stream(args, dev, local, args.stream_steps, 10,
                                                  args.stream_map_points, args.stream_frames, src=src))
+            sub("stream_mapping", lambda: stream_mapping_children(args, local))
         emit(out)
         if rc:
             sys.stderr.write("bench: GPU pose differs from the CPU path beyond the north-star tolerance: %r\n"

@@ -233,7 +233,8 @@ int velo_map_roll_overlapped(velo_ctx*, const float lo[3], const float hi[3], co
                              const float* z, size_t n);
 /* The same roll BEGUN AHEAD of the frame that needs it.  The tile rectangle of a frame comes from the pose track
  * (ROI_RANGE, MapManager.h:13,43), so the host knows it frames before: velo_map_roll_begin -- called, like
- * velo_map_roll_overlapped, between velo_icp_batch_start and _finish -- waits once for the first count (points
+ * velo_map_roll_overlapped, between velo_icp_batch_start and _finish, or (round 6) with no registration outstanding at
+ * all: the registration started next, while the roll is begun, reads the map as it was -- waits once for the first count (points
  * kept and their bounds, ~0.2 ms) and enqueues the rest of the eviction and the append on a stream of its own
  * without waiting; the registrations that follow keep reading the map AS IT WAS.  velo_map_roll_publish, called at
  * the frame the new rectangle is due (outside a registration or inside one: the main stream waits on the
@@ -249,6 +250,9 @@ int velo_map_roll_publish(velo_ctx*);
  * Takes effect at the next (re-)anchoring: velo_map_reset, or the rules above. */
 int velo_map_set_margins(velo_ctx*, const int32_t margin[3]);
 int velo_map_info_get(velo_ctx*, velo_map_info* out);
+/* Points of the map as of the last update -- begun rolls included -- and nothing else: host arithmetic, never waits
+ * (velo_map_info_get waits for the normal counts of a roll begun ahead that is still running). */
+int velo_map_size(velo_ctx*, uint64_t* n_points);
 /* Test / inspection: copy the voxel-sorted map back.  Any pointer may be NULL.
  * perm[s] = index of sorted point s in append order; cell_start has n_cells+1 entries. */
 int velo_map_download(velo_ctx*, float* x, float* y, float* z, float* nx, float* ny, float* nz,

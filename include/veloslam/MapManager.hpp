@@ -36,6 +36,21 @@ struct RegisterOptions {
     // registerResident is called next (velo_icp_batch_start / _finish keep the result apart from that).
     // What it must not do is register, or change the map.
     std::function<void()> while_registering;
+    // ---- mapping (BASELINE configs[2] as SLAM: the map GROWS from the frames; README.md:25 "[ ] Implement various SLAM
+    // algorithms", MapManager.h:13,43) -- with integrate:
+    // increments_in_roi_only: an accepted point outside the resident tile rectangle is dropped instead of waiting in its
+    //   host tile (the device map holds nothing there, so EVERY frame would add its far returns to those tiles until they
+    //   enter: the min_count rule only works where the map is resident; the point is seen again from nearer).
+    // pipeline_increments: the previous frame's increment joins the device map BESIDE this frame's registration
+    //   (velo_map_roll_begin on the roll's own stream, published before this frame's increment is taken): a frame is
+    //   registered against the map up to the frame before last, its increment is computed against the map up to the last
+    //   frame.  The same roll moves the tile rectangle to the NEXT frame's prior when next_prior says where that is (the
+    //   pose track knows), so the rollTo of the next frame finds nothing to do.  Deterministic (nothing depends on how
+    //   far the GPU has got); tests/test_gpu_parity.py runs the same schedule on the oracle.
+    bool increments_in_roi_only = false;
+    bool pipeline_increments = false;
+    bool have_next_prior = false;
+    double next_prior_x = 0, next_prior_y = 0;
 };
 
 // what the device map has been through (rolling-map bookkeeping; diagnostic)
@@ -49,6 +64,9 @@ struct MapStats {
     uint64_t points_uploaded = 0;    // host tile points sent to the device by rolls
     uint64_t points_evicted = 0;
     uint64_t increment_flushes = 0, increment_points = 0;
+    uint64_t increment_dropped = 0;  // accepted points outside the resident rectangle (increments_in_roi_only)
+    uint64_t map_updates = 0;        // device-map updates that carried increments (appends, rolls with increments folded in)
+    uint64_t updates_beside = 0;     // ... of which beside a registration (pipeline_increments)
 };
 
 class MapManager {
@@ -102,6 +120,10 @@ public:
     // that lie in resident tiles (one velo_map_append).  A roll does not call this: it takes the list
     // and folds the points into the ONE append that brings the entering tiles up (rollTo).
     bool flushIncrements();
+    // Every point of `frame` (host points: HDLManager::prepareFrame), transformed by `pose` (fp64 fma chain, rounded once
+    // to float: the increment's arithmetic), into the host tiles: the SEED of a map that is then grown from accepted
+    // increments only (the first frame of a drive at its prior).  The device map is built from the tiles at the next roll.
+    bool seedFromFrame(const HDLFrame& frame, const PoseTransform& pose);
     const MapStats& stats() const { return stats_; }
     // f3: drop every tile whose centre is further than `radius` (+ half a tile diagonal) from
     // (x, y) -- the rolling-map policy behind ROI_RANGE; returns the number of points dropped
@@ -158,8 +180,15 @@ private:
     int residentK_;
     MapStats stats_;
     std::vector<float> stage_x_, stage_y_, stage_z_;
-    std::vector<float> pend_x_, pend_y_, pend_z_;  // increments taken off the device, not yet back on it
-    bool takeIncrements();  // device list -> pend_*_ and the host tiles; the list is emptied
+    std::vector<float> pend_x_, pend_y_, pend_z_;  // increments taken off the device (in the host tiles), not yet back on it
+    std::vector<float> take_x_, take_y_, take_z_;  // (staging of one take)
+    bool roiOnly_ = false;          // RegisterOptions::increments_in_roi_only of the last registration (flushIncrements)
+    bool publishOwed_ = false;      // updateBesideRegistration began a roll: published right behind the registration's start
+    bool forcePlainFlush_ = false;  // the update beside the last registration was refused: the next frame flushes plainly
+    bool takeIncrements(bool roi_only = false);  // device list -> appended to pend_*_ and the host tiles; the list is emptied
+    // pipeline_increments: takeIncrements + ONE roll begun and published beside the registration just started
+    bool updateBesideRegistration(const RegisterOptions& opts);
+    bool boxOf(int i0, int i1, int j0, int j1, float lo[3], float hi[3]) const;
     mutable std::string err_;
 };
 

@@ -23,7 +23,7 @@ def pytest_configure(config):
 # test (alphabetically early) kept all of the K1/K2/K3 parity tests from running on the driver's box.  GPU tests
 # run in this order; inside a file the written order stays.  Files not listed go last, CPU tests are untouched
 # (they keep their alphabetical order in front / between, whatever `-m` selects).
-_GPU_ORDER = ["test_gpu_parity", "test_golden_icp", "test_gpu_fuzz", "test_gpu_hash", "test_gpu_knn",
+_GPU_ORDER = ["test_gpu_parity", "test_gpu_mapping", "test_golden_icp", "test_gpu_fuzz", "test_gpu_hash", "test_gpu_knn",
               "test_gpu_batch_invariance", "test_gpu_sum_definition", "test_gpu_streams", "test_drive", "test_cpp_api", "test_gpu_comm", "test_bench_cli"]
 
 

@@ -21,6 +21,14 @@
 //   hipcc -std=c++17 -O2 -x c++ tools/stream_driver.cpp -Iinclude -Lveloslam_amd/csrc -lveloslam_amd \
 //         -Wl,-rpath,$PWD/veloslam_amd/csrc -o tools/stream_driver
 //   tools/stream_driver DIR [--steps 100] [--warmup 10] [--threshold 512] [--roll-lead 4] [--no-integrate] [--no-overlap] [--no-roll-ahead]
+//
+// --mapping: configs[2] as SLAM (README.md:25 "[ ] Implement various SLAM algorithms"; MapManager.h:13,43).  No world.map is
+// read: the map is SEEDED with the first frame at its prior and grows only from the accepted increments of the frames
+// registered against it (RegisterOptions::integrate, increments_in_roi_only); tiles further than ROI_RANGE behind the car
+// leave the device for the host tiles and come back when the car does.  By default the increments are integrated in
+// pipeline (RegisterOptions::pipeline_increments: frame k's increment joins the device map beside frame k + 1's
+// registration, together with the move of the tile rectangle to frame k + 2's prior); --no-pipeline integrates every
+// frame's increment before the next frame is registered (host-synchronous append).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -45,9 +53,9 @@ int main(int argc, char** argv)
     }
     const std::string dir = argv[1];
     int steps = 100, warmup = 10, threshold = 512, roll_lead = 4;
-    bool integrate = true, overlap = true, roll_ahead = true;
+    bool integrate = true, overlap = true, roll_ahead = true, mapping = false, pipeline = true;
     std::string per_frame;
-    int margin = -1;
+    int margin = -1, min_count = -1;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
@@ -57,6 +65,9 @@ int main(int argc, char** argv)
         else if (a == "--margin" && i + 1 < argc) margin = std::atoi(argv[++i]);  // grid slack in x / y, voxels (MapManager's default: 16)
         else if (a == "--per-frame" && i + 1 < argc) per_frame = argv[++i];  // per-frame wall time + what the map did, one line each
         else if (a == "--no-integrate") integrate = false;
+        else if (a == "--mapping") mapping = true;
+        else if (a == "--min-count" && i + 1 < argc) min_count = std::atoi(argv[++i]);  // a voxel accepts new points while it holds fewer (default 3; --mapping: 16)
+        else if (a == "--no-pipeline") pipeline = false;
         else if (a == "--no-overlap") overlap = false;
         else if (a == "--no-roll-ahead") roll_ahead = false;  // roll the map when the frame is due, not beside the previous registration  // decode every frame when it is due, not during the previous registration
     }
@@ -75,7 +86,7 @@ int main(int argc, char** argv)
         std::fprintf(stderr, "no context: %s\n", mgr.lastError());
         return 4;
     }
-    if (!mgr.load(dir + "/world.map")) {
+    if (!mapping && !mgr.load(dir + "/world.map")) {
         std::fprintf(stderr, "cannot load world.map: %s\n", mgr.lastError());
         return 3;
     }
@@ -100,12 +111,36 @@ int main(int argc, char** argv)
     opt.k_normals = k_normals;
     opt.integrate = integrate;
     opt.append_threshold = threshold;
+    if (min_count > 0) opt.increment_min_count = min_count;
+    else if (mapping) opt.increment_min_count = 16;   // (a map made of increments alone needs voxels dense enough for a normal: k = 16)
+    if (mapping) {
+        opt.increments_in_roi_only = true;
+        opt.pipeline_increments = pipeline;
+        if (pipeline) roll_ahead = false;   // (the pipelined update moves the tile rectangle itself, one frame ahead)
+        // the seed: frame 0's points at its prior without the perturbation (the pose track's x, y; z from truth.txt)
+        FrameRef f0 = hdl.prepareFrame(frames[0]);
+        if (!f0) {
+            std::fprintf(stderr, "cannot decode the seed frame: %s\n", hdl.lastError());
+            return 5;
+        }
+        PoseTransform seed;
+        seed.T[0] = f0->carpose->T[0], seed.T[1] = f0->carpose->T[1], seed.T[2] = z0;
+        if (!mgr.seedFromFrame(*f0, seed)) {
+            std::fprintf(stderr, "seed: %s\n", mgr.lastError());
+            return 5;
+        }
+    }
 
-    double z_prev = z0, worst = 0, t_decode = 0, t_register = 0;
+    if (std::getenv("VELO_TRACE_REGISTER"))
+        std::fprintf(stderr, "stream_driver: mapping %d pipeline %d min_count %d threshold %d roll_lead %d\n", (int)mapping, (int)opt.pipeline_increments,
+                     opt.increment_min_count, opt.append_threshold, roll_lead);
+    double err_vec[3] = {0, 0, 0};
+    double z_prev = z0, worst = 0, t_decode = 0, t_register = 0, err_sum = 0, err_last = 0;
     int prepared = -1;  // the frame resident in HBM already (decoded during the previous registration)
     uint64_t pairs = 0;
     const int period = std::max(2 * n_frames - 2, 1);
-    auto frame_at = [&](int k) { const int j = k % period; return j < n_frames ? j : period - j; };
+    // (mapping: frame 0 is the seed, the drive starts at frame 1)
+    auto frame_at = [&](int k) { const int j = (k + (mapping ? 1 : 0)) % period; return j < n_frames ? j : period - j; };
     int k_now = 0;   // play position of the frame being registered
     const int k_last = warmup + steps - 1;
     auto one = [&](int f, int f_next, bool timed) -> bool {
@@ -136,6 +171,12 @@ int main(int argc, char** argv)
                 }
                 t_next = ms_since(a0);
             };
+        opt.have_next_prior = false;
+        if (mapping && f_next >= 0) {   // where the NEXT frame's prior will be: the pipelined update rolls the tiles there
+            const PoseTransform& cn = *frames[(size_t)f_next]->carpose;
+            opt.have_next_prior = true;
+            opt.next_prior_x = cn.T[0] + 0.15, opt.next_prior_y = cn.T[1] - 0.10;
+        }
         const auto a = clk::now();
         if (prepared != f && !hdl.prepareResident(fr)) {
             std::fprintf(stderr, "frame %d: %s\n", f, hdl.lastError());
@@ -170,7 +211,10 @@ int main(int argc, char** argv)
             if ((size_t)f * 3 + 2 < truth.size()) {
                 const double dx = out.T[0] - truth[(size_t)f * 3], dy = out.T[1] - truth[(size_t)f * 3 + 1],
                              dz = out.T[2] - truth[(size_t)f * 3 + 2];
-                worst = std::max(worst, std::sqrt(dx * dx + dy * dy + dz * dz));
+                err_last = std::sqrt(dx * dx + dy * dy + dz * dz);
+                err_vec[0] = dx, err_vec[1] = dy, err_vec[2] = dz;
+                err_sum += err_last;
+                worst = std::max(worst, err_last);
             }
         }
         return true;
@@ -215,13 +259,20 @@ int main(int argc, char** argv)
     velo_map_info mi;
     mi.struct_size = sizeof mi;
     velo_map_info_get(ctx, &mi);
-    std::printf("{\"host\": \"C++ (include/veloslam/*.hpp)\", \"frames\": %d, \"frames_per_s\": %.2f, \"ms_per_frame\": %.4f, "
+    std::printf("{\"host\": \"C++ (include/veloslam/*.hpp)\", \"mode\": \"%s\", \"frames\": %d, \"distinct_frames\": %d, \"frames_per_s\": %.2f, \"ms_per_frame\": %.4f, "
+                "\"mean_pose_error_m\": %.6g, \"last_pose_error_m\": %.6g, \"last_pose_error_xyz_m\": [%.4g, %.4g, %.4g], \"increment_points_per_frame\": %.1f, \"map_updates\": %llu, "
+                "\"map_updates_beside_registration\": %llu, \"increment_points_dropped_outside_roi\": %llu, \"increment_min_count\": %d, "
                 "\"stage_ms_per_frame\": {\"decode\": %.4f, \"register_roll_icp_increment\": %.4f}, "
                 "\"pairs_per_s\": %.4g, \"worst_pose_error_m\": %.15g, \"map_points\": %llu, \"map_subdiv\": %d, "
                 "\"last_update\": %d, \"tile_edge_m\": %g, \"decode_planned_ahead\": %s, \"roll_ahead\": %s, "
                 "\"roll_lead\": %d, \"map\": {\"full_builds\": %llu, \"rolls\": %llu, \"rolls_ahead\": %llu, \"rolls_begun\": %llu, \"rolls_refused\": %llu, \"tiles_entered\": %llu, \"tiles_left\": %llu, "
                 "\"points_uploaded\": %llu, \"points_evicted\": %llu, \"increment_flushes\": %llu, \"increment_points\": %llu}}\n",
-                steps, 1e3 * steps / total_ms, total_ms / steps, t_decode / steps, t_register / steps,
+                mapping ? (pipeline ? "mapping, increments integrated in pipeline" : "mapping, increments integrated synchronously") : "localisation in a pre-mapped world",
+                steps, n_frames, 1e3 * steps / total_ms, total_ms / steps,
+                err_sum / std::max(steps, 1), err_last, err_vec[0], err_vec[1], err_vec[2], (double)(s1.increment_points - s0.increment_points) / std::max(steps, 1),
+                (unsigned long long)(s1.map_updates - s0.map_updates), (unsigned long long)(s1.updates_beside - s0.updates_beside),
+                (unsigned long long)(s1.increment_dropped - s0.increment_dropped), opt.increment_min_count,
+                t_decode / steps, t_register / steps,
                 (double)pairs / (total_ms * 1e-3), worst, (unsigned long long)mi.n_points, mi.subdiv, mi.last_update, patch, overlap ? "true" : "false", (overlap && roll_ahead) ? "true" : "false",
                 (overlap && roll_ahead) ? roll_lead : 0,
                 (unsigned long long)(s1.full_builds - s0.full_builds), (unsigned long long)(s1.rolls - s0.rolls),
@@ -232,5 +283,5 @@ int main(int argc, char** argv)
                 (unsigned long long)(s1.points_evicted - s0.points_evicted),
                 (unsigned long long)(s1.increment_flushes - s0.increment_flushes),
                 (unsigned long long)(s1.increment_points - s0.increment_points));
-    return worst > 0.05 ? 6 : 0;
+    return worst > (mapping ? 0.25 : 0.05) ? 6 : 0;   // (a map grown from its own registrations drifts: centimetres over hundreds of metres)
 }

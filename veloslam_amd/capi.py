@@ -102,7 +102,7 @@ class MapInfo(C.Structure):
 EXPORTS = [
     "velo_create", "velo_destroy", "velo_last_error", "velo_abi_version", "velo_cfg_get", "velo_set_stream",
     "velo_synchronize", "velo_map_reset", "velo_map_reset_dev", "velo_map_append",
-    "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_roll_overlapped", "velo_map_roll_begin", "velo_map_roll_publish", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_download", "velo_compensate",
+    "velo_map_append_dev", "velo_map_append_sparse", "velo_map_append_sparse_dev", "velo_map_evict_outside", "velo_map_roll_overlapped", "velo_map_roll_begin", "velo_map_roll_publish", "velo_map_evict_radius", "velo_map_set_margins", "velo_map_info_get", "velo_map_size", "velo_map_download", "velo_compensate",
     "velo_compensate_dev", "velo_icp", "velo_frames_upload", "velo_frames_adopt_dev",
     "velo_icp_batch", "velo_icp_batch_async", "velo_icp_batch_fetch", "velo_icp_batch_start", "velo_icp_batch_finish", "velo_linearize",
     "velo_linearize_hints", "velo_solve_update", "velo_knn", "velo_knn_dev", "velo_decode", "velo_decode_stream", "velo_decode_stream_reset", "velo_decode_set_options", "velo_decode_fetch", "velo_decode_to_frames", "velo_decode_plan_create", "velo_decode_plan_destroy", "velo_decode_plan_fill", "velo_decode_submit", "velo_decode_submit_overlapped", "velo_decode_plan_error", "velo_increment", "velo_increment_dev", "velo_increment_registered_async", "velo_increment_all_registered_async", "velo_increment_wait", "velo_increment_pending", "velo_pending_count", "velo_pending_fetch", "velo_map_append_pending", "velo_pending_clear", "velo_comm_unique_id", "velo_comm_init", "velo_comm_destroy", "velo_comm_info",
@@ -166,6 +166,7 @@ def lib():
     L.velo_set_stats.argtypes = [vp, C.c_int]
     L.velo_pairs_total.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.velo_map_info_get.argtypes = [vp, C.POINTER(MapInfo)]
+    L.velo_map_size.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.velo_map_download.argtypes = [vp] + [vp] * 8
     L.velo_compensate.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp]
     L.velo_compensate_dev.argtypes = L.velo_compensate.argtypes
@@ -569,6 +570,12 @@ class Context:
         mi.struct_size = C.sizeof(MapInfo)
         self._chk(lib().velo_map_info_get(self.h, C.byref(mi)))
         return mi
+
+    def map_size(self):
+        """points of the map as of the last update (begun rolls included); never waits"""
+        n = C.c_uint64()
+        self._chk(lib().velo_map_size(self.h, C.byref(n)))
+        return int(n.value)
 
     def map_download(self):
         mi = self.map_info()

@@ -268,6 +268,9 @@ struct velo_ctx {
     uint32_t* h_pend_total = nullptr;  // pinned: count of the increment in flight
     hipEvent_t ev_pend = nullptr;
     bool pend_outstanding = false;
+    hipStream_t copy_stream = nullptr;  // velo_pending_fetch: the list is complete once ev_pend has fired, its copy must
+    float* h_pend_stage = nullptr;      // not queue behind the registration the main stream is busy with (pinned staging)
+    size_t h_pend_stage_cap = 0;
     uint8_t* h_result = nullptr;      // pinned: poses + per-iteration statistics of a fetch
     int32_t* h_starts = nullptr;      // pinned: beam offsets of a decode
     size_t h_starts_cap = 0;
@@ -1375,7 +1378,12 @@ int upload_T0(velo_ctx* c, const double* T0, size_t pose_bytes)
 // against a different "previous pose": in that mode they are dropped instead.
 int forget_hints_for_linearize(velo_ctx* c, int32_t* hint, size_t n_all, hipStream_t s)
 {
-    if (c->lin_hints && hint) HIP_TRY(c, hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s));
+    if (c->lin_hints && hint) {
+        HIP_TRY(c, hipMemsetAsync(hint, 0xFF, n_all * sizeof(int32_t), s));
+        // ... and the certificates with them: rho < 0 at hint < 0 certifies "no match" for an unmoved query (the split
+        // first iteration writes those), whatever d_max the next call passes -- it covered this registration's only
+        if (c->rho.p && c->rho.cap >= n_all) HIP_TRY(c, hipMemsetAsync(c->rho.p, 0, n_all * sizeof(float), s));
+    }
     return VELO_OK;
 }
 
@@ -1726,6 +1734,8 @@ void velo_destroy(velo_ctx* c)
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_starts) (void)hipHostFree(c->h_starts);
     if (c->h_pend_total) (void)hipHostFree(c->h_pend_total);
+    if (c->h_pend_stage) (void)hipHostFree(c->h_pend_stage);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->ev_pend) (void)hipEventDestroy(c->ev_pend);
     if (c->ev_inc) (void)hipEventDestroy(c->ev_inc);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
@@ -2212,12 +2222,15 @@ static bool bounds_finite(const float* p, size_t n, float& lo_a, float& hi_a)
 }
 
 static int roll_precheck(velo_ctx* c, const char* who, const float lo[3], const float hi[3], const float* x,
-                         const float* y, const float* z, size_t n, float mn[3], float mx[3])
+                         const float* y, const float* z, size_t n, float mn[3], float mx[3], bool allow_idle = false)
 {
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "%s before velo_map_reset", who);
-    if (!c->res_pending)
+    // velo_map_roll_overlapped: beside ONE registration, between its start and its finish.  velo_map_roll_begin: there,
+    // or with no registration outstanding at all (round 6: the roll then starts before the next registration is even
+    // enqueued; that registration, started while the roll is begun, reads the map as it was and counts as the roll's)
+    if (!c->res_pending && !allow_idle)
         return c->fail(VELO_E_INVALID, "%s needs a registration started with velo_icp_batch_start and not yet finished", who);
-    if (c->roll_overlapped_done) return c->fail(VELO_E_INVALID, "one overlapped roll per registration");
+    if (c->res_pending && c->roll_overlapped_done) return c->fail(VELO_E_INVALID, "one overlapped roll per registration");
     if ((lo == nullptr) != (hi == nullptr)) return c->fail(VELO_E_INVALID, "lo and hi go together");
     if (n && (!x || !y || !z)) return c->fail(VELO_E_INVALID, "null point array");
     // "Refused before anything changed" has to hold for the PAIR: the eviction publishes its map
@@ -2329,7 +2342,7 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
     const auto tr0 = std::chrono::steady_clock::now();
     auto tr_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); };
     float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
-    if (int rc = roll_precheck(c, "velo_map_roll_begin", lo, hi, x, y, z, n, mn, mx)) return rc;
+    if (int rc = roll_precheck(c, "velo_map_roll_begin", lo, hi, x, y, z, n, mn, mx, true)) return rc;
     const double t_pre = tr_us();
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->roll_stream) {
@@ -2388,6 +2401,13 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
         pz = c->h_enter + 2 * n;
     }
     const double t_copy = tr_us();
+    if (!c->res_pending) {
+        // no registration outstanding: everything enqueued so far (the last frame's increment, which reads the arrays
+        // this roll's second update may rewrite) lies before this mark
+        if (!c->ev_mark) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->ev_mark, c->stream));
+        c->mark_valid = true;
+    }
     HIP_TRY(c, hipStreamWaitEvent(c->roll_stream, c->ev_mark, 0));
     c->roll_overlapped_done = true;
     const uint64_t n_before = c->info.n_points;
@@ -2454,6 +2474,14 @@ int velo_map_info_get(velo_ctx* c, velo_map_info* out)
     full.struct_size = (uint32_t)std::min<size_t>(have, sizeof full);
     full.reserved0 = 0;
     std::memcpy(out, &full, full.struct_size);
+    return VELO_OK;
+}
+
+int velo_map_size(velo_ctx* c, uint64_t* n_points)
+{
+    if (!c || !n_points) return VELO_E_INVALID;
+    if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map");
+    *n_points = c->info.n_points;
     return VELO_OK;
 }
 
@@ -2604,7 +2632,9 @@ int velo_icp_batch_start(velo_ctx* c, const double* T0, int iters, float d_max)
     if (!c->ev_mark) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev_mark, c->stream));
     c->mark_valid = true;
-    c->roll_overlapped_done = false;
+    // (a roll begun before this registration and not yet published is this registration's roll: the registration reads
+    //  the arrays the roll left behind, a second roll beside it would rewrite them)
+    c->roll_overlapped_done = c->roll_staged;
     if (int rc = run_icp(c, T0, iters, d_max)) return rc;
     if (int rc = enqueue_result_copies(c, c->n_frames)) return rc;
     if (!c->ev_res) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_res, hipEventDisableTiming));
@@ -3301,11 +3331,27 @@ int velo_pending_fetch(velo_ctx* c, float* x, float* y, float* z, size_t cap, si
     if (c->pend_n > cap) return c->fail(VELO_E_RANGE, "%zu pending points exceed the capacity %zu", c->pend_n, cap);
     if (c->pend_n == 0) return VELO_OK;
     if (!x || !y || !z) return c->fail(VELO_E_INVALID, "null output array");
-    hipStream_t s = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(x, c->pend_x.p, c->pend_n * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(y, c->pend_y.p, c->pend_n * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(z, c->pend_z.p, c->pend_n * sizeof(float), hipMemcpyDeviceToHost, s));
+    // Every entry of the list is complete (pending_resolve waited for the last increment's event): the copy runs on a
+    // stream of its own through pinned memory.  On the ctx stream it would wait for whatever was enqueued since -- a
+    // streaming host fetches frame k's increment while frame k + 1 registers (MapManager, pipelined integration).
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    const size_t n = c->pend_n;
+    if (c->h_pend_stage_cap < 3 * n) {
+        if (c->h_pend_stage) (void)hipHostFree(c->h_pend_stage);
+        c->h_pend_stage = nullptr;
+        c->h_pend_stage_cap = 0;
+        const size_t want = 3 * n + 3 * n / 2 + 4096;
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_pend_stage, want * sizeof(float), 0));
+        c->h_pend_stage_cap = want;
+    }
+    hipStream_t s = c->copy_stream;
+    HIP_TRY(c, hipMemcpyAsync(c->h_pend_stage, c->pend_x.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_pend_stage + n, c->pend_y.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_pend_stage + 2 * n, c->pend_z.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    std::memcpy(x, c->h_pend_stage, n * sizeof(float));
+    std::memcpy(y, c->h_pend_stage + n, n * sizeof(float));
+    std::memcpy(z, c->h_pend_stage + 2 * n, n * sizeof(float));
     return VELO_OK;
 }
 

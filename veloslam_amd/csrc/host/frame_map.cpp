@@ -303,8 +303,55 @@ std::vector<std::shared_ptr<MapPatch>> MapManager::tilesInRange(double x, double
 
 void MapManager::addPoints(const float* x, const float* y, const float* z, size_t n)
 {
-    for (size_t i = 0; i < n; ++i) getPatch(x[i], y[i])->append(x + i, y + i, z + i, 1);
+    // (consecutive points of a frame or of an increment mostly share a tile: one map lookup per run, not per point --
+    //  a frame's increment is thousands of points, every frame, on the host's critical path)
+    MapPatch* last = nullptr;
+    std::pair<int, int> last_idx{0, 0};
+    for (size_t i = 0; i < n; ++i) {
+        const auto idx = getPatchIdx(x[i], y[i]);
+        if (!last || idx != last_idx) {
+            last = getPatch(x[i], y[i]).get();
+            last_idx = idx;
+        }
+        last->x.push_back(x[i]);
+        last->y.push_back(y[i]);
+        last->z.push_back(z[i]);
+    }
     dirty_ = true;
+}
+
+bool MapManager::seedFromFrame(const HDLFrame& frame, const PoseTransform& pose)
+{
+    const size_t n = frame.numPoints();
+    if (n == 0) {
+        err_ = "seedFromFrame: the frame holds no points (HDLManager::prepareFrame first)";
+        return false;
+    }
+    const Affine3x4 T = pose.getMatrix();
+    const double* t = T.data();
+    std::vector<float> sx(n), sy(n), sz(n);
+    for (size_t i = 0; i < n; ++i) {
+        const double x = frame.x[i], y = frame.y[i], z = frame.z[i];
+        sx[i] = (float)std::fma(t[0], x, std::fma(t[1], y, std::fma(t[2], z, t[3])));
+        sy[i] = (float)std::fma(t[4], x, std::fma(t[5], y, std::fma(t[6], z, t[7])));
+        sz[i] = (float)std::fma(t[8], x, std::fma(t[9], y, std::fma(t[10], z, t[11])));
+    }
+    addPoints(sx.data(), sy.data(), sz.data(), n);
+    return true;
+}
+
+bool MapManager::boxOf(int i0, int i1, int j0, int j1, float lo[3], float hi[3]) const
+{
+    // keep region of a tile rectangle: closed box on float coordinates; a tile covers [c - r/2, c + r/2), so the upper
+    // edge is the largest float below it
+    const float big = 3.0e38f;
+    lo[0] = (float)(i0 * (double)patchRange_ - patchRange_ / 2.0);
+    lo[1] = (float)(j0 * (double)patchRange_ - patchRange_ / 2.0);
+    lo[2] = -big;
+    hi[0] = std::nextafter((float)(i1 * (double)patchRange_ + patchRange_ / 2.0), -big);
+    hi[1] = std::nextafter((float)(j1 * (double)patchRange_ + patchRange_ / 2.0), -big);
+    hi[2] = big;
+    return true;
 }
 
 size_t MapManager::numPoints() const
@@ -458,6 +505,14 @@ bool MapManager::enteringTilesHoldPoints(int i0, int i1, int j0, int j1) const
     return false;
 }
 
+// device points without waiting for anything (velo_map_info_get waits for the counts of a roll begun ahead)
+static uint64_t devicePoints(velo_ctx* ctx)
+{
+    uint64_t n = 0;
+    velo_map_size(ctx, &n);
+    return n;
+}
+
 bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
 {
     if (!ctx_) return false;
@@ -470,8 +525,17 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
     // is published all the same and the plain roll below goes on from its rectangle
     if (staged_) {
         if (!publishBegun()) return false;
-        if (haveDevice_ && !dirty_ && same_cfg && i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_)
+        if (haveDevice_ && !dirty_ && same_cfg && i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_) {
+            // While a roll is begun the increments stay pending (registerCore): with a driver that begins the next roll
+            // inside every frame's while_registering they would never reach the map.  The due frame is where
+            // no roll is begun: what has been collected meanwhile goes in now.
+            if (o.integrate) {
+                size_t pending = 0;
+                velo_pending_count(ctx_, &pending, 0);
+                if (pending + pend_x_.size() >= (size_t)std::max(o.append_threshold, 1) && !flushIncrements()) return false;
+            }
             return true;
+        }
     }
     auto gather = [&](int a0, int a1, int b0, int b1, bool only_new, size_t* tiles) {
         stage_x_.clear(), stage_y_.clear(), stage_z_.clear();
@@ -497,23 +561,25 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
     const auto tt0 = tclk::now();
     auto us_since = [&](tclk::time_point a) { return std::chrono::duration<double, std::micro>(tclk::now() - a).count(); };
     // (a roll that only evicts leaves the list pending: folding a dozen points into the map is a pass over all of
-    //  it -- 0.85 ms on the stream's 11 M points -- that the next flush or the next entering column does anyway)
-    pend_x_.clear(), pend_y_.clear(), pend_z_.clear();
-    const bool enters = !overlap || enteringTilesHoldPoints(i0, i1, j0, j1);
-    if (haveDevice_ && enters && !takeIncrements()) return false;
+    //  it -- 0.85 ms on the stream's 11 M points -- that the next flush or the next entering column does anyway.
+    //  pend_ = increments already in the host tiles and not yet on the device: they go up with whatever goes up)
+    const bool enters = !overlap || enteringTilesHoldPoints(i0, i1, j0, j1) || !pend_x_.empty();
+    if (haveDevice_ && enters && !takeIncrements(o.increments_in_roi_only)) return false;
     const double t_take = us_since(tt0);
+    auto keepPendInside = [&](int a0, int a1, int b0, int b1) {   // (what left with its tile waits there, in the host tile)
+        size_t w = 0;
+        for (size_t k = 0; k < pend_x_.size(); ++k) {
+            const auto t = getPatchIdx(pend_x_[k], pend_y_[k]);
+            if (t.first < a0 || t.first > a1 || t.second < b0 || t.second > b1) continue;
+            pend_x_[w] = pend_x_[k], pend_y_[w] = pend_y_[k], pend_z_[w] = pend_z_[k];
+            ++w;
+        }
+        pend_x_.resize(w), pend_y_.resize(w), pend_z_.resize(w);
+    };
     if (overlap) {
-        velo_map_info mi;
-        mi.struct_size = sizeof mi;
-        velo_map_info_get(ctx_, &mi);
-        const uint64_t n_before = mi.n_points;
-        // keep region: the new tile rectangle (closed box on float coordinates; a tile covers
-        // [c - r/2, c + r/2), so the upper edge is the largest float below it)
-        const float big = 3.0e38f;
-        const float lo[3] = {(float)(i0 * (double)patchRange_ - patchRange_ / 2.0),
-                             (float)(j0 * (double)patchRange_ - patchRange_ / 2.0), -big};
-        const float hi[3] = {std::nextafter((float)(i1 * (double)patchRange_ + patchRange_ / 2.0), -big),
-                             std::nextafter((float)(j1 * (double)patchRange_ + patchRange_ / 2.0), -big), big};
+        const uint64_t n_before = devicePoints(ctx_);
+        float lo[3], hi[3];
+        boxOf(i0, i1, j0, j1, lo, hi);
         bool kept_something = true;
         if ((i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_) && leavingTilesHoldPoints(i0, i1, j0, j1)) {
             const int rc = velo_map_evict_outside(ctx_, lo, hi);
@@ -526,12 +592,12 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
         }
         if (kept_something) {
             const double t_evict = us_since(tt0);
-            velo_map_info_get(ctx_, &mi);
-            stats_.points_evicted += n_before - mi.n_points;
+            stats_.points_evicted += n_before - devicePoints(ctx_);
             size_t tiles = 0;
             gather(i0, i1, j0, j1, true, &tiles);
             const double t_gather = us_since(tt0);
             const size_t n_tile_points = stage_x_.size();
+            size_t n_inc = 0;
             for (size_t k = 0; k < pend_x_.size(); ++k) {
                 // (entering tiles already hold their share: takeIncrements put it into the host tiles)
                 const auto t = getPatchIdx(pend_x_[k], pend_y_[k]);
@@ -539,11 +605,17 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
                                    t.second >= std::max(j0, res_j0_) && t.second <= std::min(j1, res_j1_);
                 if (!stays) continue;
                 stage_x_.push_back(pend_x_[k]), stage_y_.push_back(pend_y_[k]), stage_z_.push_back(pend_z_[k]);
+                ++n_inc;
             }
-            if (!stage_x_.empty() &&
-                velo_map_append(ctx_, stage_x_.data(), stage_y_.data(), stage_z_.data(), stage_x_.size())) {
-                err_ = velo_last_error(ctx_);
-                return false;
+            if (!stage_x_.empty()) {
+                if (velo_map_append(ctx_, stage_x_.data(), stage_y_.data(), stage_z_.data(), stage_x_.size())) {
+                    err_ = velo_last_error(ctx_);
+                    return false;
+                }
+                pend_x_.clear(), pend_y_.clear(), pend_z_.clear();   // (on the device now, or gone with a tile that left)
+                if (n_inc) ++stats_.map_updates;
+            } else {
+                keepPendInside(i0, i1, j0, j1);
             }
             if (trace_host)
                 std::fprintf(stderr, "rollTo: take %.0f us, evict %.0f, gather %.0f (%zu points), append %.0f\n", t_take, t_evict - t_take,
@@ -571,6 +643,7 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
         err_ = velo_last_error(ctx_);
         return false;
     }
+    pend_x_.clear(), pend_y_.clear(), pend_z_.clear();   // (the host tiles held them: they came up with the build)
     ++stats_.full_builds;
     stats_.points_uploaded += stage_x_.size();
     haveDevice_ = true;
@@ -583,7 +656,9 @@ bool MapManager::rollTo(double x, double y, const RegisterOptions& o)
 
 bool MapManager::rollAhead(double x, double y, const RegisterOptions& o)
 {
-    if (!ctx_ || !haveDevice_ || dirty_) return false;
+    // (a roll begun ahead and not yet published: velo_map_roll_overlapped would publish it inside the library and this
+    //  method would then work from the stale resident rectangle -- entering tiles appended twice)
+    if (!ctx_ || !haveDevice_ || dirty_ || staged_) return false;
     int i0, i1, j0, j1;
     tileRange(x, y, i0, i1, j0, j1);
     if (o.voxel != residentVoxel_ || o.k_normals != residentK_) return false;
@@ -605,24 +680,18 @@ bool MapManager::rollAhead(double x, double y, const RegisterOptions& o)
             ++tiles;
         }
     const bool evicts = (i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_) && leavingTilesHoldPoints(i0, i1, j0, j1);
-    const float big = 3.0e38f;
-    const float lo[3] = {(float)(i0 * (double)patchRange_ - patchRange_ / 2.0),
-                         (float)(j0 * (double)patchRange_ - patchRange_ / 2.0), -big};
-    const float hi[3] = {std::nextafter((float)(i1 * (double)patchRange_ + patchRange_ / 2.0), -big),
-                         std::nextafter((float)(j1 * (double)patchRange_ + patchRange_ / 2.0), -big), big};
-    velo_map_info mi;
-    mi.struct_size = sizeof mi;
-    velo_map_info_get(ctx_, &mi);
-    const uint64_t n_before = mi.n_points;
+    float lo[3], hi[3];
+    boxOf(i0, i1, j0, j1, lo, hi);
+    const uint64_t n_before = devicePoints(ctx_);
     const int rc = velo_map_roll_overlapped(ctx_, evicts ? lo : nullptr, evicts ? hi : nullptr, stage_x_.data(),
                                             stage_y_.data(), stage_z_.data(), stage_x_.size());
-    velo_map_info_get(ctx_, &mi);
+    const uint64_t n_after = devicePoints(ctx_);
     if (rc == VELO_E_AGAIN || rc == VELO_E_INVALID) {
         // refused: what the device holds no longer matches a tile rectangle for sure (an eviction may
         // have gone through) -- the plain roll rebuilds from the tiles
-        if (mi.n_points != n_before) dirty_ = true;
+        if (n_after != n_before) dirty_ = true;
         ++stats_.rolls_refused;
-        noteRefused(i0, i1, j0, j1);
+        if (rc == VELO_E_AGAIN) noteRefused(i0, i1, j0, j1);
         return false;
     }
     if (rc) {
@@ -630,7 +699,7 @@ bool MapManager::rollAhead(double x, double y, const RegisterOptions& o)
         dirty_ = true;
         return false;
     }
-    stats_.points_evicted += n_before + stage_x_.size() - mi.n_points;
+    stats_.points_evicted += n_before + stage_x_.size() - n_after;
     stats_.points_uploaded += stage_x_.size();
     stats_.tiles_entered += tiles;
     stats_.tiles_left += (uint64_t)std::max(0, (res_i1_ - res_i0_ + 1) * (res_j1_ - res_j0_ + 1) -
@@ -673,19 +742,18 @@ bool MapManager::rollBegin(double x, double y, const RegisterOptions& o)
             ++tiles;
         }
     const bool evicts = (i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_) && leavingTilesHoldPoints(i0, i1, j0, j1);
-    const float big = 3.0e38f;
-    const float lo[3] = {(float)(i0 * (double)patchRange_ - patchRange_ / 2.0),
-                         (float)(j0 * (double)patchRange_ - patchRange_ / 2.0), -big};
-    const float hi[3] = {std::nextafter((float)(i1 * (double)patchRange_ + patchRange_ / 2.0), -big),
-                         std::nextafter((float)(j1 * (double)patchRange_ + patchRange_ / 2.0), -big), big};
-    velo_map_info mi;
-    mi.struct_size = sizeof mi;
-    velo_map_info_get(ctx_, &mi);   // (before the begin: afterwards the call would wait for the roll's counts)
+    float lo[3], hi[3];
+    boxOf(i0, i1, j0, j1, lo, hi);
+    const uint64_t n_before = devicePoints(ctx_);
     const int rc = velo_map_roll_begin(ctx_, evicts ? lo : nullptr, evicts ? hi : nullptr, stage_x_.data(),
                                        stage_y_.data(), stage_z_.data(), stage_x_.size());
-    if (rc == VELO_E_AGAIN || rc == VELO_E_INVALID) {  // refused before anything changed: the plain roll does it when due
+    if (rc == VELO_E_AGAIN || rc == VELO_E_INVALID) {
+        // Refused.  Normally before anything changed (the plain roll does it when due) -- but the roll is an eviction
+        // FOLLOWED by an append, and the append can be refused after the eviction went into the library's map (a table
+        // that passes its limit with the entering points): the device then holds no tile rectangle any more
+        if (devicePoints(ctx_) != n_before) dirty_ = true;
         ++stats_.rolls_refused;
-        noteRefused(i0, i1, j0, j1);
+        if (rc == VELO_E_AGAIN) noteRefused(i0, i1, j0, j1);   // (E_INVALID: "one roll per registration" -- ask again next frame)
         return false;
     }
     if (rc) {
@@ -695,7 +763,7 @@ bool MapManager::rollBegin(double x, double y, const RegisterOptions& o)
     }
     staged_ = true;
     st_i0_ = i0, st_i1_ = i1, st_j0_ = j0, st_j1_ = j1;
-    st_n_before_ = mi.n_points;
+    st_n_before_ = n_before;
     st_n_in_ = stage_x_.size();
     stats_.points_uploaded += stage_x_.size();
     stats_.tiles_entered += tiles;
@@ -713,35 +781,57 @@ bool MapManager::publishBegun()
         dirty_ = true;
         return false;
     }
-    velo_map_info mi;
-    mi.struct_size = sizeof mi;
-    velo_map_info_get(ctx_, &mi);   // (n_points is host arithmetic; the normal counts wait for the roll -- begun frames ago)
-    stats_.points_evicted += st_n_before_ + st_n_in_ - mi.n_points;
+    // (host arithmetic inside the library: velo_map_info_get would wait for the roll's normal counts -- a host wait on
+    //  the very path the roll begun ahead exists to clear, whenever the roll is not through yet)
+    stats_.points_evicted += st_n_before_ + st_n_in_ - devicePoints(ctx_);
     ++stats_.rolls;
     ++stats_.rolls_ahead;
     ++stats_.rolls_begun;
     res_i0_ = st_i0_, res_i1_ = st_i1_, res_j0_ = st_j0_, res_j1_ = st_j1_;
     staged_ = false;
+    // what was taken off the device while the roll was begun and lies in a tile that left: it waits in its host tile
+    size_t w = 0;
+    for (size_t k = 0; k < pend_x_.size(); ++k) {
+        const auto t = getPatchIdx(pend_x_[k], pend_y_[k]);
+        if (t.first < res_i0_ || t.first > res_i1_ || t.second < res_j0_ || t.second > res_j1_) continue;
+        pend_x_[w] = pend_x_[k], pend_y_[w] = pend_y_[k], pend_z_[w] = pend_z_[k];
+        ++w;
+    }
+    pend_x_.resize(w), pend_y_.resize(w), pend_z_.resize(w);
     return true;
 }
 
-bool MapManager::takeIncrements()
+bool MapManager::takeIncrements(bool roi_only)
 {
     size_t n = 0;
     if (velo_pending_count(ctx_, &n, 1)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
-    pend_x_.resize(n), pend_y_.resize(n), pend_z_.resize(n);
     if (n == 0) return true;
-    if (velo_pending_fetch(ctx_, pend_x_.data(), pend_y_.data(), pend_z_.data(), n, &n) || velo_pending_clear(ctx_)) {
+    take_x_.resize(n), take_y_.resize(n), take_z_.resize(n);
+    if (velo_pending_fetch(ctx_, take_x_.data(), take_y_.data(), take_z_.data(), n, &n) || velo_pending_clear(ctx_)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
+    if (roi_only && haveDevice_) {   // what fell outside the resident rectangle is not integrated (RegisterOptions)
+        size_t w = 0;
+        for (size_t k = 0; k < n; ++k) {
+            const auto t = getPatchIdx(take_x_[k], take_y_[k]);
+            if (t.first < res_i0_ || t.first > res_i1_ || t.second < res_j0_ || t.second > res_j1_) continue;
+            take_x_[w] = take_x_[k], take_y_[w] = take_y_[k], take_z_[w] = take_z_[k];
+            ++w;
+        }
+        stats_.increment_dropped += n - w;
+        n = w;
+    }
     // the host tiles follow the device map (not the other way round: dirty_ stays as it was)
     const bool was_dirty = dirty_;
-    addPoints(pend_x_.data(), pend_y_.data(), pend_z_.data(), n);
+    addPoints(take_x_.data(), take_y_.data(), take_z_.data(), n);
     dirty_ = was_dirty;
+    pend_x_.insert(pend_x_.end(), take_x_.begin(), take_x_.begin() + (std::ptrdiff_t)n);
+    pend_y_.insert(pend_y_.end(), take_y_.begin(), take_y_.begin() + (std::ptrdiff_t)n);
+    pend_z_.insert(pend_z_.end(), take_z_.begin(), take_z_.begin() + (std::ptrdiff_t)n);
     ++stats_.increment_flushes;
     stats_.increment_points += n;
     return true;
@@ -753,7 +843,7 @@ bool MapManager::flushIncrements()
     // (an explicit flush while a roll is begun: the append below would publish it inside the library -- keep the
     //  resident rectangle in step)
     if (staged_ && !publishBegun()) return false;
-    if (!takeIncrements()) return false;
+    if (!takeIncrements(roiOnly_)) return false;
     if (pend_x_.empty() || !haveDevice_) return true;
     // back up: the points in resident tiles (anything else waits in its host tile until that tile enters)
     stage_x_.clear(), stage_y_.clear(), stage_z_.clear();
@@ -763,10 +853,102 @@ bool MapManager::flushIncrements()
         stage_x_.push_back(pend_x_[k]), stage_y_.push_back(pend_y_[k]), stage_z_.push_back(pend_z_[k]);
     }
     pend_x_.clear(), pend_y_.clear(), pend_z_.clear();
-    if (!stage_x_.empty() && velo_map_append(ctx_, stage_x_.data(), stage_y_.data(), stage_z_.data(), stage_x_.size())) {
+    if (!stage_x_.empty()) {
+        if (velo_map_append(ctx_, stage_x_.data(), stage_y_.data(), stage_z_.data(), stage_x_.size())) {
+            err_ = velo_last_error(ctx_);
+            return false;
+        }
+        ++stats_.map_updates;
+    }
+    return true;
+}
+
+// pipeline_increments: BEFORE velo_icp_batch_start (the publish follows it, registerCore).  The previous frame's increment is
+// complete on the device (it ran right behind that frame's registration): it comes down (copy stream: nothing queues
+// behind the registration just started), goes into the host tiles, and back up -- with the tiles that enter on the way
+// to the next frame's rectangle, after the eviction of those that leave -- as ONE roll on the roll's own stream,
+// beside the registration; the publish makes the main stream wait for it on the device, so the increment enqueued next
+// is computed against the updated map.  The host waits for nothing but an eviction's first count.
+bool MapManager::updateBesideRegistration(const RegisterOptions& o)
+{
+    if (staged_ && !publishBegun()) return false;
+    if (!takeIncrements(o.increments_in_roi_only)) return false;
+    int i0 = res_i0_, i1 = res_i1_, j0 = res_j0_, j1 = res_j1_;
+    if (o.have_next_prior) tileRange(o.next_prior_x, o.next_prior_y, i0, i1, j0, j1);
+    const bool moves = !(i0 == res_i0_ && i1 == res_i1_ && j0 == res_j0_ && j1 == res_j1_);
+    if (!moves && pend_x_.empty()) return true;
+    if (moves && !(i0 <= res_i1_ && i1 >= res_i0_ && j0 <= res_j1_ && j1 >= res_j0_)) return true;  // a jump: rollTo rebuilds
+    if (moves && refusedBefore(i0, i1, j0, j1)) {   // (the library said no to this move: the increments alone, the move when due)
+        i0 = res_i0_, i1 = res_i1_, j0 = res_j0_, j1 = res_j1_;
+        if (pend_x_.empty()) return true;
+    }
+    stage_x_.clear(), stage_y_.clear(), stage_z_.clear();
+    size_t tiles = 0;
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            if (i >= res_i0_ && i <= res_i1_ && j >= res_j0_ && j <= res_j1_) continue;
+            auto it = patches_.find({i, j});
+            if (it == patches_.end() || it->second->size() == 0) continue;
+            const MapPatch& p = *it->second;
+            stage_x_.insert(stage_x_.end(), p.x.begin(), p.x.end());
+            stage_y_.insert(stage_y_.end(), p.y.begin(), p.y.end());
+            stage_z_.insert(stage_z_.end(), p.z.begin(), p.z.end());
+            ++tiles;
+        }
+    const size_t n_tile_points = stage_x_.size();
+    size_t n_inc = 0;
+    for (size_t k = 0; k < pend_x_.size(); ++k) {   // (entering tiles hold their share already)
+        const auto t = getPatchIdx(pend_x_[k], pend_y_[k]);
+        const bool stays = t.first >= std::max(i0, res_i0_) && t.first <= std::min(i1, res_i1_) &&
+                           t.second >= std::max(j0, res_j0_) && t.second <= std::min(j1, res_j1_);
+        if (!stays) continue;
+        stage_x_.push_back(pend_x_[k]), stage_y_.push_back(pend_y_[k]), stage_z_.push_back(pend_z_[k]);
+        ++n_inc;
+    }
+    const bool shrinks = i0 > res_i0_ || i1 < res_i1_ || j0 > res_j0_ || j1 < res_j1_;
+    const bool evicts = shrinks && leavingTilesHoldPoints(i0, i1, j0, j1);
+    if (!evicts && stage_x_.empty()) {   // (only empty tiles changed hands)
+        res_i0_ = i0, res_i1_ = i1, res_j0_ = j0, res_j1_ = j1;
+        pend_x_.clear(), pend_y_.clear(), pend_z_.clear();
+        return true;
+    }
+    float lo[3], hi[3];
+    boxOf(i0, i1, j0, j1, lo, hi);
+    const uint64_t n_before = devicePoints(ctx_);
+    int rc = velo_map_roll_begin(ctx_, evicts ? lo : nullptr, evicts ? hi : nullptr, stage_x_.data(), stage_y_.data(),
+                                 stage_z_.data(), stage_x_.size());
+    if (rc == VELO_OK) publishOwed_ = true;   // (registerCore: right after velo_icp_batch_start)
+    if (rc == VELO_E_AGAIN || rc == VELO_E_INVALID) {
+        // not beside a registration (a hashed table, a map without normals whose grid would move ...): the increments
+        // stay in pend_ and the rectangle where it is -- the plain roll / flush of the next frame does both
+        if (devicePoints(ctx_) != n_before) dirty_ = true;
+        ++stats_.rolls_refused;
+        if (rc == VELO_E_AGAIN && moves) noteRefused(i0, i1, j0, j1);
+        forcePlainFlush_ = true;
+        return true;
+    }
+    if (rc) {
         err_ = velo_last_error(ctx_);
+        dirty_ = true;
         return false;
     }
+    const uint64_t n_after = devicePoints(ctx_);
+    stats_.points_evicted += n_before + stage_x_.size() - n_after;
+    stats_.points_uploaded += n_tile_points;
+    stats_.tiles_entered += tiles;
+    if (moves) {
+        stats_.tiles_left += (uint64_t)std::max(0, (res_i1_ - res_i0_ + 1) * (res_j1_ - res_j0_ + 1) -
+                                                       (std::min(i1, res_i1_) - std::max(i0, res_i0_) + 1) *
+                                                           (std::min(j1, res_j1_) - std::max(j0, res_j0_) + 1));
+        ++stats_.rolls;
+        ++stats_.rolls_ahead;
+    }
+    if (n_inc) {
+        ++stats_.map_updates;
+        ++stats_.updates_beside;
+    }
+    res_i0_ = i0, res_i1_ = i1, res_j0_ = j0, res_j1_ = j1;
+    pend_x_.clear(), pend_y_.clear(), pend_z_.clear();
     return true;
 }
 
@@ -777,23 +959,41 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
     using tclk = std::chrono::steady_clock;
     const auto tt0 = tclk::now();
     auto us_since = [&](tclk::time_point a) { return std::chrono::duration<double, std::micro>(tclk::now() - a).count(); };
+    roiOnly_ = o.increments_in_roi_only;
+    const bool pipelined = o.integrate && o.pipeline_increments;
     if (!rollTo(init.T[0], init.T[1], o)) return false;
+    if (forcePlainFlush_) {   // (the library refused the update beside the last registration: plainly, now)
+        forcePlainFlush_ = false;
+        if (!flushIncrements()) return false;
+    }
     const double t_roll = us_since(tt0);
     const Affine3x4 T0 = init.getMatrix();
     // one registration of the resident frames; the other frames of a multi-frame decode keep the
     // prior they are given here only if they are registered by their own call
     velo_icp_result local[4];
-    velo_cfg eff;
-    velo_cfg_get(ctx_, &eff);
     if (frame < 0 || frame >= 4) {
         err_ = "frame index out of range (the context holds up to 4 resident frames)";
         return false;
     }
     double T0s[4 * 12];
     for (int f = 0; f < 4; ++f) std::memcpy(T0s + 12 * f, T0.data(), sizeof(double) * 12);
+    // pipelined integration: the map update with the PREVIOUS frame's increment is begun first (the roll's own stream:
+    // it runs beside this registration, which is enqueued next and reads the map as it was) ...
+    if (pipelined && !updateBesideRegistration(o)) return false;
+    const double t_update = us_since(tt0);
     if (velo_icp_batch_start(ctx_, T0s, o.iters, o.d_max)) {
         err_ = velo_last_error(ctx_);
         return false;
+    }
+    // ... and published right behind the registration: the main stream waits for the roll ON THE DEVICE, whatever is
+    // enqueued from here on -- this frame's increment first of all -- sees the updated map
+    if (publishOwed_) {
+        publishOwed_ = false;
+        if (velo_map_roll_publish(ctx_)) {
+            err_ = velo_last_error(ctx_);
+            dirty_ = true;
+            return false;
+        }
     }
     // the accepted increment joins the device-side pending list at the pose the registration
     // leaves on the device: nothing is fetched, nothing blocks, so it is enqueued right behind
@@ -812,8 +1012,8 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
         return false;
     }
     if (trace_host && us_since(tt0) > 900.0)
-        std::fprintf(stderr, "registerCore: rollTo %.0f us, start+increment %.0f, while_registering %.0f, finish %.0f\n", t_roll,
-                     t_start - t_roll, t_while - t_start, us_since(tt0) - t_while);
+        std::fprintf(stderr, "registerCore: rollTo %.0f us, update begun %.0f, start + publish + increment %.0f, while_registering %.0f, finish %.0f\n",
+                     t_roll, t_update - t_roll, t_start - t_update, t_while - t_start, us_since(tt0) - t_while);
     const velo_icp_result& r = local[frame];
     if (result) *result = r;
     Affine3x4 M;
@@ -822,13 +1022,15 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
     p.timestamp = timestamp;
     for (int i = 0; i < 3; ++i) p.V[i] = init.V[i];
     *out = p;
-    if (o.integrate) {
+    if (o.integrate && !pipelined) {
         if (o.append_threshold <= 1) {  // "after every frame": wait for this one
             if (!staged_ && !flushIncrements()) return false;
         } else {
             size_t pending = 0;
             velo_pending_count(ctx_, &pending, 0);  // without waiting: the frame in flight counts next time
-            // (while a roll is begun the increments stay pending: they join the map at the first flush after it)
+            // (while a roll is begun the increments stay pending -- a flush would publish it before it is due: they join
+            //  the map in the rollTo of the frame the roll IS due at, right after its publish and before the driver can
+            //  begin the next one, so a driver that keeps a roll begun at every frame no longer starves the map: ADVICE r5)
             if (pending >= (size_t)o.append_threshold && !staged_ && !flushIncrements()) return false;
         }
     }

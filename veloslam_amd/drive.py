@@ -163,6 +163,39 @@ def export_synthetic(out_dir, n_frames=64, world_points=12_000_000, patch_range=
     return meta
 
 
+def export_mapping_drive(out_dir, n_frames=640, device="cpu", patch_range=10.0, voxel=1.0, k_normals=16, speed=10.0,
+                         scene_length=None):
+    """A drive to MAP (BASELINE configs[2] as SLAM): n_frames consecutive revolutions, `speed` / 10 m apart, straight
+    down synth.LongScene -- a street longer than the drive, so that every frame sees ground no frame saw before.  No
+    world.map is written: the map starts from the first frame and grows from accepted increments only
+    (tools/stream_driver --mapping).  The ray casting and the packet assembly run in torch on `device`."""
+    os.makedirs(out_dir, exist_ok=True)
+    length = float(scene_length) if scene_length else speed * 0.1 * n_frames + 150.0
+    sc = synth.LongScene(length)
+    mo = synth.Motion(p0=(0.0, 0.0, synth.SENSOR_HEIGHT), speed=speed)
+    cal = synth.hdl64_calibration()
+    pk, ts = synth.make_frame_packets_device(sc, mo, list(range(n_frames)), cal, device)
+    buf = np.ascontiguousarray(pk.reshape(-1, 1206).cpu().numpy())
+    times = np.ascontiguousarray(ts.reshape(-1), dtype=np.int64)
+    rc = capi.lib().velo_pcap_write(os.path.join(out_dir, "drive.pcap").encode(), capi._p(buf), capi._p(times), buf.shape[0])
+    if rc:
+        raise capi.VeloError(rc, "velo_pcap_write")
+    write_carposes(os.path.join(out_dir, "carposes.txt"), mo.ins_track(int(times[0]), int(times[-1])))
+    write_db_xml(os.path.join(out_dir, "db.xml"), cal)
+    truth = [[float(v) for v in mo.pose(int(ts[k][0]))[0]] for k in range(n_frames)]
+    meta = dict(n_frames=n_frames, z0=truth[0][2], patch_range=patch_range, voxel=voxel, k_normals=k_normals,
+                world_points=0, tiles=0, true_positions=truth, scene_length=length,
+                note="synthetic, to be mapped: veloslam_amd/synth.py LongScene, constant %g m/s, 5 deg/s yaw; no world.map: "
+                     "the map is seeded with frame 0 and grown from accepted increments" % speed)
+    with open(os.path.join(out_dir, "drive.json"), "w") as f:
+        json.dump(meta, f)
+    with open(os.path.join(out_dir, "truth.txt"), "w") as f:
+        f.write("%.17g %g %g %d %g\n" % (truth[0][2], patch_range, voxel, k_normals, 0.0))
+        for t in truth:
+            f.write("%.17g %.17g %.17g\n" % tuple(t))
+    return meta
+
+
 def load(drive_dir):
     """Everything a replay needs, through the C ABI (velo_pcap_read, velo_pcap_index,
     velo_carposes_read, velo_load_corrections).  Packet stamps get the reference's + 8 h so that

@@ -468,3 +468,165 @@ def perturbed_guess(T_true, dt=(0.30, -0.20, 0.05), drot_deg=(0.5, -0.3, 1.0)):
     M[:, :3] = Rp @ M[:, :3]
     M[:, 3] += np.array(dt)
     return M.reshape(12)
+
+
+# ------------------------------------------------------------------------------------------------
+# A world long enough to DRIVE through (BASELINE configs[2] measured as mapping: the map starts from
+# the first frame and grows only from accepted increments, so the car has to keep seeing new ground).
+class LongScene:
+    """A street: ground |y| <= 100 m for x in [-100, length + 100]; side walls y = +-40 m (8 m high) all
+    along it; every 50 m a pair of fins (cross walls, 12 m into the street from either side wall: what
+    constrains x); per 100 m block 24 cylinders and 12 yawed boxes, seeded per block, clear of the lane.
+    Same surface kinds and sizes as Scene, a different arrangement; ray casting is written once for numpy
+    and torch (`xp`), culled to what lies within the sensor's range of the ray origins."""
+
+    def __init__(self, length=800.0, seed=7):
+        self.length = float(length)
+        self.x_lo, self.x_hi = -100.0, self.length + 100.0
+        self.ground_half = 100.0
+        self.wall_y, self.wall_h = 40.0, 8.0
+        self.fin_depth, self.fin_every = 12.0, 50.0
+        self.fin_x = np.arange(self.x_lo + 25.0, self.x_hi, self.fin_every)
+        self.cyl_r, self.cyl_h = 0.3, 6.0
+        self.box_half = np.array([2.0, 1.0, 0.75])
+        cyl, box = [], []
+        nb = int(math.ceil((self.x_hi - self.x_lo) / 100.0))
+        for b in range(nb):
+            rng = np.random.default_rng(seed * 1000 + b)
+            x0 = self.x_lo + 100.0 * b
+            k = 0
+            while k < 24:
+                p = rng.uniform([x0, -36], [x0 + 100.0, 36])
+                if abs(p[1]) > 5.0:
+                    cyl.append(p)
+                    k += 1
+            k = 0
+            while k < 12:
+                p = rng.uniform([x0 + 3, -33], [x0 + 97.0, 33])
+                if abs(p[1]) > 6.0:
+                    box.append([p[0], p[1], rng.uniform(0, 180)])
+                    k += 1
+        self.cyl = np.array(cyl)
+        self.box = np.array(box)
+
+    def raycast(self, o, d, xp=np):
+        """o, d: (n, 3) float64 origins / unit directions (numpy arrays or torch tensors, `xp` the module) ->
+        hit distance (inf = miss)."""
+        is_np = xp is np
+        ox, oy, oz = o[:, 0], o[:, 1], o[:, 2]
+        dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+        inf = float("inf")
+        best = xp.full_like(ox, inf)
+        eps = 1e-9
+        cx = float(ox.mean()) if is_np else float(ox.mean().item())   # (one revolution: the origins are ~1 m apart)
+        reach = MAX_RANGE + 5.0
+
+        def take(best, t, ok):
+            return xp.where(ok & (t < best), t, best)
+
+        ctxm = np.errstate(divide="ignore", invalid="ignore") if is_np else _NullCtx()
+        with ctxm:
+            t = -oz / dz
+            hx, hy = ox + t * dx, oy + t * dy
+            best = take(best, t, (t > eps) & (hx >= self.x_lo) & (hx <= self.x_hi) & (xp.abs(hy) <= self.ground_half))
+            for sgn in (-1.0, 1.0):
+                t = (sgn * self.wall_y - oy) / dy
+                hx, hz = ox + t * dx, oz + t * dz
+                best = take(best, t, (t > eps) & (hx >= self.x_lo) & (hx <= self.x_hi) & (hz >= 0) & (hz <= self.wall_h))
+            for fx in self.fin_x[np.abs(self.fin_x - cx) <= reach]:
+                t = (float(fx) - ox) / dx
+                hy, hz = oy + t * dy, oz + t * dz
+                ay = xp.abs(hy)
+                best = take(best, t, (t > eps) & (ay <= self.wall_y) & (ay >= self.wall_y - self.fin_depth) &
+                            (hz >= 0) & (hz <= self.wall_h))
+            a = dx * dx + dy * dy
+            for c in self.cyl[np.abs(self.cyl[:, 0] - cx) <= reach]:
+                rx, ry = ox - float(c[0]), oy - float(c[1])
+                b = rx * dx + ry * dy
+                cc = rx * rx + ry * ry - self.cyl_r ** 2
+                disc = b * b - a * cc
+                t = (-b - xp.sqrt(xp.where(disc >= 0, disc, xp.full_like(disc, float("nan"))))) / a
+                hz = oz + t * dz
+                best = take(best, t, (disc >= 0) & (t > eps) & (hz >= 0) & (hz <= self.cyl_h))
+            hxb, hyb, hzb = (float(v) for v in self.box_half)
+            big = 1.0e300
+            for bx in self.box[np.abs(self.box[:, 0] - cx) <= reach]:
+                yaw = math.radians(bx[2])
+                cy, sy = math.cos(yaw), math.sin(yaw)
+                rx, ry = ox - float(bx[0]), oy - float(bx[1])
+                lo3 = (cy * rx + sy * ry, -sy * rx + cy * ry, oz - hzb)
+                ld3 = (cy * dx + sy * dy, -sy * dx + cy * dy, dz)
+                tn = xp.full_like(ox, -big)
+                tf = xp.full_like(ox, big)
+                for lo_, ld_, h_ in zip(lo3, ld3, (hxb, hyb, hzb)):
+                    t1, t2 = (-h_ - lo_) / ld_, (h_ - lo_) / ld_
+                    # (a ray parallel to the slab: 0/0 -> nan compares false everywhere: the slab is ignored, as nanmax did)
+                    lo_t, hi_t = xp.minimum(t1, t2), xp.maximum(t1, t2)
+                    tn = xp.where(lo_t > tn, lo_t, tn)
+                    tf = xp.where(hi_t < tf, hi_t, tf)
+                best = take(best, tn, (tn <= tf) & (tn > eps))
+        return best
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def make_frame_packets_device(scene, motion, frame_indices, calib, device, seed=42, range_noise=0.02):
+    """make_frame_packets for many frames with the ray casting and the packet assembly in torch on `device`
+    (600 revolutions take seconds instead of minutes).  Same sensor model, wire layout and noise model; another
+    random stream.  -> (uint8 tensor [n_frames, 300, 1206] on `device`, int64 numpy times [n_frames, 300])."""
+    import torch
+    f64 = torch.float64
+    cos_lut, sin_lut = rot_lut()
+    az_idx = (20 * np.arange(N_AZ)) % 36000
+    pkt_of_az = np.arange(N_AZ) // AZ_PER_PKT
+    az_c = np.empty((N_AZ, 64))
+    az_s = np.empty((N_AZ, 64))
+    for l in range(64):
+        if calib[l, 0] == 0:
+            az_c[:, l] = cos_lut[az_idx]
+            az_s[:, l] = sin_lut[az_idx]
+        else:
+            rad = ((az_idx / 100.0) - calib[l, 0]) * math.pi / 180.0
+            az_c[:, l] = np.cos(rad)
+            az_s[:, l] = np.sin(rad)
+    cv, sv = calib[:, 6][None, :], calib[:, 5][None, :]
+    hoff, voff = calib[:, 4][None, :], calib[:, 3][None, :]
+    dir_s = torch.as_tensor(np.stack([cv * az_s, cv * az_c, np.broadcast_to(sv, az_s.shape)], -1), device=device, dtype=f64)
+    org_s = torch.as_tensor(np.stack([-hoff * az_c, hoff * az_s, np.broadcast_to(voff, az_s.shape)], -1), device=device, dtype=f64)
+    dcorr = torch.as_tensor(calib[:, 2][None, :].copy(), device=device, dtype=f64)
+    az_t = torch.as_tensor(az_idx, device=device, dtype=torch.int64)
+    gen = torch.Generator(device=device)
+    out, times = [], []
+    hdr = torch.empty((N_AZ, 2, 4), dtype=torch.uint8, device=device)
+    hdr[:, :, 0] = 0xFF
+    hdr[:, 0, 1] = 0xEE
+    hdr[:, 1, 1] = 0xDD
+    hdr[:, :, 2] = (az_t & 0xFF).to(torch.uint8)[:, None]
+    hdr[:, :, 3] = (az_t >> 8).to(torch.uint8)[:, None]
+    for fi in frame_indices:
+        t_frame = motion.t0_us + int(fi) * FRAME_US
+        poses = [motion.pose(int(t_frame + p * PKT_US)) for p in range(PKTS_PER_FRAME)]
+        Rw = torch.as_tensor(np.stack([euler_matrix(*pz[1]) for pz in poses])[pkt_of_az], device=device, dtype=f64)
+        Tw = torch.as_tensor(np.stack([pz[0] for pz in poses])[pkt_of_az], device=device, dtype=f64)
+        dir_w = torch.einsum("aij,alj->ali", Rw, dir_s).reshape(-1, 3)
+        org_w = (torch.einsum("aij,alj->ali", Rw, org_s) + Tw[:, None, :]).reshape(-1, 3)
+        dist = scene.raycast(org_w, dir_w, xp=torch).reshape(N_AZ, 64)
+        gen.manual_seed(int(seed) * 100003 + int(fi))
+        dist = dist + range_noise * torch.randn(dist.shape, generator=gen, device=device, dtype=f64) - dcorr
+        ok = torch.isfinite(dist) & (dist < MAX_RANGE) & (dist > 0.9)
+        raw = torch.where(ok, torch.round(dist / 0.002), torch.zeros_like(dist)).clamp(0, 65535).to(torch.int64)
+        inten = torch.randint(1, 255, raw.shape, generator=gen, device=device, dtype=torch.int64)
+        body = torch.stack([(raw & 0xFF), (raw >> 8), inten], -1).to(torch.uint8).reshape(N_AZ, 2, 96)
+        blocks = torch.cat([hdr, body], 2).reshape(PKTS_PER_FRAME, 1200)
+        t_pkt = t_frame + np.arange(PKTS_PER_FRAME, dtype=np.int64) * PKT_US
+        stamp = torch.as_tensor(((t_pkt % 3_600_000_000) & 0xFFFFFFFF).astype(np.int64), device=device)
+        tail = torch.stack([(stamp >> s) & 0xFF for s in (0, 8, 16, 24)] + [torch.zeros_like(stamp)] * 2, 1).to(torch.uint8)
+        out.append(torch.cat([blocks, tail], 1))
+        times.append(t_pkt)
+    return torch.stack(out), np.stack(times)
