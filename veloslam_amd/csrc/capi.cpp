@@ -177,6 +177,12 @@ struct velo_ctx {
     // ---- a roll begun ahead of the frame that needs it (velo_map_roll_begin .. velo_map_roll_publish)
     hipStream_t roll_stream = nullptr;  // a stream of its own: a decode on the side stream must not queue behind 2 ms of roll
     hipEvent_t ev_roll = nullptr;       // the roll's last kernel
+    // Round 6: the rolled map's GEOMETRY (points, fine table) is complete long before its normals are (the re-estimation of
+    // the dirty neighbourhoods is half of an append).  An increment reads geometry only: the publish makes the main stream
+    // wait for this event, and whatever reads normals / vox_near next (a registration) waits for ev_roll then.
+    hipEvent_t ev_roll_geom = nullptr;
+    bool roll_geom_recorded = false;    // the LAST update of the begun roll recorded it (an incremental update with normals)
+    bool normals_wait_owed = false;     // published on the geometry event: the main stream has not yet waited for ev_roll
     bool roll_staged = false;           // begun, not yet published
     bool defer_counts = false;          // inside velo_map_roll_begin: nothing waits for the device after the first count
     struct RollResults {                // pinned: what the device reports when the roll is through
@@ -251,7 +257,9 @@ struct velo_ctx {
     DevBuf<uint32_t> order_keys, order_keys2, order_idx, order;
     DevBuf<int32_t> corr;
     DevBuf<int32_t> hint;  // last correspondence per query slot (search-radius hint), -1 = none
-    DevBuf<float> rho;     // certified uniqueness radius per query slot (valid with hint >= 0)
+    DevBuf<float> rho;     // certified uniqueness radius per query slot (valid with hint >= 0); < 0 with hint < 0: no candidate within -rho
+    DevBuf<int32_t> hint2; // latency path (round 6): runner-up of the last search per query slot ...
+    DevBuf<float> rho3;    // ... and the radius inside which winner and runner-up are the only map points (FrameView)
     DevBuf<double> poses_prev;  // pose each frame was linearised at in the previous iteration
     DevBuf<unsigned long long> pairs_total;  // pairs processed by every registration iteration so far
     DevBuf<float> d2;
@@ -284,14 +292,14 @@ struct velo_ctx {
     struct GraphKey {
         int iters = 0, ni = 0, n_frames = 0, variant = 0;
         float dmax2 = 0;
-        const void *hint = nullptr, *rho = nullptr, *items = nullptr, *stream = nullptr, *sq = nullptr;
+        const void *hint = nullptr, *rho = nullptr, *items = nullptr, *stream = nullptr, *sq = nullptr, *hint2 = nullptr;
         uint64_t map_gen = 0, frames_gen = 0;
         int n_split = 0;
         bool operator==(const GraphKey& o) const
         {
             return iters == o.iters && ni == o.ni && n_frames == o.n_frames && variant == o.variant &&
                    dmax2 == o.dmax2 && hint == o.hint && rho == o.rho && items == o.items && stream == o.stream &&
-                   map_gen == o.map_gen && frames_gen == o.frames_gen && n_split == o.n_split && sq == o.sq;
+                   map_gen == o.map_gen && frames_gen == o.frames_gen && n_split == o.n_split && sq == o.sq && hint2 == o.hint2;
         }
     } graph_key;
     uint64_t map_gen = 0, frames_gen = 0;
@@ -464,12 +472,14 @@ int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, const uint32_t*
 // A roll begun ahead and not yet published is published now: every entry point that changes or reads the map
 // as a whole starts here.  (The registrations do not: they keep reading the map before the roll -- mv_read.)
 static int resolve_roll_counts(velo_ctx* c);
+static int settle_normals_fwd(velo_ctx* c);
 static int settle_roll(velo_ctx* c)
 {
     // (the counts too: a plain update that follows publishes its own, and must not be overwritten by a late read)
     if (int rc = resolve_roll_counts(c)) return rc;
-    if (!c->roll_staged) return VELO_OK;
-    return velo_map_roll_publish(c);
+    if (c->roll_staged)
+        if (int rc = velo_map_roll_publish(c)) return rc;
+    return settle_normals_fwd(c);
 }
 // info.n_invalid_normals / n_normals_recomputed of a roll begun ahead: known when its last kernel is through
 static int resolve_roll_counts(velo_ctx* c)
@@ -487,10 +497,37 @@ static int resolve_roll_counts(velo_ctx* c)
 // running registration is using them -- the reset queues behind it on the main stream)
 static int reset_hints(velo_ctx* c, hipStream_t hs)
 {
+    // A registration never reads what an earlier one left (its first iteration passes poses_prev = nullptr: every stored
+    // hint and certificate is stale by definition and is overwritten).  Only velo_linearize in hinted mode carries state
+    // from call to call: the four fills per map update are its alone (a stream publishes a map update every frame).
+    if (!c->lin_hints) return VELO_OK;
     if (c->hint.p && c->hint.cap)
         HIP_TRY(c, hipMemsetAsync(c->hint.p, 0xFF, c->hint.cap * sizeof(int32_t), hs));
     if (c->rho.p && c->rho.cap)  // 0 = no certificate (negative values certify "no match")
         HIP_TRY(c, hipMemsetAsync(c->rho.p, 0, c->rho.cap * sizeof(float), hs));
+    if (c->hint2.p && c->hint2.cap) HIP_TRY(c, hipMemsetAsync(c->hint2.p, 0xFF, c->hint2.cap * sizeof(int32_t), hs));
+    if (c->rho3.p && c->rho3.cap) HIP_TRY(c, hipMemsetAsync(c->rho3.p, 0, c->rho3.cap * sizeof(float), hs));
+    return VELO_OK;
+}
+
+static int settle_normals(velo_ctx* c);
+static int settle_normals_fwd(velo_ctx* c) { return settle_normals(c); }
+// main-stream readers of normals / vox_near (registrations, linearise, map updates, downloads) after a publish on the
+// geometry event: the rest of the roll
+static int settle_normals(velo_ctx* c)
+{
+    if (!c->normals_wait_owed) return VELO_OK;
+    c->normals_wait_owed = false;
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_roll, 0));
+    return VELO_OK;
+}
+// inside an update of a roll begun ahead, after the sorted arrays and the table are written and before the normals are
+static int mark_roll_geometry(velo_ctx* c)
+{
+    if (!c->defer_counts) return VELO_OK;
+    if (!c->ev_roll_geom) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_roll_geom, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_roll_geom, c->stream));   // (c->stream is the roll's stream here: roll_run)
+    c->roll_geom_recorded = true;
     return VELO_OK;
 }
 
@@ -908,6 +945,7 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done, int* grow
         const size_t nvox = (size_t)dims[0] * dims[1] * dims[2];
         HIP_TRY(c, reserve_slack(c->dirty, nvox));
         HIP_TRY(c, hipMemsetAsync(c->dirty.p, 0, nvox, s));
+        if (int rc = mark_roll_geometry(c)) return rc;   // (points + table of the updated map are enqueued: the normals follow)
         HIP_TRY(c, launch_mark_dirty(c->nk_sorted.p, (uint32_t)m, nullptr, g, c->dirty.p, s));
         if (int rc = refresh_dirty_normals(c, g, k, c->nk_sorted.p, (uint32_t)m)) return rc;
         if (c->defer_counts)
@@ -1409,6 +1447,13 @@ static hipError_t launch_iteration(velo_ctx* c, int it, bool split, const FrameV
                             nullptr, hint, rho, prev, stats || (split && split_debug), c->plan_lat ? 2 : 1, s, dc.lat_lanes);
 }
 
+// (measurement aid: VELO_NO_PAIR_CERT=1 runs the latency path without the pair certificates of round 6)
+static bool pair_certificates_off()
+{
+    static const bool off = getenv("VELO_NO_PAIR_CERT") != nullptr;
+    return off;
+}
+
 int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
 {
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map: call velo_map_reset first");
@@ -1419,6 +1464,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     if (!(d_max > 0.0f) || !(d_max <= c->mv_read.h))
         return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv_read.h);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = settle_normals(c)) return rc;
     hipStream_t s = c->stream;
     c->ev_used = 0;
     c->ev_kind.clear();
@@ -1442,6 +1488,15 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             HIP_TRY(c, c->rho.reserve(n_all));
             rho = c->rho.p;
         }
+    }
+    // pair certificates: the latency kernels' (FrameView::hint2 / rho3; the throughput kernel never looks at them)
+    int32_t* hint2 = nullptr;
+    float* rho3 = nullptr;
+    if (hint && rho && c->plan_lat && c->cfg.linearize_variant == VELO_VARIANT_BALL && !pair_certificates_off()) {
+        HIP_TRY(c, c->hint2.reserve(n_all));
+        HIP_TRY(c, c->rho3.reserve(n_all));
+        hint2 = c->hint2.p;
+        rho3 = c->rho3.p;
     }
     HIP_TRY(c, c->poses_prev.reserve((size_t)c->cfg.max_batch * 12));
     // the split iterations need hints AND certificates (the third launch lives on them), the pruned search, plain
@@ -1488,6 +1543,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         key.frames_gen = c->frames_gen;
         key.n_split = n_split;
         key.sq = c->sq.p;
+        key.hint2 = hint2;
         if (!c->graph_exec || !(key == c->graph_key)) {
             if (c->graph_exec) {
                 (void)hipGraphExecDestroy(c->graph_exec);
@@ -1496,7 +1552,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
             HIP_TRY(c, hipStreamSynchronize(s));
             HIP_TRY(c, hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
             hipError_t e = hipSuccess;  // (the pose upload stays outside the graph: its source alternates)
-            FrameView fv{c->ax, c->ay, c->az, nullptr};
+            FrameView fv{c->ax, c->ay, c->az, nullptr, hint2, rho3};
             if (n_split > 0) e = hipMemsetAsync(c->sq_count.p, 0, VELO_MAX_ITERS * sizeof(unsigned), s);
             for (int it = 0; it < iters && e == hipSuccess; ++it) {
                 const bool split = it < n_split;
@@ -1529,7 +1585,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         return forget_hints_for_linearize(c, hint, n_all, s);
     }
     if (int rc = upload_T0(c, T0, pose_bytes)) return rc;
-    FrameView fv{c->ax, c->ay, c->az, nullptr};
+    FrameView fv{c->ax, c->ay, c->az, nullptr, hint2, rho3};
     if (int rc = maybe_sort_frames(c, fv)) return rc;
     // hints never outlive a registration: results do not depend on earlier calls
     if (n_split > 0) HIP_TRY(c, hipMemsetAsync(c->sq_count.p, 0, VELO_MAX_ITERS * sizeof(unsigned), s));
@@ -1721,6 +1777,7 @@ void velo_destroy(velo_ctx* c)
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);  // (pinned buffers below may still be its sources)
     if (c->roll_stream) (void)hipStreamSynchronize(c->roll_stream);
     if (c->ev_roll) (void)hipEventDestroy(c->ev_roll);
+    if (c->ev_roll_geom) (void)hipEventDestroy(c->ev_roll_geom);
     if (c->roll_stream) (void)hipStreamDestroy(c->roll_stream);
     if (c->h_roll) (void)hipHostFree(c->h_roll);
     if (c->h_enter) (void)hipHostFree(c->h_enter);
@@ -2162,6 +2219,7 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     unsigned long long invalid = kept;
     c->n_done_host = 0;
     if (k > 0) {
+        if (int rc = mark_roll_geometry(c)) return rc;
         if (int rc = refresh_dirty_normals(c, g, k, c->nk_sorted.p, n - kept)) return rc;
         // (the running count: compact_sorted took the leavers off, the re-estimation adjusted the rest)
         if (c->defer_counts)
@@ -2283,6 +2341,7 @@ static int roll_run(velo_ctx* c, hipStream_t rs, DevBuf<char>& scratch, const fl
     c->overlap_done = 0;
     c->overlap_main = main_stream;
     int rc = VELO_OK;
+    c->roll_geom_recorded = false;
     if (lo) {
         KeepRegion g{};
         for (int a = 0; a < 3; ++a) {
@@ -2291,7 +2350,10 @@ static int roll_run(velo_ctx* c, hipStream_t rs, DevBuf<char>& scratch, const fl
         }
         rc = evict_impl(c, g);
     }
-    if (rc == VELO_OK && n) rc = map_append_impl(c, x, y, z, n, false);
+    if (rc == VELO_OK && n) {
+        c->roll_geom_recorded = false;   // (the last update's geometry is the rolled map's)
+        rc = map_append_impl(c, x, y, z, n, false);
+    }
     c->overlap_update = false;
     std::swap(c->temp.p, scratch.p);
     std::swap(c->temp.cap, scratch.cap);
@@ -2343,6 +2405,9 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
     auto tr_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); };
     float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     if (int rc = roll_precheck(c, "velo_map_roll_begin", lo, hi, x, y, z, n, mn, mx, true)) return rc;
+    // (the previous roll was published on its geometry event and the main stream still owes the wait for its normals: enqueued
+    //  NOW, before ev_roll is recorded again for this roll -- afterwards the wait would be for the roll begun here)
+    if (int rc = settle_normals(c)) return rc;
     const double t_pre = tr_us();
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->roll_stream) {
@@ -2443,8 +2508,16 @@ int velo_map_roll_publish(velo_ctx* c)
     if (!c) return VELO_E_INVALID;
     if (!c->roll_staged) return VELO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    // the main stream waits ON THE DEVICE for the roll's last kernel; what it runs from here on reads the new map
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_roll, 0));
+    // the main stream waits ON THE DEVICE for the roll; what it runs from here on reads the new map.  For the rolled
+    // map's geometry only where the roll says when that is complete: an increment enqueued next reads points and table,
+    // the first reader of normals (the next registration: settle_normals) waits for the roll's last kernel
+    if (c->roll_geom_recorded && c->ev_roll_geom) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_roll_geom, 0));
+        c->normals_wait_owed = true;
+    } else {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_roll, 0));
+    }
+    c->roll_geom_recorded = false;
     c->mv_read = c->mv;
     c->roll_staged = false;
     ++c->map_gen;  // (captured graphs and hints of the old map are stale)
@@ -2691,6 +2764,7 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
     if (!(d_max > 0.0f) || !(d_max <= c->mv_read.h))
         return c->fail(VELO_E_RANGE, "d_max must be in (0, voxel=%g]", (double)c->mv_read.h);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = settle_normals(c)) return rc;
     hipStream_t s = c->stream;
     const size_t n_all = (size_t)c->frame_start[c->n_frames];
     const size_t q0 = (size_t)c->frame_start[frame], q1 = (size_t)c->frame_start[frame + 1];

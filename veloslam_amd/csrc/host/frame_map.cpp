@@ -979,12 +979,14 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
     for (int f = 0; f < 4; ++f) std::memcpy(T0s + 12 * f, T0.data(), sizeof(double) * 12);
     // pipelined integration: the map update with the PREVIOUS frame's increment is begun first (the roll's own stream:
     // it runs beside this registration, which is enqueued next and reads the map as it was) ...
-    if (pipelined && !updateBesideRegistration(o)) return false;
+    static const bool update_after_start = std::getenv("VELO_UPDATE_AFTER_START") != nullptr;   // (measurement aid: A/B of the order)
+    if (pipelined && !update_after_start && !updateBesideRegistration(o)) return false;
     const double t_update = us_since(tt0);
     if (velo_icp_batch_start(ctx_, T0s, o.iters, o.d_max)) {
         err_ = velo_last_error(ctx_);
         return false;
     }
+    if (pipelined && update_after_start && !updateBesideRegistration(o)) return false;
     // ... and published right behind the registration: the main stream waits for the roll ON THE DEVICE, whatever is
     // enqueued from here on -- this frame's increment first of all -- sees the updated map
     if (publishOwed_) {

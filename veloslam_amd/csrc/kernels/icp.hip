@@ -402,11 +402,20 @@ struct SearchLds {
 // flight together; indices are clamped to the range start (a candidate evaluated twice is
 // harmless under '<=').  (Carrying the winner's coordinates through the walk to save the
 // later re-fetch was measured: the extra selects and registers cost more than the fetch.)
-template <int W, bool STATS>
+template <int W, bool STATS, bool PAIR = false>
 __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float qy, float qz,
                                             SearchLds& L, int tid, int nr, float& bd, int& bj,
-                                            float& sd, Tally<STATS>& tl)
+                                            float& sd, Tally<STATS>& tl, int* sj_io = nullptr, float* td_io = nullptr)
 {
+    static_assert(!PAIR || W >= 8, "the runner-up is tracked in the latency kernel's branch-free walk only");
+    // PAIR (round 6): also the INDEX of the second-smallest candidate and the third-smallest distance -- what a pair
+    // certificate needs ({winner, runner-up} are the only map points within sqrt(td)).
+    int sj = -1;
+    float td = sd;
+    if constexpr (PAIR) {
+        sj = *sj_io;
+        td = *td_io;
+    }
     // W candidates per trip drawn ACROSS ranges: a lane with three short ranges needs one or
     // two trips instead of three (measured 54 vs 57.5 us per launch against one range per
     // trip).  Slots past the end repeat the last index and are masked.  sd tracks the
@@ -437,8 +446,13 @@ __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float q
             // Latency kernel: branch-free, a dead slot is a candidate at infinity.
             if constexpr (W >= 8) {  // (latency kernel: registers to spare)
                 const float e = live[u] ? dist2(c[u], qx, qy, qz) : INFINITY;
-                sd = __builtin_amdgcn_fmed3f(bd, e, sd);
                 const bool better = e <= bd;
+                if constexpr (PAIR) {
+                    const bool second = e < sd;                 // enters the best two
+                    td = second ? sd : fminf(td, e);            // the old second drops to third, or e competes for third
+                    sj = better ? bj : (second ? jj[u] : sj);
+                }
+                sd = __builtin_amdgcn_fmed3f(bd, e, sd);
                 bj = better ? jj[u] : bj;
                 bd = better ? e : bd;
             } else {
@@ -452,6 +466,10 @@ __device__ __forceinline__ void walk_ranges(const MapView& mv, float qx, float q
             }
         }
         more = (j > lo) || (k < nr);
+    }
+    if constexpr (PAIR) {
+        *sj_io = sj;
+        *td_io = td;
     }
 }
 
@@ -487,16 +505,20 @@ __device__ __forceinline__ int finish_block(float bd, float sd, float gr, float&
 // distances per axis computed once, and the pruning thresholds folded into one compare per test
 // (`x > ub0 * 1.00002f` prunes a subset of what `x * 0.99999f > ub0` pruned: still conservative,
 // the results -- not the pruning decisions -- are what is exact).
-template <int ABL, bool STATS, int W, bool HASH>
+template <int ABL, bool STATS, int W, bool HASH, bool PAIR = false>
 __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& g, float qx,
                                             float qy, float qz, float ub0, SearchLds& L,
                                             int tid, float& bd, int& bj, float& cert,
-                                            float& gr_out, Tally<STATS>& tl)
+                                            float& gr_out, Tally<STATS>& tl, int* sj_out = nullptr, float* cert3 = nullptr)
 {
     bd = ub0;
     bj = -1;
     cert = 0.0f;  // radius (m) around the query inside which the winner is the only map point
     gr_out = 0.0f;
+    if constexpr (PAIR) {
+        *sj_out = -1;   // runner-up of a FINAL stage A ...
+        *cert3 = 0.0f;  // ... and the radius inside which winner and runner-up are the only map points
+    }
     if (!g.near) return kFinal;  // no voxel of the 27 exists: no candidates at all
     // (ub0 may be tightened below by the own-cell probe; bd follows it before the walk)
     const float hf = mv.h / (float)mv.S;
@@ -588,9 +610,51 @@ __device__ __forceinline__ int search_block(const MapView& mv, const QueryCell& 
     if (ABL >= 2) nr = min(nr, 0);
     bd = ub0;
     float sd = ub0;  // everything not scanned inside the block is further than sqrt(ub0)
-    walk_ranges<W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd, tl);
-    if (ABL >= 1) return kFinal;
-    return finish_block(bd, sd, gr, cert);
+    if constexpr (PAIR) {
+        int sj = -1;
+        float td = ub0;  // (likewise the third)
+        walk_ranges<W, STATS, true>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd, tl, &sj, &td);
+        const int st = finish_block(bd, sd, gr, cert);
+        if (st == kFinal && bj >= 0 && sj >= 0) {
+            // third-best scanned / pruned-cell bound / block faces, rounded down: as the uniqueness radius, one rank on
+            *sj_out = sj;
+            *cert3 = fmaxf(fminf(bsqrt(td) * 0.999999f, gr) - 1e-6f, 0.0f);
+        }
+        return st;
+    } else {
+        walk_ranges<W>(mv, qx, qy, qz, L, tid, nr, bd, bj, sd, tl);
+        if (ABL >= 1) return kFinal;
+        return finish_block(bd, sd, gr, cert);
+    }
+}
+
+// Round 6, latency kernels: the whole wavefront scans EVERY candidate of one query -- all points of the 27 voxels around
+// it, the oracle's candidate set literally -- and returns the smallest squared distance (INFINITY: no candidate at
+// all).  For a query that has just been found WITHOUT a match this is what turns "nothing within d_max here" into a
+// certificate with room to move: every candidate is at least that far from here, so at least that far minus delta
+// from wherever the query goes inside the same voxel.  Rows of fine cells over the lanes, each row at the full width
+// of the three voxels.
+__device__ __forceinline__ float scan_block_wave(const MapView& mv, float qx, float qy, float qz, int lane)
+{
+    const QueryCell g = locate(mv, qx, qy, qz);
+    float best = INFINITY;
+    const int vx0 = max(g.cx - 1, 0), vx1 = min(g.cx + 1, mv.nx - 1);
+    const int vy0 = max(g.cy - 1, 0), vy1 = min(g.cy + 1, mv.ny - 1);
+    const int vz0 = max(g.cz - 1, 0), vz1 = min(g.cz + 1, mv.nz - 1);
+    if (vx0 <= vx1 && vy0 <= vy1 && vz0 <= vz1) {
+        const int S = mv.S;
+        const int ny = (vy1 - vy0 + 1) * S, nz = (vz1 - vz0 + 1) * S;
+        for (int r = lane; r < ny * nz; r += 64) {
+            const int fz = vz0 * S + r / ny, fy = vy0 * S + r % ny;
+            const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
+            int j0, j1;
+            if (!row_range_rt(mv, row, vx0 * S, (vx1 + 1) * S - 1, j0, j1)) continue;
+            for (int j = j0; j < j1; ++j) best = fminf(best, dist2(mv.pts[(unsigned)j], qx, qy, qz));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = fminf(best, __shfl_xor(best, off, 64));
+    return best;
 }
 
 // stage B, per-lane form (used when most lanes of a wavefront are stragglers, i.e. the first
@@ -1097,11 +1161,19 @@ __device__ __forceinline__ void linearize_body(
         int bj = -1;
         float rho_new_out = 0.0f;  // certified radius for the next iteration (0 = none)
         bool state_same = false;   // hint and rho unchanged: nothing to write back
+        // pair certificate left for the next iteration (latency kernels, fv.hint2 != nullptr): runner-up / radius
+        constexpr bool PAIR = LAT && VARIANT == 1;
+        [[maybe_unused]] int pair_j = -1;
+        [[maybe_unused]] float pair_rho = 0.0f;
+        [[maybe_unused]] bool scanned_nomatch = false;  // certified WITHOUT a match by the block scan (rho_new_out < 0 holds the radius)
         if (VARIANT >= 1) {
             bool queued = false;
             int st = kFinal;
             float blk_gr = 0.0f;  // guaranteed radius of the stage-A block around this query
             float qx = 0.f, qy = 0.f, qz = 0.f;
+            float ub0 = dmax2;
+            bool certified = false;
+            [[maybe_unused]] bool want_scan = false;
             if (live) {
                 xform(T, sxq, syq, szq, px, py, pz);
                 qx = (float)px;
@@ -1115,8 +1187,6 @@ __device__ __forceinline__ void linearize_body(
                 //        other map point is at least rho - delta away: if the hinted point is
                 //        strictly closer than that, it is the unique nearest neighbour and the
                 //        search is skipped altogether.  All margins round against skipping.
-                float ub0 = dmax2;
-                bool certified = false;
                 if (hj >= 0) {
                     tl.candidates(1);
                     tl.addq(rho ? 4 : 0);
@@ -1138,6 +1208,47 @@ __device__ __forceinline__ void linearize_body(
                             bj = hj;
                             rho_new_out = room;
                             state_same = still;  // hint == hj and rho unchanged
+                            if constexpr (PAIR) {
+                                // the pair certificate travels along (same winner, same runner-up, delta less room): it
+                                // takes over when the uniqueness radius has been used up by the steps of a slowly
+                                // converging registration -- without it such a query was searched every few iterations
+                                if (fv.hint2 && !still) {
+                                    pair_j = fv.hint2[uq];
+                                    pair_rho = fmaxf((fv.rho3[uq] - delta) * 0.999999f - 1e-7f, 0.0f);
+                                    tl.addq(8);
+                                }
+                            }
+                        }
+                        if constexpr (PAIR) {
+                            // PAIR CERTIFICATE (round 6).  The uniqueness radius of a query whose two nearest candidates
+                            // are nearly equidistant is the distance to the runner-up: no room at all, and on a map made
+                            // of scans (consecutive returns of one scan line, centimetres apart) hundreds of queries per
+                            // frame were searched at EVERY iteration -- each holding its wavefront for a search while
+                            // 99.5 % of the launch had long finished.  rho3 = radius around the previous position inside
+                            // which {hint, hint2} are the only map points: both are gathered, the nearer under the
+                            // oracle's order (d2, then index) is the nearest neighbour if it lies inside rho3 - delta.
+                            if (!certified && fv.hint2) {
+                                const int h2 = fv.hint2[uq];
+                                const float r3 = fv.rho3[uq];
+                                tl.addq(8);
+                                if (h2 >= 0 && r3 > 0.0f) {
+                                    tl.candidates(1);
+                                    const float room3 = still ? r3 : (r3 - delta) * 0.999999f - 1e-7f;
+                                    const float d2sq = dist2(mv.pts[(unsigned)h2], qx, qy, qz);
+                                    const bool second_wins = d2sq < d1sq || (d2sq == d1sq && h2 < hj);
+                                    const float dn_sq = second_wins ? d2sq : d1sq, df_sq = second_wins ? d1sq : d2sq;
+                                    const float dn = bsqrt(dn_sq) * 1.000001f + 1e-7f;
+                                    if (dn < room3) {
+                                        certified = true;
+                                        bd = dn_sq;
+                                        bj = second_wins ? h2 : hj;
+                                        // uniqueness radius of the winner: its partner, or the radius of the pair
+                                        rho_new_out = fmaxf(fminf(bsqrt(df_sq) * 0.999999f - 1e-6f, room3), 0.0f);
+                                        pair_j = second_wins ? hj : h2;
+                                        pair_rho = room3;
+                                    }
+                                }
+                            }
                         }
                     }
                     // search a little beyond the hinted point so that the result certifies a
@@ -1160,9 +1271,51 @@ __device__ __forceinline__ void linearize_body(
                             certified = true;  // (bd = INFINITY, bj = -1: no pair)
                             rho_new_out = rho_in;
                             state_same = true;
+                        } else if constexpr (PAIR) {
+                            // Round 6: -rho is a radius around the previous position c inside which the query's candidate set
+                            // (the 27 voxels around c's voxel) holds NO point.  In the same voxel the candidate set is the
+                            // same, and every candidate is at least -rho - delta from here: beyond d_max -> still no match.
+                            // Otherwise the wavefront scans the block (below): a moved query without a match was the
+                            // costliest search of a converged launch, every iteration anew.
+                            const float ex = qx - (float)cx, ey = qy - (float)cy, ez = qz - (float)cz;
+                            const float delta = bsqrt(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * 1.000001f + 1e-7f;
+                            const float room = (-rho_in - delta) * 0.999999f - 1e-7f;
+                            const bool same_voxel =
+                                cell_coord(qx, mv.ox, mv.inv_h, mv.nx) == cell_coord((float)cx, mv.ox, mv.inv_h, mv.nx) &&
+                                cell_coord(qy, mv.oy, mv.inv_h, mv.ny) == cell_coord((float)cy, mv.oy, mv.inv_h, mv.ny) &&
+                                cell_coord(qz, mv.oz, mv.inv_h, mv.nz) == cell_coord((float)cz, mv.oz, mv.inv_h, mv.nz);
+                            if (same_voxel && room > 0.0f && room * room * 0.99999f > dmax2) {
+                                certified = true;
+                                rho_new_out = -room;
+                                scanned_nomatch = true;
+                            } else {
+                                // (scanned once the registration has settled to centimetre steps: a badly placed frame's first
+                                //  iterations have thousands of queries without a match, and a radius a 10 cm step uses up)
+                                want_scan = fv.hint2 != nullptr && delta < 0.01f;   // (the features of round 6 switch together: VELO_NO_PAIR_CERT)
+                            }
                         }
                     }
                 }
+            }
+            if constexpr (PAIR) {
+                // the block scans of this wavefront's moved no-match queries, one after the other, EVERY lane of the
+                // wavefront on each (outside `if (live)`: the lanes past the end of a frame scan their rows too)
+                unsigned long long wm = __ballot(want_scan);
+                // (at most 8 per wavefront and round: a run of such queries along a scan line is worked off over a few
+                //  iterations -- the others go through the search proper once more, which leaves them "nothing within
+                //  d_max here" again)
+                for (int n_scan = 0; wm && n_scan < 8; ++n_scan) {
+                    const int src = __ffsll((long long)wm) - 1;
+                    wm &= wm - 1;
+                    const float m2 = scan_block_wave(mv, __shfl(qx, src, 64), __shfl(qy, src, 64), __shfl(qz, src, 64), lane);
+                    if (lane == src && m2 * 0.99999f > dmax2) {   // (else: something within reach -- the search proper decides)
+                        certified = true;
+                        rho_new_out = -fminf(fmaxf(bsqrt(m2) * 0.999999f - 1e-6f, 0.0f), 1.0e30f);
+                        scanned_nomatch = true;
+                    }
+                }
+            }
+            if (live) {
                 VELO_COUNT(1, certified);
                 if (!certified) {
                     const QueryCell g = locate(mv, qx, qy, qz);
@@ -1173,9 +1326,14 @@ __device__ __forceinline__ void linearize_body(
                         g.cy < mv.ny && g.cz >= 0 && g.cz < mv.nz)
                         empty = mv.vox_near[((size_t)g.cz * mv.ny + g.cy) * mv.nx + g.cx] == 0;
                     tl.add(hj < 0 && mv.vox_near ? 1 : 0);
-                    if (!empty)
-                        st = search_block<(VARIANT >= 11 ? VARIANT - 10 : 0), STATS, (LAT ? VELO_WALK_W_LAT : VELO_WALK_W), HASH>(
-                            mv, g, qx, qy, qz, ub0, s_u.s, lane, bd, bj, rho_new_out, blk_gr, tl);
+                    if (!empty) {
+                        if constexpr (PAIR)
+                            st = search_block<0, STATS, VELO_WALK_W_LAT, HASH, true>(
+                                mv, g, qx, qy, qz, ub0, s_u.s, lane, bd, bj, rho_new_out, blk_gr, tl, &pair_j, &pair_rho);
+                        else
+                            st = search_block<(VARIANT >= 11 ? VARIANT - 10 : 0), STATS, (LAT ? VELO_WALK_W_LAT : VELO_WALK_W), HASH>(
+                                mv, g, qx, qy, qz, ub0, s_u.s, lane, bd, bj, rho_new_out, blk_gr, tl);
+                    }
                     VELO_COUNT(3, empty);
                     VELO_COUNT(2, !empty);
                 }
@@ -1183,12 +1341,25 @@ __device__ __forceinline__ void linearize_body(
             VELO_COUNT(4, live && st == kFinal);
             queued = st == kStraggler;
             if (queued) rho_new_out = 0.0f;
+            if constexpr (PAIR) {
+                if (queued) {
+                    pair_j = -1;
+                    pair_rho = 0.0f;
+                }
+            }
             if constexpr (SEARCH_ONLY) {
                 if (live && !queued) {
                     const bool ok = (bj >= 0) && (bd <= dmax2);
                     if (!(state_same && (ok || bj < 0))) {
                         hint[uq] = ok ? bj : -1;
-                        rho[uq] = rho_new_out;
+                        // (no match: the search covered the whole d_max -- "no candidate within d_max of here")
+                        rho[uq] = ok ? rho_new_out : (PAIR && !scanned_nomatch ? -fmaxf(bsqrt(dmax2) * 0.999999f - 1e-6f, 0.0f) : rho_new_out);
+                        if constexpr (PAIR) {
+                            if (fv.hint2) {
+                                fv.hint2[uq] = ok ? pair_j : -1;
+                                fv.rho3[uq] = ok ? pair_rho : 0.0f;
+                            }
+                        }
                     }
                 }
                 const unsigned long long qm = __ballot(queued);
@@ -1267,7 +1438,21 @@ __device__ __forceinline__ void linearize_body(
             // (a certified, unmoved query with a still-valid match -- or still without one -- keeps its state: no stores)
             if (!(state_same && (ok || bj < 0))) {
                 if (hint) hint[uq] = ok ? bj : -1;
-                if (VARIANT >= 1 && rho) rho[uq] = rho_new_out;
+                if constexpr (PAIR) {
+                    // no match: whichever search said so covered the whole d_max ("no candidate within d_max of here":
+                    // the next iteration certifies it if the query has not moved, scans the block if it has); a block
+                    // scan's or a moved certificate's own radius stands
+                    if (rho) rho[uq] = ok ? rho_new_out : (scanned_nomatch ? rho_new_out : -fmaxf(bsqrt(dmax2) * 0.999999f - 1e-6f, 0.0f));
+                    // the pair of a final stage A / of a pair certificate; anything else leaves none (a uniqueness
+                    // certificate that moved does not carry the pair's radius along)
+                    if (fv.hint2) {
+                        fv.hint2[uq] = ok ? pair_j : -1;
+                        fv.rho3[uq] = ok ? pair_rho : 0.0f;
+                    }
+                    tl.addq(fv.hint2 ? 8 : 0);
+                } else {
+                    if (VARIANT >= 1 && rho) rho[uq] = rho_new_out;
+                }
                 tl.addq((hint ? 4 : 0) + ((VARIANT >= 1 && rho) ? 4 : 0));
             }
             if (WRITE_CORR) {
@@ -1469,8 +1654,13 @@ __global__ __launch_bounds__(kSearchBThreads, 4) void k_search_b(
                 const bool ok = (rbj >= 0) && (rbd <= dmax2);
                 hint[uq] = ok ? rbj : -1;
                 // (nothing within the ball, and the ball was the whole d_max: "no match at this position", see linearize_body)
+                // -radius: "no candidate within d_max of here" (linearize_body reads it)
                 rho[uq] = rbj >= 0 ? fmaxf(fminf(bsqrt(rsd) * 0.999999f, mv.h - 2.0f * mg) - 1e-6f, 0.0f)
-                                   : (__int_as_float(en.z) >= dmax2 ? -1.0f : 0.0f);
+                                   : (__int_as_float(en.z) >= dmax2 ? -fmaxf(bsqrt(dmax2) * 0.999999f - 1e-6f, 1e-30f) : 0.0f);
+                if (fv.hint2) {  // (a straggler's result carries no pair)
+                    fv.hint2[uq] = -1;
+                    fv.rho3[uq] = 0.0f;
+                }
             }
         }
     } else {
@@ -1493,7 +1683,11 @@ __global__ __launch_bounds__(kSearchBThreads, 4) void k_search_b(
             if (active) {
                 const bool ok = (rbj >= 0) && (rbd <= dmax2);
                 hint[uq] = ok ? rbj : -1;
-                rho[uq] = rbj >= 0 ? rcert : (__int_as_float(en.z) >= dmax2 ? -1.0f : 0.0f);
+                rho[uq] = rbj >= 0 ? rcert : (__int_as_float(en.z) >= dmax2 ? -fmaxf(bsqrt(dmax2) * 0.999999f - 1e-6f, 1e-30f) : 0.0f);
+                if (fv.hint2) {
+                    fv.hint2[uq] = -1;
+                    fv.rho3[uq] = 0.0f;
+                }
             }
         }
     }

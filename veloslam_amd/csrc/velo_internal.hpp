@@ -44,6 +44,12 @@ struct FrameView {
     // copies and order[q] is the ORIGINAL index of slot q (used only to write the per-query
     // diagnostics back in caller order); nullptr = identity.
     const int32_t* order;
+    // Round 6, latency kernels only (nullptr = off): PAIR CERTIFICATES.  hint2[q] = the runner-up of query q's last
+    // search, rho3[q] = a radius around the query's previous position inside which the winner and the runner-up are
+    // the ONLY map points -- a query whose two nearest candidates are nearly equidistant (consecutive returns of one
+    // scan line in a map made of scans) has no uniqueness radius to speak of, and was searched at every iteration.
+    int32_t* hint2;
+    float* rho3;
 };
 
 // One work item of the linearise kernel: a run of consecutive queries of one frame.
