@@ -51,7 +51,9 @@ extern "C" {
 
 /* 2: velo_map_info carries a caller-filled struct_size (and grew); velo_cfg carries abi_version,
  *    checked by velo_create; cfg zero values map_subdiv = automatic, linearize_variant = ball */
-#define VELO_ABI_VERSION 2
+/* 3: velo_cfg grew the tuning knobs that used to be environment variables (split_iterations ... pair_certificates);
+ *    velo_map_size; velo_map_roll_begin may be called with no registration outstanding */
+#define VELO_ABI_VERSION 3
 #define VELO_MAX_ITERS 64
 #define VELO_MAX_RANKS 64   /* ranks of one exchange communicator */
 #define VELO_MAX_KNORMALS 32
@@ -118,6 +120,25 @@ typedef struct velo_cfg {
                                decompositions of a large one.  Speed only: results do not depend on it */
     uint32_t abi_version;   /* = VELO_ABI_VERSION (the header the caller was compiled against) */
     int32_t reserved[2];
+    /* ---- ABI 3: the tuning knobs that used to be read from the environment at velo_create.
+     * Speed only, every one of them: results never depend on them (tests hold each setting to the oracle).  0 = the
+     * default everywhere.  The old environment variables are still read as MEASUREMENT OVERRIDES of a zero field
+     * (tools/ab_*.sh), documented here and nowhere consulted when the field is set. */
+    int32_t split_iterations;   /* first iterations run as three launches (stage A of every query / the launch's
+                                   stragglers together / the ordinary kernel on certified hints): 0 = default (1, on
+                                   the latency path), n > 0 = n, -1 = never.  [VELO_SPLIT_ITERS] */
+    int32_t split_batches;      /* 1: ... on the throughput path too (measured slower there).  [VELO_SPLIT_BATCH] */
+    int32_t split_per_wave_max; /* stragglers up to which the second launch gives each a wavefront of its own:
+                                   0 = default (131072), n > 0 = n, -1 = none (always 64 per wavefront).
+                                   [VELO_SPLIT_PER_WAVE_MAX] */
+    int32_t solve_threads;      /* workgroup size of k_reduce_solve: 0 = default (1024), 256 / 512 / 1024.
+                                   [VELO_SOLVE_THREADS] */
+    int32_t roll_cus;           /* CUs the stream of a roll begun ahead may use: 0 = default (three quarters of the
+                                   device, the last two CUs of every shader engine left free), n >= 32 = n (rounded
+                                   down to whole engines' worth), -1 = no CU mask.  [VELO_ROLL_CUS, VELO_ROLL_NO_CU_MASK] */
+    int32_t pair_certificates;  /* latency kernels: pair certificates + no-match certificates with a radius
+                                   (round 6): 0 = default (on), -1 = off.  [VELO_NO_PAIR_CERT] */
+    int32_t reserved2[2];
 } velo_cfg;
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */

@@ -129,3 +129,89 @@ def test_rank_order_pack_refuses_bad_plans():
         assert c.exchange_pack_dev(buf.data_ptr(), [16, 16, 16, 16], 16, *args, 64) == 64
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_replicas_stay_identical_through_the_product_exchange_path(world, oracle):
+    """the replica property held on the PRODUCT, not on the oracle's RollingMap.  W ranks are emulated by
+    W contexts on one GPU (RCCL refuses two ranks on one device; what it would move is copied here): every step each
+    rank registers its own frame against its replica of the map and takes the accepted increment
+    (velo_increment_all_registered_async); the blocks are laid out as the max-padded all-gather leaves them
+    (velo_exchange_plan) and EVERY context packs them in rank order (velo_exchange_pack_dev) and inserts them
+    voxel-downsampled (velo_map_append_sparse_dev).  After every step all W maps -- permutation, fine table, normal
+    bits -- are identical, and identical to ONE context that registers the W frames of the step as one batch."""
+    from tests.util_scene import make_workload
+    steps = 2
+    wl = make_workload(map_points=150_000, n_frames=world * steps, first_frame=3)
+    comp = []
+    for f in wl["frames"]:
+        s = f["sensor"]
+        comp.append(oracle.compensate(s["x"], s["y"], s["z"], s["pkt"], f["table"]))
+    # a map with a hole in it, so that every frame has something to contribute
+    mx, my, mz = wl["map"]
+    keep = (np.abs(my) > 6.0) | (mx < -20.0)
+    base = tuple(a[keep] for a in (mx, my, mz))
+    ranks = [capi.Context(0, max_batch=2, map_margin=8) for _ in range(world)]
+    single = capi.Context(0, max_batch=world, map_margin=8)
+    dev = torch.device("cuda")
+    min_count = 3
+
+    def tables(c):
+        g = c.map_download()
+        return g["perm"], g["cell_start"], g["nx"].view(np.uint32), g["ny"].view(np.uint32), g["nz"].view(np.uint32)
+
+    try:
+        for c in ranks + [single]:
+            c.map_reset(*base, 1.0, 16)
+        n_max = max(c_[0].size for c_ in comp)
+        for s in range(steps):
+            frames = list(range(s * world, (s + 1) * world))
+            # ---- W ranks, one frame each
+            blocks, counts = [], []
+            for r, fi in enumerate(frames):
+                c = ranks[r]
+                c.frames_upload([tuple(comp[fi])])
+                c.icp_batch_async(wl["frames"][fi]["T0"].reshape(1, 12), 12, 1.0)
+                out = torch.empty((3, n_max), dtype=torch.float32, device=dev)
+                torch.cuda.synchronize()
+                c.increment_all_registered_async(min_count, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+                n = c.increment_wait()
+                c.synchronize()
+                assert n > 0
+                blocks.append(out[:, :n].clone())
+                counts.append(int(n))
+            offs, pad, total = capi.exchange_plan(counts)
+            recv = torch.zeros(world * 3 * pad, dtype=torch.float32, device=dev)   # what the padded all-gather leaves
+            for r in range(world):
+                recv[r * 3 * pad:(r + 1) * 3 * pad].view(3, pad)[:, :counts[r]] = blocks[r]
+            torch.cuda.synchronize()
+            accepted = []
+            for c in ranks:
+                packed = torch.empty((3, total), dtype=torch.float32, device=dev)
+                torch.cuda.synchronize()
+                got = c.exchange_pack_dev(recv.data_ptr(), counts, pad, packed[0].data_ptr(), packed[1].data_ptr(),
+                                          packed[2].data_ptr(), total)
+                assert got == total
+                accepted.append(c.map_append_sparse_dev(packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr(),
+                                                        total, min_count))
+                c.synchronize()
+            assert len(set(accepted)) == 1 and 0 < accepted[0] <= total
+            # ---- one rank, the same W frames as one batch
+            single.frames_upload([tuple(comp[fi]) for fi in frames])
+            single.icp_batch_async(np.stack([wl["frames"][fi]["T0"] for fi in frames]), 12, 1.0)
+            out = torch.empty((3, n_max * world), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            single.increment_all_registered_async(min_count, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+            n1 = single.increment_wait()
+            assert n1 == total                 # (frame order == rank order: the same list)
+            a1 = single.map_append_sparse_dev(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), n1, min_count)
+            single.synchronize()
+            assert a1 == accepted[0]
+            ref = tables(single)
+            for c in ranks:
+                got = tables(c)
+                for a, b in zip(got, ref):
+                    assert np.array_equal(a, b)
+    finally:
+        for c in ranks + [single]:
+            c.close()

@@ -616,17 +616,16 @@ def test_split_first_iteration_changes_nothing(omap, wl, comp, monkeypatch):
     stragglers packed 64 to a wavefront: the same poses, pair counts and residuals to the last bit (and the
     oracle's pose).  The frame is also registered against a map with a hole under a third of it: queries without
     any match (the no-match certificate of the third launch)."""
-    def run(split, force, batch, pts, per_wave_max=None):
-        monkeypatch.setenv("VELO_SPLIT_ITERS", str(split))
-        if batch:
-            monkeypatch.setenv("VELO_SPLIT_BATCH", "1")
-        else:
-            monkeypatch.delenv("VELO_SPLIT_BATCH", raising=False)
-        if per_wave_max is None:
-            monkeypatch.delenv("VELO_SPLIT_PER_WAVE_MAX", raising=False)
-        else:
-            monkeypatch.setenv("VELO_SPLIT_PER_WAVE_MAX", str(per_wave_max))
-        c = capi.Context(0, max_batch=2, force_kernel=force)
+    for v in ("VELO_SPLIT_ITERS", "VELO_SPLIT_BATCH", "VELO_SPLIT_PER_WAVE_MAX", "VELO_NO_PAIR_CERT"):
+        monkeypatch.delenv(v, raising=False)      # (the knobs are velo_cfg fields since ABI 3: nothing comes from outside)
+
+    def run(split, force, batch, pts, per_wave_max=None, pair=0):
+        c = capi.Context(0, max_batch=2, force_kernel=force, split_iterations=split if split > 0 else -1,
+                         split_batches=1 if batch else 0,
+                         split_per_wave_max=0 if per_wave_max is None else (per_wave_max if per_wave_max > 0 else -1),
+                         pair_certificates=pair)
+        cf = c.cfg()
+        assert cf.split_iterations == (split if split > 0 else -1) and cf.pair_certificates == pair
         try:
             c.map_reset(*pts, 1.0, 16)
             c.frames_upload([tuple(comp[0])])
@@ -646,6 +645,9 @@ def test_split_first_iteration_changes_nothing(omap, wl, comp, monkeypatch):
         assert run(1, capi.KERNEL_LATENCY, False, pts, per_wave_max=0) == base      # phase B packed 64 to a wavefront
         assert run(2, capi.KERNEL_THROUGHPUT, True, pts) == base                  # forced on the throughput kernel
         assert run(1, capi.KERNEL_THROUGHPUT, True, pts, per_wave_max=0) == base
+        # round 6: the latency kernels' pair certificates and no-match certificates with a radius, off -- the same bits
+        assert run(1, capi.KERNEL_LATENCY, False, pts, pair=-1) == base
+        assert run(0, capi.KERNEL_LATENCY, False, pts, pair=-1) == base
     T_o, _, _ = omap.icp(*comp[0], wl["frames"][0]["T0"], 12, 1.0)
     dp, dr = pose_delta(run(1, capi.KERNEL_LATENCY, False, wl["map"])[0], T_o)
     assert dp <= POS_TOL and dr <= ROT_TOL

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in capi.EXPORTS:
         assert name + "(" in hdr, "velo.h does not declare " + name
         assert getattr(L, name) is not None
-    assert L.velo_abi_version() == capi.VELO_ABI_VERSION == 2
+    assert L.velo_abi_version() == capi.VELO_ABI_VERSION == 3
     assert ("#define VELO_ABI_VERSION %d" % capi.VELO_ABI_VERSION) in hdr
 
 

@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("VELO_LIB") or os.path.join(CSRC, "libveloslam_amd.so")  # VELO_LIB: A/B builds
 
 VELO_MAX_ITERS = 64
-VELO_ABI_VERSION = 2   # include/velo.h; lib() refuses a library that reports another
+VELO_ABI_VERSION = 3   # include/velo.h; lib() refuses a library that reports another
 VELO_MAX_RANKS = 64
 VARIANT_BALL, VARIANT_SCAN = 1, 100  # velo_cfg.linearize_variant (0 = default = BALL)
 KERNEL_AUTO, KERNEL_THROUGHPUT, KERNEL_LATENCY = 0, 1, 2  # velo_cfg.force_kernel
@@ -53,7 +53,11 @@ class Cfg(C.Structure):
                 ("use_graph", C.c_int32), ("map_subdiv", C.c_int32), ("use_hints", C.c_int32),
                 ("rounds_per_block", C.c_int32), ("map_margin", C.c_int32),
                 ("map_full_rebuild", C.c_int32), ("map_hash_load", C.c_int32), ("force_kernel", C.c_int32), ("plan_wave_slots", C.c_int32), ("abi_version", C.c_uint32),
-                ("reserved", C.c_int32 * 2)]
+                ("reserved", C.c_int32 * 2),
+                # ABI 3: the tuning knobs (include/velo.h)
+                ("split_iterations", C.c_int32), ("split_batches", C.c_int32), ("split_per_wave_max", C.c_int32),
+                ("solve_threads", C.c_int32), ("roll_cus", C.c_int32), ("pair_certificates", C.c_int32),
+                ("reserved2", C.c_int32 * 2)]
 
 
 class Pose(C.Structure):
@@ -419,7 +423,8 @@ class Context:
 
     def __init__(self, device=0, max_batch=64, sort_frames=0, linearize_variant=1, map_subdiv=3,
                  use_hints=2, use_graph=1, rounds_per_block=0, map_margin=0, map_full_rebuild=0,
-                 map_hash_load=0, force_kernel=0, plan_wave_slots=0):
+                 map_hash_load=0, force_kernel=0, plan_wave_slots=0, split_iterations=0, split_batches=0,
+                 split_per_wave_max=0, solve_threads=0, roll_cus=0, pair_certificates=0):
         L = lib()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -436,6 +441,12 @@ class Context:
         cfg.map_hash_load = map_hash_load
         cfg.force_kernel = force_kernel
         cfg.plan_wave_slots = plan_wave_slots
+        cfg.split_iterations = split_iterations
+        cfg.split_batches = split_batches
+        cfg.split_per_wave_max = split_per_wave_max
+        cfg.solve_threads = solve_threads
+        cfg.roll_cus = roll_cus
+        cfg.pair_certificates = pair_certificates
         self.h = L.velo_create(device, C.byref(cfg))
         if not self.h:
             raise VeloError(-3, L.velo_last_error(None).decode())

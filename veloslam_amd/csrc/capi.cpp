@@ -150,7 +150,8 @@ struct velo_ctx {
     DevBuf<uint32_t> tile_bounds;   // per 1 024-entry tile of the table: launch_table_shift / _remap
     DevBuf<int4> sq;                // the split iteration's straggler queue (one slot per query) ...
     DevBuf<unsigned> sq_count;      // ... and its length, one counter per iteration of a registration
-    int split_iters = 1;            // iterations 0 .. split_iters - 1 run as three launches (VELO_SPLIT_ITERS)
+    bool pair_certs = true;         // latency kernels: pair + no-match certificates (cfg.pair_certificates)
+    int split_iters = 1;            // iterations 0 .. split_iters - 1 run as three launches (cfg.split_iterations)
     bool split_batch = false;       // ... on the throughput path too (VELO_SPLIT_BATCH: measurements and tests)
     unsigned split_per_wave_max = 131072;  // stragglers up to which phase B gives each a wavefront of its own (a latency-path launch: two or three frames at most)
     DevBuf<uint8_t> vox_near_alt;
@@ -1447,13 +1448,6 @@ static hipError_t launch_iteration(velo_ctx* c, int it, bool split, const FrameV
                             nullptr, hint, rho, prev, stats || (split && split_debug), c->plan_lat ? 2 : 1, s, dc.lat_lanes);
 }
 
-// (measurement aid: VELO_NO_PAIR_CERT=1 runs the latency path without the pair certificates of round 6)
-static bool pair_certificates_off()
-{
-    static const bool off = getenv("VELO_NO_PAIR_CERT") != nullptr;
-    return off;
-}
-
 int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
 {
     if (!c->has_map) return c->fail(VELO_E_NOMAP, "no map: call velo_map_reset first");
@@ -1492,7 +1486,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
     // pair certificates: the latency kernels' (FrameView::hint2 / rho3; the throughput kernel never looks at them)
     int32_t* hint2 = nullptr;
     float* rho3 = nullptr;
-    if (hint && rho && c->plan_lat && c->cfg.linearize_variant == VELO_VARIANT_BALL && !pair_certificates_off()) {
+    if (hint && rho && c->plan_lat && c->cfg.linearize_variant == VELO_VARIANT_BALL && c->pair_certs) {
         HIP_TRY(c, c->hint2.reserve(n_all));
         HIP_TRY(c, c->rho3.reserve(n_all));
         hint2 = c->hint2.p;
@@ -1560,7 +1554,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
                 e = launch_iteration(c, it, split, fv, dmax2, hint, rho, false, false, s);
                 if (e == hipSuccess)
                     e = launch_reduce_solve(c->partials.p, dc.fbs, dc.lay, c->n_frames, c->poses.p,
-                                            c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
+                                            c->stats.p, it, c->cfg.solve_threads, nullptr, 1, c->poses_prev.p,
                                             c->pairs_total.p, s, (int)(c->partials.cap / kAccStride), dc.lay0,
                                             dc.lay0->nbig != 0 || c->n_frames > 1);
             }
@@ -1599,7 +1593,7 @@ int run_icp(velo_ctx* c, const double* T0, int iters, float d_max)
         {
             Timed t(c, 1);
             HIP_TRY(c, launch_reduce_solve(c->partials.p, dc.fbs, dc.lay, c->n_frames, c->poses.p,
-                                           c->stats.p, it, iters, nullptr, 1, c->poses_prev.p,
+                                           c->stats.p, it, c->cfg.solve_threads, nullptr, 1, c->poses_prev.p,
                                            c->pairs_total.p, s, (int)(c->partials.cap / kAccStride), dc.lay0,
                                            dc.lay0->nbig != 0 || c->n_frames > 1));
         }
@@ -1734,9 +1728,19 @@ velo_ctx* velo_create(int device_id, const velo_cfg* cfg)
     c->cfg.struct_size = sizeof(velo_cfg);
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 64;
     if (c->cfg.plan_wave_slots > 0) c->wave_slots = c->cfg.plan_wave_slots;
-    if (const char* e = getenv("VELO_SPLIT_ITERS")) c->split_iters = std::max(0, std::min(atoi(e), VELO_MAX_ITERS));   // (A/B: 0 = never split)
-    c->split_batch = getenv("VELO_SPLIT_BATCH") != nullptr;
-    if (const char* e = getenv("VELO_SPLIT_PER_WAVE_MAX")) c->split_per_wave_max = (unsigned)std::max(0, atoi(e));
+    // the tuning knobs: velo_cfg (ABI 3); a ZERO field may be overridden by the old environment variable (A/B scripts)
+    if (c->cfg.split_iterations > 0) c->split_iters = std::min(c->cfg.split_iterations, VELO_MAX_ITERS);
+    else if (c->cfg.split_iterations < 0) c->split_iters = 0;
+    else if (const char* e = getenv("VELO_SPLIT_ITERS")) c->split_iters = std::max(0, std::min(atoi(e), VELO_MAX_ITERS));
+    c->split_batch = c->cfg.split_batches != 0 || getenv("VELO_SPLIT_BATCH") != nullptr;
+    if (c->cfg.split_per_wave_max > 0) c->split_per_wave_max = (unsigned)c->cfg.split_per_wave_max;
+    else if (c->cfg.split_per_wave_max < 0) c->split_per_wave_max = 0;
+    else if (const char* e = getenv("VELO_SPLIT_PER_WAVE_MAX")) c->split_per_wave_max = (unsigned)std::max(0, atoi(e));
+    if (c->cfg.solve_threads != 0 && c->cfg.solve_threads != 256 && c->cfg.solve_threads != 512 && c->cfg.solve_threads != 1024) {
+        g_create_error = "velo_cfg.solve_threads must be 0, 256, 512 or 1024";
+        return nullptr;
+    }
+    c->pair_certs = c->cfg.pair_certificates >= 0 && !(c->cfg.pair_certificates == 0 && getenv("VELO_NO_PAIR_CERT"));
     // 0 = the default (fast, pruned) kernel for every consumer -- C, C++ MapManager and Python
     // alike; the exhaustive validation kernel has to be asked for by name
     if (c->cfg.linearize_variant == 0) c->cfg.linearize_variant = VELO_VARIANT_BALL;
@@ -2426,12 +2430,14 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
         const int ncu = prop.multiProcessorCount;
         std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
         int roll_cus = ncu - ncu / 4;
-        if (const char* e = getenv("VELO_ROLL_CUS")) {   // (measurement aid: how many CUs the roll may use)
-            const int v = atoi(e);
-            if (v >= 32 && v <= ncu) roll_cus = v / 32 * 32;
+        int want_cus = c->cfg.roll_cus;
+        if (want_cus == 0) {   // (measurement overrides of the default)
+            if (const char* e = getenv("VELO_ROLL_CUS")) want_cus = atoi(e);
+            if (getenv("VELO_ROLL_NO_CU_MASK")) want_cus = -1;
         }
+        if (want_cus >= 32 && want_cus <= ncu) roll_cus = want_cus / 32 * 32;
         for (int i = 0; i < roll_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-        if (getenv("VELO_ROLL_NO_CU_MASK") || hipExtStreamCreateWithCUMask(&c->roll_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        if (want_cus < 0 || hipExtStreamCreateWithCUMask(&c->roll_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
             (void)hipGetLastError();
             if (getenv("VELO_TRACE_ROLL")) std::fprintf(stderr, "velo: the roll's stream has no CU mask\n");
             HIP_TRY(c, hipStreamCreateWithFlags(&c->roll_stream, hipStreamNonBlocking));
@@ -2797,7 +2803,7 @@ int velo_linearize(velo_ctx* c, int frame, const double T[12], float d_max, int3
                                 // (the frames are cut for one kernel: say which, item counts no longer do)
                                 c->cfg.linearize_variant == VELO_VARIANT_BALL ? (c->plan_lat ? 2 : 1) : c->cfg.force_kernel,
                                 s, c->lat_first_lanes));
-    HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p + frame, c->lay.p + frame, 1, c->poses.p, nullptr, 0, 1,
+    HIP_TRY(c, launch_reduce_solve(c->partials.p, c->fbs.p + frame, c->lay.p + frame, 1, c->poses.p, nullptr, 0, c->cfg.solve_threads,
                                    c->acc.p, 0, nullptr, nullptr, s));
     if (corr)
         HIP_TRY(c, hipMemcpyAsync(corr, c->corr.p + q0, (q1 - q0) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -2836,7 +2842,7 @@ int velo_solve_update(velo_ctx* c, const double acc[29], double T[12], int32_t* 
     HIP_TRY(c, hipMemcpyAsync(pose.p, T, 12 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(fbs.p, range, sizeof range, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));  // the sources are stack arrays
-    HIP_TRY(c, launch_reduce_solve(part.p, fbs.p, lay.p, 1, pose.p, st.p, 0, 1, nullptr, 1, nullptr, nullptr, s));
+    HIP_TRY(c, launch_reduce_solve(part.p, fbs.p, lay.p, 1, pose.p, st.p, 0, c->cfg.solve_threads, nullptr, 1, nullptr, nullptr, s));
     velo_icp_iter it0;
     HIP_TRY(c, hipMemcpyAsync(T, pose.p, 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&it0, st.p, sizeof it0, hipMemcpyDeviceToHost, s));

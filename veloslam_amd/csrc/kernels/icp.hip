@@ -2120,11 +2120,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(
 
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start, const RowLayout* layout,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
-                               int iters_total, double* acc_out, int do_update, double* poses_prev,
+                               int solve_threads, double* acc_out, int do_update, double* poses_prev,
                                unsigned long long* pairs_total, hipStream_t s, int spec_rows,
                                const RowLayout* layout0, bool mixed)
 {
-    (void)iters_total;
     if (n_frames == 0) return hipSuccess;
     static_assert(sizeof(RowLayout) == sizeof(int4), "RowLayout is read as an int4");
     int4 l0 = make_int4(0, 0, 0, 0);
@@ -2139,7 +2138,9 @@ hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_bloc
     // one.  What cured that was not a smaller solve (256 threads still waited 0.2 - 0.35 ms per launch and cost the
     // stream 7 % by its four trips) but keeping two CUs of every shader engine free of the roll (capi.cpp,
     // velo_map_roll_begin; profiles/r05/roll_begin_trace_*.txt).  VELO_SOLVE_THREADS pins another size (measurement).
-    const int threads = solve_threads_override() ? solve_threads_override() : 1024;
+    // (cfg.solve_threads; 0 = the default, which the measurement variable VELO_SOLVE_THREADS may override)
+    const int threads = (solve_threads == 256 || solve_threads == 512 || solve_threads == 1024)
+                            ? solve_threads : (solve_threads_override() ? solve_threads_override() : 1024);
 #define VELO_LAUNCH_SOLVE(MX, TT)                                                                                      \
     hipLaunchKernelGGL((k_reduce_solve<MX, TT>), dim3(n_frames), dim3(TT), 0, s, partials, frame_block_start,          \
                        reinterpret_cast<const int4*>(layout), poses, stats, iter, acc_out, do_update, poses_prev,       \

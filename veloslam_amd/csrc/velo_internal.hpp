@@ -209,7 +209,7 @@ struct RowLayout {
 constexpr int32_t kMaxRowSlots = 32 * 32 * 256;
 hipError_t launch_reduce_solve(const double* partials, const int32_t* frame_block_start, const RowLayout* layout,
                                int n_frames, double* poses, velo_icp_iter* stats, int iter,
-                               int iters_total, double* acc_out, int do_update, double* poses_prev,
+                               int solve_threads /* 0 = default, 256 / 512 / 1024 */, double* acc_out, int do_update, double* poses_prev,
                                unsigned long long* pairs_total, hipStream_t s, int spec_rows = 0,
                                const RowLayout* layout0 = nullptr, bool mixed = true);
 // (mixed = false: the caller vouches that every frame's layout has nbig == 0 -- rows of one size)
