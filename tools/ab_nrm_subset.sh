@@ -1,0 +1,10 @@
+#!/bin/bash
+# A/B of the re-estimation kernel of the incremental map updates: cooperative (default) vs per lane (VELO_NRM_SUBSET_WAVE=1)
+D=/tmp/mapdrive_248; L=/tmp/drv_loc
+[ -f $D/drive.pcap ] || python bench.py --export-mapping-drive $D --mapping-frames 248 2>&1 | tail -1
+[ -f $L/drive.pcap ] || python bench.py --export-drive $L --stream-frames 64 2>&1 | tail -1
+for i in 1 2; do
+for v in "" "VELO_NRM_SUBSET_WAVE=1"; do
+  echo "== mapping $v: $(env $v tools/stream_driver $D --mapping --steps 200 --warmup 40 --threshold 1 | python3 -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['frames_per_s'], r['worst_pose_error_m'], r['map_points'])")"
+  echo "== localisation $v: $(env $v tools/stream_driver $L --steps 256 --warmup 128 | python3 -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['frames_per_s'], r['worst_pose_error_m'], r['map_points'])")"
+done; done

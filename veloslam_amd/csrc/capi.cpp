@@ -455,7 +455,7 @@ int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, const uint32_t*
         // bound (every point), the surplus workgroups leave at once -- and the count of normals re-estimated
         // goes to pinned memory for whoever asks after the roll (velo_map_info_get)
         HIP_TRY(c, launch_normals_subset(mv, c->perm.p, k, c->work.p, mv.n, chg_keys, n_chg, c->nrm.p,
-                                         c->invalid_cnt.p, c->work_cnt.p + 1, s, c->work_cnt.p));
+                                         c->invalid_cnt.p, c->work_cnt.p + 1, s, c->work_cnt.p, c->cfg.force_kernel));
         HIP_TRY(c, hipMemcpyAsync(&c->h_roll->n_done, c->work_cnt.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         return VELO_OK;
     }
@@ -463,7 +463,7 @@ int refresh_dirty_normals(velo_ctx* c, const MapView& mv, int k, const uint32_t*
     HIP_TRY(c, hipMemcpyAsync(&n_work, c->work_cnt.p, sizeof n_work, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, launch_normals_subset(mv, c->perm.p, k, c->work.p, (int)n_work, chg_keys, n_chg,
-                                     c->nrm.p, c->invalid_cnt.p, c->work_cnt.p + 1, s));
+                                     c->nrm.p, c->invalid_cnt.p, c->work_cnt.p + 1, s, nullptr, c->cfg.force_kernel));
     HIP_TRY(c, hipMemcpyAsync(&c->n_done_host, c->work_cnt.p + 1, sizeof(unsigned),
                               hipMemcpyDeviceToHost, s));
     return VELO_OK;

@@ -572,6 +572,88 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_normals_wave(MapView mv, co
     }
 }
 
+// ---- the same for a WORK LIST of sorted points (the incremental map update's re-estimation, round 6): kNrmSubsetGroup
+// listed points per wavefront, searched one after the other by all 64 lanes, then one lane per point.  The per-lane
+// kernel (map_build.hip k_normals_subset) runs ~150 dependent round trips per lane and a map update lists only tens of
+// thousands of points -- less than one wavefront per SIMD: 290 us of pure latency per update of a map grown from
+// increments, 680 us per tile column entering a dense map.  Same lists, same order, same arithmetic: the same bits.
+// The invalid-normal count is maintained by difference, as there.
+#ifndef VELO_NRM_SUBSET_GROUP
+#define VELO_NRM_SUBSET_GROUP 16
+#endif
+constexpr int kNrmSubsetGroup = VELO_NRM_SUBSET_GROUP;
+static_assert(kNrmSubsetGroup >= 1 && kNrmSubsetGroup <= 64, "points per wavefront");
+
+template <bool HASH>
+__global__ __launch_bounds__(kKnnWaveThreads) void k_normals_wave_subset(MapView mv, const uint32_t* __restrict__ perm, int k,
+                                                                         const int32_t* __restrict__ work, int n_work,
+                                                                         const unsigned* __restrict__ n_work_dev,
+                                                                         float4* __restrict__ nrm,
+                                                                         unsigned long long* __restrict__ invalid,
+                                                                         unsigned* __restrict__ n_done)
+{
+    __shared__ int s_j[kKnnWaveThreads / 64][kNrmSubsetGroup * kNrmWaveStride];
+    __shared__ float s_rk[kKnnWaveThreads / 64][kNrmSubsetGroup];
+    __shared__ int s_cnt[kKnnWaveThreads / 64][kNrmSubsetGroup];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = n_work_dev ? (int)min(*n_work_dev, (unsigned)n_work) : n_work;
+    const float rn = kNormalRadius * mv.h;
+    const float r2 = rn * rn;
+    const long long stride = (long long)gridDim.x * (kKnnWaveThreads / 64) * kNrmSubsetGroup;
+    for (long long g0 = ((long long)blockIdx.x * (kKnnWaveThreads / 64) + w) * kNrmSubsetGroup; g0 < nw; g0 += stride) {
+        const int np = (int)min((long long)kNrmSubsetGroup, (long long)nw - g0);   // (wavefront-uniform)
+        for (int p = 0; p < np; ++p) {
+            const int sp = work[g0 + p];
+            const float4 q = mv.pts[sp];
+            Ent<true> e;
+            KnnCounts ct;
+            wave_knn<true, HASH, false>(mv, perm, q.x, q.y, q.z, r2, k, lane, e, ct);
+            const bool have = lane < k && e.hi != kKeyMax;
+            const int cnt = __popcll(__ballot(have));
+            if (lane < 32) s_j[w][p * kNrmWaveStride + lane] = e.pay;
+            if (lane == 0) {
+                const unsigned kth = (unsigned)__builtin_amdgcn_readlane((int)e.hi, k - 1);
+                s_cnt[w][p] = cnt;
+                s_rk[w][p] = cnt == k ? __uint_as_float(kth) : r2;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < np) {
+            const int sp = work[g0 + lane];
+            const float4 old = nrm[sp];
+            const int cnt = s_cnt[w][lane];
+            const float4 nv = pca_normal(cnt, s_rk[w][lane], [&](int i) { return mv.pts[s_j[w][lane * kNrmWaveStride + i]]; });
+            nrm[sp] = nv;
+            const int was = (old.w >= 0.0f && old.x == 0.f && old.y == 0.f && old.z == 0.f) ? 1 : 0;
+            const int now = (nv.x == 0.f && nv.y == 0.f && nv.z == 0.f) ? 1 : 0;
+            if (now != was) atomicAdd(invalid, (unsigned long long)(long long)(now - was));
+            if (n_done) atomicAdd(n_done, 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // (the parked lists are rewritten by the next group)
+    }
+}
+
+hipError_t launch_normals_wave_subset(const MapView& mv, const uint32_t* perm, int k, const int32_t* work, int n_work,
+                                      float4* nrm, unsigned long long* d_invalid, unsigned* d_done, hipStream_t s,
+                                      const unsigned* n_work_dev)
+{
+    if (n_work <= 0) return hipSuccess;
+    const int wpb = kKnnWaveThreads / 64;
+    const long long nw = ((long long)n_work + kNrmSubsetGroup - 1) / kNrmSubsetGroup;
+    long long nb = (nw + wpb - 1) / wpb;
+    if (n_work_dev && nb > 4096) nb = 4096;   // (length still on the device: a bounded grid that strides, as k_normals_subset's)
+    if (mv.cell_start)
+        hipLaunchKernelGGL((k_normals_wave_subset<false>), dim3((unsigned)nb), dim3(kKnnWaveThreads), 0, s, mv, perm, k, work, n_work,
+                           n_work_dev, nrm, d_invalid, d_done);
+    else
+        hipLaunchKernelGGL((k_normals_wave_subset<true>), dim3((unsigned)nb), dim3(kKnnWaveThreads), 0, s, mv, perm, k, work, n_work,
+                           n_work_dev, nrm, d_invalid, d_done);
+    return hipGetLastError();
+}
+
 hipError_t launch_normals_wave(const MapView& mv, const uint32_t* perm, int k, float4* nrm,
                                unsigned long long* d_invalid, hipStream_t s)
 {

@@ -1055,12 +1055,32 @@ hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& 
     return hipGetLastError();
 }
 
+// which kernel re-estimates a work list.  MEASURED (round 6, profiles/r06/ab_nrm_subset.txt): the cooperative kernel
+// finishes a list sooner when it runs alone, but a stream's updates run BESIDE a registration, and there its ~1 000 vector
+// instructions per point compete for the issue slots the registration needs, where the per-lane kernel mostly waits
+// for memory: mapping stream 788 frames/s against 858, localisation stream 1 400 against 1 470.  The per-lane kernel stays
+// the default; mode 2 (cfg.force_kernel) or VELO_NRM_SUBSET_WAVE=1 select the cooperative one (tests hold both to the
+// oracle; same bits).
+bool normals_subset_use_wave(const MapView& mv, int n_work, int mode)
+{
+    (void)mv;
+    (void)n_work;
+    if (mode == 1) return false;
+    if (mode == 2) return true;
+    static const bool wave = getenv("VELO_NRM_SUBSET_WAVE") != nullptr;
+    return wave;
+}
+
 hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
                                  const int32_t* work, int n_work, const uint32_t* chg_keys,
                                  uint32_t n_chg, float4* nrm, unsigned long long* d_invalid,
-                                 unsigned* d_done, hipStream_t s, const unsigned* n_work_dev)
+                                 unsigned* d_done, hipStream_t s, const unsigned* n_work_dev, int mode)
 {
     if (n_work <= 0) return hipSuccess;
+    // Round 6: the cooperative form (kernels/knn_wave.hip k_normals_wave_subset: a wavefront per listed point for the
+    // search, a lane per point for the PCA), on request -- see normals_subset_use_wave.  mode: cfg.force_kernel.
+    if (!chg_keys && k >= 1 && normals_subset_use_wave(mv, n_work, mode))
+        return launch_normals_wave_subset(mv, perm, k, work, n_work, nrm, d_invalid, d_done, s, n_work_dev);
     // (length on the device: a bounded grid that strides over the list -- 4 096 workgroups cover 524 288 points in one
     //  pass, more than a roll of the stream marks; the roll's stream keeps a quarter of the CUs free, capi.cpp)
     const int blocks = (n_work + kNrmThreads - 1) / kNrmThreads;

@@ -138,8 +138,13 @@ hipError_t launch_select_dirty(const uint32_t* keys, uint32_t n, const MapView& 
 hipError_t launch_normals_subset(const MapView& mv, const uint32_t* perm, int k,
                                  const int32_t* work, int n_work, const uint32_t* chg_keys,
                                  uint32_t n_chg, float4* nrm, unsigned long long* d_invalid,
-                                 unsigned* d_done, hipStream_t s, const unsigned* n_work_dev = nullptr);
-// (n_work_dev != nullptr: n_work is an upper bound, the length of the list is read on the device)
+                                 unsigned* d_done, hipStream_t s, const unsigned* n_work_dev = nullptr, int mode = 0);
+// (n_work_dev != nullptr: n_work is an upper bound, the length of the list is read on the device;
+//  mode = cfg.force_kernel: 1 = one lane per listed point, 2 = one wavefront per listed point, 0 = the default)
+bool normals_subset_use_wave(const MapView& mv, int n_work, int mode);
+hipError_t launch_normals_wave_subset(const MapView& mv, const uint32_t* perm, int k, const int32_t* work, int n_work,
+                                      float4* nrm, unsigned long long* d_invalid, unsigned* d_done, hipStream_t s,
+                                      const unsigned* n_work_dev);
 hipError_t launch_removed_keys(const uint32_t* keys, const uint32_t* keep, const uint32_t* offs,
                                uint32_t n, uint32_t* out, hipStream_t s);
 hipError_t launch_count_invalid(const float4* nrm, uint32_t n, unsigned long long* d_invalid,
