@@ -27,7 +27,12 @@ At N = 1 the same line carries, measured in this run:
                 (10 M-point map, 16 frames): the HBM-roofline record proper
   single_frame  F = 1 latency (BASELINE configs[1] read literally)
   stream        BASELINE configs[2]: packets -> decode -> register -> increment ->
-                rolling map (evicted by ROI_RANGE around the pose), frames/s
+                rolling map (evicted by ROI_RANGE around the pose), frames/s -- localisation in a
+                pre-mapped world
+  stream_mapping  configs[2] AS SLAM (round 6): the map seeded with one frame and grown ONLY from the
+                accepted increments of the frames registered against it, 600 timed frames
+  roofline.hbm_sized  the fractions measured on HBM-sized working sets (dense, knn32_100m, stream,
+                stream_mapping), nested where the driver keeps them; roofline.single_frame_ms
   incl_h2d      batch frames/s with the sensor frames uploaded from pinned host memory
                 inside the timed region
   cpu_baseline  oracle/icp.c on this box's host cores: 1 thread and all-core (best
@@ -504,11 +509,12 @@ def synthetic_drive(args, dev, src):
                 patch_range=pr, tile_of=tile_of, n_tiles=len(tile_of))
 
 
-def stream_roofline(fps):
+def stream_roofline(fps, key="stream"):
     """BASELINE configs[2] "sustained frames/s + rocprof HBM GB/s": the fabric-side bytes every kernel of a frame moves
     (PMC, per dispatch, summed: profiles/collect.sh on the C++ replay of the same drive) x the frames per second of
-    THIS run = the sustained rate; beside it the rate while a kernel runs"""
-    tr = traffic_for("stream")
+    THIS run = the sustained rate; beside it the rate while a kernel runs.  key: "stream" (localisation in a pre-mapped
+    world) or "stream_mapping" (the map grown from increments)"""
+    tr = traffic_for(key)
     if not tr:
         return None
     return {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -652,6 +658,7 @@ def stream_mapping_children(args, local):
                                                                         int(rec.get("increment_min_count", 0)), ROI_RANGE, args.iters))
     rec["process"] = "own (child of bench.py)"
     rec["export_s"] = t_export
+    rec["roofline"] = stream_roofline(rec["frames_per_s"], "stream_mapping")
     rec["synchronous_integration"] = {k: recs["synchronous"][k] for k in (
         "frames_per_s", "ms_per_frame", "increment_points_per_frame", "map_updates", "worst_pose_error_m",
         "mean_pose_error_m", "map_points")}

@@ -184,10 +184,9 @@ for k in krd:
                         source="profiles/%s/pmc_knn_stream.json" % R,
                         correction="reads = 32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B; writes = WRITE_SIZE")
 
-# ---- the stream (BASELINE configs[2]): every kernel of the C++ replay, bytes and time per frame
-srd, swr, sdur = by_kernel("stream_rdreq"), by_kernel("stream_write"), trace_durations("stream_trace")
-
-
+# ---- the streams (BASELINE configs[2]): every kernel of the C++ replay, bytes and time per frame -- the localisation
+# stream ("stream": a pre-mapped world) and, since round 6, the MAPPING stream ("stream_mapping": the map grown from
+# accepted increments, tools/stream_driver --mapping)
 def family(k):
     for pat, fam in (("k_linearize", "registration (k_linearize_lat)"), ("k_search_a", "registration (split first iteration: k_search_a / _b)"),
                      ("k_search_b", "registration (split first iteration: k_search_a / _b)"), ("k_reduce_solve", "registration (k_reduce_solve)"),
@@ -202,7 +201,10 @@ def family(k):
     return "other"
 
 
-if srd and swr:
+def stream_traffic(prefix, key, program, per_kernel_out):
+    srd, swr, sdur = by_kernel(prefix + "_rdreq"), by_kernel(prefix + "_write"), trace_durations(prefix + "_trace")
+    if not (srd and swr):
+        return
     frames_pmc = max(len(v.get("TCC_EA0_RDREQ_128B_sum", [])) for k, v in srd.items() if "k_decode_emit" in k) if any("k_decode_emit" in k for k in srd) else 0
     frames_wr = max(len(v.get("WRITE_SIZE", [])) for k, v in swr.items() if "k_decode_emit" in k) if any("k_decode_emit" in k for k in swr) else 0
     frames_tr = max((len(v) for k, v in sdur.items() if "k_decode_emit" in k), default=0)
@@ -222,28 +224,38 @@ if srd and swr:
     tot_us = sum(v["kernel_us"] for v in fam.values())
     plain = None
     try:
-        plain = json.loads(open(os.path.join(SRC, "stream_plain.json")).read().strip().splitlines()[-1])
+        plain = json.loads(open(os.path.join(SRC, prefix + "_plain.json")).read().strip().splitlines()[-1])
     except Exception:  # noqa: BLE001
         pass
-    traffic["stream"] = dict(frames_counted=dict(pmc_read=frames_pmc, pmc_write=frames_wr, trace=frames_tr),
-                             hbm_bytes_per_frame=tot_b, kernel_us_per_frame=tot_us,
-                             GBps_while_a_kernel_runs=(tot_b / (tot_us * 1e-6) / 1e9) if tot_us else None,
-                             by_family={k: v for k, v in sorted(fam.items(), key=lambda kv: -(kv[1]["read_bytes"] + kv[1]["write_bytes"]))},
-                             plain_run_frames_per_s=(plain or {}).get("frames_per_s"),
-                             sustained_GBps_at_plain_rate=(tot_b * plain["frames_per_s"] / 1e9) if plain and plain.get("frames_per_s") else None,
-                             source="profiles/%s/pmc_knn_stream.json" % R,
-                             program="tools/stream_driver (C++: veloslam::HDLManager + MapManager over the C ABI), 200 timed + 20 "
-                                     "warm-up frames of the exported synthetic drive; three rocprofv3 passes (kernel trace; read "
-                                     "requests by size class; WRITE_SIZE), counters per dispatch summed over every kernel and "
-                                     "divided by the frames decoded (k_decode_emit dispatches).  Copies (packets in, results "
-                                     "out: < 0.5 MB per frame) are not kernels and are not in these bytes",
-                             correction="reads = 32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B; writes = WRITE_SIZE")
-    json.dump(dict(knn={k: dict(rd=dict(krd[k]), wr=dict(kwr.get(k, {}))) for k in krd if "k_knn" in k},
-                   stream_per_kernel=per_kernel),
-              open(os.path.join(DST, "pmc_knn_stream.json"), "w"), indent=1)
-    st = sorted(glob.glob(os.path.join(SRC, "stream_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    traffic[key] = dict(frames_counted=dict(pmc_read=frames_pmc, pmc_write=frames_wr, trace=frames_tr),
+                        hbm_bytes_per_frame=tot_b, kernel_us_per_frame=tot_us,
+                        GBps_while_a_kernel_runs=(tot_b / (tot_us * 1e-6) / 1e9) if tot_us else None,
+                        by_family={k: v for k, v in sorted(fam.items(), key=lambda kv: -(kv[1]["read_bytes"] + kv[1]["write_bytes"]))},
+                        plain_run_frames_per_s=(plain or {}).get("frames_per_s"),
+                        sustained_GBps_at_plain_rate=(tot_b * plain["frames_per_s"] / 1e9) if plain and plain.get("frames_per_s") else None,
+                        source="profiles/%s/pmc_knn_stream.json" % R,
+                        program=program,
+                        correction="reads = 32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B; writes = WRITE_SIZE")
+    per_kernel_out[key] = per_kernel
+    st = sorted(glob.glob(os.path.join(SRC, prefix + "_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if st:
-        shutil.copy(st[-1], os.path.join(DST, "kernel_stats_stream_cpp.csv"))
+        shutil.copy(st[-1], os.path.join(DST, "kernel_stats_%s_cpp.csv" % key))
+
+
+_pk = {}
+stream_traffic("stream", "stream",
+               "tools/stream_driver (C++: veloslam::HDLManager + MapManager over the C ABI), 200 timed + 20 "
+               "warm-up frames of the exported synthetic drive; three rocprofv3 passes (kernel trace; read "
+               "requests by size class; WRITE_SIZE), counters per dispatch summed over every kernel and "
+               "divided by the frames decoded (k_decode_emit dispatches).  Copies (packets in, results "
+               "out: < 0.5 MB per frame) are not kernels and are not in these bytes", _pk)
+stream_traffic("mapping", "stream_mapping",
+               "tools/stream_driver --mapping (the map seeded with frame 0 and grown from accepted increments, integrated in "
+               "pipeline), 200 timed + 40 warm-up frames of the exported drive to be mapped; the same three rocprofv3 passes", _pk)
+if _pk:
+    json.dump(dict(knn={k: dict(rd=dict(krd[k]), wr=dict(kwr.get(k, {}))) for k in krd if "k_knn" in k},
+                   stream_per_kernel=_pk.get("stream", {}), stream_mapping_per_kernel=_pk.get("stream_mapping", {})),
+              open(os.path.join(DST, "pmc_knn_stream.json"), "w"), indent=1)
 st = sorted(glob.glob(os.path.join(SRC, "knn_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if st:
     shutil.copy(st[-1], os.path.join(DST, "kernel_stats_knn.csv"))
