@@ -188,7 +188,9 @@ typedef struct velo_map_info {
     int32_t table_kind;   /* 0 = dense prefix table, 1 = hash over the occupied fine cells */
     int32_t reserved;
     uint64_t table_slots; /* entries of the dense table / slots of the hash */
-    uint64_t table_occupied; /* hash: occupied fine cells (load = occupied / slots); dense: 0 */
+    uint64_t table_occupied; /* hash: occupied ROW PIECES -- the S fine cells of a voxel along one fine row, the unit the
+                                sparse table is keyed by since round 6 (load = occupied / slots; 16 or 32 bytes per slot);
+                                dense: 0 */
 } velo_map_info;
 
 /* ---- lifetime -------------------------------------------------------------- */

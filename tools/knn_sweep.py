@@ -65,8 +65,9 @@ for h, S, load in [(h, S, l) for h in a.voxels for S in a.subdivs for l in a.has
                 nz = occ[occ > 0]
                 table += " occupancy %.1f %%, pts/occupied cell mean %.1f max %d" % (100.0 * nz.size / occ.size, nz.mean(), nz.max())
         else:
-            table = "hash %.1f M slots (%.2f GB) load %.2f over %.0f M cells, pts/occupied cell %.1f" % (
-                mi.table_slots / 1e6, 16 * mi.table_slots / 1e9, mi.table_occupied / mi.table_slots, mi.n_cells / 1e6,
+            slot_bytes = 32 if mi.subdiv > 4 else 16     # (row-piece hash: one int4 per slot up to S = 4, two beyond)
+            table = "hash %.1f M slots (%.2f GB) load %.2f over %.0f M cells, pts/occupied row piece %.1f" % (
+                mi.table_slots / 1e6, slot_bytes * mi.table_slots / 1e9, mi.table_occupied / mi.table_slots, mi.n_cells / 1e6,
                 mi.n_points / max(mi.table_occupied, 1))
         comp = c.compensate(fr["x"], fr["y"], fr["z"], fr["pkt"], tab)
         c.frames_upload([comp])

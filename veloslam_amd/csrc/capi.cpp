@@ -607,10 +607,15 @@ int build_table(velo_ctx* c, MapView& mv, const uint32_t* keys_sorted, size_t n,
         mv.cell_start = c->cell_start.p;
         mv.hash = nullptr;
         mv.hash_cap = 0;
+        mv.hash_stride = 1;
+        mv.s_magic = 0;
         return VELO_OK;
     }
-    HIP_TRY(c, c->run_cnt.reserve(1));
-    HIP_TRY(c, launch_count_runs(keys_sorted, n, c->run_cnt.p, s));
+    // round 6: keyed by ROW PIECE (the S fine cells of a voxel along a fine row: velo_internal.hpp MapView), one probe per
+    // voxel a row window touches instead of one per fine cell
+    const int S = mv.S > 0 ? mv.S : c->map_S;
+    HIP_TRY(c, c->run_cnt.reserve(2));
+    HIP_TRY(c, launch_count_runs(keys_sorted, n, S, c->run_cnt.p, s));
     unsigned long long occ = 0;
     HIP_TRY(c, hipMemcpyAsync(&occ, c->run_cnt.p, sizeof occ, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -618,11 +623,22 @@ int build_table(velo_ctx* c, MapView& mv, const uint32_t* keys_sorted, size_t n,
     const double want = std::ceil((double)std::max<unsigned long long>(occ, 1) * 100.0 / (double)pct) + 1.0;
     if (want >= 4294967295.0) return c->fail(VELO_E_RANGE, "hash table of %.3g slots", want);
     const size_t cap = (size_t)std::max(want, 16.0);
-    HIP_TRY(c, c->hash_tab.reserve(cap));
-    HIP_TRY(c, launch_hash_build(keys_sorted, n, c->hash_tab.p, (uint32_t)cap, s));
+    const uint32_t stride = S > 4 ? 2u : 1u;
+    HIP_TRY(c, c->hash_tab.reserve(cap * stride));
+    unsigned* d_over = reinterpret_cast<unsigned*>(c->run_cnt.p + 1);
+    HIP_TRY(c, launch_hash_build(keys_sorted, n, c->hash_tab.p, (uint32_t)cap, S, d_over, s));
+    unsigned over = 0;
+    HIP_TRY(c, hipMemcpyAsync(&over, d_over, sizeof over, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (over)
+        return c->fail(VELO_E_RANGE, "a row piece of the sparse table holds 65 536 points or more (its 16-bit offsets do not fit): "
+                       "use a smaller voxel or the dense table");
     mv.cell_start = nullptr;
     mv.hash = c->hash_tab.p;
     mv.hash_cap = (uint32_t)cap;
+    mv.hash_stride = stride;
+    // ceil(2^64 / S): 2^64 / S is whole for S = 2, 4, 8 (then ~0ull / S + 1 is exactly it), otherwise floor + 1
+    mv.s_magic = S >= 2 ? (~0ull / (unsigned long long)S + 1ull) : 0ull;
     c->info.table_slots = cap;
     c->info.table_occupied = occ;
     return VELO_OK;
@@ -716,6 +732,7 @@ int rebuild_map(velo_ctx* c, float voxel, int k_normals, const float* grid_org =
         HIP_TRY(c, launch_gather(c->raw_x.p, c->raw_y.p, c->raw_z.p, c->perm.p, n, c->pts.p, s));
     }
     MapView mv{};
+    mv.S = S;   // (the sparse table is keyed by row piece = fine key / S)
     if (int rc = build_table(c, mv, c->keys_sorted.p, n, ncell)) return rc;
     mv.pts = c->pts.p;
     mv.nrm = c->nrm.p;

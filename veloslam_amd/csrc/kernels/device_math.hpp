@@ -39,26 +39,66 @@ __device__ __forceinline__ uint32_t cell_slot(const MapView& mv, uint32_t key)
     // multiplicative hash, then a multiply-shift range reduction: any capacity, no division
     return (uint32_t)(((unsigned long long)(key * 0x9E3779B1u) * mv.hash_cap) >> 32);
 }
-
-// occupied fine cell `key` -> its index range; false = the cell is empty
-__device__ __forceinline__ bool cell_find(const MapView& mv, uint32_t key, int& start, int& end)
+// v / S for a 32-bit v by the 64-bit reciprocal ceil(2^64 / S): floor((v * magic) / 2^64), exact (the excess is below
+// 2^-32 and a fraction of v / S is at most (S - 1) / S); two multiplies instead of a run-time division
+__device__ __forceinline__ uint32_t div_S(const MapView& mv, uint32_t v)
 {
-    uint32_t h = cell_slot(mv, key);
+    if (mv.S == 1) return v;   // (uniform)
+    const uint32_t mh = (uint32_t)(mv.s_magic >> 32), ml = (uint32_t)mv.s_magic;
+    const unsigned long long t = (unsigned long long)v * mh + __umulhi(v, ml);
+    return (uint32_t)(t >> 32);
+}
+
+// One ROW PIECE (the S fine cells of a voxel along a fine row) of the sparse table.  found = the piece holds points.
+struct Piece {
+    int start;        // first sorted index of the piece
+    uint32_t o[4];    // o[0] = o1 | o2 << 16, ... : points of the piece in sub-cells < c, c = 1 .. S
+};
+__device__ __forceinline__ bool piece_find(const MapView& mv, uint32_t pkey, Piece& p)
+{
+    uint32_t h = cell_slot(mv, pkey);
     for (;;) {
-        const int4 e = mv.hash[h];
-        if ((uint32_t)e.x == key) {
-            start = e.y;
-            end = e.z;
+        const int4 e = mv.hash[(size_t)h * mv.hash_stride];
+        if ((uint32_t)e.x == pkey) {
+            p.start = e.y;
+            p.o[0] = (uint32_t)e.z;
+            p.o[1] = (uint32_t)e.w;
+            p.o[2] = p.o[3] = 0;
+            if (mv.hash_stride > 1) {
+                const int4 f = mv.hash[(size_t)h * mv.hash_stride + 1];
+                p.o[2] = (uint32_t)f.x;
+                p.o[3] = (uint32_t)f.y;
+            }
             return true;
         }
         if ((uint32_t)e.x == 0xffffffffu) return false;
         h = h + 1 == mv.hash_cap ? 0u : h + 1;
     }
 }
+// points of the piece in sub-cells < c (c = 0 .. S)
+__device__ __forceinline__ int piece_off(const Piece& p, int c)
+{
+    if (c == 0) return 0;
+    const uint32_t w = p.o[(c - 1) >> 1];
+    return (int)(((c - 1) & 1) ? (w >> 16) : (w & 0xffffu));
+}
+
+// occupied fine cell `key` -> its index range; false = the cell is empty
+__device__ __forceinline__ bool cell_find(const MapView& mv, uint32_t key, int& start, int& end)
+{
+    const uint32_t pk = div_S(mv, key);
+    const int c = (int)(key - pk * (uint32_t)mv.S);
+    Piece p;
+    if (!piece_find(mv, pk, p)) return false;
+    start = p.start + piece_off(p, c);
+    end = p.start + piece_off(p, c + 1);
+    return end > start;
+}
 
 // index range [jlo, jhi) of the fine cells x0..x1 (inclusive, x0 <= x1, both inside the row) of
 // the row whose first cell has key `row`.  Cells of a row are consecutive in the sorted order,
-// so in sparse mode the range runs from the first occupied cell's start to the last one's end.
+// so in sparse mode the range runs from the first occupied cell's start to the last one's end:
+// one probe per VOXEL the window touches (a 3-cell window: two at most).
 template <bool HASH>
 __device__ __forceinline__ bool row_range(const MapView& mv, size_t row, int x0, int x1, int& jlo,
                                           int& jhi)
@@ -68,10 +108,16 @@ __device__ __forceinline__ bool row_range(const MapView& mv, size_t row, int x0,
         jhi = mv.cell_start[row + (size_t)x1 + 1];
         return jhi > jlo;
     }
+    const uint32_t base = div_S(mv, (uint32_t)row);   // (row is a multiple of fx = nx * S: exact) = row index * nx
+    const int S = mv.S;
+    const int va = (int)div_S(mv, (uint32_t)x0), vb = (int)div_S(mv, (uint32_t)x1);
     bool any = false;
-    for (int x = x0; x <= x1; ++x) {
-        int a, b;
-        if (cell_find(mv, (uint32_t)(row + (size_t)x), a, b)) {
+    for (int v = va; v <= vb; ++v) {
+        Piece p;
+        if (!piece_find(mv, base + (uint32_t)v, p)) continue;
+        const int c0 = max(x0 - v * S, 0), c1 = min(x1 - v * S, S - 1);
+        const int a = p.start + piece_off(p, c0), b = p.start + piece_off(p, c1 + 1);
+        if (b > a) {
             if (!any) jlo = a;
             jhi = b;
             any = true;

@@ -195,55 +195,75 @@ __global__ __launch_bounds__(256) void k_cell_start(const uint32_t* __restrict__
 }
 
 // ---- sparse table ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_count_runs(const uint32_t* __restrict__ keys, size_t n,
+__global__ __launch_bounds__(256) void k_count_runs(const uint32_t* __restrict__ keys, size_t n, uint32_t S,
                                                     unsigned long long* __restrict__ total)
 {
     unsigned c = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+        c += (i == 0 || keys[i] / S != keys[i - 1] / S) ? 1u : 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, (unsigned long long)c);
 }
-// the first point of every run of equal keys inserts {key, start, end}: end by a binary search
-// for the first greater key; the slot is claimed with a compare-and-swap on the key word
+// Row-piece hash (MapView): the first point of every run of equal PIECE keys (fine key / S: the S fine cells of a voxel
+// along a fine row, consecutive in the sorted order) inserts {piece key, start, offsets}: o_c = points of the piece in
+// sub-cells < c, by a binary search for the first key >= piece * S + c; the slot is claimed with a compare-and-swap on
+// the key word.  A piece of 65 536 points or more does not fit its 16-bit offsets: *overflow is raised.
 __global__ __launch_bounds__(256) void k_hash_build(const uint32_t* __restrict__ keys, size_t n,
-                                                    int4* __restrict__ hash, uint32_t cap)
+                                                    int4* __restrict__ hash, uint32_t cap, uint32_t S, uint32_t stride,
+                                                    unsigned* __restrict__ overflow)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t k = keys[i];
-        if (i != 0 && keys[i - 1] == k) continue;
-        size_t lo = i + 1, hi = n;  // first index whose key exceeds k
-        while (lo < hi) {
-            const size_t mid = (lo + hi) >> 1;
-            if (keys[mid] > k) hi = mid; else lo = mid + 1;
+        const uint32_t pk = keys[i] / S;
+        if (i != 0 && keys[i - 1] / S == pk) continue;
+        uint32_t off[9];
+        off[0] = 0;
+        size_t from = i;
+        for (uint32_t c = 1; c <= S; ++c) {   // first index of the run whose key is >= pk * S + c (64-bit: pk * S + S may pass 2^32)
+            const unsigned long long want = (unsigned long long)pk * S + c;
+            size_t lo = from, hi = n;
+            while (lo < hi) {
+                const size_t mid = (lo + hi) >> 1;
+                if ((unsigned long long)keys[mid] >= want) hi = mid; else lo = mid + 1;
+            }
+            off[c] = (uint32_t)(lo - i);
+            from = lo;
         }
-        uint32_t h = (uint32_t)(((unsigned long long)(k * 0x9E3779B1u) * cap) >> 32);
+        for (uint32_t c = S + 1; c <= 8; ++c) off[c] = off[S];
+        if (off[S] >= 65536u) atomicOr(overflow, 1u);
+        uint32_t h = (uint32_t)(((unsigned long long)(pk * 0x9E3779B1u) * cap) >> 32);
         for (;;) {
-            const unsigned prev = atomicCAS(reinterpret_cast<unsigned*>(&hash[h].x), 0xffffffffu, k);
+            const unsigned prev = atomicCAS(reinterpret_cast<unsigned*>(&hash[(size_t)h * stride].x), 0xffffffffu, pk);
             if (prev == 0xffffffffu) break;
             h = h + 1 == cap ? 0u : h + 1;
         }
-        hash[h].y = (int)i;
-        hash[h].z = (int)lo;
-        hash[h].w = 0;
+        int4& e = hash[(size_t)h * stride];
+        e.y = (int)i;
+        e.z = (int)((off[1] & 0xffffu) | (off[2] << 16));
+        e.w = (int)((off[3] & 0xffffu) | (off[4] << 16));
+        if (stride > 1)
+            hash[(size_t)h * stride + 1] = make_int4((int)((off[5] & 0xffffu) | (off[6] << 16)),
+                                                     (int)((off[7] & 0xffffu) | (off[8] << 16)), 0, 0);
     }
 }
-hipError_t launch_count_runs(const uint32_t* sorted_keys, size_t n, unsigned long long* d_count, hipStream_t s)
+hipError_t launch_count_runs(const uint32_t* sorted_keys, size_t n, int S, unsigned long long* d_count, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess || n == 0) return e;
     const size_t g = (n + 255) / 256;
-    hipLaunchKernelGGL(k_count_runs, dim3((int)(g > 8192 ? 8192 : g)), dim3(256), 0, s, sorted_keys, n, d_count);
+    hipLaunchKernelGGL(k_count_runs, dim3((int)(g > 8192 ? 8192 : g)), dim3(256), 0, s, sorted_keys, n, (uint32_t)S, d_count);
     return hipGetLastError();
 }
-hipError_t launch_hash_build(const uint32_t* sorted_keys, size_t n, int4* hash, uint32_t cap, hipStream_t s)
+hipError_t launch_hash_build(const uint32_t* sorted_keys, size_t n, int4* hash, uint32_t cap, int S, unsigned* d_overflow,
+                             hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(hash, 0xFF, (size_t)cap * sizeof(int4), s);
+    const uint32_t stride = S > 4 ? 2u : 1u;
+    hipError_t e = hipMemsetAsync(hash, 0xFF, (size_t)cap * stride * sizeof(int4), s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_overflow, 0, sizeof(unsigned), s);
     if (e != hipSuccess || n == 0) return e;
     const size_t g = (n + 255) / 256;
     hipLaunchKernelGGL(k_hash_build, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, s, sorted_keys, n, hash,
-                       cap);
+                       cap, (uint32_t)S, stride, d_overflow);
     return hipGetLastError();
 }
 

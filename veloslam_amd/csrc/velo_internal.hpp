@@ -22,11 +22,18 @@ struct MapView {
     const float4* pts;     // [n] sorted by FINE cell key (stable)
     const float4* nrm;     // [n]
     const int32_t* cell_start;  // [fx*fy*fz + 1] fine-cell table: number of keys < k (dense mode)
-    // sparse mode (cell_start == nullptr): open-addressing hash over the OCCUPIED fine cells,
-    // entry = {fine key, first sorted index, one past the last, 0}; key 0xffffffff = empty slot.
-    // slot = ((key * 0x9E3779B1) * capacity) >> 32, linear probing.  Same sorted order, same answers.
+    // sparse mode (cell_start == nullptr): open-addressing hash over the OCCUPIED ROW PIECES (round 6; until then: over
+    // the occupied fine cells, one probe per cell -- 27 per query of stage A, most of them unsuccessful).  A row piece
+    // = the S fine cells of one voxel along one fine row: piece key = fine key / S = row * nx + voxel-x, and the points
+    // of a piece are consecutive in the sorted order.  entry = {piece key, first sorted index, o1 | o2 << 16,
+    // o3 | o4 << 16} (+ a second int4 {o5 | o6 << 16, o7 | o8 << 16, 0, 0} when S > 4: hash_stride = 2): o_c = points
+    // of the piece in sub-cells < c (16 bits each: a piece holds fewer than 65 536 points, checked at build).
+    // key 0xffffffff = empty slot.  slot = ((key * 0x9E3779B1) * capacity) >> 32, linear probing.  Same sorted order,
+    // same answers.
     const int4* hash;
     uint32_t hash_cap;
+    uint32_t hash_stride;  // int4 per slot: 1 (S <= 4) or 2
+    uint64_t s_magic;      // ceil(2^64 / S) (S >= 2): v / S = (v * s_magic) >> 64 exactly for every 32-bit v
     const uint8_t* vox_near;    // [nx*ny*nz] 0 = no map point in the 27 voxels around (or nullptr)
     float ox, oy, oz, inv_h, h;
     int nx, ny, nz;        // voxels per axis
@@ -106,8 +113,11 @@ size_t cell_start_bounds(size_t ncell);
 hipError_t launch_cell_start(const uint32_t* sorted_keys, size_t n, size_t ncell,
                              int32_t* cell_start, uint32_t* tile_scratch, hipStream_t s);
 // sparse table: number of occupied fine cells, then the hash itself (cap slots)
-hipError_t launch_count_runs(const uint32_t* sorted_keys, size_t n, unsigned long long* d_count, hipStream_t s);
-hipError_t launch_hash_build(const uint32_t* sorted_keys, size_t n, int4* hash, uint32_t cap, hipStream_t s);
+hipError_t launch_count_runs(const uint32_t* sorted_keys, size_t n, int S, unsigned long long* d_count, hipStream_t s);
+// (runs of equal PIECE keys = fine key / S: the occupied row pieces of the sparse table)
+hipError_t launch_hash_build(const uint32_t* sorted_keys, size_t n, int4* hash, uint32_t cap, int S, unsigned* d_overflow,
+                             hipStream_t s);
+// (row-piece hash: MapView.  *d_overflow != 0 afterwards: a piece holds 65 536 points or more -- its offsets do not fit)
 hipError_t launch_normals(const MapView& mv, const uint32_t* perm, int k, float4* nrm,
                           unsigned long long* d_invalid, hipStream_t s, int mode = 0);
 // (mode as launch_knn's: the full-map normals of a dense map go through the cooperative search)
