@@ -177,6 +177,13 @@ struct velo_ctx {
                            // velo_map_roll_begin and velo_map_roll_publish, when it is still the map before the roll
     // ---- a roll begun ahead of the frame that needs it (velo_map_roll_begin .. velo_map_roll_publish)
     hipStream_t roll_stream = nullptr;  // a stream of its own: a decode on the side stream must not queue behind 2 ms of roll
+    // Round 6: ... and a second one WITHOUT the CU mask for LIGHT rolls (a mapping stream's per-frame update: a few thousand
+    // points into a map of a few hundred thousand).  The mask keeps a registration's 1 024-thread solve from waiting behind
+    // a roll that fills the chip for milliseconds (tile columns of 500 k points into 11 M); a light roll never fills it, and
+    // on the masked queue it ran -- and made the registration beside it run -- 20 % slower (profiles/r06/ab_roll_cus.txt).
+    hipStream_t roll_stream_light = nullptr;
+    hipStream_t roll_last = nullptr;    // the stream the last roll ran on (the next one waits for it: they share buffers)
+    bool ev_roll_recorded = false;
     hipEvent_t ev_roll = nullptr;       // the roll's last kernel
     // Round 6: the rolled map's GEOMETRY (points, fine table) is complete long before its normals are (the re-estimation of
     // the dirty neighbourhoods is half of an append).  An increment reads geometry only: the publish makes the main stream
@@ -1797,9 +1804,11 @@ void velo_destroy(velo_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);  // (pinned buffers below may still be its sources)
     if (c->roll_stream) (void)hipStreamSynchronize(c->roll_stream);
+    if (c->roll_stream_light) (void)hipStreamSynchronize(c->roll_stream_light);
     if (c->ev_roll) (void)hipEventDestroy(c->ev_roll);
     if (c->ev_roll_geom) (void)hipEventDestroy(c->ev_roll_geom);
     if (c->roll_stream) (void)hipStreamDestroy(c->roll_stream);
+    if (c->roll_stream_light) (void)hipStreamDestroy(c->roll_stream_light);
     if (c->h_roll) (void)hipHostFree(c->h_roll);
     if (c->h_enter) (void)hipHostFree(c->h_enter);
     (void)velo_comm_destroy(c);
@@ -1851,6 +1860,7 @@ int velo_synchronize(velo_ctx* c)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->roll_stream) HIP_TRY(c, hipStreamSynchronize(c->roll_stream));  // (a roll begun ahead runs on its own stream)
+    if (c->roll_stream_light) HIP_TRY(c, hipStreamSynchronize(c->roll_stream_light));
     return VELO_OK;
 }
 
@@ -2470,7 +2480,7 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
     if (n) {
         if (c->h_enter_cap < 3 * n) {
             if (c->h_enter) {
-                HIP_TRY(c, hipStreamSynchronize(c->roll_stream));
+                if (c->roll_last) HIP_TRY(c, hipStreamSynchronize(c->roll_last));
                 (void)hipHostFree(c->h_enter);
                 c->h_enter = nullptr;
                 c->h_enter_cap = 0;
@@ -2479,7 +2489,7 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
             HIP_TRY(c, hipHostMalloc((void**)&c->h_enter, want * sizeof(float), 0));
             c->h_enter_cap = want;
         } else {
-            HIP_TRY(c, hipStreamSynchronize(c->roll_stream));  // (the previous roll's copy out of this buffer: long done)
+            if (c->roll_last) HIP_TRY(c, hipStreamSynchronize(c->roll_last));  // (the previous roll's copy out of this buffer: long done)
         }
         std::memcpy(c->h_enter, x, n * sizeof(float));
         std::memcpy(c->h_enter + n, y, n * sizeof(float));
@@ -2496,7 +2506,16 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
         HIP_TRY(c, hipEventRecord(c->ev_mark, c->stream));
         c->mark_valid = true;
     }
-    HIP_TRY(c, hipStreamWaitEvent(c->roll_stream, c->ev_mark, 0));
+    // which stream: the CU-masked one for a roll that can fill the chip for milliseconds, the plain one for a light roll
+    // (cfg.roll_cus = -1 / VELO_ROLL_NO_CU_MASK: the first is unmasked too; VELO_ROLL_LIGHT_MAX: the threshold, measurement)
+    static const long light_max = [] { const char* e = getenv("VELO_ROLL_LIGHT_MAX"); return e ? atol(e) : 32768L; }();
+    const bool heavy = (long)n > light_max || (lo != nullptr && c->info.n_points > 2000000ull);
+    if (!heavy && !c->roll_stream_light) HIP_TRY(c, hipStreamCreateWithFlags(&c->roll_stream_light, hipStreamNonBlocking));
+    hipStream_t rs = heavy ? c->roll_stream : c->roll_stream_light;
+    if (c->ev_roll_recorded && c->roll_last && c->roll_last != rs)
+        HIP_TRY(c, hipStreamWaitEvent(rs, c->ev_roll, 0));   // (the previous roll, on the other stream: same buffers)
+    c->roll_last = rs;
+    HIP_TRY(c, hipStreamWaitEvent(rs, c->ev_mark, 0));
     c->roll_overlapped_done = true;
     const uint64_t n_before = c->info.n_points;
     c->defer_counts = true;
@@ -2510,14 +2529,15 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
     c->h_roll->n_done = 0;
     c->roll_counts_pending = false;
     const uint64_t gen0 = c->map_gen;
-    const int rc = roll_run(c, c->roll_stream, c->roll_temp, lo, hi, px, py, pz, n);
+    const int rc = roll_run(c, rs, c->roll_temp, lo, hi, px, py, pz, n);
     if (trace_roll)
         std::fprintf(stderr, "roll_begin: precheck %.0f us, pinned copy %.0f, evict%s + append of %zu enqueued %.0f (rc %d)\n", t_pre,
                      t_copy - t_pre, lo ? "" : " (none)", n, tr_us() - t_copy, rc);
     c->defer_counts = false;
     c->have_enter_mm = false;
     c->roll_extra = 0;
-    const hipError_t e = hipEventRecord(c->ev_roll, c->roll_stream);
+    const hipError_t e = hipEventRecord(c->ev_roll, rs);
+    c->ev_roll_recorded = e == hipSuccess;
     if (c->map_gen != gen0) c->roll_staged = true;  // (something was published into mv: the readers are behind it now)
     (void)n_before;
     if (rc == VELO_E_AGAIN) return c->fail(VELO_E_AGAIN, "this update needs the map rebuilt: not beside a registration");
