@@ -2441,7 +2441,11 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
     if (int rc = settle_normals(c)) return rc;
     const double t_pre = tr_us();
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->roll_stream) {
+    // which stream: the CU-masked one for a roll that can fill the chip for milliseconds, the plain one for a light roll
+    // (cfg.roll_cus = -1 / VELO_ROLL_NO_CU_MASK: the first is unmasked too; VELO_ROLL_LIGHT_MAX: the threshold, measurement)
+    static const long light_max = [] { const char* e = getenv("VELO_ROLL_LIGHT_MAX"); return e ? atol(e) : 32768L; }();
+    const bool heavy = (long)n > light_max || (lo != nullptr && c->info.n_points > 2000000ull);
+    if (heavy && !c->roll_stream) {   // (made when first needed: a mapping stream never creates it)
         // A stream that may use THREE QUARTERS of the CUs (8 of every XCD's 32 are masked out).  The roll's kernels
         // fill whatever they may run on for 2 ms; the registration on the main stream is a chain of small dependent
         // kernels, one of them (k_reduce_solve) a single 1 024-thread workgroup that needs a nearly empty CU -- beside
@@ -2506,10 +2510,6 @@ int velo_map_roll_begin(velo_ctx* c, const float lo[3], const float hi[3], const
         HIP_TRY(c, hipEventRecord(c->ev_mark, c->stream));
         c->mark_valid = true;
     }
-    // which stream: the CU-masked one for a roll that can fill the chip for milliseconds, the plain one for a light roll
-    // (cfg.roll_cus = -1 / VELO_ROLL_NO_CU_MASK: the first is unmasked too; VELO_ROLL_LIGHT_MAX: the threshold, measurement)
-    static const long light_max = [] { const char* e = getenv("VELO_ROLL_LIGHT_MAX"); return e ? atol(e) : 32768L; }();
-    const bool heavy = (long)n > light_max || (lo != nullptr && c->info.n_points > 2000000ull);
     if (!heavy && !c->roll_stream_light) HIP_TRY(c, hipStreamCreateWithFlags(&c->roll_stream_light, hipStreamNonBlocking));
     hipStream_t rs = heavy ? c->roll_stream : c->roll_stream_light;
     if (c->ev_roll_recorded && c->roll_last && c->roll_last != rs)
