@@ -249,9 +249,9 @@ int velo_map_evict_radius(velo_ctx*, const float center_xy[2], float radius);
  * copies of the sorted arrays, the fine table and the near-voxel flags, and wait on the device for
  * everything older than the registration; whatever is enqueued afterwards sees the new map.  Same map
  * as the two plain calls, bit for bit -- also when the update re-anchors the grid or grows it (the map is then
- * rebuilt into the other copies; round 5).  VELO_E_AGAIN (refused before anything changed): a hashed table, a
- * map without normals (k = 0) whose grid would have to move, cfg.map_full_rebuild -- do those with the plain
- * calls after velo_icp_batch_finish.  The call waits for the side stream. */
+ * rebuilt into the other copies; round 5) and with a hashed table (its other copy; round 6).  VELO_E_AGAIN (refused before
+ * anything changed): a map without normals (k = 0) whose grid would have to move, cfg.map_full_rebuild -- do those with
+ * the plain calls after velo_icp_batch_finish.  The call waits for the side stream. */
 int velo_map_roll_overlapped(velo_ctx*, const float lo[3], const float hi[3], const float* x, const float* y,
                              const float* z, size_t n);
 /* The same roll BEGUN AHEAD of the frame that needs it.  The tile rectangle of a frame comes from the pose track

@@ -58,7 +58,7 @@ struct MapStats {
     uint64_t full_builds = 0;        // velo_map_reset: first ROI, or voxel / k changed, or nothing could be kept
     uint64_t rolls = 0;              // ROI changes applied incrementally (evict + append entering tiles)
     uint64_t rolls_ahead = 0;        // ... of which beside the previous frame's registration (rollAhead)
-    uint64_t rolls_refused = 0;      // rollAhead / rollBegin attempts the library refused (a hashed table, a map without normals: since round 5 a re-anchor is not one): done by the plain roll
+    uint64_t rolls_refused = 0;      // rollAhead / rollBegin attempts the library refused (a map without normals whose grid would move; since round 5 a re-anchor is not one, since round 6 a hashed table neither): done by the plain roll
     uint64_t rolls_begun = 0;        // ... begun several frames ahead (rollBegin) and published when due
     uint64_t tiles_entered = 0, tiles_left = 0;
     uint64_t points_uploaded = 0;    // host tile points sent to the device by rolls

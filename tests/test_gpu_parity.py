@@ -1369,7 +1369,8 @@ def test_config2_full_size_properties(oracle):
         c.close()
 
 
-def test_map_rolled_beside_a_registration_equals_the_plain_roll():
+@pytest.mark.parametrize("hash_load", [0, 50], ids=["dense-table", "hashed-table"])
+def test_map_rolled_beside_a_registration_equals_the_plain_roll(hash_load):
     """velo_map_roll_overlapped: eviction + append on the second stream WHILE a registration runs on
     the first.  Four rolls in a row (so that all three sets of sorted arrays, both tables and both
     near-voxel maps come round), each beside a registration: (a) that registration's result is the
@@ -1384,7 +1385,9 @@ def test_map_rolled_beside_a_registration_equals_the_plain_roll():
     f = wl["frames"][0]
     s = f["sensor"]
     big = 3.0e38
-    A = capi.Context(0, max_batch=2, map_margin=16)
+    # (round 6: the roll is begun ahead with a HASHED table too -- context A's; B, the plain calls, keeps the dense one:
+    #  the downloads compare the dense prefix table either one stands for)
+    A = capi.Context(0, max_batch=2, map_margin=16, map_hash_load=hash_load)
     B = capi.Context(0, max_batch=2, map_margin=16)
     try:
         for c in (A, B):
@@ -1679,7 +1682,8 @@ def test_knn_exact_ties_on_a_lattice_both_kernels(oracle, k):
             c.close()
 
 
-def test_map_roll_begun_ahead_and_published_later_equals_the_plain_roll():
+@pytest.mark.parametrize("hash_load", [0, 50], ids=["dense-table", "hashed-table"])
+def test_map_roll_begun_ahead_and_published_later_equals_the_plain_roll(hash_load):
     """velo_map_roll_begin / velo_map_roll_publish: the roll enqueued on a stream of its own while a
     registration runs, published THREE registrations later.  Four such rolls in a row (all three sets of sorted arrays,
     both tables, both near-voxel maps come round): (a) the registration it was begun beside and the ones up to the
@@ -1694,7 +1698,9 @@ def test_map_roll_begun_ahead_and_published_later_equals_the_plain_roll():
     f = wl["frames"][0]
     s = f["sensor"]
     big = 3.0e38
-    A = capi.Context(0, max_batch=2, map_margin=16)
+    # (round 6: the roll is begun ahead with a HASHED table too -- context A's; B, the plain calls, keeps the dense one:
+    #  the downloads compare the dense prefix table either one stands for)
+    A = capi.Context(0, max_batch=2, map_margin=16, map_hash_load=hash_load)
     B = capi.Context(0, max_batch=2, map_margin=16)
     try:
         for c in (A, B):

@@ -134,6 +134,7 @@ struct velo_ctx {
     DevBuf<float4> pts, nrm;
     DevBuf<int32_t> cell_start;
     DevBuf<int4> hash_tab;     // sparse fine-cell table (cfg.map_hash_load / extents beyond 2^31 cells)
+    DevBuf<int4> hash_tab_alt; // ... its other copy: an update beside a registration builds the table the registration does not read
     DevBuf<unsigned long long> run_cnt;  // scratch: occupied fine cells
     bool use_hash = false;
     DevBuf<unsigned> mm_scratch;
@@ -631,6 +632,12 @@ int build_table(velo_ctx* c, MapView& mv, const uint32_t* keys_sorted, size_t n,
     if (want >= 4294967295.0) return c->fail(VELO_E_RANGE, "hash table of %.3g slots", want);
     const size_t cap = (size_t)std::max(want, 16.0);
     const uint32_t stride = S > 4 ? 2u : 1u;
+    if (c->overlap_update && c->overlap_done == 0) {
+        // beside a registration (round 6: a hashed table is no longer a reason to refuse a roll begun ahead): the
+        // registration probes hash_tab -- the new table goes into the other copy, as the dense table's does
+        std::swap(c->hash_tab.p, c->hash_tab_alt.p);
+        std::swap(c->hash_tab.cap, c->hash_tab_alt.cap);
+    }
     HIP_TRY(c, c->hash_tab.reserve(cap * stride));
     unsigned* d_over = reinterpret_cast<unsigned*>(c->run_cnt.p + 1);
     HIP_TRY(c, launch_hash_build(keys_sorted, n, c->hash_tab.p, (uint32_t)cap, S, d_over, s));
@@ -898,7 +905,7 @@ int append_incremental(velo_ctx* c, size_t n_old, size_t m, int* done, int* grow
     g.fz = dims[2] * S;
     const size_t ncell = (size_t)g.fx * g.fy * g.fz;
     const size_t total = n_old + m;
-    if (c->overlap_update && (grew || c->use_hash || c->cfg.map_full_rebuild)) {
+    if (c->overlap_update && (grew || c->cfg.map_full_rebuild)) {
         // (done == 0.  A grown grid beside a registration: the caller rebuilds on THIS grid -- same origin, grown dims --
         //  into the other copies, which is what the in-place re-encoding below leaves, bit for bit)
         if (grew && grown_dims)
@@ -1981,7 +1988,7 @@ static int map_append_impl(velo_ctx* c, const float* x, const float* y, const fl
     const int k = c->info.k_normals;
     // beside a registration the rebuild needs the carried normals (it then writes the other copies of everything the
     // registration reads); without them, with the A/B switch or a hashed table it is refused, nothing changed
-    if (c->overlap_update && (k <= 0 || c->cfg.map_full_rebuild || c->use_hash)) {
+    if (c->overlap_update && (k <= 0 || c->cfg.map_full_rebuild)) {
         c->raw_n = n_old;
         return VELO_E_AGAIN;
     }
@@ -2178,7 +2185,7 @@ static int evict_impl(velo_ctx* c, const KeepRegion& region)
     // beside a registration: the re-anchoring rebuild goes into the other copies of the arrays and of the table (round 5:
     // rebuild_map / build_table), like an incremental update; what is still refused -- before anything changed -- is a
     // rebuild in place (A/B switch), a hashed table, a map without normals (its rebuild rewrites pts / nrm in place)
-    if (c->overlap_update && (c->cfg.map_full_rebuild || c->use_hash || (anchor && k <= 0)))
+    if (c->overlap_update && (c->cfg.map_full_rebuild || (anchor && k <= 0)))
         return VELO_E_AGAIN;
     if (anchor || c->cfg.map_full_rebuild) {
         CarryNormals cr;
@@ -2328,7 +2335,7 @@ static int roll_precheck(velo_ctx* c, const char* who, const float lo[3], const 
     // Everything the append's refusal depends on is known here: the entering points are host arrays, and an
     // eviction that goes ahead beside a registration keeps the grid (origin, dims) -- one that would
     // re-anchor is refused by evict_impl itself before it changes anything.
-    if (c->use_hash || c->cfg.map_full_rebuild)
+    if (c->cfg.map_full_rebuild)
         return c->fail(VELO_E_AGAIN, "this update needs the map rebuilt: not beside a registration");
     if (n) {
         const float* src[3] = {x, y, z};
