@@ -117,6 +117,25 @@ __device__ __forceinline__ void sort64(Ent<PAY>& e, int lane)
     cmpx<16>(e, u4, 0); cmpx<8>(e, u3, 0);  cmpx<4>(e, u2, 0); cmpx<2>(e, u1, 0); cmpx<1>(e, u0, 0);
 }
 
+// Round 6: the same result for a wavefront whose LOWER half is already ascending and whose upper half holds at most `ns`
+// unsorted entries in its first lanes (32 .. 32 + ns - 1; the rest empty = the largest key): the stages that sort
+// groups of 2^m lanes are needed only up to the group that holds the survivors (they leave the sorted lower half and the
+// empty lanes as they are), then the six stages of the 32 + 32 merge.  ns <= 4: 9 stages, <= 8: 12, <= 16: 16, else the
+// full 21 -- a chunk leaves 4 - 8 survivors on average (the list's k-th entry already bounds them).
+template <bool PAY>
+__device__ __forceinline__ void merge64(Ent<PAY>& e, int lane, int ns)
+{
+    const bool u0 = lane & 1, u1 = lane & 2, u2 = lane & 4, u3 = lane & 8, u4 = lane & 16, u5 = lane & 32;
+    const int a63 = (63 - lane) << 2;
+    if (ns > 1) cmpx<1>(e, u0, 0);
+    if (ns > 2) { cmpx<3>(e, u1, 0);  cmpx<1>(e, u0, 0); }
+    if (ns > 4) { cmpx<7>(e, u2, 0);  cmpx<2>(e, u1, 0);  cmpx<1>(e, u0, 0); }
+    if (ns > 8) { cmpx<15>(e, u3, 0); cmpx<4>(e, u2, 0);  cmpx<2>(e, u1, 0); cmpx<1>(e, u0, 0); }
+    if (ns > 16) { cmpx<31>(e, u4, 0); cmpx<8>(e, u3, 0);  cmpx<4>(e, u2, 0); cmpx<2>(e, u1, 0); cmpx<1>(e, u0, 0); }
+    cmpx<63>(e, u5, a63);
+    cmpx<16>(e, u4, 0); cmpx<8>(e, u3, 0);  cmpx<4>(e, u2, 0); cmpx<2>(e, u1, 0); cmpx<1>(e, u0, 0);
+}
+
 // The k nearest map points of q within sqrt(r2), ascending, in lanes 0 .. k-1 of `e` (empty entries: hi ==
 // kKeyMax).  Wavefront-uniform control flow throughout; all 64 lanes must be active.
 //   lanes 0-31:  the list, kept sorted;  lanes 32-63: staging for the survivors of the chunk in hand.
@@ -165,8 +184,11 @@ __device__ __forceinline__ void wave_knn(const MapView& mv, const uint32_t* __re
     const int xs1 = HASH ? 0 : __builtin_amdgcn_readlane(xs_lane, 1), xs3 = HASH ? 0 : __builtin_amdgcn_readlane(xs_lane, 3),
               xs4 = HASH ? 0 : __builtin_amdgcn_readlane(xs_lane, 4);
 
-    auto flush = [&]() {  // merge the staging half into the list; the k-th entry is the new acceptance bound
-        sort64<TIE_RAW>(e, lane);
+    auto flush = [&](int ns_staged) {  // merge the staging half (ns_staged entries, 64 = anywhere) into the list; the k-th entry is the new acceptance bound
+#ifndef VELO_KNN_FULL_SORT
+#define VELO_KNN_FULL_SORT 0   // 1: always the full 21-stage sort (the form until round 6; A/B)
+#endif
+        if (VELO_KNN_FULL_SORT || ns_staged >= 64) sort64<TIE_RAW>(e, lane); else merge64<TIE_RAW>(e, lane, ns_staged);
         if constexpr (STATS) ct.sorts += 1;
         kd_hi = (unsigned)__builtin_amdgcn_readlane((int)e.hi, k - 1);
         kd_lo = (unsigned)__builtin_amdgcn_readlane((int)e.lo, k - 1);
@@ -192,7 +214,7 @@ __device__ __forceinline__ void wave_knn(const MapView& mv, const uint32_t* __re
             e.hi = ok ? chi : kKeyMax;
             e.lo = ok ? clo : kKeyMax;
             if constexpr (TIE_RAW) e.pay = ok ? j : -1;
-            flush();
+            flush(64);
             return;
         }
         int ns = __popcll(m);
@@ -243,13 +265,14 @@ __device__ __forceinline__ void wave_knn(const MapView& mv, const uint32_t* __re
             const unsigned rlo = (unsigned)__builtin_amdgcn_ds_permute(dest, (int)clo);
             int rpay = 0;
             if constexpr (TIE_RAW) rpay = __builtin_amdgcn_ds_permute(dest, j);
-            const bool recv = lane >= 32 && lane < 32 + __popcll(take);
+            const int n_take = __popcll(take);
+            const bool recv = lane >= 32 && lane < 32 + n_take;
             if (recv) {
                 e.hi = rhi;
                 e.lo = rlo;
                 if constexpr (TIE_RAW) e.pay = rpay;
             }
-            flush();
+            flush(n_take);
             ok = ok && !mine && precedes_kd(chi, clo);
             m = __ballot(ok);
             if (m == 0) break;
