@@ -977,9 +977,13 @@ bool MapManager::registerCore(int frame, int64_t timestamp, const PoseTransform&
     }
     double T0s[4 * 12];
     for (int f = 0; f < 4; ++f) std::memcpy(T0s + 12 * f, T0.data(), sizeof(double) * 12);
-    // pipelined integration: the map update with the PREVIOUS frame's increment is begun first (the roll's own stream:
-    // it runs beside this registration, which is enqueued next and reads the map as it was) ...
-    static const bool update_after_start = std::getenv("VELO_UPDATE_AFTER_START") != nullptr;   // (measurement aid: A/B of the order)
+    // pipelined integration: the map update with the PREVIOUS frame's increment runs on the roll's own stream beside this
+    // registration, which reads the map as it was ...
+    // The roll is begun right BEHIND the registration's start: the ~200 us of host work it takes (the increment's fetch, the
+    // host tiles, ~25 launches) then run while the GPU registers.  (A/B, profiles/r06/ab_mapping_order.txt: while every roll
+    // ran on the CU-masked stream, beginning it BEFORE the start won -- 830 against 720 frames/s; with the light roll on a
+    // plain stream it is the other way round -- 1 115 - 1 145 against 970 - 1 050.  VELO_UPDATE_BEFORE_START=1: the other order.)
+    static const bool update_after_start = std::getenv("VELO_UPDATE_BEFORE_START") == nullptr;
     if (pipelined && !update_after_start && !updateBesideRegistration(o)) return false;
     const double t_update = us_since(tt0);
     if (velo_icp_batch_start(ctx_, T0s, o.iters, o.d_max)) {
