@@ -130,7 +130,7 @@ def parse():
                          "when it changes (host tiles); radius = round 2's loop: every --evict-every frames evict "
                          "beyond ROI_RANGE of the pose and append the world points that came within range (device-resident world)")
     ap.add_argument("--stream-frames", type=int, default=64, help="distinct synthetic frames (played forwards and backwards)")
-    ap.add_argument("--stream-steps", type=int, default=256, help="stream sub-record: timed frames")
+    ap.add_argument("--stream-steps", type=int, default=600, help="stream sub-record: timed frames (SURVEY 8d config 3: 600)")
     ap.add_argument("--stream-warmup", type=int, default=128,
                     help="stream sub-record: untimed frames first (128 = once forwards and backwards through the "
                          "64-frame drive: every buffer has seen its largest size)")
