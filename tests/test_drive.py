@@ -290,3 +290,43 @@ def test_cpp_stream_driver_rolls_the_device_map_and_matches_python(tmp_path):
     assert a["decode_planned_ahead"] and not b["decode_planned_ahead"] and a["map"]["rolls_ahead"] == 0
     assert cpp["roll_ahead"] and cpp["map"]["rolls_ahead"] + cpp["map"]["rolls_refused"] >= 1
     assert abs(cpp["worst_pose_error_m"] - b["worst_pose_error_m"]) < 1e-4 and cpp["map"]["rolls"] == b["map"]["rolls"]
+
+
+@pytest.mark.gpu
+def test_cpp_stream_driver_maps_a_drive_from_its_own_frames(tmp_path):
+    """Round 6, configs[2] as SLAM from the C++ host (veloslam::MapManager::seedFromFrame + RegisterOptions::integrate /
+    increments_in_roi_only / pipeline_increments): no world.map -- the map is seeded with frame 0 and grows from the accepted
+    increments.  Every frame updates the map; the pipelined schedule gives the same poses, map and increments whichever
+    way its host calls are ordered and whichever stream the roll runs on (nothing depends on timing); the synchronous
+    integration is another schedule (each registration sees one frame's increment more) and stays within centimetres of it."""
+    import torch
+    drive.export_mapping_drive(str(tmp_path), n_frames=26, device=torch.device("cuda:0"))
+    torch.cuda.synchronize()
+    exe = build_driver()
+
+    def run(extra=(), env_extra=None):
+        env = dict(os.environ)
+        for k in ("VELO_UPDATE_BEFORE_START", "VELO_ROLL_LIGHT_MAX", "VELO_NO_PAIR_CERT"):
+            env.pop(k, None)
+        env.update(env_extra or {})
+        o = subprocess.run([exe, str(tmp_path), "--mapping", "--steps", "20", "--warmup", "4", "--threshold", "1"] + list(extra),
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert o.returncode == 0, o.stderr[-2000:]
+        return json.loads(o.stdout.strip().splitlines()[-1])
+
+    def sig(r):
+        return (r["worst_pose_error_m"], r["mean_pose_error_m"], r["map_points"], r["increment_points_per_frame"],
+                r["map_updates"], r["map"]["points_evicted"], r["map"]["increment_points"])
+
+    a = run()
+    assert a["mode"].startswith("mapping, increments integrated in pipeline")
+    assert a["map_updates"] >= 20 and a["map_updates_beside_registration"] >= 19
+    assert a["increment_points_per_frame"] > 2000 and a["worst_pose_error_m"] < 0.05
+    assert a["map"]["full_builds"] == 0 and a["map"]["rolls_refused"] == 0
+    assert a["map_points"] > 150_000                                  # the seed frame and what 24 frames added to it
+    for env_extra in ({"VELO_UPDATE_BEFORE_START": "1"}, {"VELO_ROLL_LIGHT_MAX": "-1"}, {"VELO_NO_PAIR_CERT": "1"}):
+        assert sig(run(env_extra=env_extra)) == sig(a), env_extra
+    s = run(extra=["--no-pipeline"])
+    assert s["mode"].startswith("mapping, increments integrated synchronously")
+    assert s["worst_pose_error_m"] < 0.05 and s["increment_points_per_frame"] > 2000
+    assert abs(s["worst_pose_error_m"] - a["worst_pose_error_m"]) < 0.03
