@@ -140,6 +140,15 @@ typedef struct velo_cfg {
                                    (round 6): 0 = default (on), -1 = off.  [VELO_NO_PAIR_CERT] */
     int32_t reserved2[2];
 } velo_cfg;
+/* Environment variables the library still reads, ALL of them measurement aids (A/B scripts under tools/; results never
+ * depend on them, and none is needed for any documented behaviour):
+ *   tracing            VELO_TRACE_ROLL, VELO_TRACE_REGISTER (MapManager), VELO_KNN_TRACE, VELO_SPLIT_DEBUG
+ *   overrides of a ZERO cfg field (see above)   VELO_SPLIT_ITERS, VELO_SPLIT_BATCH, VELO_SPLIT_PER_WAVE_MAX,
+ *                      VELO_SOLVE_THREADS, VELO_ROLL_CUS, VELO_ROLL_NO_CU_MASK, VELO_NO_PAIR_CERT
+ *   A/B of round 6     VELO_ROLL_LIGHT_MAX (entering points up to which a roll begun ahead runs on the plain stream
+ *                      instead of the CU-masked one: default 32768, -1 = never), VELO_NRM_SUBSET_WAVE (the cooperative
+ *                      re-estimation kernel for incremental updates), VELO_SORT_MERGE (rocPRIM's merge-sort path),
+ *                      VELO_UPDATE_BEFORE_START (MapManager: the pipelined roll begun before the registration's start) */
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */
 #define VELO_TIME_INVALID INT64_MIN
