@@ -85,8 +85,10 @@ def _inside(x, y, rng, pr):
     return (ti >= rng[0]) & (ti <= rng[1]) & (tj >= rng[2]) & (tj <= rng[3])
 
 
-@pytest.mark.parametrize("n_frames,speed,min_count,want_points", [(42, 30.0, 384, 2_000_000)], ids=["2M-grown-map"])
-def test_mapping_stream_pipelined_vs_oracle(oracle, n_frames, speed, min_count, want_points):
+@pytest.mark.parametrize("n_frames,speed,min_count,want_points,hash_load",
+                         [(42, 30.0, 384, 2_000_000, 0), (14, 30.0, 20, 150_000, 50)],
+                         ids=["2M-grown-map", "hashed-table"])
+def test_mapping_stream_pipelined_vs_oracle(oracle, n_frames, speed, min_count, want_points, hash_load):
     import torch
     pr, voxel, k_normals, S, iters, d_max = 10.0, 1.0, 16, 3, 20, 1.0
     sc = synth.LongScene(speed * 0.1 * n_frames + 150.0)
@@ -95,7 +97,8 @@ def test_mapping_stream_pipelined_vs_oracle(oracle, n_frames, speed, min_count, 
     pk, ts = synth.make_frame_packets_device(sc, mo, list(range(n_frames)), cal, torch.device("cuda:0"))
     pk = pk.cpu().numpy()
     torch.cuda.synchronize()
-    c = capi.Context(0, max_batch=4, map_subdiv=S, map_margin=16, use_graph=1, use_hints=2)
+    # (hash_load: the sparse table keyed by row piece -- rolls begun ahead are no longer refused with it, round 6)
+    c = capi.Context(0, max_batch=4, map_subdiv=S, map_margin=16, use_graph=1, use_hints=2, map_hash_load=hash_load)
     c.map_set_margins(16, 16, 2)
     tiles = Tiles(pr)
     rm = None
@@ -191,7 +194,7 @@ def test_mapping_stream_pipelined_vs_oracle(oracle, n_frames, speed, min_count, 
         rm.append(*pend)
         check_map("end")
         assert rm.n >= want_points, rm.n
-        assert n_evictions >= 3 and n_updates >= n_frames - 3
+        assert n_evictions >= (3 if n_frames > 20 else 1) and n_updates >= n_frames - 3
         assert n_inc / (n_frames - 1) >= 2000
         # the device map holds exactly what the host tiles of its rectangle hold (MapManager's invariant)
         tx, ty, tz = tiles.gather(res)
