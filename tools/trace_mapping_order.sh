@@ -1,3 +1,5 @@
+#!/bin/bash
+# where the host's time inside registerCore goes in both orders of the pipelined update (VELO_TRACE_REGISTER): mapping stream, C++ host
 D=/tmp/mapdrive_248
 python bench.py --export-mapping-drive $D --mapping-frames 248 2>&1 | tail -1
 for v in "" "VELO_UPDATE_BEFORE_START=1"; do
