@@ -45,7 +45,7 @@ constexpr int kSerialMax = VELO_KNN_SERIAL_MAX;
 constexpr unsigned kKeyMax = 0xffffffffu;  // hi word of an empty entry (a NaN pattern: no distance has it)
 
 // [0] queries, [1] candidate points fetched, [2] fine rows looked up, [3] fine cells those rows span,
-// [4] chunks (64-candidate requests), [5] sorts, [6] one-by-one insertions
+// [4] chunks (64-candidate requests; 32 in k_knn_wave2), [5] sorts, [6] one-by-one insertions, [7] k_knn_wave2: queries that went on beyond the 3 x 3 rows
 __device__ unsigned long long g_knn_stats[8];
 struct KnnCounts {
     unsigned cand = 0, rows = 0, cells = 0, chunks = 0, sorts = 0, serial = 0;
@@ -503,6 +503,297 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN_WAVES_PER_SIMD) void k_kn
     }
 }
 
+// ==== TWO QUERIES PER WAVEFRONT (round 6) =====================================================
+// k_knn_wave is bound by vector issue (~1 000 instructions per query, each issued for 64 lanes of which the list uses
+// 32).  Here every HALF-wavefront owns a query: the list of k <= 32 entries lives in the half's 32 lanes, candidates
+// come 32 per side and trip, and what used to be wavefront-uniform scalars (bound, k-th entry, row cursors) are
+// per-lane values that agree inside a half; loops run while either half has work, each half's effects are predicated.
+// Survivors of a chunk are compacted into a second register (the stage), sorted by as many stages as the larger
+// survivor count needs, and merged by ONE in-lane step -- list[i] = min(list[i], stage[31 - i]): an ascending and a
+// descending sequence, so the minima are the 32 smallest of the 64 and bitonic -- plus the five half-cleaner steps.
+// Dense table, index ties (the query kernel).  The 3 x 3 rows around the query are walked nearest first out of table
+// entries looked up in one load; a query whose bound still reaches beyond that block afterwards (rare on the dense maps
+// this kernel is chosen for) goes on through the other rows of its 27 voxels in plain order.  Same k smallest under
+// (d2, index): the same bits.
+__device__ __forceinline__ bool key_less(unsigned ahi, unsigned alo, unsigned bhi, unsigned blo)
+{
+    return ahi < bhi || (ahi == bhi && alo < blo);
+}
+template <int X>
+__device__ __forceinline__ void cmpx2(unsigned& hi, unsigned& lo, bool upper)
+{
+    const unsigned phi = (unsigned)lane_xor<X>((int)hi, 0), plo = (unsigned)lane_xor<X>((int)lo, 0);
+    const bool pless = (((unsigned long long)phi << 32) | plo) < (((unsigned long long)hi << 32) | lo);
+    const bool take = pless != upper;
+    hi = take ? phi : hi;
+    lo = take ? plo : lo;
+}
+
+#ifndef VELO_KNN2_WAVES_PER_SIMD
+#define VELO_KNN2_WAVES_PER_SIMD 8
+#endif
+template <bool STATS>
+__global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_knn_wave2(MapView mv, const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ z, int n, Pose12 T, float r2, int k,
+                                                               int32_t* __restrict__ idx, float* __restrict__ d2o,
+                                                               int32_t* __restrict__ count)
+{
+    const int lane = threadIdx.x & 63, hl = lane & 31, hb = lane & 32;   // lane in the half, first lane of the half
+    const int pair0 = 2 * ((int)blockIdx.x * (kKnnWaveThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    if (pair0 >= n) return;  // (wavefront-uniform)
+    const int qi = pair0 + (lane >> 5);
+    const bool have_q = qi < n;
+    auto shfl32 = [&](int v, int src) { return __builtin_amdgcn_ds_bpermute((hb + src) << 2, v); };
+    auto shfl32f = [&](float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute((hb + src) << 2, __float_as_int(v))); };
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    {
+        double px, py, pz;
+        const int qc = have_q ? qi : pair0;
+        xform(T.t, x[qc], y[qc], z[qc], px, py, pz);
+        qx = (float)px, qy = (float)py, qz = (float)pz;
+    }
+    unsigned e_hi = kKeyMax, e_lo = kKeyMax;      // the list: entry hl of this half's query, ascending
+    unsigned kd_hi = kKeyMax, kd_lo = kKeyMax;    // (per half) the k-th entry: a candidate must precede it
+    float bound = r2;                             // (per half) min(r2, d2 of the k-th entry)
+    const int cx = cell_coord(qx, mv.ox, mv.inv_h, mv.nx);
+    const int cy = cell_coord(qy, mv.oy, mv.inv_h, mv.ny);
+    const int cz = cell_coord(qz, mv.oz, mv.inv_h, mv.nz);
+    const int vx0 = max(cx - 1, 0), vx1 = min(cx + 1, mv.nx - 1);
+    const int vy0 = max(cy - 1, 0), vy1 = min(cy + 1, mv.ny - 1);
+    const int vz0 = max(cz - 1, 0), vz1 = min(cz + 1, mv.nz - 1);
+    const bool valid = have_q && vx0 <= vx1 && vy0 <= vy1 && vz0 <= vz1;
+    const int S = mv.S;
+    const float hf = mv.h / (float)S;
+    const float inv_hf = mv.inv_h * (float)S;
+    const float ux = (qx - mv.ox) * inv_hf, uy = (qy - mv.oy) * inv_hf, uz = (qz - mv.oz) * inv_hf;
+    const float mg = 1e-6f * (float)max(max(mv.nx, mv.ny), mv.nz) * mv.h + 1e-6f;
+    const int x0 = vx0 * S, x1 = (vx1 + 1) * S - 1;
+    const int y0 = vy0 * S, y1 = (vy1 + 1) * S - 1;
+    const int z0 = vz0 * S, z1 = (vz1 + 1) * S - 1;
+    const int hx = min(max((int)floorf(fminf(fmaxf(ux, -4.0f), 2.0e9f)), x0), x1 + 1);
+    const int hy = min(max((int)floorf(fminf(fmaxf(uy, -4.0f), 2.0e9f)), y0), y1);
+    const int hz = min(max((int)floorf(fminf(fmaxf(uz, -4.0f), 2.0e9f)), z0), z1);
+    // The nine rows in the order they are visited, nearest first: own row, the neighbours on the query's side of its cell,
+    // then the others -- (dy, dz) of visit t in units of (sny, snz), two bits each (value + 1), as in wave_knn.
+    constexpr unsigned kDy = 1u | 2u << 2 | 1u << 4 | 2u << 6 | 0u << 8 | 1u << 10 | 0u << 12 | 2u << 14 | 0u << 16;
+    constexpr unsigned kDz = 1u | 1u << 2 | 2u << 4 | 2u << 6 | 1u << 8 | 0u << 10 | 2u << 12 | 0u << 14 | 0u << 16;
+    // Everything a visit needs is looked up once, by the lanes of the half, in VISIT order: lane 3 t + c holds the table
+    // entries of visit t's row at positions c (x0, hx - 1, hx) and 3 + c (hx + 1, hx + 2, x1 + 1) -- 54 entries per query in
+    // one load round -- and lane t the row's squared gap to the query.
+    auto tab_pos = [&](int c) { return c == 0 ? x0 : c == 5 ? x1 + 1 : min(max(hx - 2 + c, x0), x1 + 1); };
+    int tab_lo = 0, tab_hi = 0;
+    float g2l = INFINITY;
+    float og2;  // squared gap to the nearest row outside the 3 x 3 block (two rows away), with the margin of the row test
+    {
+        const int sny = uy - (float)hy >= 0.5f ? 1 : -1, snz = uz - (float)hz >= 0.5f ? 1 : -1;
+        auto row_of = [&](int t, int& fy, int& fz) {
+            fy = hy + ((int)((kDy >> (2 * t)) & 3u) - 1) * sny;
+            fz = hz + ((int)((kDz >> (2 * t)) & 3u) - 1) * snz;
+            return fy >= y0 && fy <= y1 && fz >= z0 && fz <= z1;
+        };
+        int fy, fz;
+        const int tt = hl / 3, c = hl - 3 * tt;
+        if (row_of(min(tt, 8), fy, fz) && valid && hl < 27) {
+            const int32_t* row = mv.cell_start + ((size_t)fz * mv.fy + fy) * mv.fx;
+            tab_lo = row[tab_pos(c)];
+            tab_hi = row[tab_pos(3 + c)];
+        }
+        if (row_of(min(hl, 8), fy, fz)) {
+            const float gy = fmaxf(fmaxf((float)fy - uy, uy - (float)(fy + 1)) * hf - mg, 0.0f);
+            const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
+            g2l = gz * gz + gy * gy;
+        }
+        const float oy = fmaxf(fminf(uy - (float)(hy - 1), (float)(hy + 2) - uy) * hf - mg, 0.0f);
+        const float oz = fmaxf(fminf(uz - (float)(hz - 1), (float)(hz + 2) - uz) * hf - mg, 0.0f);
+        const float og = fminf(oy, oz);
+        og2 = og * og * 0.99999f;
+    }
+    const bool u0 = hl & 1, u1 = hl & 2, u2 = hl & 4, u3 = hl & 8, u4 = hl & 16;
+    unsigned n_cand = 0, n_rows = 0, n_cells = 0, n_chunks = 0, n_sorts = 0;
+
+    // merge the stage (s_hi, s_lo: at most ns_max entries in the first lanes of either half, the rest empty) into the list
+    auto merge_stage = [&](unsigned s_hi, unsigned s_lo, int ns_max) {
+        // sort the stage ascending: only the stages the larger survivor count needs (uniform)
+        if (ns_max > 1) cmpx2<1>(s_hi, s_lo, u0);
+        if (ns_max > 2) { cmpx2<3>(s_hi, s_lo, u1); cmpx2<1>(s_hi, s_lo, u0); }
+        if (ns_max > 4) { cmpx2<7>(s_hi, s_lo, u2); cmpx2<2>(s_hi, s_lo, u1); cmpx2<1>(s_hi, s_lo, u0); }
+        if (ns_max > 8) { cmpx2<15>(s_hi, s_lo, u3); cmpx2<4>(s_hi, s_lo, u2); cmpx2<2>(s_hi, s_lo, u1); cmpx2<1>(s_hi, s_lo, u0); }
+        if (ns_max > 16) { cmpx2<31>(s_hi, s_lo, u4); cmpx2<8>(s_hi, s_lo, u3); cmpx2<4>(s_hi, s_lo, u2); cmpx2<2>(s_hi, s_lo, u1); cmpx2<1>(s_hi, s_lo, u0); }
+        // list[i] = min(list[i], stage[31 - i]) -- the 32 smallest of the 64, bitonic -- then the half-cleaner
+        {
+            const unsigned r_hi = (unsigned)lane_xor<31>((int)s_hi, 0), r_lo = (unsigned)lane_xor<31>((int)s_lo, 0);
+            const bool take = (((unsigned long long)r_hi << 32) | r_lo) < (((unsigned long long)e_hi << 32) | e_lo);
+            e_hi = take ? r_hi : e_hi;
+            e_lo = take ? r_lo : e_lo;
+        }
+        cmpx2<16>(e_hi, e_lo, u4); cmpx2<8>(e_hi, e_lo, u3); cmpx2<4>(e_hi, e_lo, u2); cmpx2<2>(e_hi, e_lo, u1); cmpx2<1>(e_hi, e_lo, u0);
+        if constexpr (STATS) n_sorts += 1;
+        kd_hi = (unsigned)shfl32((int)e_hi, k - 1);
+        kd_lo = (unsigned)shfl32((int)e_lo, k - 1);
+        bound = kd_hi == kKeyMax ? r2 : fminf(r2, __uint_as_float(kd_hi));
+    };
+    auto precedes_kd = [&](unsigned h, unsigned l) -> bool {
+        return (((unsigned long long)h << 32) | l) < (((unsigned long long)kd_hi << 32) | kd_lo);
+    };
+    // one chunk of up to 32 candidates per half, one per lane; `ok`: this lane holds a candidate that may enter the list
+    auto process = [&](unsigned chi, unsigned clo, bool ok, unsigned long long m) {
+        const unsigned mh = hb ? (unsigned)(m >> 32) : (unsigned)m;   // this half's survivors
+        const int ns = __popc(mh);
+        const int ns_max = max(__popc((unsigned)m), __popc((unsigned)(m >> 32)));   // (uniform)
+        // compact the survivors into the first lanes of the half's stage
+        const int rank = __popc(mh & ((1u << hl) - 1u));
+        const int dest = (hb + (ok ? rank : 31)) << 2;   // (the others aim at the half's last lane: emptied below; none if ns == 32)
+        unsigned s_hi = (unsigned)__builtin_amdgcn_ds_permute(dest, (int)chi);
+        unsigned s_lo = (unsigned)__builtin_amdgcn_ds_permute(dest, (int)clo);
+        if (hl >= ns) {
+            s_hi = kKeyMax;
+            s_lo = kKeyMax;
+        }
+        merge_stage(s_hi, s_lo, ns_max);
+    };
+    // the chunks of both sides of a row.  When the survivors of the two fit one stage together (< 32 in either half: the
+    // rule once the list is full) they are merged at once; otherwise side a, then what is left of side b.
+    auto process_ab = [&](const float4& ca, int ja, bool in_a, const float4& cb, int jb, bool in_b) {
+        const float d2a = dist2(ca, qx, qy, qz), d2b = dist2(cb, qx, qy, qz);
+        const unsigned ahi = __float_as_uint(d2a), alo = (unsigned)ja, bhi = __float_as_uint(d2b), blo = (unsigned)jb;
+        const bool ok_a = in_a && d2a <= r2 && precedes_kd(ahi, alo);
+        bool ok_b = in_b && d2b <= r2 && precedes_kd(bhi, blo);
+        const unsigned long long ma = __ballot(ok_a);
+        unsigned long long mb = __ballot(ok_b);
+        if ((ma | mb) == 0) return;  // (uniform)
+        const int t0 = __popc((unsigned)ma) + __popc((unsigned)mb), t1 = __popc((unsigned)(ma >> 32)) + __popc((unsigned)(mb >> 32));
+        const int ns_max = max(t0, t1);  // (uniform)
+        if (ns_max < 32) {
+            const unsigned mha = hb ? (unsigned)(ma >> 32) : (unsigned)ma, mhb = hb ? (unsigned)(mb >> 32) : (unsigned)mb;
+            const unsigned below = (1u << hl) - 1u;
+            const int nsa = __popc(mha), tot = nsa + __popc(mhb);
+            const int da = (hb + (ok_a ? __popc(mha & below) : 31)) << 2;         // (lane 31 of the half: never a survivor's place here)
+            const int db = (hb + (ok_b ? nsa + __popc(mhb & below) : 31)) << 2;
+            const unsigned pa_hi = (unsigned)__builtin_amdgcn_ds_permute(da, (int)ahi), pa_lo = (unsigned)__builtin_amdgcn_ds_permute(da, (int)alo);
+            const unsigned pb_hi = (unsigned)__builtin_amdgcn_ds_permute(db, (int)bhi), pb_lo = (unsigned)__builtin_amdgcn_ds_permute(db, (int)blo);
+            unsigned s_hi = hl < nsa ? pa_hi : pb_hi, s_lo = hl < nsa ? pa_lo : pb_lo;
+            if (hl >= tot) {
+                s_hi = kKeyMax;
+                s_lo = kKeyMax;
+            }
+            merge_stage(s_hi, s_lo, ns_max);
+            return;
+        }
+        if (ma) {
+            process(ahi, alo, ok_a, ma);
+            ok_b = ok_b && precedes_kd(bhi, blo);
+            mb = __ballot(ok_b);
+        }
+        if (mb) process(bhi, blo, ok_b, mb);
+    };
+
+    // visits 0 .. 8: the block (its table entries are in hand); from 9 on, for the queries whose bound still reaches beyond
+    // the block (the nearest rows outside it are two rows away): the other rows of the 27 voxels, slab by slab -- row
+    // (y0 + iy, z0 + iz) of either half, its table entries fetched by three lanes.  The order of the visits only decides
+    // how early the bound tightens, never the result.
+    bool beyond = false;
+    int iy = 0, iz = 0;
+    const int span = 3 * S;
+    for (int t = 0;; ++t) {
+        float g2;
+        int mid, b0, a1, fa, fb;
+        bool do_row;
+        if (t < 9) {
+            g2 = shfl32f(g2l, t);
+            do_row = valid && g2 * 0.99999f <= bound;
+            if (!__any(do_row)) continue;  // (uniform)
+            const float xr = (__builtin_amdgcn_sqrtf(fmaxf(bound - g2 * 0.99999f, 0.0f)) * 1.00001f + 2.0f * mg) * inv_hf;
+            fa = max(x0, (int)floorf(fmaxf(ux - xr, -4.0f)));
+            fb = min(x1, (int)floorf(fminf(ux + xr, 2.0e9f)));
+            do_row = do_row && fa <= fb;
+            const int lo_c = fa >= hx ? 2 : (fa >= tab_pos(1) ? 1 : 0);  // largest looked-up position <= fa
+            const int hi_c = fb + 1 <= hx ? 2 : (fb + 1 <= tab_pos(3) ? 3 : (fb + 1 <= tab_pos(4) ? 4 : 5));
+            mid = shfl32(tab_lo, 3 * t + 2), b0 = shfl32(tab_lo, 3 * t + lo_c);
+            const int a1h = shfl32(tab_hi, 3 * t + max(hi_c - 3, 0));
+            a1 = hi_c == 2 ? mid : a1h;
+        } else {
+            if (t == 9) beyond = valid && !(og2 > bound);
+            if (!__any(beyond) || iz >= span) break;  // (uniform)
+            const int fy = y0 + iy, fz = z0 + iz;
+            const float uy = (qy - mv.oy) * inv_hf, uz = (qz - mv.oz) * inv_hf;
+            const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
+            const bool slab = beyond && fz <= z1 && gz * gz * 0.99999f <= bound;
+            if (iy == 0 && !__any(slab)) {  // (uniform) nothing of this slab is in reach of either query
+                ++iz;
+                continue;
+            }
+            const float gy = fmaxf(fmaxf((float)fy - uy, uy - (float)(fy + 1)) * hf - mg, 0.0f);
+            g2 = gz * gz + gy * gy;
+            do_row = slab && fy <= y1 && !(abs(fy - hy) <= 1 && abs(fz - hz) <= 1) && g2 * 0.99999f <= bound;
+            if (++iy >= span) {
+                iy = 0;
+                ++iz;
+            }
+            if (!__any(do_row)) continue;  // (uniform)
+            const float xr = (__builtin_amdgcn_sqrtf(fmaxf(bound - g2 * 0.99999f, 0.0f)) * 1.00001f + 2.0f * mg) * inv_hf;
+            fa = max(x0, (int)floorf(fmaxf(ux - xr, -4.0f)));
+            fb = min(x1, (int)floorf(fminf(ux + xr, 2.0e9f)));
+            do_row = do_row && fa <= fb;
+            const int hxr = min(max(hx, fa), fb + 1);  // the split column inside [fa, fb + 1]
+            int v = 0;
+            if (do_row && hl < 3) v = mv.cell_start[((size_t)fz * mv.fy + fy) * mv.fx + (size_t)(hl == 0 ? fa : hl == 1 ? hxr : fb + 1)];
+            b0 = shfl32(v, 0), mid = shfl32(v, 1), a1 = shfl32(v, 2);
+        }
+        do_row = do_row && a1 > b0;
+        if (!__any(do_row)) continue;  // (uniform)
+        if constexpr (STATS) {
+            if (do_row && hl == 0) {
+                n_rows += 1;
+                n_cells += (unsigned)(fb - fa + 1);
+            }
+        }
+        // both parts walked from the query's column outwards: [mid, a1) ascending, [b0, mid) descending, 32 per trip
+        int a = mid, b = mid;
+        bool act_a = do_row && a < a1, act_b = do_row && b > b0;
+        while (__any(act_a || act_b)) {
+            const int ja = a + hl, jb = b - 1 - hl;
+            float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = ca;
+            if (act_a) ca = mv.pts[min(ja, a1 - 1)];
+            if (act_b) cb = mv.pts[max(jb, b0)];
+            if constexpr (STATS) {
+                if (hl == 0) {
+                    n_cand += (unsigned)((act_a ? min(32, a1 - a) : 0) + (act_b ? min(32, b - b0) : 0));
+                    n_chunks += (unsigned)act_a + (unsigned)act_b;
+                }
+            }
+            process_ab(ca, ja, act_a && ja < a1, cb, jb, act_b && jb >= b0);
+            a += 32;
+            b -= 32;
+            // candidates still to come lie in the last one's cell or beyond it
+            const float lxa = shfl32f(ca.x, 31), lxb = shfl32f(cb.x, 31);
+            const int fca = fine_coord_w(lxa, mv.ox, mv.inv_h, S), fcb = fine_coord_w(lxb, mv.ox, mv.inv_h, S);
+            const float gxa = fmaxf(((float)fca - ux) * hf - mg, 0.0f), gxb = fmaxf((ux - (float)(fcb + 1)) * hf - mg, 0.0f);
+            act_a = act_a && a < a1 && !((gxa * gxa + g2) * 0.99999f > bound);
+            act_b = act_b && b > b0 && !((gxb * gxb + g2) * 0.99999f > bound);
+        }
+    }
+    {
+        const bool have = have_q && hl < k && e_hi != kKeyMax;
+        const unsigned long long hv = __ballot(have);
+        if (have_q && hl < k) {
+            idx[(size_t)qi * k + hl] = have ? (int)e_lo : -1;
+            d2o[(size_t)qi * k + hl] = have ? __uint_as_float(e_hi) : INFINITY;
+        }
+        if (have_q && hl == 0 && count) count[qi] = __popc(hb ? (unsigned)(hv >> 32) : (unsigned)hv);
+    }
+    if constexpr (STATS) {
+        if (hl == 0 && have_q) {
+            atomicAdd(&g_knn_stats[0], 1ull);
+            atomicAdd(&g_knn_stats[1], (unsigned long long)n_cand);
+            atomicAdd(&g_knn_stats[2], (unsigned long long)n_rows);
+            atomicAdd(&g_knn_stats[3], (unsigned long long)n_cells);
+            atomicAdd(&g_knn_stats[4], (unsigned long long)n_chunks);
+            atomicAdd(&g_knn_stats[5], (unsigned long long)n_sorts);
+            if (beyond) atomicAdd(&g_knn_stats[7], 1ull);
+        }
+    }
+}
+
 // workgroups to launch for nb logical ones (the XCD mapping wants whole groups of 8 runs)
 static int knn_grid(int nb)
 {
@@ -524,12 +815,18 @@ hipError_t launch_knn_wave(const MapView& mv, const float* x, const float* y, co
     const int per_xcd = 0;
     const dim3 grid(knn_grid(nb)), block(kKnnWaveThreads);
     const bool hash = mv.cell_start == nullptr;
+    // dense table: two queries per wavefront (VELO_KNN_ONE_PER_WAVE=1: one, as until round 6 -- A/B)
+    static const bool one_per_wave = getenv("VELO_KNN_ONE_PER_WAVE") != nullptr;
+    const bool two = !hash && k <= 32 && !one_per_wave;
+    const dim3 grid2((unsigned)(((n + 1) / 2 + wpb - 1) / wpb));
     if (stats_out) {
         const unsigned long long z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z8, sizeof z8);
         if (e != hipSuccess) return e;
         if (hash)
             hipLaunchKernelGGL((k_knn_wave<true, true>), grid, block, 0, s, mv, x, y, z, (int)n, per_xcd, T, dmax2, k, idx, d2, count);
+        else if (two)
+            hipLaunchKernelGGL((k_knn_wave2<true>), grid2, block, 0, s, mv, x, y, z, (int)n, T, dmax2, k, idx, d2, count);
         else
             hipLaunchKernelGGL((k_knn_wave<false, true>), grid, block, 0, s, mv, x, y, z, (int)n, per_xcd, T, dmax2, k, idx, d2, count);
         e = hipStreamSynchronize(s);
@@ -538,13 +835,15 @@ hipError_t launch_knn_wave(const MapView& mv, const float* x, const float* y, co
         if (e == hipSuccess && getenv("VELO_KNN_TRACE")) {  // (measurement aid: the extra counters, to stderr)
             unsigned long long h[8];
             if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_knn_stats), sizeof h) == hipSuccess && h[0])
-                fprintf(stderr, "knn_wave per query: %.1f candidates in %.2f chunks, %.2f rows, %.2f sorts, %.2f insertions\n",
-                        (double)h[1] / h[0], (double)h[4] / h[0], (double)h[2] / h[0], (double)h[5] / h[0], (double)h[6] / h[0]);
+                fprintf(stderr, "knn_wave per query: %.1f candidates in %.2f chunks, %.2f rows, %.2f sorts, %.2f insertions; %.4f went on beyond the 3 x 3 rows\n",
+                        (double)h[1] / h[0], (double)h[4] / h[0], (double)h[2] / h[0], (double)h[5] / h[0], (double)h[6] / h[0], (double)h[7] / h[0]);
         }
         return e;
     }
     if (hash)
         hipLaunchKernelGGL((k_knn_wave<true, false>), grid, block, 0, s, mv, x, y, z, (int)n, per_xcd, T, dmax2, k, idx, d2, count);
+    else if (two)
+        hipLaunchKernelGGL((k_knn_wave2<false>), grid2, block, 0, s, mv, x, y, z, (int)n, T, dmax2, k, idx, d2, count);
     else
         hipLaunchKernelGGL((k_knn_wave<false, false>), grid, block, 0, s, mv, x, y, z, (int)n, per_xcd, T, dmax2, k, idx, d2, count);
     return hipGetLastError();
