@@ -1278,6 +1278,7 @@ def knn_record(args, d, dev, local):
     # the map does not have to cross the fabric twice in a launch)
     hashed = mi.table_kind == 1
     wave_kernel = float(mi.n_points) >= 1.5 * float(mi.dims[0]) * mi.dims[1] * mi.dims[2]   # (map_build.hip knn_use_wave; cfg.force_kernel = 0)
+    two_per_wave = wave_kernel and not hashed and k <= 32 and not os.environ.get("VELO_KNN_ONE_PER_WAVE")   # (knn_wave.hip launch_knn_wave)
     q_bytes = n * (12 + 8 * k + 4) + 96
     tab_req = st["cells"] * 16 if hashed else st["rows"] * 8
     map_req = st["candidates"] * 16 + tab_req
@@ -1307,7 +1308,8 @@ def knn_record(args, d, dev, local):
            # bytes are served by L2 / Infinity Cache (neighbouring queries share rows): `traffic` (PMC, fabric
            # side of L2) is what crosses to memory, `traffic_frac` that figure against the HBM peak -- the honest
            # HBM utilisation, and small: the kernel is bound by instruction issue and latency (`limiter`), not HBM.
-           "roofline": {"bound": "hbm", "kernel": "k_knn_wave (one wavefront per query)" if wave_kernel else "k_knn<32> (one lane per query)",
+           "roofline": {"bound": "hbm", "kernel": ("k_knn_wave2 (two queries per wavefront)" if two_per_wave else
+                                                   "k_knn_wave (one wavefront per query)" if wave_kernel else "k_knn<32> (one lane per query)"),
                         "achieved": alg / (1e-6 * launch_us) / 1e9,
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (1e-6 * launch_us) / 1e9 / HBM_PEAK_GBPS,
                         "algorithmic_bytes_per_launch": alg, "query_bytes_per_launch": q_bytes,
@@ -1320,11 +1322,23 @@ def knn_record(args, d, dev, local):
                         "traffic_rocprof_avg_launch_us": tr.get("rocprof_avg_launch_us") if tr else None,
                         "traffic_GBps": (tr["hbm_bytes_per_launch"] / (1e-6 * launch_us) / 1e9) if tr else None,
                         "traffic_frac": (tr["hbm_bytes_per_launch"] / (1e-6 * launch_us) / 1e9 / HBM_PEAK_GBPS) if tr else None,
-                        "limiter": ("vector-instruction issue and latency, not HBM: ~1 000 vector instructions per query "
+                        "limiter": ("vector-instruction issue, not HBM: ~1 300 vector instructions per wavefront = per TWO "
+                                    "queries (five to six stage sorts + 32 + 32 merges on 64-bit keys, four trips of 2 x 32 "
+                                    "candidates, the row geometry), 8 wavefronts per SIMD; most of the requested bytes never "
+                                    "leave L2 / Infinity Cache (`traffic` against `requested_GBps`)"
+                                    if two_per_wave else
+                                    "vector-instruction issue and latency, not HBM: ~1 000 vector instructions per query "
                                     "(two to three 64-lane bitonic sorts, five 64-candidate chunks, the row geometry) on "
                                     "one wavefront each; PMC: 70 % of the requested bytes never leave L2 / Infinity Cache"
                                     if wave_kernel else "dependent L2 / LDS round trips per lane"),
-                        "note": ("one wavefront per query (the map is dense: points >= 0.25 x fine cells): rows walked from "
+                        "note": ("two queries per wavefront, one per 32-lane half (dense table, k <= 32): the k-best list is one "
+                                 "entry per lane of the half; per trip 32 candidates from either side of the query's column, "
+                                 "the survivors of both compacted into one stage, sorted by as many stages as the count needs "
+                                 "and merged by one reversed min + five half-cleaner steps; rows nearest first with an exact "
+                                 "early stop, the table entries of the 3 x 3 rows around the query looked up in one load "
+                                 "(VELO_KNN_ONE_PER_WAVE=1: the one-query-per-wavefront kernel of round 5, 0.17 ms here)"
+                                 if two_per_wave else
+                                 "one wavefront per query (the map is dense: points >= 0.25 x fine cells): rows walked from "
                                  "the query's column outwards with an exact early stop, 64 candidates per coalesced request, "
                                  "survivors merged into the k-best list (one entry per lane) by a 64-lane bitonic sort; the "
                                  "table entries of the 3 x 3 rows around the query looked up in one load"

@@ -181,6 +181,9 @@ def test_replicas_stay_identical_through_the_product_exchange_path(world, oracle
                 blocks.append(out[:, :n].clone())
                 counts.append(int(n))
             offs, pad, total = capi.exchange_plan(counts)
+            print("replicas W=%d step %d: increment points per rank %s" % (world, s, counts))
+            if s == 0:          # (the hole in the map: every rank brings an increment of MAPPING volume, VERDICT r5 item 1 iii)
+                assert min(counts) >= 2000
             recv = torch.zeros(world * 3 * pad, dtype=torch.float32, device=dev)   # what the padded all-gather leaves
             for r in range(world):
                 recv[r * 3 * pad:(r + 1) * 3 * pad].view(3, pad)[:, :counts[r]] = blocks[r]

@@ -1,5 +1,6 @@
-"""The wavefront-cooperative search of kernels/knn_wave.hip (one wavefront per query: BASELINE configs[4]'s
-32-NN, and the full-map normals of dense maps) against the oracle, bit for bit, on maps built to reach every
+"""The wavefront-cooperative search of kernels/knn_wave.hip (BASELINE configs[4]'s 32-NN -- two queries per wavefront on a
+dense table (k_knn_wave2, round 6), one per wavefront on the sparse one -- and the full-map normals of dense maps)
+against the oracle, bit for bit, on maps built to reach every
 path of it: chunks with no / few / many / more than 32 survivors, rows longer than one chunk on both sides of
 the query's column (the early stop), rows outside the pre-fetched 3 x 3 block, exact ties, the sparse table.
 Production picks the kernel by density (knn_use_wave); here cfg.force_kernel = 2 pins it at small sizes."""
@@ -85,6 +86,39 @@ def test_wave_knn_sparse_and_uniform_maps_reach_rows_beyond_the_prefetched_block
                     assert np.array_equal(gd.view(np.uint32), od.view(np.uint32)), (subdiv, load, k)
             finally:
                 c.close()
+
+
+def test_two_queries_per_wavefront_odd_counts_ties_and_lone_halves(oracle):
+    """k_knn_wave2 (dense table, k <= 32: one query per 32-lane HALF of a wavefront, both walked in lock step): query counts
+    that leave the last wavefront with one query, pairs whose halves differ as much as they can -- a query in the thick of
+    the map beside one with nothing in reach, beside one outside the grid, beside one whose bound goes on beyond the 3 x 3
+    rows -- and exact ties (every map point twice: equal d2, the lower index first)."""
+    m = _blob(21, 20_000)
+    m = np.concatenate([m, m[:, ::2]], axis=1)                       # duplicates: ties on d2 at every query
+    rng = np.random.default_rng(22)
+    near = m[:, rng.choice(m.shape[1], 600, replace=False)] + rng.normal(0, 0.03, (3, 600)).astype(np.float32)
+    lonely = np.stack([rng.uniform(0, 6, 600), rng.uniform(3.5, 6, 600), rng.uniform(1.2, 2.0, 600)])   # above the floor, off the wall
+    outside = np.stack([rng.uniform(-40, -30, 600), rng.uniform(50, 60, 600), rng.uniform(-9, 9, 600)])
+    q = np.empty((3, 1800), np.float32)
+    q[:, 0::3], q[:, 1::3], q[:, 2::3] = near, lonely, outside       # every pair of neighbours in the frame is a mixed pair
+    for subdiv in (8, 3):
+        om = oracle.Map(*m, 1.0, 0, subdiv)
+        c = capi.Context(0, max_batch=2, map_subdiv=subdiv, force_kernel=capi.KERNEL_LATENCY)
+        try:
+            c.map_reset(*m, 1.0, 0)
+            assert c.map_info().table_kind == 0
+            for n in (1, 2, 3, 255, 1799, 1800):
+                qs = tuple(np.ascontiguousarray(a[:n]) for a in q)
+                c.frames_upload([qs])
+                for k, dmax in ((32, 1.0), (32, 0.15), (7, 0.5), (1, 1.0)):
+                    oi, od, oc = om.knn(*qs, I12, dmax, k)
+                    gi, gd, gc = c.knn(0, I12, dmax, k, n)
+                    assert np.array_equal(gc, oc), (subdiv, n, k, dmax)
+                    assert np.array_equal(gi, oi), (subdiv, n, k, dmax)
+                    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32)), (subdiv, n, k, dmax)
+            assert (oc == 0).any() and (oc == k).any()
+        finally:
+            c.close()
 
 
 @pytest.mark.parametrize("k", [8, 16, 32])

@@ -611,6 +611,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
     const bool u0 = hl & 1, u1 = hl & 2, u2 = hl & 4, u3 = hl & 8, u4 = hl & 16;
     unsigned n_cand = 0, n_rows = 0, n_cells = 0, n_chunks = 0, n_sorts = 0;
 
+    bool fresh = true;  // (uniform) nothing has been merged yet
     // merge the stage (s_hi, s_lo: at most ns_max entries in the first lanes of either half, the rest empty) into the list
     auto merge_stage = [&](unsigned s_hi, unsigned s_lo, int ns_max) {
         // sort the stage ascending: only the stages the larger survivor count needs (uniform)
@@ -619,14 +620,18 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
         if (ns_max > 4) { cmpx2<7>(s_hi, s_lo, u2); cmpx2<2>(s_hi, s_lo, u1); cmpx2<1>(s_hi, s_lo, u0); }
         if (ns_max > 8) { cmpx2<15>(s_hi, s_lo, u3); cmpx2<4>(s_hi, s_lo, u2); cmpx2<2>(s_hi, s_lo, u1); cmpx2<1>(s_hi, s_lo, u0); }
         if (ns_max > 16) { cmpx2<31>(s_hi, s_lo, u4); cmpx2<8>(s_hi, s_lo, u3); cmpx2<4>(s_hi, s_lo, u2); cmpx2<2>(s_hi, s_lo, u1); cmpx2<1>(s_hi, s_lo, u0); }
-        // list[i] = min(list[i], stage[31 - i]) -- the 32 smallest of the 64, bitonic -- then the half-cleaner
-        {
+        if (fresh) {  // (uniform) both lists are still empty: the sorted stage is the list
+            e_hi = s_hi;
+            e_lo = s_lo;
+            fresh = false;
+        } else {
+            // list[i] = min(list[i], stage[31 - i]) -- the 32 smallest of the 64, bitonic -- then the half-cleaner
             const unsigned r_hi = (unsigned)lane_xor<31>((int)s_hi, 0), r_lo = (unsigned)lane_xor<31>((int)s_lo, 0);
             const bool take = (((unsigned long long)r_hi << 32) | r_lo) < (((unsigned long long)e_hi << 32) | e_lo);
             e_hi = take ? r_hi : e_hi;
             e_lo = take ? r_lo : e_lo;
+            cmpx2<16>(e_hi, e_lo, u4); cmpx2<8>(e_hi, e_lo, u3); cmpx2<4>(e_hi, e_lo, u2); cmpx2<2>(e_hi, e_lo, u1); cmpx2<1>(e_hi, e_lo, u0);
         }
-        cmpx2<16>(e_hi, e_lo, u4); cmpx2<8>(e_hi, e_lo, u3); cmpx2<4>(e_hi, e_lo, u2); cmpx2<2>(e_hi, e_lo, u1); cmpx2<1>(e_hi, e_lo, u0);
         if constexpr (STATS) n_sorts += 1;
         kd_hi = (unsigned)shfl32((int)e_hi, k - 1);
         kd_lo = (unsigned)shfl32((int)e_lo, k - 1);
@@ -752,9 +757,8 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
         bool act_a = do_row && a < a1, act_b = do_row && b > b0;
         while (__any(act_a || act_b)) {
             const int ja = a + hl, jb = b - 1 - hl;
-            float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = ca;
-            if (act_a) ca = mv.pts[min(ja, a1 - 1)];
-            if (act_b) cb = mv.pts[max(jb, b0)];
+            // (both loads in flight at once: a side that is done reads point 0 and ignores it)
+            const float4 ca = mv.pts[act_a ? min(ja, a1 - 1) : 0], cb = mv.pts[act_b ? max(jb, b0) : 0];
             if constexpr (STATS) {
                 if (hl == 0) {
                     n_cand += (unsigned)((act_a ? min(32, a1 - a) : 0) + (act_b ? min(32, b - b0) : 0));
@@ -764,12 +768,15 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             process_ab(ca, ja, act_a && ja < a1, cb, jb, act_b && jb >= b0);
             a += 32;
             b -= 32;
+            act_a = act_a && a < a1;
+            act_b = act_b && b > b0;
+            if (!__any(act_a || act_b)) break;  // (uniform: most rows end with their first trip)
             // candidates still to come lie in the last one's cell or beyond it
             const float lxa = shfl32f(ca.x, 31), lxb = shfl32f(cb.x, 31);
             const int fca = fine_coord_w(lxa, mv.ox, mv.inv_h, S), fcb = fine_coord_w(lxb, mv.ox, mv.inv_h, S);
             const float gxa = fmaxf(((float)fca - ux) * hf - mg, 0.0f), gxb = fmaxf((ux - (float)(fcb + 1)) * hf - mg, 0.0f);
-            act_a = act_a && a < a1 && !((gxa * gxa + g2) * 0.99999f > bound);
-            act_b = act_b && b > b0 && !((gxb * gxb + g2) * 0.99999f > bound);
+            act_a = act_a && !((gxa * gxa + g2) * 0.99999f > bound);
+            act_b = act_b && !((gxb * gxb + g2) * 0.99999f > bound);
         }
     }
     {
@@ -817,7 +824,7 @@ hipError_t launch_knn_wave(const MapView& mv, const float* x, const float* y, co
     const bool hash = mv.cell_start == nullptr;
     // dense table: two queries per wavefront (VELO_KNN_ONE_PER_WAVE=1: one, as until round 6 -- A/B)
     static const bool one_per_wave = getenv("VELO_KNN_ONE_PER_WAVE") != nullptr;
-    const bool two = !hash && k <= 32 && !one_per_wave;
+    const bool two = !hash && k <= 32 && mv.n > 0 && !one_per_wave;
     const dim3 grid2((unsigned)(((n + 1) / 2 + wpb - 1) / wpb));
     if (stats_out) {
         const unsigned long long z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
