@@ -1,5 +1,7 @@
-// knn_wave.hip -- a10 with k > 1 on dense maps, and the map normals of dense maps: ONE WAVEFRONT PER QUERY
-// (gfx950, wave64).  Semantics: DESIGN.md "ICP semantics" (the k smallest candidates under the total order
+// knn_wave.hip -- a10 with k > 1 on dense maps, and the map normals of dense maps: the search of a query by the lanes
+// of a wavefront together (gfx950, wave64) -- ONE WAVEFRONT PER QUERY (wave_knn: k_knn_wave on the sparse table, the
+// normals kernels) and, since round 6, TWO QUERIES PER WAVEFRONT on the dense table (k_knn_wave2, further down: the
+// configs[4] kernel).  Semantics: DESIGN.md "ICP semantics" (the k smallest candidates under the total order
 // (d2, index) within the radius, candidates = the 27 voxels around the query); checked bit for bit against
 // oracle/icp.c (vo_knn, point_normal) in tests/.
 //
@@ -60,6 +62,11 @@ __device__ __forceinline__ int fine_coord_w(float p, float o, float inv_h, int S
     sub = min(max(sub, 0), S - 1);
     return (int)c * S + sub;
 }
+
+// ballots straight from the condition: HIP's __ballot(int) / __any(int) first turn the condition into an integer and
+// compare it with zero again (two vector instructions each); these are one scalar AND with EXEC
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 // ---- lane exchanges: value of lane (lane ^ X) ------------------------------------------------------------
 // X = 1, 2, 3: DPP quad_perm; 7, 15: DPP row_half_mirror / row_mirror; 8: DPP row_ror:8; 4, 16, 31: ds_swizzle
@@ -208,7 +215,7 @@ __device__ __forceinline__ void wave_knn(const MapView& mv, const uint32_t* __re
         const float d2 = dist2(c, qx, qy, qz);
         const unsigned chi = __float_as_uint(d2), clo = TIE_RAW ? tie : (unsigned)j;
         bool ok = in && d2 <= r2 && precedes_kd(chi, clo);
-        unsigned long long m = __ballot(ok);
+        unsigned long long m = ballot64(ok);
         if (m == 0) return;
         if (empty) {  // the first candidates of a query: they ARE the 64 entries to sort
             e.hi = ok ? chi : kKeyMax;
@@ -227,7 +234,7 @@ __device__ __forceinline__ void wave_knn(const MapView& mv, const uint32_t* __re
                 if (!precedes_kd(nhi, nlo)) continue;  // the list tightened meanwhile
                 if constexpr (STATS) ct.serial += 1;
                 const bool mine_first = e.hi < nhi || (e.hi == nhi && e.lo < nlo);
-                const int pos = __popcll(__ballot(lane < 32 && mine_first));
+                const int pos = __popcll(ballot64(lane < 32 && mine_first));
                 // lane i <- lane i - 1 (DPP wave_shr:1)
                 const unsigned up_hi = (unsigned)__builtin_amdgcn_update_dpp((int)e.hi, (int)e.hi, 0x138, 0xf, 0xf, false);
                 const unsigned up_lo = (unsigned)__builtin_amdgcn_update_dpp((int)e.lo, (int)e.lo, 0x138, 0xf, 0xf, false);
@@ -274,7 +281,7 @@ __device__ __forceinline__ void wave_knn(const MapView& mv, const uint32_t* __re
             }
             flush(n_take);
             ok = ok && !mine && precedes_kd(chi, clo);
-            m = __ballot(ok);
+            m = ballot64(ok);
             if (m == 0) break;
             ns = __popcll(m);
         }
@@ -431,8 +438,8 @@ __device__ __forceinline__ void wave_knn(const MapView& mv, const uint32_t* __re
                         int st = 0, en = 0;
                         bool found = false;
                         if (lane <= fb - fa) found = cell_find(mv, (uint32_t)(row + (size_t)(fa + lane)), st, en);
-                        const unsigned long long ma = __ballot(found && fa + lane >= hxr);
-                        const unsigned long long mb = __ballot(found && fa + lane < hxr);
+                        const unsigned long long ma = ballot64(found && fa + lane >= hxr);
+                        const unsigned long long mb = ballot64(found && fa + lane < hxr);
                         a0 = a1 = b0 = b1 = 0;
                         if (ma) {
                             a0 = __builtin_amdgcn_readlane(st, __ffsll((long long)ma) - 1);
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN_WAVES_PER_SIMD) void k_kn
         idx[(size_t)i * k + lane] = have ? (int)e.lo : -1;
         d2o[(size_t)i * k + lane] = have ? __uint_as_float(e.hi) : INFINITY;
     }
-    const int cnt = __popcll(__ballot(have));
+    const int cnt = __popcll(ballot64(have));
     if (lane == 0) {
         if (count) count[i] = cnt;
         if constexpr (STATS) {
@@ -523,7 +530,11 @@ template <int X>
 __device__ __forceinline__ void cmpx2(unsigned& hi, unsigned& lo, bool upper)
 {
     const unsigned phi = (unsigned)lane_xor<X>((int)hi, 0), plo = (unsigned)lane_xor<X>((int)lo, 0);
+#ifdef VELO_KNN2_CMP32
+    const bool pless = phi < hi || (phi == hi && plo < lo);
+#else
     const bool pless = (((unsigned long long)phi << 32) | plo) < (((unsigned long long)hi << 32) | lo);
+#endif
     const bool take = pless != upper;
     hi = take ? phi : hi;
     lo = take ? plo : lo;
@@ -598,7 +609,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             tab_lo = row[tab_pos(c)];
             tab_hi = row[tab_pos(3 + c)];
         }
-        if (row_of(min(hl, 8), fy, fz)) {
+        if (row_of(min(hl, 8), fy, fz) && valid) {
             const float gy = fmaxf(fmaxf((float)fy - uy, uy - (float)(fy + 1)) * hf - mg, 0.0f);
             const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
             g2l = gz * gz + gy * gy;
@@ -663,8 +674,8 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
         const unsigned ahi = __float_as_uint(d2a), alo = (unsigned)ja, bhi = __float_as_uint(d2b), blo = (unsigned)jb;
         const bool ok_a = in_a && d2a <= r2 && precedes_kd(ahi, alo);
         bool ok_b = in_b && d2b <= r2 && precedes_kd(bhi, blo);
-        const unsigned long long ma = __ballot(ok_a);
-        unsigned long long mb = __ballot(ok_b);
+        const unsigned long long ma = ballot64(ok_a);
+        unsigned long long mb = ballot64(ok_b);
         if ((ma | mb) == 0) return;  // (uniform)
         const int t0 = __popc((unsigned)ma) + __popc((unsigned)mb), t1 = __popc((unsigned)(ma >> 32)) + __popc((unsigned)(mb >> 32));
         const int ns_max = max(t0, t1);  // (uniform)
@@ -687,7 +698,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
         if (ma) {
             process(ahi, alo, ok_a, ma);
             ok_b = ok_b && precedes_kd(bhi, blo);
-            mb = __ballot(ok_b);
+            mb = ballot64(ok_b);
         }
         if (mb) process(bhi, blo, ok_b, mb);
     };
@@ -704,9 +715,17 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
         int mid, b0, a1, fa, fb;
         bool do_row;
         if (t < 9) {
+            // the visits from t on that either query's bound still reaches (lanes 0 .. 8 of a half hold their gaps): the
+            // others cost nothing
+            const unsigned long long rb = ballot64(g2l * 0.99999f <= bound);
+            const unsigned todo = (((unsigned)rb | (unsigned)(rb >> 32)) & 0x1ffu) >> t;
+            if (todo == 0) {  // (uniform)
+                t = 8;
+                continue;
+            }
+            t += __builtin_ctz(todo);
             g2 = shfl32f(g2l, t);
-            do_row = valid && g2 * 0.99999f <= bound;
-            if (!__any(do_row)) continue;  // (uniform)
+            do_row = g2 * 0.99999f <= bound;
             const float xr = (__builtin_amdgcn_sqrtf(fmaxf(bound - g2 * 0.99999f, 0.0f)) * 1.00001f + 2.0f * mg) * inv_hf;
             fa = max(x0, (int)floorf(fmaxf(ux - xr, -4.0f)));
             fb = min(x1, (int)floorf(fminf(ux + xr, 2.0e9f)));
@@ -718,12 +737,12 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             a1 = hi_c == 2 ? mid : a1h;
         } else {
             if (t == 9) beyond = valid && !(og2 > bound);
-            if (!__any(beyond) || iz >= span) break;  // (uniform)
+            if (!any64(beyond) || iz >= span) break;  // (uniform)
             const int fy = y0 + iy, fz = z0 + iz;
             const float uy = (qy - mv.oy) * inv_hf, uz = (qz - mv.oz) * inv_hf;
             const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
             const bool slab = beyond && fz <= z1 && gz * gz * 0.99999f <= bound;
-            if (iy == 0 && !__any(slab)) {  // (uniform) nothing of this slab is in reach of either query
+            if (iy == 0 && !any64(slab)) {  // (uniform) nothing of this slab is in reach of either query
                 ++iz;
                 continue;
             }
@@ -734,7 +753,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
                 iy = 0;
                 ++iz;
             }
-            if (!__any(do_row)) continue;  // (uniform)
+            if (!any64(do_row)) continue;  // (uniform)
             const float xr = (__builtin_amdgcn_sqrtf(fmaxf(bound - g2 * 0.99999f, 0.0f)) * 1.00001f + 2.0f * mg) * inv_hf;
             fa = max(x0, (int)floorf(fmaxf(ux - xr, -4.0f)));
             fb = min(x1, (int)floorf(fminf(ux + xr, 2.0e9f)));
@@ -745,7 +764,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             b0 = shfl32(v, 0), mid = shfl32(v, 1), a1 = shfl32(v, 2);
         }
         do_row = do_row && a1 > b0;
-        if (!__any(do_row)) continue;  // (uniform)
+        if (!any64(do_row)) continue;  // (uniform)
         if constexpr (STATS) {
             if (do_row && hl == 0) {
                 n_rows += 1;
@@ -755,7 +774,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
         // both parts walked from the query's column outwards: [mid, a1) ascending, [b0, mid) descending, 32 per trip
         int a = mid, b = mid;
         bool act_a = do_row && a < a1, act_b = do_row && b > b0;
-        while (__any(act_a || act_b)) {
+        while (any64(act_a || act_b)) {
             const int ja = a + hl, jb = b - 1 - hl;
             // (both loads in flight at once: a side that is done reads point 0 and ignores it)
             const float4 ca = mv.pts[act_a ? min(ja, a1 - 1) : 0], cb = mv.pts[act_b ? max(jb, b0) : 0];
@@ -770,7 +789,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             b -= 32;
             act_a = act_a && a < a1;
             act_b = act_b && b > b0;
-            if (!__any(act_a || act_b)) break;  // (uniform: most rows end with their first trip)
+            if (!any64(act_a || act_b)) break;  // (uniform: most rows end with their first trip)
             // candidates still to come lie in the last one's cell or beyond it
             const float lxa = shfl32f(ca.x, 31), lxb = shfl32f(cb.x, 31);
             const int fca = fine_coord_w(lxa, mv.ox, mv.inv_h, S), fcb = fine_coord_w(lxb, mv.ox, mv.inv_h, S);
@@ -781,7 +800,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
     }
     {
         const bool have = have_q && hl < k && e_hi != kKeyMax;
-        const unsigned long long hv = __ballot(have);
+        const unsigned long long hv = ballot64(have);
         if (have_q && hl < k) {
             idx[(size_t)qi * k + hl] = have ? (int)e_lo : -1;
             d2o[(size_t)qi * k + hl] = have ? __uint_as_float(e_hi) : INFINITY;
@@ -883,7 +902,7 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_normals_wave(MapView mv, co
         KnnCounts ct;
         wave_knn<true, HASH, false>(mv, perm, q.x, q.y, q.z, r2, k, lane, e, ct);
         const bool have = lane < k && e.hi != kKeyMax;
-        const int cnt = __popcll(__ballot(have));
+        const int cnt = __popcll(ballot64(have));
         if (lane < 32) s_j[w][p * kNrmWaveStride + lane] = e.pay;
         if (lane == 0) {
             const unsigned kth = (unsigned)__builtin_amdgcn_readlane((int)e.hi, k - 1);
@@ -939,7 +958,7 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_normals_wave_subset(MapView
             KnnCounts ct;
             wave_knn<true, HASH, false>(mv, perm, q.x, q.y, q.z, r2, k, lane, e, ct);
             const bool have = lane < k && e.hi != kKeyMax;
-            const int cnt = __popcll(__ballot(have));
+            const int cnt = __popcll(ballot64(have));
             if (lane < 32) s_j[w][p * kNrmWaveStride + lane] = e.pay;
             if (lane == 0) {
                 const unsigned kth = (unsigned)__builtin_amdgcn_readlane((int)e.hi, k - 1);
