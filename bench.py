@@ -1322,10 +1322,11 @@ def knn_record(args, d, dev, local):
                         "traffic_rocprof_avg_launch_us": tr.get("rocprof_avg_launch_us") if tr else None,
                         "traffic_GBps": (tr["hbm_bytes_per_launch"] / (1e-6 * launch_us) / 1e9) if tr else None,
                         "traffic_frac": (tr["hbm_bytes_per_launch"] / (1e-6 * launch_us) / 1e9 / HBM_PEAK_GBPS) if tr else None,
-                        "limiter": ("vector-instruction issue, not HBM: ~1 300 vector instructions per wavefront = per TWO "
-                                    "queries (five to six stage sorts + 32 + 32 merges on 64-bit keys, four trips of 2 x 32 "
-                                    "candidates, the row geometry), 8 wavefronts per SIMD; most of the requested bytes never "
-                                    "leave L2 / Infinity Cache (`traffic` against `requested_GBps`)"
+                        "limiter": ("vector-instruction issue, not HBM: 1 422 vector instructions per wavefront = per TWO "
+                                    "queries (profiles/r06/pmc_knn_sq.txt; five to six stage sorts + 32 + 32 merges on 64-bit "
+                                    "keys, four trips of 2 x 32 candidates, the row geometry), x 4 cycles / (1 024 SIMDs x the "
+                                    "launch) = 1.0; most of the requested bytes never leave L2 / Infinity Cache (`traffic` "
+                                    "against `requested_GBps`)"
                                     if two_per_wave else
                                     "vector-instruction issue and latency, not HBM: ~1 000 vector instructions per query "
                                     "(two to three 64-lane bitonic sorts, five 64-candidate chunks, the row geometry) on "

@@ -57,6 +57,7 @@ bash tools/pmc_mapping.sh > $OUT/pmc_mapping.log 2>&1
 cp gpurun_out/pmc_mapping.txt profiles/$R/pmc_mapping_certificates.txt 2>/dev/null
 MCS="3 8 20 32" bash tools/mapping_try.sh 248 200 40 2>&1 | grep "==\|^{" | cut -c1-900 > profiles/$R/mapping_min_count_sweep.txt
 bash tools/ab_nrm_subset.sh 2>&1 | grep "==" > profiles/$R/ab_nrm_subset_rerun.txt
+bash tools/knn2_try.sh > profiles/$R/ab_knn_two_per_wave_rerun.txt 2>&1     # k_knn_wave2 against k_knn_wave, the same box
 LEADS="4 0" STEPS=300 DRV_TIMEOUT=60 bash tools/per_frame.sh 2>&1 | cut -c1-260 > profiles/$R/per_frame_summary.txt
 timeout 900 python3 -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > profiles/$R/gpu_suite.txt
 
