@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 CSVs of profiles/collect.sh (gpurun_out/prof_<round>/) into the small
+"""Turn the raw rocprofv3 CSVs of profiles/collect.sh (/tmp/prof_<round>/ on the GPU box) into the small
 summaries committed under profiles/<round>/ and into profiles/traffic.json, which bench.py reads
 for roofline.traffic (key "F<frames>_M<map points>": same batch, same map as the bench record).
 
@@ -24,7 +24,7 @@ import sys
 
 R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof_" + R)
+SRC = os.environ.get("PROF_SRC", os.path.join("/tmp", "prof_" + R))    # (collect.sh keeps the raw CSVs out of gpurun_out/)
 DST = os.path.join(ROOT, "profiles", R)
 os.makedirs(DST, exist_ok=True)
 # configuration = how many map builds have been dispatched so far (bench.py --only dense: the
