@@ -29,6 +29,7 @@
 // pipeline (RegisterOptions::pipeline_increments: frame k's increment joins the device map beside frame k + 1's
 // registration, together with the move of the tile rectangle to frame k + 2's prior); --no-pipeline integrates every
 // frame's increment before the next frame is registered (host-synchronous append).
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -36,7 +37,12 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
+#include <execinfo.h>
+#include <pthread.h>
+#include <signal.h>
+#include <unistd.h>
 #include "veloslam/HDLManager.hpp"
 #include "veloslam/MapManager.hpp"
 #include "veloslam/TransformManager.hpp"
@@ -44,6 +50,52 @@
 using namespace veloslam;
 using clk = std::chrono::steady_clock;
 static double ms_since(clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); }
+
+// ---- watchdog (--watchdog SECONDS, default 30; 0 = none): a stream host that makes no progress for that long says where
+// it stands -- frame, phase, and the main thread's call stack (the velo_* entry point and the HIP call under it) -- and
+// exits with code 7 instead of hanging until somebody's timeout kills it silently.
+static std::atomic<unsigned> g_beat{0};
+static std::atomic<const char*> g_phase{"setup"};
+static std::atomic<int> g_frame{-1};
+static void beat(const char* phase, int frame = -2)
+{
+    g_phase.store(phase, std::memory_order_relaxed);
+    if (frame != -2) g_frame.store(frame, std::memory_order_relaxed);
+    g_beat.fetch_add(1, std::memory_order_relaxed);
+}
+static void on_stall_signal(int)
+{
+    void* bt[64];
+    const int n = backtrace(bt, 64);
+    backtrace_symbols_fd(bt, n, 2);
+    _exit(7);
+}
+static void start_watchdog(int seconds)
+{
+    if (seconds <= 0) return;
+    struct sigaction sa;
+    std::memset(&sa, 0, sizeof sa);
+    sa.sa_handler = on_stall_signal;
+    sigaction(SIGUSR1, &sa, nullptr);
+    const pthread_t main_thread = pthread_self();
+    std::thread([seconds, main_thread] {
+        unsigned last = g_beat.load();
+        int still = 0;
+        for (;;) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(500));
+            const unsigned now = g_beat.load();
+            still = now == last ? still + 1 : 0;
+            last = now;
+            if (still >= 2 * seconds) {
+                std::fprintf(stderr, "stream_driver: NO PROGRESS for %d s at frame %d in %s; the main thread's stack:\n", seconds,
+                             g_frame.load(), g_phase.load());
+                pthread_kill(main_thread, SIGUSR1);
+                std::this_thread::sleep_for(std::chrono::seconds(3));
+                _exit(7);
+            }
+        }
+    }).detach();
+}
 
 int main(int argc, char** argv)
 {
@@ -55,7 +107,7 @@ int main(int argc, char** argv)
     int steps = 100, warmup = 10, threshold = 512, roll_lead = 4;
     bool integrate = true, overlap = true, roll_ahead = true, mapping = false, pipeline = true;
     std::string per_frame;
-    int margin = -1, min_count = -1;
+    int margin = -1, min_count = -1, watchdog = 30;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
@@ -65,6 +117,7 @@ int main(int argc, char** argv)
         else if (a == "--margin" && i + 1 < argc) margin = std::atoi(argv[++i]);  // grid slack in x / y, voxels (MapManager's default: 16)
         else if (a == "--per-frame" && i + 1 < argc) per_frame = argv[++i];  // per-frame wall time + what the map did, one line each
         else if (a == "--no-integrate") integrate = false;
+        else if (a == "--watchdog" && i + 1 < argc) watchdog = std::atoi(argv[++i]);
         else if (a == "--mapping") mapping = true;
         else if (a == "--min-count" && i + 1 < argc) min_count = std::atoi(argv[++i]);  // a voxel accepts new points while it holds fewer (default 3; --mapping: 20)
         else if (a == "--no-pipeline") pipeline = false;
@@ -95,6 +148,7 @@ int main(int argc, char** argv)
         const int32_t mg[3] = {margin, margin, 2};
         velo_map_set_margins(ctx, mg);
     }
+    start_watchdog(watchdog);
     // ---- the drive: one stub per revolution, points decoded on the GPU when asked for
     HDLManager hdl(ctx);
     if (!hdl.setCalibFile(dir + "/db.xml") || !hdl.loadOffline(dir + "/carposes.txt", dir + "/drive.pcap") ||
@@ -153,7 +207,9 @@ int main(int argc, char** argv)
         if (overlap && f_next >= 0)
             opt.while_registering = [&hdl, &mgr, &opt, &frames, f_next, &next_ok, &t_next, roll_ahead, roll_lead, &frame_at, &k_now, k_last] {
                 const auto a0 = clk::now();
+                beat("registerResident > while_registering: decode of the next frame");
                 next_ok = hdl.prepareResidentDuringRegistration(frames[(size_t)f_next]);
+                beat("registerResident > while_registering: roll ahead");
                 // ... and the map is rolled towards the ROI of a frame to come beside the registration as well (the
                 // prior's x, y come from the pose track, not from this registration's result): begun as soon as one
                 // of the next roll_lead frames names another tile rectangle, published when that frame is due
@@ -170,6 +226,7 @@ int main(int argc, char** argv)
                     mgr.rollAhead(c2.T[0] + 0.15, c2.T[1] - 0.10, opt);
                 }
                 t_next = ms_since(a0);
+                beat("registerResident (after while_registering)");
             };
         opt.have_next_prior = false;
         if (mapping && f_next >= 0) {   // where the NEXT frame's prior will be: the pipelined update rolls the tiles there
@@ -178,6 +235,7 @@ int main(int argc, char** argv)
             opt.next_prior_x = cn.T[0] + 0.15, opt.next_prior_y = cn.T[1] - 0.10;
         }
         const auto a = clk::now();
+        beat("prepareResident", f);
         if (prepared != f && !hdl.prepareResident(fr)) {
             std::fprintf(stderr, "frame %d: %s\n", f, hdl.lastError());
             return false;
@@ -191,6 +249,7 @@ int main(int argc, char** argv)
         PoseTransform out;
         velo_icp_result res;
         const auto b = clk::now();
+        beat("registerResident");
         if (!mgr.registerResident(0, fr->timestamp, init, opt, &out, &res)) {
             std::fprintf(stderr, "registerResident failed at frame %d: %s\n", f, mgr.lastError());
             return false;
@@ -221,8 +280,10 @@ int main(int argc, char** argv)
     };
     for (int k = 0; k < warmup; ++k) {
         k_now = k;
+        beat("warm-up");
         if (!one(frame_at(k), frame_at(k + 1), false)) return 5;
     }
+    beat("velo_synchronize after the warm-up");
     velo_synchronize(ctx);
     const MapStats s0 = mgr.stats();
     const auto t0 = clk::now();
