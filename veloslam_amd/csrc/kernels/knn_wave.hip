@@ -704,12 +704,28 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
     };
 
     // visits 0 .. 8: the block (its table entries are in hand); from 9 on, for the queries whose bound still reaches beyond
-    // the block (the nearest rows outside it are two rows away): the other rows of the 27 voxels, slab by slab -- row
-    // (y0 + iy, z0 + iz) of either half, its table entries fetched by three lanes.  The order of the visits only decides
-    // how early the bound tightens, never the result.
+    // the block (the nearest rows outside it are two rows away): the other rows of the 27 voxels CENTRE-OUT as wave_knn
+    // walks them -- slabs hz, hz + 1, hz - 1, hz + 2, ... and in a slab rows hy, hy + 1, hy - 1, ... of either half, a
+    // direction given up once neither query's bound reaches it (gaps only grow outwards, bounds only shrink) -- a row's
+    // table entries fetched by three lanes.  The order of the visits only decides how early the bound tightens, never
+    // the result.
     bool beyond = false;
-    int iy = 0, iz = 0;
+    int gdz = 0, gsz = 0, gdy = -1, gsy = 0;          // (uniform) slab hz +- gdz, row hy +- gdy; gdy < 0: the slab is yet to be entered
+    bool any_z = false, any_y = false, gen_done = false;  // (uniform)
+    bool slab_ok = false;                             // (per half) the slab is in range and in reach
+    float gz2 = 0.0f;                                 // (per half) its squared gap
     const int span = 3 * S;
+    auto next_slab = [&]() {
+        gdy = -1;
+        if (gsz == 0 && gdz > 0) {
+            gsz = 1;
+        } else {
+            gsz = 0;
+            if (!any_z || gdz >= span) gen_done = true;
+            gdz += 1;
+            any_z = false;
+        }
+    };
     for (int t = 0;; ++t) {
         float g2;
         int mid, b0, a1, fa, fb;
@@ -737,21 +753,33 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             a1 = hi_c == 2 ? mid : a1h;
         } else {
             if (t == 9) beyond = valid && !(og2 > bound);
-            if (!any64(beyond) || iz >= span) break;  // (uniform)
-            const int fy = y0 + iy, fz = z0 + iz;
+            if (!any64(beyond) || gen_done) break;  // (uniform)
             const float uy = (qy - mv.oy) * inv_hf, uz = (qz - mv.oz) * inv_hf;
-            const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
-            const bool slab = beyond && fz <= z1 && gz * gz * 0.99999f <= bound;
-            if (iy == 0 && !any64(slab)) {  // (uniform) nothing of this slab is in reach of either query
-                ++iz;
-                continue;
+            const int fz = gsz ? hz - gdz : hz + gdz;
+            if (gdy < 0) {  // enter slab (gdz, gsz)
+                const float gz = fmaxf(fmaxf((float)fz - uz, uz - (float)(fz + 1)) * hf - mg, 0.0f);
+                gz2 = gz * gz;
+                slab_ok = beyond && fz >= z0 && fz <= z1 && gz2 * 0.99999f <= bound;
+                if (!any64(slab_ok)) {  // (uniform) nothing of this slab is in reach of either query
+                    next_slab();
+                    continue;
+                }
+                any_z = true;
+                gdy = 0, gsy = 0, any_y = false;
             }
+            const int fy = gsy ? hy - gdy : hy + gdy;
             const float gy = fmaxf(fmaxf((float)fy - uy, uy - (float)(fy + 1)) * hf - mg, 0.0f);
-            g2 = gz * gz + gy * gy;
-            do_row = slab && fy <= y1 && !(abs(fy - hy) <= 1 && abs(fz - hz) <= 1) && g2 * 0.99999f <= bound;
-            if (++iy >= span) {
-                iy = 0;
-                ++iz;
+            g2 = gz2 + gy * gy;
+            const bool reach = slab_ok && fy >= y0 && fy <= y1 && g2 * 0.99999f <= bound;
+            any_y = any_y || any64(reach);
+            do_row = reach && !(gdy <= 1 && gdz <= 1);  // (the block's rows were walked above)
+            // the next row: the other side of this distance, then one further out -- unless neither side was in reach
+            if (gsy == 0 && gdy > 0) {
+                gsy = 1;
+            } else {
+                gsy = 0;
+                if (!any_y || gdy >= span) next_slab();
+                else gdy += 1, any_y = false;
             }
             if (!any64(do_row)) continue;  // (uniform)
             const float xr = (__builtin_amdgcn_sqrtf(fmaxf(bound - g2 * 0.99999f, 0.0f)) * 1.00001f + 2.0f * mg) * inv_hf;
