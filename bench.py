@@ -1322,7 +1322,7 @@ def knn_record(args, d, dev, local):
                         "traffic_rocprof_avg_launch_us": tr.get("rocprof_avg_launch_us") if tr else None,
                         "traffic_GBps": (tr["hbm_bytes_per_launch"] / (1e-6 * launch_us) / 1e9) if tr else None,
                         "traffic_frac": (tr["hbm_bytes_per_launch"] / (1e-6 * launch_us) / 1e9 / HBM_PEAK_GBPS) if tr else None,
-                        "limiter": ("vector-instruction issue, not HBM: 1 422 vector instructions per wavefront = per TWO "
+                        "limiter": ("vector-instruction issue, not HBM: ~1 440 vector instructions per wavefront = per TWO "
                                     "queries (profiles/r06/pmc_knn_sq.txt; five to six stage sorts + 32 + 32 merges on 64-bit "
                                     "keys, four trips of 2 x 32 candidates, the row geometry), x 4 cycles / (1 024 SIMDs x the "
                                     "launch) = 1.0; most of the requested bytes never leave L2 / Infinity Cache (`traffic` "
