@@ -1278,7 +1278,8 @@ def knn_record(args, d, dev, local):
     # the map does not have to cross the fabric twice in a launch)
     hashed = mi.table_kind == 1
     wave_kernel = float(mi.n_points) >= 1.5 * float(mi.dims[0]) * mi.dims[1] * mi.dims[2]   # (map_build.hip knn_use_wave; cfg.force_kernel = 0)
-    two_per_wave = wave_kernel and not hashed and k <= 32 and not os.environ.get("VELO_KNN_ONE_PER_WAVE")   # (knn_wave.hip launch_knn_wave)
+    two_per_wave = (wave_kernel and k <= 32 and (not hashed or 3 * int(mi.subdiv) <= 32)
+                    and not os.environ.get("VELO_KNN_ONE_PER_WAVE"))   # (knn_wave.hip launch_knn_wave)
     q_bytes = n * (12 + 8 * k + 4) + 96
     tab_req = st["cells"] * 16 if hashed else st["rows"] * 8
     map_req = st["candidates"] * 16 + tab_req

@@ -543,7 +543,7 @@ __device__ __forceinline__ void cmpx2(unsigned& hi, unsigned& lo, bool upper)
 #ifndef VELO_KNN2_WAVES_PER_SIMD
 #define VELO_KNN2_WAVES_PER_SIMD 8
 #endif
-template <bool STATS>
+template <bool STATS, bool HASH>
 __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_knn_wave2(MapView mv, const float* __restrict__ x, const float* __restrict__ y,
                                                                const float* __restrict__ z, int n, Pose12 T, float r2, int k,
                                                                int32_t* __restrict__ idx, float* __restrict__ d2o,
@@ -603,11 +603,13 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             return fy >= y0 && fy <= y1 && fz >= z0 && fz <= z1;
         };
         int fy, fz;
-        const int tt = hl / 3, c = hl - 3 * tt;
-        if (row_of(min(tt, 8), fy, fz) && valid && hl < 27) {
-            const int32_t* row = mv.cell_start + ((size_t)fz * mv.fy + fy) * mv.fx;
-            tab_lo = row[tab_pos(c)];
-            tab_hi = row[tab_pos(3 + c)];
+        if constexpr (!HASH) {
+            const int tt = hl / 3, c = hl - 3 * tt;
+            if (row_of(min(tt, 8), fy, fz) && valid && hl < 27) {
+                const int32_t* row = mv.cell_start + ((size_t)fz * mv.fy + fy) * mv.fx;
+                tab_lo = row[tab_pos(c)];
+                tab_hi = row[tab_pos(3 + c)];
+            }
         }
         if (row_of(min(hl, 8), fy, fz) && valid) {
             const float gy = fmaxf(fmaxf((float)fy - uy, uy - (float)(fy + 1)) * hf - mg, 0.0f);
@@ -726,11 +728,12 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             any_z = false;
         }
     };
-    for (int t = 0;; ++t) {
+    // (sparse table: no entries in hand -- every row, the block's too, is reached by the centre-out walk)
+    for (int t = HASH ? 9 : 0;; ++t) {
         float g2;
-        int mid, b0, a1, fa, fb;
+        int a0, b1 = 0, b0, a1, fa, fb;   // right part [a0, a1), left part [b0, b1) of the row's window (dense table: b1 == a0)
         bool do_row;
-        if (t < 9) {
+        if (!HASH && t < 9) {
             // the visits from t on that either query's bound still reaches (lanes 0 .. 8 of a half hold their gaps): the
             // others cost nothing
             const unsigned long long rb = ballot64(g2l * 0.99999f <= bound);
@@ -748,11 +751,13 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             do_row = do_row && fa <= fb;
             const int lo_c = fa >= hx ? 2 : (fa >= tab_pos(1) ? 1 : 0);  // largest looked-up position <= fa
             const int hi_c = fb + 1 <= hx ? 2 : (fb + 1 <= tab_pos(3) ? 3 : (fb + 1 <= tab_pos(4) ? 4 : 5));
-            mid = shfl32(tab_lo, 3 * t + 2), b0 = shfl32(tab_lo, 3 * t + lo_c);
+            const int mid = shfl32(tab_lo, 3 * t + 2);
+            b0 = shfl32(tab_lo, 3 * t + lo_c);
             const int a1h = shfl32(tab_hi, 3 * t + max(hi_c - 3, 0));
             a1 = hi_c == 2 ? mid : a1h;
+            a0 = mid;
         } else {
-            if (t == 9) beyond = valid && !(og2 > bound);
+            if (t == 9) beyond = HASH ? valid : (valid && !(og2 > bound));
             if (!any64(beyond) || gen_done) break;  // (uniform)
             const float uy = (qy - mv.oy) * inv_hf, uz = (qz - mv.oz) * inv_hf;
             const int fz = gsz ? hz - gdz : hz + gdz;
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             g2 = gz2 + gy * gy;
             const bool reach = slab_ok && fy >= y0 && fy <= y1 && g2 * 0.99999f <= bound;
             any_y = any_y || any64(reach);
-            do_row = reach && !(gdy <= 1 && gdz <= 1);  // (the block's rows were walked above)
+            do_row = reach && (HASH || !(gdy <= 1 && gdz <= 1));  // (dense table: the block's rows were walked above)
             // the next row: the other side of this distance, then one further out -- unless neither side was in reach
             if (gsy == 0 && gdy > 0) {
                 gsy = 1;
@@ -787,11 +792,24 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
             fb = min(x1, (int)floorf(fminf(ux + xr, 2.0e9f)));
             do_row = do_row && fa <= fb;
             const int hxr = min(max(hx, fa), fb + 1);  // the split column inside [fa, fb + 1]
-            int v = 0;
-            if (do_row && hl < 3) v = mv.cell_start[((size_t)fz * mv.fy + fy) * mv.fx + (size_t)(hl == 0 ? fa : hl == 1 ? hxr : fb + 1)];
-            b0 = shfl32(v, 0), mid = shfl32(v, 1), a1 = shfl32(v, 2);
+            const size_t row = ((size_t)fz * mv.fy + fy) * mv.fx;
+            if constexpr (!HASH) {
+                int v = 0;
+                if (do_row && hl < 3) v = mv.cell_start[row + (size_t)(hl == 0 ? fa : hl == 1 ? hxr : fb + 1)];
+                b0 = shfl32(v, 0), a0 = shfl32(v, 1), a1 = shfl32(v, 2);
+            } else {  // one lane of the half per cell of [fa, fb] (3 S <= 32 cells): one probe round for the whole row
+                int st = 0, en = 0;
+                bool found = false;
+                if (do_row && hl <= fb - fa) found = cell_find(mv, (uint32_t)(row + (size_t)(fa + hl)), st, en);
+                const unsigned long long ba = ballot64(found && fa + hl >= hxr), bb = ballot64(found && fa + hl < hxr);
+                const unsigned ma = hb ? (unsigned)(ba >> 32) : (unsigned)ba, mb = hb ? (unsigned)(bb >> 32) : (unsigned)bb;
+                const int sa0 = shfl32(st, ma ? __ffs((int)ma) - 1 : 0), sa1 = shfl32(en, ma ? 31 - __clz((int)ma) : 0);
+                const int sb0 = shfl32(st, mb ? __ffs((int)mb) - 1 : 0), sb1 = shfl32(en, mb ? 31 - __clz((int)mb) : 0);
+                a0 = ma ? sa0 : 0, a1 = ma ? sa1 : 0, b0 = mb ? sb0 : 0, b1 = mb ? sb1 : 0;
+            }
         }
-        do_row = do_row && a1 > b0;
+        if constexpr (!HASH) b1 = a0;
+        do_row = do_row && (HASH ? (a1 > a0 || b1 > b0) : a1 > b0);
         if (!any64(do_row)) continue;  // (uniform)
         if constexpr (STATS) {
             if (do_row && hl == 0) {
@@ -799,8 +817,8 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN2_WAVES_PER_SIMD) void k_k
                 n_cells += (unsigned)(fb - fa + 1);
             }
         }
-        // both parts walked from the query's column outwards: [mid, a1) ascending, [b0, mid) descending, 32 per trip
-        int a = mid, b = mid;
+        // both parts walked from the query's column outwards: [a0, a1) ascending, [b0, b1) descending, 32 per trip
+        int a = a0, b = b1;
         bool act_a = do_row && a < a1, act_b = do_row && b > b0;
         while (any64(act_a || act_b)) {
             const int ja = a + hl, jb = b - 1 - hl;
@@ -869,18 +887,21 @@ hipError_t launch_knn_wave(const MapView& mv, const float* x, const float* y, co
     const int per_xcd = 0;
     const dim3 grid(knn_grid(nb)), block(kKnnWaveThreads);
     const bool hash = mv.cell_start == nullptr;
-    // dense table: two queries per wavefront (VELO_KNN_ONE_PER_WAVE=1: one, as until round 6 -- A/B)
+    // two queries per wavefront (VELO_KNN_ONE_PER_WAVE=1: one, as until round 6 -- A/B)
     static const bool one_per_wave = getenv("VELO_KNN_ONE_PER_WAVE") != nullptr;
-    const bool two = !hash && k <= 32 && mv.n > 0 && !one_per_wave;
+    // (sparse table: a half's 32 lanes probe the cells of a row's window, 3 S of them at most)
+    const bool two = k <= 32 && mv.n > 0 && !one_per_wave && (!hash || 3 * mv.S <= 32);
     const dim3 grid2((unsigned)(((n + 1) / 2 + wpb - 1) / wpb));
     if (stats_out) {
         const unsigned long long z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z8, sizeof z8);
         if (e != hipSuccess) return e;
-        if (hash)
-            hipLaunchKernelGGL((k_knn_wave<true, true>), grid, block, 0, s, mv, x, y, z, (int)n, per_xcd, T, dmax2, k, idx, d2, count);
+        if (two && hash)
+            hipLaunchKernelGGL((k_knn_wave2<true, true>), grid2, block, 0, s, mv, x, y, z, (int)n, T, dmax2, k, idx, d2, count);
         else if (two)
-            hipLaunchKernelGGL((k_knn_wave2<true>), grid2, block, 0, s, mv, x, y, z, (int)n, T, dmax2, k, idx, d2, count);
+            hipLaunchKernelGGL((k_knn_wave2<true, false>), grid2, block, 0, s, mv, x, y, z, (int)n, T, dmax2, k, idx, d2, count);
+        else if (hash)
+            hipLaunchKernelGGL((k_knn_wave<true, true>), grid, block, 0, s, mv, x, y, z, (int)n, per_xcd, T, dmax2, k, idx, d2, count);
         else
             hipLaunchKernelGGL((k_knn_wave<false, true>), grid, block, 0, s, mv, x, y, z, (int)n, per_xcd, T, dmax2, k, idx, d2, count);
         e = hipStreamSynchronize(s);
@@ -894,10 +915,12 @@ hipError_t launch_knn_wave(const MapView& mv, const float* x, const float* y, co
         }
         return e;
     }
-    if (hash)
-        hipLaunchKernelGGL((k_knn_wave<true, false>), grid, block, 0, s, mv, x, y, z, (int)n, per_xcd, T, dmax2, k, idx, d2, count);
+    if (two && hash)
+        hipLaunchKernelGGL((k_knn_wave2<false, true>), grid2, block, 0, s, mv, x, y, z, (int)n, T, dmax2, k, idx, d2, count);
     else if (two)
-        hipLaunchKernelGGL((k_knn_wave2<false>), grid2, block, 0, s, mv, x, y, z, (int)n, T, dmax2, k, idx, d2, count);
+        hipLaunchKernelGGL((k_knn_wave2<false, false>), grid2, block, 0, s, mv, x, y, z, (int)n, T, dmax2, k, idx, d2, count);
+    else if (hash)
+        hipLaunchKernelGGL((k_knn_wave<true, false>), grid, block, 0, s, mv, x, y, z, (int)n, per_xcd, T, dmax2, k, idx, d2, count);
     else
         hipLaunchKernelGGL((k_knn_wave<false, false>), grid, block, 0, s, mv, x, y, z, (int)n, per_xcd, T, dmax2, k, idx, d2, count);
     return hipGetLastError();
