@@ -165,9 +165,9 @@ def read_bytes(cs):
 krd, kwr, kdur = by_kernel("knn_rdreq"), by_kernel("knn_write"), trace_durations("knn_trace")
 for k in krd:
     # (per-lane / wavefront-cooperative form; the cooperative kernel's parameters are <sparse table, counting>;
-    # k_knn_wave2<counting>: two queries per wavefront, dense tables, round 6)
+    # k_knn_wave2<counting, sparse table>: two queries per wavefront, round 6)
     if "k_knn<32, false>" not in k and "k_knn_wave<false, false>" not in k and "k_knn_wave<true, false>" not in k \
-            and "k_knn_wave2<false>" not in k:
+            and "k_knn_wave2<false, " not in k:          # (k_knn_wave2<counting, sparse table>)
         continue
     n = len(krd[k]["TCC_EA0_RDREQ_128B_sum"])
     nw = len(kwr.get(k, {}).get("WRITE_SIZE", []))
