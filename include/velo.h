@@ -108,8 +108,8 @@ typedef struct velo_cfg {
                                (load factor 0.5) beyond that; 5..90: always the hash, at that load
                                factor in percent.  Same sorted order, same results either way. */
     int32_t force_kernel;   /* (also pins velo_knn's kernel and the full-build normals': 1 = one lane per
-                               query, 2 = wavefront-cooperative (velo_knn on a dense table: two queries per
-                               wavefront), 0 = by the map's density.)
+                               query, 2 = wavefront-cooperative (velo_knn: two queries per wavefront),
+                               0 = by the map's density.)
                                0: the linearise kernel is chosen by the size of the registration
                                (latency kernel below 2048 x 256 queries, ~4 frames; throughput kernel
                                above); 1: always the throughput kernel, 2: always the latency kernel
@@ -150,7 +150,7 @@ typedef struct velo_cfg {
  *                      instead of the CU-masked one: default 32768, -1 = never), VELO_NRM_SUBSET_WAVE (the cooperative
  *                      re-estimation kernel for incremental updates), VELO_SORT_MERGE (rocPRIM's merge-sort path),
  *                      VELO_UPDATE_BEFORE_START (MapManager: the pipelined roll begun before the registration's start),
- *                      VELO_KNN_ONE_PER_WAVE (velo_knn on a dense table: one query per wavefront, the kernel of round 5) */
+ *                      VELO_KNN_ONE_PER_WAVE (velo_knn: one query per wavefront, the kernel of round 5) */
 
 /* PoseTransform (type_defs.h:86-147) with ptime flattened to microseconds. */
 #define VELO_TIME_INVALID INT64_MIN

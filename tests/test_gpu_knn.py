@@ -1,5 +1,5 @@
-"""The wavefront-cooperative search of kernels/knn_wave.hip (BASELINE configs[4]'s 32-NN -- two queries per wavefront on a
-dense table (k_knn_wave2, round 6), one per wavefront on the sparse one -- and the full-map normals of dense maps)
+"""The wavefront-cooperative search of kernels/knn_wave.hip (BASELINE configs[4]'s 32-NN -- two queries per wavefront
+(k_knn_wave2, round 6: dense and sparse table) -- and the full-map normals of dense maps, one point per wavefront)
 against the oracle, bit for bit, on maps built to reach every
 path of it: chunks with no / few / many / more than 32 survivors, rows longer than one chunk on both sides of
 the query's column (the early stop), rows outside the pre-fetched 3 x 3 block, exact ties, the sparse table.
