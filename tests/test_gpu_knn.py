@@ -88,8 +88,9 @@ def test_wave_knn_sparse_and_uniform_maps_reach_rows_beyond_the_prefetched_block
                 c.close()
 
 
-def test_two_queries_per_wavefront_odd_counts_ties_and_lone_halves(oracle):
-    """k_knn_wave2 (dense table, k <= 32: one query per 32-lane HALF of a wavefront, both walked in lock step): query counts
+@pytest.mark.parametrize("load", [0, 50], ids=["dense-table", "sparse-table"])
+def test_two_queries_per_wavefront_odd_counts_ties_and_lone_halves(oracle, load):
+    """k_knn_wave2 (k <= 32: one query per 32-lane HALF of a wavefront, both walked in lock step): query counts
     that leave the last wavefront with one query, pairs whose halves differ as much as they can -- a query in the thick of
     the map beside one with nothing in reach, beside one outside the grid, beside one whose bound goes on beyond the 3 x 3
     rows -- and exact ties (every map point twice: equal d2, the lower index first)."""
@@ -103,10 +104,10 @@ def test_two_queries_per_wavefront_odd_counts_ties_and_lone_halves(oracle):
     q[:, 0::3], q[:, 1::3], q[:, 2::3] = near, lonely, outside       # every pair of neighbours in the frame is a mixed pair
     for subdiv in (8, 3):
         om = oracle.Map(*m, 1.0, 0, subdiv)
-        c = capi.Context(0, max_batch=2, map_subdiv=subdiv, force_kernel=capi.KERNEL_LATENCY)
+        c = capi.Context(0, max_batch=2, map_subdiv=subdiv, map_hash_load=load, force_kernel=capi.KERNEL_LATENCY)
         try:
             c.map_reset(*m, 1.0, 0)
-            assert c.map_info().table_kind == 0
+            assert c.map_info().table_kind == (1 if load else 0)
             for n in (1, 2, 3, 255, 1799, 1800):
                 qs = tuple(np.ascontiguousarray(a[:n]) for a in q)
                 c.frames_upload([qs])
