@@ -518,14 +518,11 @@ __global__ __launch_bounds__(kKnnWaveThreads, VELO_KNN_WAVES_PER_SIMD) void k_kn
 // Survivors of a chunk are compacted into a second register (the stage), sorted by as many stages as the larger
 // survivor count needs, and merged by ONE in-lane step -- list[i] = min(list[i], stage[31 - i]): an ascending and a
 // descending sequence, so the minima are the 32 smallest of the 64 and bitonic -- plus the five half-cleaner steps.
-// Dense table, index ties (the query kernel).  The 3 x 3 rows around the query are walked nearest first out of table
-// entries looked up in one load; a query whose bound still reaches beyond that block afterwards (rare on the dense maps
-// this kernel is chosen for) goes on through the other rows of its 27 voxels in plain order.  Same k smallest under
-// (d2, index): the same bits.
-__device__ __forceinline__ bool key_less(unsigned ahi, unsigned alo, unsigned bhi, unsigned blo)
-{
-    return ahi < bhi || (ahi == bhi && alo < blo);
-}
+// Index ties (the query kernel), either table.  Dense table: the 3 x 3 rows around the query are walked nearest first out
+// of table entries looked up in one load; a query whose bound still reaches beyond that block afterwards (none on
+// configs[4], half of them at a 0.5 m voxel edge) goes on through the other rows of its 27 voxels centre-out, as
+// wave_knn walks them.  Sparse table: every row comes out of that walk, the lanes of a half probing the cells of a row's
+// window in one round.  Same k smallest under (d2, index): the same bits.
 template <int X>
 __device__ __forceinline__ void cmpx2(unsigned& hi, unsigned& lo, bool upper)
 {
