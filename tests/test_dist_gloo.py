@@ -85,9 +85,9 @@ def _replica_worker(rank, world, port, q):
         digests = []
         for rnd in range(3):
             rng = np.random.default_rng(1000 * rnd + rank)
-            n = [300, 0, 41][(rank + rnd) % 3]
+            n = [2600, 0, 2041][(rank + rnd) % 3]      # (mapping volume: the mapping stream accepts 2 300 points per frame)
             mine = rng.uniform(1, 11, (3, n)).astype(np.float32)
-            buf = torch.zeros((3, 512), dtype=torch.float32)
+            buf = torch.zeros((3, 4096), dtype=torch.float32)
             buf[:, :n] = torch.from_numpy(mine)
             blocks, counts = exchange_increments(buf, n)
             for b in blocks:                      # rank order
